@@ -812,7 +812,7 @@ def kiops(tau_out, A, u, *, mmin=10, mmax=128, m=None, tol=1.0e-7, opnorm=None, 
         m = min(mmin, mmax)
     if ishermitian is None:
         ishermitian = _ishermitian_matrix(A)
-    tau_arr = np.atleast_1d(np.asarray(tau_out, dtype=float))
+    tau_arr = np.atleast_1d(np.asarray(tau_out, dtype=float)).ravel(order="F")   # linear indexing
     if u.ndim == 1:
         u = u.reshape(-1, 1)
     n, ppo = u.shape
