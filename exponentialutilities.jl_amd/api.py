@@ -1,0 +1,747 @@
+"""Host-side mirror of the ExponentialUtilities.jl Krylov API over the C ABI (libexpv_mi.so).
+
+Julia is not available in this image, so the host language above the C ABI is Python; names,
+argument meaning, defaults and error behaviour follow the reference so the parity tests read like
+the reference's own tests:
+
+    reference (Julia)                              here
+    ---------------------------------------------  -----------------------------------------
+    KrylovSubspace{T,U}(n, maxiter, augmented)     KrylovSubspace(T, U, n, maxiter, augmented)
+    arnoldi(A, b; m, ishermitian, tol, iop)        arnoldi(A, b, m=, ishermitian=, tol=, iop=)
+    arnoldi!(Ks, A, b; ...) / lanczos!(Ks, A, b)   arnoldi_(Ks, A, b, ...) / lanczos_(Ks, A, b, ...)
+    expv(t, A, b; mode, ...) / expv!(w, t, Ks)     expv(t, A, b, mode=, ...) / expv_(w, t, Ks)
+    phiv(t, A, b, k; ...) / phiv!(w, t, Ks, k)     phiv(t, A, b, k, ...) / phiv_(w, t, Ks, k, ...)
+    expv_timestep / phiv_timestep (! forms)        expv_timestep / phiv_timestep (+ trailing _)
+    kiops(tau_out, A, u; ...)                      kiops(tau_out, A, u, ...)
+
+Vectors may be numpy arrays (staged through HBM by the library) or torch CUDA tensors / DeviceArray
+(used in place, nothing crosses PCIe).  Every O(n) operation runs in the HIP kernels of csrc/.
+"""
+import ctypes as C
+import math
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib as L
+
+__all__ = [
+    "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
+    "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
+    "phiv_timestep_", "kiops", "timestep_caches", "ExpvMIError", "DimensionMismatch", "host_expm",
+    "host_phiv_dense", "host_symtridiag_expcol",
+]
+
+ExpvMIError = L.ExpvMIError
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (arnoldi.jl:217-218) -- raised for status 1."""
+
+
+def _check(code, ctx=None):
+    if code == 0:
+        return
+    try:
+        L.check(code, ctx)
+    except L.ExpvMIError as e:
+        if e.code == 1:
+            raise DimensionMismatch(str(e)) from None
+        if e.code == 3:
+            raise AssertionError(str(e)) from None
+        if e.code == 8:
+            raise IndexError(str(e)) from None
+        raise
+
+
+# ---------------------------------------------------------------------------------------------
+# context and raw device memory
+# ---------------------------------------------------------------------------------------------
+class Context:
+    """One GPU + one HIP stream (expv_mi_ctx_create).  ``stream`` may be a torch.cuda.Stream."""
+
+    def __init__(self, device=None, stream=None):
+        lib = L.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        sptr = None
+        if stream is not None:
+            sptr = C.c_void_p(getattr(stream, "cuda_stream", stream))
+        h = C.c_void_p()
+        _check(lib.expv_mi_ctx_create(int(device), sptr, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._stream_keepalive = stream
+        self._finalizer = weakref.finalize(self, lib.expv_mi_ctx_destroy, h)
+
+    def sync(self):
+        _check(L.load().expv_mi_ctx_sync(self._h), self._h)
+
+    # per-kernel timing for bench.py's roofline leg
+    def prof_enable(self, on=True):
+        L.load().expv_mi_prof_enable(self._h, int(bool(on)))
+
+    def prof_reset(self):
+        _check(L.load().expv_mi_prof_reset(self._h), self._h)
+
+    def prof_get(self):
+        out = {}
+        for name, kid in L.KERNEL_IDS.items():
+            n, ms = C.c_int64(0), C.c_double(0.0)
+            _check(L.load().expv_mi_prof_get(self._h, kid, C.byref(n), C.byref(ms)), self._h)
+            if n.value:
+                out[name] = {"launches": int(n.value), "total_ms": float(ms.value)}
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+class DeviceArray:
+    """A column-major HBM array owned by the library (expv_mi_malloc); the Julia shim's MIVector/MIMatrix."""
+
+    def __init__(self, shape, dtype, ctx=None):
+        self.ctx = ctx or default_context()
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _check(L.load().expv_mi_malloc(self.ctx._h, nbytes, C.byref(p)), self.ctx._h)
+        self.ptr = p.value
+        self.nbytes = nbytes
+        self._finalizer = weakref.finalize(self, L.load().expv_mi_free, self.ctx._h, p)
+
+    @classmethod
+    def from_host(cls, a, ctx=None):
+        a = np.asfortranarray(a)
+        d = cls(a.shape, a.dtype, ctx)
+        _check(L.load().expv_mi_memcpy_h2d(d.ctx._h, d.ptr, a.ctypes.data, a.nbytes), d.ctx._h)
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype, order="F")
+        _check(L.load().expv_mi_memcpy_d2h(self.ctx._h, out.ctypes.data, self.ptr, self.nbytes), self.ctx._h)
+        return out
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _np_dtype_of(x):
+    if isinstance(x, DeviceArray):
+        return x.dtype
+    if _is_torch(x):
+        import torch
+        return {torch.float64: np.dtype(np.float64), torch.complex128: np.dtype(np.complex128)}.get(
+            x.dtype, np.dtype(np.float64) if not x.is_complex() else np.dtype(np.complex128))
+    return np.asarray(x).dtype
+
+
+def _code(dt):
+    return L.C64 if np.issubdtype(np.dtype(dt), np.complexfloating) else L.F64
+
+
+def _work_dtype(*dts):
+    return np.dtype(np.complex128) if any(np.issubdtype(np.dtype(d), np.complexfloating) for d in dts) \
+        else np.dtype(np.float64)
+
+
+class _Arg:
+    """A caller array resolved to (pointer, loc, leading dimension) + what must stay alive."""
+
+    def __init__(self, x, dtype, writable=False):
+        self.src = x
+        self.dtype = np.dtype(dtype)
+        self.back = None
+        if isinstance(x, DeviceArray):
+            if x.dtype != self.dtype:
+                raise TypeError(f"device array has dtype {x.dtype}, need {self.dtype}")
+            self.ptr, self.loc, self.shape = x.ptr, L.DEVICE, x.shape
+            self.ld = x.shape[0]
+            self.keep = x
+        elif _is_torch(x):
+            import torch
+            want = torch.complex128 if self.dtype.kind == "c" else torch.float64
+            if not x.is_cuda:
+                raise TypeError("torch tensors must live on the GPU (or pass a numpy array)")
+            if x.dtype != want:
+                if writable:
+                    raise TypeError(f"output tensor must be {want}")
+                x = x.to(want)
+            if x.dim() == 1:
+                if x.stride(0) != 1:
+                    if writable:
+                        raise TypeError("output vector must be contiguous")
+                    x = x.contiguous()
+                self.ld = x.shape[0]
+            else:
+                if x.stride(0) != 1:   # need column-major
+                    if writable:
+                        raise TypeError("output matrix must be column-major (e.g. torch.empty(k, n).t())")
+                    x = x.t().contiguous().t()
+                self.ld = x.stride(1) if x.shape[1] > 1 else max(x.shape[0], 1)
+            self.ptr, self.loc, self.shape, self.keep = x.data_ptr(), L.DEVICE, tuple(x.shape), x
+        else:
+            a = np.asarray(x)
+            if writable:
+                if a.dtype != self.dtype or not (a.flags.f_contiguous or a.ndim == 1 and a.flags.c_contiguous):
+                    # write into a staging array and copy back (keeps Julia-like in-place semantics)
+                    self.back = a
+                    a = np.empty(a.shape, dtype=self.dtype, order="F")
+            else:
+                a = np.asfortranarray(a, dtype=self.dtype)
+            self.ptr, self.loc, self.shape, self.keep = a.ctypes.data, L.HOST, a.shape, a
+            self.ld = a.shape[0] if a.ndim >= 1 else 1
+            self.host = a
+
+    def finish(self):
+        if self.back is not None:
+            if np.iscomplexobj(self.host) and not np.iscomplexobj(self.back):
+                raise TypeError("InexactError: complex result into a real array")
+            self.back[...] = self.host
+
+
+def _empty_like(ref, shape, dtype):
+    """Allocate an output next to where `ref` lives (numpy -> numpy, torch -> torch, DeviceArray -> same)."""
+    dtype = np.dtype(dtype)
+    if isinstance(ref, DeviceArray):
+        return DeviceArray(shape, dtype, ref.ctx)
+    if _is_torch(ref):
+        import torch
+        tdt = torch.complex128 if dtype.kind == "c" else torch.float64
+        if len(shape) == 1:
+            return torch.empty(shape[0], dtype=tdt, device=ref.device)
+        return torch.empty((shape[1], shape[0]), dtype=tdt, device=ref.device).t()   # column-major
+    return np.empty(shape, dtype=dtype, order="F")
+
+
+# ---------------------------------------------------------------------------------------------
+# operators (the contract of docs/src/interfaces.md:7-36)
+# ---------------------------------------------------------------------------------------------
+class MIOperator:
+    """Device-resident operator: scipy CSC/CSR matrix, dense ndarray, or a matrix-free callable.
+
+    ``MIOperator(A)`` uploads once (CSC is converted to CSR32 on the way; setup cost).  Exposes
+    ``shape``, ``dtype``, ``ishermitian`` (LinearAlgebra.ishermitian), ``nnz`` and ``opnorm_inf``.
+    """
+
+    def __init__(self, A, ctx=None, dtype=None, ishermitian=None, matvec=None, shape=None):
+        lib = L.load()
+        self.ctx = ctx or default_context()
+        self.src = A
+        h = C.c_void_p()
+        self._cb = None
+        if matvec is not None:          # matrix-free: matvec(x_dev_tensor) -> y_dev_tensor (torch, on the stream)
+            n = int(shape[0])
+            dt = np.dtype(dtype or np.float64)
+            self._matvec = matvec
+
+            def _cb(user, xp, yp, stream):
+                try:
+                    import torch
+                    x = _torch_view(xp, n, dt)
+                    y = _torch_view(yp, n, dt)
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                        y.copy_(matvec(x))
+                    return 0
+                except Exception:   # pragma: no cover - surfaced as ArgumentError by the library
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            self._cb = L.MATVEC_FN(_cb)
+            _check(lib.expv_mi_op_create_callback(self.ctx._h, _code(dt), n, self._cb, None,
+                                                  int(bool(ishermitian)), 0, C.byref(h)), self.ctx._h)
+        elif hasattr(A, "tocsc") and hasattr(A, "indptr"):
+            dt = _work_dtype(A.dtype if dtype is None else dtype)
+            n = A.shape[0]
+            if A.shape[0] != A.shape[1]:
+                raise DimensionMismatch("operator must be square")
+            if A.format == "csr":
+                M = A.astype(dt)
+                M.sort_indices()
+                ip, ix = M.indptr, M.indices
+                ib = 8 if ip.dtype.itemsize == 8 else 4
+                ip = np.ascontiguousarray(ip, dtype=np.int64 if ib == 8 else np.int32)
+                ix = np.ascontiguousarray(ix, dtype=np.int64 if ib == 8 else np.int32)
+                vals = np.ascontiguousarray(M.data, dtype=dt)
+                _check(lib.expv_mi_op_create_csr(self.ctx._h, _code(dt), n, ip.ctypes.data, ix.ctypes.data,
+                                                 vals.ctypes.data, ib, 0, C.byref(h)), self.ctx._h)
+            else:                       # Julia's SparseMatrixCSC layout
+                M = A.tocsc().astype(dt)
+                M.sort_indices()
+                cp = np.ascontiguousarray(M.indptr, dtype=np.int64)
+                rv = np.ascontiguousarray(M.indices, dtype=np.int64)
+                vals = np.ascontiguousarray(M.data, dtype=dt)
+                _check(lib.expv_mi_op_create_csc(self.ctx._h, _code(dt), n, cp.ctypes.data, rv.ctypes.data,
+                                                 vals.ctypes.data, 0, C.byref(h)), self.ctx._h)
+        else:
+            if _is_torch(A):
+                dt = _np_dtype_of(A)
+                arg = _Arg(A, dt)
+                n = A.shape[0]
+                _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, arg.ptr, arg.ld, L.DEVICE,
+                                                   C.byref(h)), self.ctx._h)
+                self._keep = arg
+            else:
+                M = np.asarray(A)
+                dt = _work_dtype(M.dtype if dtype is None else dtype)
+                M = np.asfortranarray(M, dtype=dt)
+                if M.ndim != 2 or M.shape[0] != M.shape[1]:
+                    raise DimensionMismatch("operator must be square")
+                n = M.shape[0]
+                _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, M.ctypes.data, max(n, 1), L.HOST,
+                                                   C.byref(h)), self.ctx._h)
+        self._h = h
+        self._finalizer = weakref.finalize(self, lib.expv_mi_op_destroy, h)
+        n_, nnz, herm, opn, dtc = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
+        _check(lib.expv_mi_op_info(h, C.byref(n_), C.byref(nnz), C.byref(herm), C.byref(opn), C.byref(dtc)))
+        self.shape = (int(n_.value), int(n_.value))
+        self.nnz = int(nnz.value)
+        self.ishermitian = bool(herm.value) if ishermitian is None else bool(ishermitian)
+        self.opnorm_inf = float(opn.value)
+        self.dtype = np.dtype(np.complex128 if dtc.value == L.C64 else np.float64)
+
+    def astype(self, dtype):
+        dtype = _work_dtype(dtype)
+        if dtype == self.dtype:
+            return self
+        if self.src is None or self._cb is not None:
+            raise TypeError("cannot convert a matrix-free operator to another element type")
+        key = "_as_" + dtype.name
+        if not hasattr(self, key):
+            setattr(self, key, MIOperator(self.src, self.ctx, dtype=dtype))
+        return getattr(self, key)
+
+    def matvec(self, x):
+        """mul!(y, A, x)."""
+        xa = _Arg(x, self.dtype)
+        y = _empty_like(x, (self.shape[0],), self.dtype)
+        ya = _Arg(y, self.dtype, writable=True)
+        _check(L.load().expv_mi_op_apply(self._h, xa.ptr, xa.loc, ya.ptr, ya.loc), self.ctx._h)
+        ya.finish()
+        return y
+
+    __matmul__ = matvec
+
+
+def _torch_view(ptr, n, dt):
+    import torch
+
+    class _Shim:
+        pass
+
+    s = _Shim()
+    s.__cuda_array_interface__ = {"shape": (n,), "typestr": "<c16" if np.dtype(dt).kind == "c" else "<f8",
+                                  "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(s, device="cuda")
+
+
+def _as_operator(A, want_dtype=None, ctx=None):
+    if isinstance(A, MIOperator):
+        op = A
+    else:
+        cache = getattr(_as_operator, "_cache", None)
+        if cache is None:
+            cache = _as_operator._cache = {}
+        key = id(A)
+        ent = cache.get(key)
+        if ent is None or ent[0]() is not A:
+            op = MIOperator(A, ctx)
+            try:
+                cache[key] = (weakref.ref(A), op)
+            except TypeError:
+                pass
+            if len(cache) > 16:
+                cache.pop(next(iter(cache)))
+        else:
+            op = ent[1]
+    if want_dtype is not None and np.dtype(want_dtype).kind == "c" and op.dtype.kind != "c":
+        op = op.astype(np.complex128)
+    return op
+
+
+# ---------------------------------------------------------------------------------------------
+# KrylovSubspace                                                        arnoldi.jl:50-93
+# ---------------------------------------------------------------------------------------------
+class KrylovSubspace:
+    """KrylovSubspace{T,U}(n, maxiter, augmented): V in HBM, H on the host (a live numpy view)."""
+
+    def __init__(self, T, U=None, n=0, maxiter=30, augmented=0, ctx=None):
+        lib = L.load()
+        self.ctx = ctx or default_context()
+        self.T = _work_dtype(T)
+        self.U = _work_dtype(T if U is None else U)
+        if self.U.kind == "c" and self.T.kind != "c":
+            raise TypeError("U complex with T real")
+        self.n = int(n)
+        h = C.c_void_p()
+        _check(lib.expv_mi_ks_create(self.ctx._h, _code(self.T), _code(self.U), self.n, int(maxiter),
+                                     int(augmented), C.byref(h)), self.ctx._h)
+        self._h = h
+        self._finalizer = weakref.finalize(self, lib.expv_mi_ks_destroy, h)
+
+    def _get(self):
+        m, mi, aug, beta, wb = C.c_int(), C.c_int(), C.c_int(), C.c_double(), C.c_int()
+        _check(L.load().expv_mi_ks_get(self._h, C.byref(m), C.byref(mi), C.byref(aug), C.byref(beta), C.byref(wb)))
+        return m.value, mi.value, aug.value, beta.value, bool(wb.value)
+
+    m = property(lambda s: s._get()[0], lambda s, v: _check(L.load().expv_mi_ks_set_m(s._h, int(v)), s.ctx._h))
+    maxiter = property(lambda s: s._get()[1])
+    augmented = property(lambda s: s._get()[2])
+    beta = property(lambda s: s._get()[3])
+    wasbreakdown = property(lambda s: s._get()[4])
+
+    @property
+    def H(self):
+        """Ks.H -- live view of the host matrix, (maxiter+1) x (maxiter + (augmented != 0))."""
+        p, ld, nr, nc = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        _check(L.load().expv_mi_ks_H(self._h, C.byref(p), C.byref(ld), C.byref(nr), C.byref(nc)))
+        k = 2 if self.U.kind == "c" else 1
+        buf = (C.c_double * (ld.value * nc.value * k)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=self.U).reshape((nc.value, ld.value)).T
+        return a[: nr.value, :]
+
+    def getH(self):
+        m, _, aug, _, _ = self._get()
+        return self.H[: m + 1, : m + (aug != 0)]
+
+    def V_host(self, col0=0, ncols=None):
+        m, mi, aug, _, _ = self._get()
+        if ncols is None:
+            ncols = mi + 1 - col0
+        out = np.empty((self.n + aug, ncols), dtype=self.T, order="F")
+        _check(L.load().expv_mi_ks_V_download(self._h, int(col0), int(ncols), out.ctypes.data, max(out.shape[0], 1)),
+               self.ctx._h)
+        return out
+
+    def getV(self):
+        return self.V_host(0, self.m + 1)
+
+    def resize(self, maxiter):
+        _check(L.load().expv_mi_ks_resize(self._h, int(maxiter)), self.ctx._h)
+        return self
+
+
+def _opts(m=None, tol=1e-7, iop=0, init=0, ishermitian=None, ortho="auto"):
+    o = L.ArnoldiOpts()
+    L.load().expv_mi_arnoldi_opts_default(C.byref(o))
+    o.m = int(m) if m is not None else 0
+    o.tol = float(tol)
+    o.iop = int(iop)
+    o.init = int(init)
+    o.ishermitian = -1 if ishermitian is None else int(bool(ishermitian))
+    o.ortho = {"auto": L.ORTHO_AUTO, "mgs": L.ORTHO_MGS, "lowsync": L.ORTHO_LOWSYNC}[ortho] \
+        if isinstance(ortho, str) else int(ortho)
+    return o
+
+
+def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0, init=0, ortho="auto"):
+    """arnoldi!(Ks, A, b; tol, m, ishermitian, opnorm, iop, init)  (arnoldi.jl:345-377).
+    ``opnorm`` is accepted and ignored, like the reference."""
+    op = _as_operator(A, Ks.T, Ks.ctx)
+    if op.dtype != Ks.T:
+        raise TypeError(f"operator eltype {op.dtype} does not fit KrylovSubspace{{{Ks.T}}}")
+    ba = _Arg(b, Ks.T)
+    if int(np.prod(ba.shape)) != op.shape[0]:
+        raise DimensionMismatch(f"length(b) [{int(np.prod(ba.shape))}] == size(A,1) [{op.shape[0]}] doesn't hold")
+    if ishermitian is None:
+        ishermitian = op.ishermitian
+    o = _opts(m, tol, iop, init, ishermitian, ortho)
+    _check(L.load().expv_mi_arnoldi(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
+    return Ks
+
+
+def lanczos_(Ks, A, b, *, tol=1e-7, m=None, opnorm=None, init=0):
+    """lanczos!(Ks, A, b; tol, m)  (arnoldi.jl:456-490)."""
+    op = _as_operator(A, Ks.T, Ks.ctx)
+    ba = _Arg(b, Ks.T)
+    if int(np.prod(ba.shape)) != op.shape[0]:
+        raise DimensionMismatch("length(b) == size(A,1) doesn't hold")
+    o = _opts(m, tol, 0, init, True, "auto")
+    _check(L.load().expv_mi_lanczos(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
+    return Ks
+
+
+def arnoldi(A, b, *, m=None, ishermitian=None, **kw):
+    """arnoldi(A, b; m = min(30, size(A,1)), ishermitian = LinearAlgebra.ishermitian(A), kwargs...)
+    (arnoldi.jl:161-180)."""
+    bdt = _np_dtype_of(b)
+    op = _as_operator(A, None)
+    T = _work_dtype(op.dtype, bdt)
+    op = _as_operator(op, T)
+    if m is None:
+        m = min(30, op.shape[0])
+    if ishermitian is None:
+        ishermitian = op.ishermitian
+    U = np.dtype(np.float64) if ishermitian else T
+    n = b.shape[0] if hasattr(b, "shape") else len(b)
+    Ks = KrylovSubspace(T, U, n, m, 0, op.ctx)
+    return arnoldi_(Ks, op, b, m=m, ishermitian=ishermitian, **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# expv / phiv                                                     krylov_phiv.jl:125-653
+# ---------------------------------------------------------------------------------------------
+def _t_parts(t):
+    tc = isinstance(t, (complex, np.complexfloating))
+    return float(np.real(t)), float(np.imag(t)) if tc else 0.0, tc
+
+
+def expv_(w, t, Ks):
+    """expv!(w, t, Ks)  (krylov_phiv.jl:200-280)."""
+    tr, ti, tc = _t_parts(t)
+    wdt = _np_dtype_of(w)
+    if (tc or Ks.T.kind == "c") and wdt.kind != "c":
+        raise TypeError("InexactError: w must be complex when t or the basis is complex")
+    wa = _Arg(w, _work_dtype(wdt), writable=True)
+    if wa.shape[0] != Ks.n + Ks.augmented:
+        raise AssertionError("Dimension mismatch")
+    _check(L.load().expv_mi_expv_ks(Ks._h, tr, ti, wa.ptr, wa.loc, _code(wa.dtype)), Ks.ctx._h)
+    wa.finish()
+    return w
+
+
+def expv(t, A, b, *, mode="happy_breakdown", **kw):
+    """expv(t, A, b; mode = :happy_breakdown | :error_estimate, kwargs...)  (krylov_phiv.jl:125-160)."""
+    if isinstance(A, KrylovSubspace):       # expv(t, Ks)  (:161-168)
+        Ks = A
+        w = np.empty(Ks.n, dtype=_work_dtype(Ks.T, np.complex128 if _t_parts(t)[2] else np.float64), order="F")
+        return expv_(w, t, Ks)
+    tr, ti, tc = _t_parts(t)
+    tdt = np.complex128 if tc else np.float64
+    op = _as_operator(A, None)
+    bdt = _np_dtype_of(b)
+    n = b.shape[0]
+    if mode == "happy_breakdown":
+        Ks = arnoldi(op, b, **kw)
+        w = _empty_like(b, (n,), _work_dtype(tdt, op.dtype, bdt))
+        return expv_(w, t, Ks)
+    if mode == "error_estimate":        # _expv_ee  (:145-160)
+        m = kw.pop("m", min(30, op.shape[0]))
+        tol = kw.pop("tol", 1e-7)
+        rtol = kw.pop("rtol", math.sqrt(tol))
+        ish = kw.pop("ishermitian", None)
+        if ish is None:
+            ish = op.ishermitian
+        T = _work_dtype(tdt, op.dtype, bdt)
+        opT = _as_operator(op, T)
+        if not ish:
+            raise RuntimeError("Error estimation not yet available for non-Hermitian matrices.")
+        Ks = KrylovSubspace(T, np.float64, op.shape[0], m, 0, op.ctx)
+        w = _empty_like(b, (n,), T)
+        ba, wa = _Arg(b, T), _Arg(w, T, writable=True)
+        _check(L.load().expv_mi_expv_error_estimate(Ks._h, opT._h, tr, ti, ba.ptr, ba.loc, wa.ptr, wa.loc,
+                                                    float(tol), float(rtol), int(m), int(bool(ish))), Ks.ctx._h)
+        wa.finish()
+        expv.last_subspace = Ks
+        return w
+    raise ValueError(f"Unknown Krylov iteration termination mode, {mode}")     # ArgumentError (:132)
+
+
+def phiv_(w, t, Ks, k, *, correct=False, errest=False):
+    """phiv!(w, t, Ks, k; correct, errest)  (krylov_phiv.jl:607-653)."""
+    tr, ti, tc = _t_parts(t)
+    wdt = _np_dtype_of(w)
+    if (tc or Ks.T.kind == "c") and wdt.kind != "c":
+        raise TypeError("InexactError: w must be complex when t or the basis is complex")
+    wa = _Arg(w, _work_dtype(wdt), writable=True)
+    if len(wa.shape) != 2 or wa.shape[0] != Ks.n + Ks.augmented or wa.shape[1] != k + 1:
+        raise AssertionError("Dimension mismatch")
+    err = C.c_double(0.0)
+    _check(L.load().expv_mi_phiv_ks(Ks._h, tr, ti, int(k), int(bool(correct)), wa.ptr, wa.ld, wa.loc,
+                                    _code(wa.dtype), C.byref(err)), Ks.ctx._h)
+    wa.finish()
+    return (w, err.value) if errest else w
+
+
+def phiv(t, A, b, k=None, *, correct=False, errest=False, **kw):
+    """phiv(t, A, b, k; correct, errest, kwargs...) and phiv(t, Ks, k; ...)  (krylov_phiv.jl:563-575)."""
+    if isinstance(A, KrylovSubspace):
+        Ks, kk = A, b
+        w = np.empty((Ks.n, kk + 1), dtype=_work_dtype(Ks.T, np.complex128 if _t_parts(t)[2] else np.float64),
+                     order="F")
+        return phiv_(w, t, Ks, kk, correct=correct, errest=errest)
+    Ks = arnoldi(A, b, **kw)
+    wdt = _work_dtype(_np_dtype_of(b), Ks.T, np.complex128 if _t_parts(t)[2] else np.float64)
+    w = _empty_like(b, (b.shape[0], k + 1), wdt)
+    return phiv_(w, t, Ks, k, correct=correct, errest=errest)
+
+
+# ---------------------------------------------------------------------------------------------
+# expv_timestep / phiv_timestep                           krylov_phiv_adaptive.jl:57-453
+# ---------------------------------------------------------------------------------------------
+class _TsCaches:
+    def __init__(self, ctx, dtype, n, maxiter, p):
+        h = C.c_void_p()
+        _check(L.load().expv_mi_timestep_caches_create(ctx._h, _code(dtype), int(n), int(maxiter), int(p),
+                                                       C.byref(h)), ctx._h)
+        self._h, self.ctx = h, ctx
+        self._finalizer = weakref.finalize(self, L.load().expv_mi_timestep_caches_destroy, h)
+
+
+def timestep_caches(u_prototype, maxiter, p, ctx=None):
+    """_phiv_timestep_caches(u_prototype, maxiter, p)  (krylov_phiv_adaptive.jl:502-511)."""
+    return _TsCaches(ctx or default_context(), _work_dtype(_np_dtype_of(u_prototype)), u_prototype.shape[0],
+                     maxiter, p)
+
+
+def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0, correct=False, caches=None,
+                   adaptive=False, delta=1.2, ishermitian=None, gamma=0.8, NA=0, verbose=False, ortho="auto",
+                   out=None, stats=None):
+    """phiv_timestep!(U, ts, A, B; ...)  (krylov_phiv_adaptive.jl:260-453).  ``ts`` is sorted in place."""
+    Bdt = _np_dtype_of(B)
+    T = _work_dtype(Bdt)
+    op = _as_operator(A, T)
+    if op.dtype != T:
+        T = _work_dtype(op.dtype, T)
+    n = op.shape[0]
+    Ba = _Arg(B, T)
+    ncoef = Ba.shape[1] if len(Ba.shape) == 2 else 1
+    Ua = _Arg(U, T, writable=True)
+    nsnap = Ua.shape[1] if len(Ua.shape) == 2 else 1
+    ts_arr = ts if isinstance(ts, np.ndarray) and ts.dtype == np.float64 and ts.flags.c_contiguous \
+        else np.ascontiguousarray(ts, dtype=np.float64)
+    if len(ts_arr) != nsnap:
+        raise AssertionError("Dimension mismatch")
+    if not (n == Ba.shape[0] == Ua.shape[0]):
+        raise AssertionError("Dimension mismatch")
+    o = L.TimestepOpts()
+    L.load().expv_mi_timestep_opts_default(C.byref(o))
+    o.tau, o.tol, o.delta, o.gamma = float(tau), float(tol), float(delta), float(gamma)
+    if opnorm is not None:
+        o.has_opnorm = 1
+        o.opnorm = float(opnorm if np.isscalar(opnorm) else opnorm(A if not isinstance(A, MIOperator) else A.src,
+                                                                   np.inf))
+    o.m = int(m) if m is not None else 0
+    o.iop, o.correct, o.adaptive = int(iop), int(bool(correct)), int(bool(adaptive))
+    o.ishermitian = -1 if ishermitian is None else int(bool(ishermitian))
+    o.verbose = int(bool(verbose))
+    o.ortho = {"auto": 0, "mgs": 1, "lowsync": 2}[ortho] if isinstance(ortho, str) else int(ortho)
+    o.NA = int(NA)
+    sink = out if out is not None else print
+    cb = L.PRINT_FN(lambda line, user: sink(line.decode()))
+    o.print = cb
+    st = L.TimestepStats()
+    _check(L.load().expv_mi_phiv_timestep(op.ctx._h, op._h, int(nsnap), ts_arr.ctypes.data_as(L._pd), Ba.ptr, Ba.ld,
+                                          int(ncoef), Ba.loc, Ua.ptr, Ua.ld, Ua.loc, C.byref(o),
+                                          caches._h if caches is not None else None, C.byref(st)), op.ctx._h)
+    Ua.finish()
+    if ts_arr is not ts and isinstance(ts, np.ndarray):
+        ts[...] = ts_arr
+    if stats is not None:
+        stats.update(num_timesteps=st.num_timesteps, matvecs=st.matvecs, m=st.m_final, arnoldi_calls=st.arnoldi_calls)
+    return U
+
+
+def phiv_timestep(ts, A, B, **kw):
+    """phiv_timestep(ts, A, B; ...)  (krylov_phiv_adaptive.jl:184-191)."""
+    op = _as_operator(A, None)
+    T = _work_dtype(_np_dtype_of(B), op.dtype)
+    n = op.shape[0]
+    if np.isscalar(ts):
+        u = _empty_like(B, (n,), T)
+        return phiv_timestep_(u, np.array([float(ts)]), op, B, **kw)
+    ts = np.ascontiguousarray(ts, dtype=np.float64)
+    U = _empty_like(B, (n, len(ts)), T)
+    return phiv_timestep_(U, ts, op, B, **kw)
+
+
+def expv_timestep(ts, A, b, **kw):
+    """expv_timestep(ts, A, b; ...)  (krylov_phiv_adaptive.jl:57-67): the p = 0 case."""
+    return phiv_timestep(ts, A, b, **kw)
+
+
+def expv_timestep_(u, ts, A, b, **kw):
+    """expv_timestep!(u, t, A, b; ...)  (krylov_phiv_adaptive.jl:99-114)."""
+    if np.isscalar(ts):
+        ts = np.array([float(ts)])
+    return phiv_timestep_(u, ts, A, b, **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# kiops                                                                    kiops.jl:57-281
+# ---------------------------------------------------------------------------------------------
+def kiops(tau_out, A, u, *, mmin=10, mmax=128, m=None, tol=1e-7, opnorm=None, iop=2, ishermitian=None, task1=False,
+          ortho="auto", allow_complex=False):
+    """kiops(tau_out, A, u; mmin, mmax, m, tol, iop, ishermitian, task1) -> (w, stats).
+
+    The reference is real-only (kiops.jl:89, arnoldi.jl:197-200).  ``allow_complex=True`` selects the
+    mathematical extension this build defines for complex operands (no reference behaviour exists)."""
+    op = _as_operator(A, None)
+    udt = _np_dtype_of(u)
+    T = _work_dtype(op.dtype, udt)
+    if T.kind == "c" and not allow_complex:
+        raise TypeError("kiops: complex operands have no method in the reference (kiops.jl:89, arnoldi.jl:197)")
+    op = _as_operator(op, T)
+    tau_nd = np.ndim(tau_out)
+    tau_arr = np.atleast_1d(np.asarray(tau_out, dtype=np.float64)).ravel(order="F").copy()
+    tau_ncols = 1 if tau_nd < 2 else np.shape(tau_out)[1]
+    ua = _Arg(u, T)
+    ncols_u = ua.shape[1] if len(ua.shape) == 2 else 1
+    n = op.shape[0]
+    if ua.shape[0] != n:
+        raise DimensionMismatch("size(u,1) == size(A,1) doesn't hold")
+    w = _empty_like(u, (n, 1), T)
+    wa = _Arg(w, T, writable=True)
+    o = L.KiopsOpts()
+    L.load().expv_mi_kiops_opts_default(C.byref(o))
+    o.mmin, o.mmax, o.iop, o.task1 = int(mmin), int(mmax), int(iop), int(bool(task1))
+    o.m = int(m) if m is not None else 0
+    o.tol = float(tol)
+    o.ishermitian = -1 if ishermitian is None else int(bool(ishermitian))
+    o.ortho = {"auto": 0, "mgs": 1, "lowsync": 2}[ortho] if isinstance(ortho, str) else int(ortho)
+    st = (C.c_int64 * 5)()
+    _check(L.load().expv_mi_kiops(op.ctx._h, op._h, tau_arr.ctypes.data_as(L._pd), int(tau_arr.size), int(tau_ncols),
+                                  ua.ptr, ua.ld, int(ncols_u), ua.loc, wa.ptr, wa.ld, wa.loc, C.byref(o), st),
+           op.ctx._h)
+    wa.finish()
+    return w, tuple(int(x) for x in st)
+
+
+# ---------------------------------------------------------------------------------------------
+# host small-dense functions (no GPU needed)
+# ---------------------------------------------------------------------------------------------
+def host_expm(A):
+    """exponential!(copy(A), ExpMethodHigham2005Base()) on the host (exp_baseexp.jl:112-161)."""
+    A = np.array(A, dtype=_work_dtype(np.asarray(A).dtype), order="F", copy=True)
+    n = A.shape[0]
+    _check(L.load().expv_mi_host_expm(_code(A.dtype), n, A.ctypes.data, max(n, 1)))
+    return A
+
+
+def host_phiv_dense(A, v, k):
+    """phiv_dense(A, v, k)  (phi.jl:75-115)."""
+    dt = _work_dtype(np.asarray(A).dtype, np.asarray(v).dtype)
+    A = np.asfortranarray(A, dtype=dt)
+    v = np.ascontiguousarray(v, dtype=dt)
+    m = A.shape[0]
+    w = np.empty((m, k + 1), dtype=dt, order="F")
+    _check(L.load().expv_mi_host_phiv_dense(_code(dt), m, int(k), A.ctypes.data, max(m, 1), v.ctypes.data,
+                                            w.ctypes.data))
+    return w
+
+
+def host_symtridiag_expcol(d, e, t):
+    """Z*(exp.(t*lambda).*Z[1,:]) for SymTridiagonal(d, e)  (krylov_phiv.jl:227-228)."""
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    e = np.ascontiguousarray(e, dtype=np.float64)
+    n = d.size
+    out = np.empty(n, dtype=np.complex128)
+    tr, ti, _ = _t_parts(t)
+    _check(L.load().expv_mi_host_symtridiag_expcol(n, d.ctypes.data_as(L._pd), e.ctypes.data_as(L._pd), tr, ti,
+                                                   out.ctypes.data_as(L._pd)))
+    return out

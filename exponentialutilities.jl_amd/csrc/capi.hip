@@ -1,0 +1,687 @@
+// capi.hip -- the extern "C" surface declared in include/expv_mi.h.  Nothing here throws.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+
+#include "engine.h"
+
+using namespace expv_mi;
+using dense::cd;
+using dense::Mat;
+
+namespace {
+thread_local std::string g_last_error;  // failures before a context exists
+
+template <class F>
+int guarded(Ctx *ctx, F &&f) {
+  try {
+    f();
+    return EXPV_MI_OK;
+  } catch (const Err &e) {
+    (ctx ? ctx->last_error : g_last_error) = e.msg;
+    return e.code;
+  } catch (const dense::SingularError &e) {
+    (ctx ? ctx->last_error : g_last_error) = e.what();
+    return EXPV_MI_SINGULAR;
+  } catch (const std::bad_alloc &) {
+    (ctx ? ctx->last_error : g_last_error) = "host allocation failed";
+    return EXPV_MI_OUT_OF_MEMORY;
+  } catch (const std::exception &e) {
+    (ctx ? ctx->last_error : g_last_error) = e.what();
+    return EXPV_MI_ARGUMENT_ERROR;
+  }
+}
+
+// CSC (any index base) -> CSR32, rows sorted by column; also the transpose for the Hermitian test
+template <class V>
+void csc_to_csr(int64_t n, const int64_t *colptr, const int64_t *rowval, const V *nz, int base, std::vector<int32_t> &rp,
+                std::vector<int32_t> &ci, std::vector<V> &va) {
+  const int64_t nnz = colptr[n] - base;
+  rp.assign(n + 1, 0);
+  ci.resize(nnz);
+  va.resize(nnz);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t r = rowval[k] - base;
+    if (r < 0 || r >= n) fail(EXPV_MI_ARGUMENT_ERROR, "sparse operator: row index out of range");
+    rp[r + 1]++;
+  }
+  for (int64_t r = 0; r < n; ++r) rp[r + 1] += rp[r];
+  std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  for (int64_t c = 0; c < n; ++c)
+    for (int64_t k = colptr[c] - base; k < colptr[c + 1] - base; ++k) {
+      const int64_t r = rowval[k] - base;
+      const int32_t dst = fill[r]++;
+      ci[dst] = (int32_t)c;
+      va[dst] = nz[k];
+    }
+}
+
+inline double absd(double x) { return std::fabs(x); }
+inline double absd(const cd &x) { return std::abs(x); }
+inline double conjd(double x) { return x; }
+inline cd conjd(const cd &x) { return std::conj(x); }
+inline bool iszero(double x) { return x == 0.0; }
+inline bool iszero(const cd &x) { return x.real() == 0.0 && x.imag() == 0.0; }
+
+// LinearAlgebra.ishermitian on CSR32 (explicit zeros ignored) and opnorm(A, Inf)
+template <class V>
+void csr_props(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, const std::vector<V> &va,
+               int *herm, double *opn) {
+  double best = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    double s = 0;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) s += absd(va[k]);
+    best = std::max(best, s);
+  }
+  *opn = best;
+  // transpose by counting sort, then compare row by row
+  std::vector<int32_t> tp(n + 1, 0);
+  for (size_t k = 0; k < ci.size(); ++k)
+    if (!iszero(va[k])) tp[ci[k] + 1]++;
+  for (int64_t r = 0; r < n; ++r) tp[r + 1] += tp[r];
+  std::vector<int32_t> tc(tp[n]);
+  std::vector<V> tv(tp[n]);
+  std::vector<int32_t> fill(tp.begin(), tp.end() - 1);
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k)
+      if (!iszero(va[k])) {
+        const int32_t d = fill[ci[k]]++;
+        tc[d] = (int32_t)r;
+        tv[d] = va[k];
+      }
+  bool h = true;
+  for (int64_t r = 0; r < n && h; ++r) {
+    // entries of row r of A (sorted by column when built from CSC; sort a copy otherwise)
+    std::vector<std::pair<int32_t, V>> a;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k)
+      if (!iszero(va[k])) a.emplace_back(ci[k], va[k]);
+    std::sort(a.begin(), a.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    const int32_t t0 = tp[r], t1 = tp[r + 1];
+    if ((int32_t)a.size() != t1 - t0) { h = false; break; }
+    for (int32_t q = 0; q < t1 - t0; ++q)
+      if (a[q].first != tc[t0 + q] || !(a[q].second == conjd(tv[t0 + q]))) { h = false; break; }
+  }
+  *herm = h ? 1 : 0;
+}
+
+template <class V>
+void upload_csr(Op &op, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, const std::vector<V> &va) {
+  Ctx *c = op.ctx;
+  op.rowptr.alloc(sizeof(int32_t) * rp.size());
+  op.col.alloc(sizeof(int32_t) * std::max<size_t>(ci.size(), 1));
+  op.val.alloc(sizeof(V) * std::max<size_t>(va.size(), 1));
+  HIPCHECK(hipMemcpyAsync(op.rowptr.p, rp.data(), sizeof(int32_t) * rp.size(), hipMemcpyHostToDevice, c->stream));
+  if (!ci.empty()) {
+    HIPCHECK(hipMemcpyAsync(op.col.p, ci.data(), sizeof(int32_t) * ci.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.val.p, va.data(), sizeof(V) * va.size(), hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
+}
+
+template <class V>
+void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+  op.kind = OP_CSR;
+  op.n = n;
+  op.nnz = (int64_t)ci.size();
+  csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
+  upload_csr<V>(op, rp, ci, va);
+}
+
+const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",
+                                             "fused_a",   "fused_b", "lincomb", "aug",    "batch"};
+}  // namespace
+
+extern "C" {
+
+const char *expv_mi_version(void) { return "expv_mi 0.1.0 (gfx950)"; }
+
+int expv_mi_ctx_create(int device_id, void *stream, expv_mi_ctx_t *out) {
+  return guarded(nullptr, [&] {
+    if (!out) fail(EXPV_MI_ARGUMENT_ERROR, "ctx_create: null output");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+      fail(EXPV_MI_HIP_ERROR, "no HIP device available: the product path has no CPU fallback");
+    if (device_id < 0 || device_id >= count) fail(EXPV_MI_ARGUMENT_ERROR, "ctx_create: device id out of range");
+    std::unique_ptr<expv_mi_ctx_s> c(new expv_mi_ctx_s());
+    c->device = device_id;
+    HIPCHECK(hipSetDevice(device_id));
+    if (stream) {
+      c->stream = reinterpret_cast<hipStream_t>(stream);
+      c->owns_stream = false;
+    } else {
+      HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->owns_stream = true;
+    }
+    *out = c.release();
+  });
+}
+int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
+  if (!ctx) return EXPV_MI_OK;
+  (void)hipSetDevice(ctx->device);
+  for (auto &p : ctx->prof)
+    for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return EXPV_MI_OK;
+}
+int expv_mi_ctx_sync(expv_mi_ctx_t ctx) {
+  return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipStreamSynchronize(ctx->stream)); });
+}
+const char *expv_mi_last_error(expv_mi_ctx_t ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int expv_mi_malloc(expv_mi_ctx_t ctx, size_t bytes, void **dptr) {
+  return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipMalloc(dptr, bytes ? bytes : 1)); });
+}
+int expv_mi_free(expv_mi_ctx_t ctx, void *dptr) {
+  return guarded(ctx, [&] { ctx->use(); if (dptr) HIPCHECK(hipFree(dptr)); });
+}
+int expv_mi_memcpy_h2d(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+int expv_mi_memcpy_d2h(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int expv_mi_prof_enable(expv_mi_ctx_t ctx, int on) { ctx->prof_on = on != 0; return EXPV_MI_OK; }
+int expv_mi_prof_reset(expv_mi_ctx_t ctx) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof) {
+      for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+      p.ev.clear();
+      p.launches = 0;
+      p.total_ms = 0;
+    }
+  });
+}
+int expv_mi_prof_get(expv_mi_ctx_t ctx, int kid, int64_t *launches, double *total_ms) {
+  return guarded(ctx, [&] {
+    if (kid < 0 || kid >= EXPV_MI_K_COUNT) fail(EXPV_MI_ARGUMENT_ERROR, "prof_get: bad kernel id");
+    ctx->use();
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ProfSlot &p = ctx->prof[kid];
+    for (auto &ev : p.ev) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) p.total_ms += ms;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    p.ev.clear();
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = p.total_ms;
+  });
+}
+const char *expv_mi_prof_name(int kid) { return (kid >= 0 && kid < EXPV_MI_K_COUNT) ? kKernelNames[kid] : "?"; }
+
+// ------------------------------------------------------------------ operators ---------------
+int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                          const void *nzval, int index_base, expv_mi_op_t *out) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    if (n < 0 || n > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: n out of range for CSR32");
+    if (colptr[n] - index_base > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: nnz exceeds CSR32");
+    std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
+    op->ctx = ctx;
+    op->dtype = dtype;
+    std::vector<int32_t> rp, ci;
+    if (dtype == EXPV_MI_C64) {
+      std::vector<cd> va;
+      csc_to_csr<cd>(n, colptr, rowval, reinterpret_cast<const cd *>(nzval), index_base, rp, ci, va);
+      make_csr_op<cd>(*op, n, rp, ci, va);
+    } else {
+      std::vector<double> va;
+      csc_to_csr<double>(n, colptr, rowval, reinterpret_cast<const double *>(nzval), index_base, rp, ci, va);
+      make_csr_op<double>(*op, n, rp, ci, va);
+    }
+    *out = op.release();
+  });
+}
+
+int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *rowptr, const void *colind,
+                          const void *vals, int idx_bytes, int index_base, expv_mi_op_t *out) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    if (idx_bytes != 4 && idx_bytes != 8) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: idx_bytes must be 4 or 8");
+    if (n < 0 || n > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: n out of range for CSR32");
+    auto rpv = [&](int64_t i) -> int64_t {
+      return (idx_bytes == 8 ? reinterpret_cast<const int64_t *>(rowptr)[i] : reinterpret_cast<const int32_t *>(rowptr)[i]) - index_base;
+    };
+    auto civ = [&](int64_t k) -> int64_t {
+      return (idx_bytes == 8 ? reinterpret_cast<const int64_t *>(colind)[k] : reinterpret_cast<const int32_t *>(colind)[k]) - index_base;
+    };
+    const int64_t nnz = rpv(n);
+    if (nnz > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: nnz exceeds CSR32");
+    std::vector<int32_t> rp(n + 1), ci(nnz);
+    for (int64_t i = 0; i <= n; ++i) rp[i] = (int32_t)rpv(i);
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int64_t cc = civ(k);
+      if (cc < 0 || cc >= n) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: column index out of range");
+      ci[k] = (int32_t)cc;
+    }
+    std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
+    op->ctx = ctx;
+    op->dtype = dtype;
+    if (dtype == EXPV_MI_C64) {
+      std::vector<cd> va(reinterpret_cast<const cd *>(vals), reinterpret_cast<const cd *>(vals) + nnz);
+      make_csr_op<cd>(*op, n, rp, ci, va);
+    } else {
+      std::vector<double> va(reinterpret_cast<const double *>(vals), reinterpret_cast<const double *>(vals) + nnz);
+      make_csr_op<double>(*op, n, rp, ci, va);
+    }
+    *out = op.release();
+  });
+}
+
+int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *A, int64_t lda, int loc,
+                            expv_mi_op_t *out) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    if (n < 0 || lda < n) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_dense: bad n / lda");
+    std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
+    op->ctx = ctx;
+    op->dtype = dtype;
+    op->kind = OP_DENSE;
+    op->n = n;
+    const size_t esz = dtype_size(dtype);
+    if (loc == EXPV_MI_HOST) {
+      // properties on the host copy: ishermitian, opnorm(A, Inf), count(!iszero, A)
+      int64_t nz = 0;
+      bool h = true;
+      std::vector<double> rows(n, 0.0);
+      auto at = [&](int64_t i, int64_t j) -> cd {
+        if (dtype == EXPV_MI_C64) {
+          const double *p = reinterpret_cast<const double *>(A) + 2 * (j * lda + i);
+          return cd(p[0], p[1]);
+        }
+        return cd(reinterpret_cast<const double *>(A)[j * lda + i], 0.0);
+      };
+      for (int64_t j = 0; j < n; ++j)
+        for (int64_t i = 0; i < n; ++i) {
+          const cd v = at(i, j);
+          if (v != cd(0)) ++nz;
+          rows[i] += std::abs(v);
+          if (h && i <= j && v != std::conj(at(j, i))) h = false;
+        }
+      op->nnz = nz;
+      op->ishermitian = h ? 1 : 0;
+      op->opnorm_inf = n ? *std::max_element(rows.begin(), rows.end()) : 0.0;
+      const int64_t ldd = (n + 1) / 2 * 2;  // even leading dimension keeps 16-B column alignment
+      op->dense.alloc((size_t)std::max<int64_t>(ldd * n, 1) * esz);
+      if (n) HIPCHECK(hipMemcpy2DAsync(op->dense.p, ldd * esz, A, lda * esz, n * esz, n, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHECK(hipStreamSynchronize(ctx->stream));
+      op->dense_ptr = op->dense.p;
+      op->lda = ldd;
+    } else {
+      op->dense_ptr = A;  // caller keeps it alive
+      op->lda = lda;
+      op->nnz = n * n;
+      op->ishermitian = 0;
+      op->opnorm_inf = NAN;
+    }
+    const int64_t rows_per_block = dev::BLOCK * (16 / (int64_t)esz);
+    const int64_t gx = std::max<int64_t>(1, (n + rows_per_block - 1) / rows_per_block);
+    int split = (int)std::min<int64_t>(64, std::max<int64_t>(1, (1024 + gx - 1) / gx));
+    if (n < 64) split = 1;
+    op->gemv_split = split;
+    if (split > 1) op->gemv_scratch.alloc((size_t)split * n * esz);
+    *out = op.release();
+  });
+}
+
+int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_matvec_fn fn, void *user,
+                               int ishermitian, int64_t nnz_hint, expv_mi_op_t *out) {
+  return guarded(ctx, [&] {
+    if (!fn) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_callback: null callback");
+    std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
+    op->ctx = ctx;
+    op->dtype = dtype;
+    op->kind = OP_CALLBACK;
+    op->n = n;
+    op->nnz = nnz_hint;
+    op->ishermitian = ishermitian > 0;
+    op->opnorm_inf = NAN;
+    op->fn = fn;
+    op->user = user;
+    *out = op.release();
+  });
+}
+
+int expv_mi_op_destroy(expv_mi_op_t op) {
+  if (op) {
+    (void)hipSetDevice(op->ctx->device);
+    delete op;
+  }
+  return EXPV_MI_OK;
+}
+
+int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian, double *opnorm_inf, int *dtype) {
+  if (!op) return EXPV_MI_ARGUMENT_ERROR;
+  if (n) *n = op->n;
+  if (nnz) *nnz = op->nnz;
+  if (ishermitian) *ishermitian = op->ishermitian;
+  if (opnorm_inf) *opnorm_inf = op->opnorm_inf;
+  if (dtype) *dtype = op->dtype;
+  return EXPV_MI_OK;
+}
+
+int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc) {
+  return guarded(op->ctx, [&] {
+    Ctx *c = op->ctx;
+    c->use();
+    const size_t bytes = (size_t)op->n * dtype_size(op->dtype);
+    DevBuf xt, yt;
+    const void *xd = stage_in(c, x, x_loc, bytes, xt);
+    void *yd = y;
+    if (y_loc == EXPV_MI_HOST) { yt.alloc(bytes + 16); yd = yt.p; }
+    op_apply_dev(*op, xd, yd, nullptr, 0);
+    if (y_loc == EXPV_MI_HOST) HIPCHECK(hipMemcpyAsync(y, yd, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+  });
+}
+
+// ------------------------------------------------------------------ KrylovSubspace ----------
+int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, int maxiter, int augmented,
+                      expv_mi_ks_t *out) {
+  return guarded(ctx, [&] {
+    std::unique_ptr<expv_mi_ks_s> ks(new expv_mi_ks_s());
+    ks_alloc(*ks, ctx, dtype_T, dtype_U, n, maxiter, augmented);
+    *out = ks.release();
+  });
+}
+int expv_mi_ks_destroy(expv_mi_ks_t ks) {
+  if (ks) {
+    (void)hipSetDevice(ks->ctx->device);
+    delete ks;
+  }
+  return EXPV_MI_OK;
+}
+int expv_mi_ks_resize(expv_mi_ks_t ks, int maxiter) {
+  return guarded(ks->ctx, [&] {
+    if (maxiter < 1) fail(EXPV_MI_ARGUMENT_ERROR, "resize!: maxiter >= 1 required");
+    ks_resize(*ks, maxiter);
+  });
+}
+int expv_mi_ks_get(expv_mi_ks_t ks, int *m, int *maxiter, int *augmented, double *beta, int *wasbreakdown) {
+  if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  if (m) *m = ks->m;
+  if (maxiter) *maxiter = ks->maxiter;
+  if (augmented) *augmented = ks->augmented;
+  if (beta) *beta = ks->beta;
+  if (wasbreakdown) *wasbreakdown = ks->wasbreakdown ? 1 : 0;
+  return EXPV_MI_OK;
+}
+int expv_mi_ks_set_m(expv_mi_ks_t ks, int m) {
+  return guarded(ks->ctx, [&] {
+    if (m < 0 || m > ks->maxiter) fail(EXPV_MI_ARGUMENT_ERROR, "Ks.m out of range");
+    ks->m = m;
+  });
+}
+int expv_mi_ks_H(expv_mi_ks_t ks, void **H, int *ldh, int *nrows, int *ncols) {
+  if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  if (H) *H = ks->H.data();
+  if (ldh) *ldh = ks->ldh;
+  if (nrows) *nrows = ks->maxiter + 1;
+  if (ncols) *ncols = ks->hcols;
+  return EXPV_MI_OK;
+}
+int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64_t ld_dst) {
+  return guarded(ks->ctx, [&] {
+    ks->ctx->use();
+    if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    const size_t esz = dtype_size(ks->dtypeT);
+    copy_out_2d(ks->ctx, dst, EXPV_MI_HOST, ld_dst, ks->V.as<char>() + (size_t)col0 * ks->ldv * esz, ks->ldv,
+                ks->rows(), ncols, esz);
+  });
+}
+int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, int64_t ld_src) {
+  return guarded(ks->ctx, [&] {
+    ks->ctx->use();
+    if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    const size_t esz = dtype_size(ks->dtypeT);
+    if (ncols > 0 && ks->rows() > 0)
+      HIPCHECK(hipMemcpy2DAsync(ks->V.as<char>() + (size_t)col0 * ks->ldv * esz, ks->ldv * esz, src, ld_src * esz,
+                                ks->rows() * esz, ncols, hipMemcpyHostToDevice, ks->ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ks->ctx->stream));
+    ks->gram_rows = std::min(ks->gram_rows, col0);   // Gram rows of overwritten vectors are stale
+  });
+}
+int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv) {
+  if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  if (V) *V = ks->V.p;
+  if (ldv) *ldv = ks->ldv;
+  return EXPV_MI_OK;
+}
+
+void expv_mi_arnoldi_opts_default(expv_mi_arnoldi_opts *o) {
+  o->m = 0;
+  o->iop = 0;
+  o->init = 0;
+  o->ishermitian = -1;
+  o->ortho = EXPV_MI_ORTHO_AUTO;
+  o->reserved = 0;
+  o->tol = 1.0e-7;
+}
+
+int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, const expv_mi_arnoldi_opts *opts) {
+  return guarded(ks->ctx, [&] {
+    expv_mi_arnoldi_opts o;
+    if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+    DevBuf tmp;
+    const void *bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
+    arnoldi_run(*ks, *op, bd, o, nullptr, false);
+  });
+}
+int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, const expv_mi_arnoldi_opts *opts) {
+  return guarded(ks->ctx, [&] {
+    expv_mi_arnoldi_opts o;
+    if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+    DevBuf tmp;
+    const void *bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
+    arnoldi_run(*ks, *op, bd, o, nullptr, true);
+  });
+}
+int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t ldb, int p, int b_loc, const void *w,
+                        int w_loc, double *w_aug_host, double t, double mu, const expv_mi_arnoldi_opts *opts) {
+  return guarded(ks->ctx, [&] {
+    expv_mi_arnoldi_opts o;
+    if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+    const size_t esz = dtype_size(ks->dtypeT);
+    DevBuf bt, wt;
+    int64_t ldbd = ldb;
+    ArnoldiAug aug;
+    aug.B = stage_in_2d(ks->ctx, B, b_loc, ks->n, p, ldb, esz, bt, &ldbd);
+    aug.ldb = ldbd;
+    aug.p = p;
+    aug.w = stage_in(ks->ctx, w, w_loc, (size_t)ks->n * esz, wt);
+    aug.w_aug_host = w_aug_host;
+    aug.t = t;
+    aug.mu = mu;
+    arnoldi_run(*ks, *op, nullptr, o, &aug, false);
+  });
+}
+
+// ------------------------------------------------------------------ evaluation --------------
+int expv_mi_expv_ks(expv_mi_ks_t ks, double t_re, double t_im, void *w, int w_loc, int w_dtype) {
+  return guarded(ks->ctx, [&] { expv_eval(*ks, t_re, t_im, w, w_loc, w_dtype); });
+}
+int expv_mi_phiv_ks(expv_mi_ks_t ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc,
+                    int w_dtype, double *errest) {
+  return guarded(ks->ctx, [&] {
+    if (ldw < ks->n) fail(EXPV_MI_ASSERTION, "Dimension mismatch: size(w,1) == size(V,1)");
+    phiv_eval(*ks, t_re, t_im, k, correct, W, ldw, w_loc, w_dtype, errest);
+  });
+}
+int expv_mi_combine(expv_mi_ks_t ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype,
+                    double beta_scale, void *W, int64_t ldw, int w_loc, int w_dtype) {
+  return guarded(ks->ctx, [&] {
+    combine_host_coef(*ks, mcols, ncols, coef_host, ldc, coef_dtype, beta_scale, W, ldw, w_loc, w_dtype);
+  });
+}
+
+int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, const void *b, int b_loc, void *w,
+                 int w_loc, int w_dtype, const expv_mi_arnoldi_opts *opts, expv_mi_expv_stats *stats) {
+  return guarded(ctx, [&] {
+    expv_mi_arnoldi_opts o;
+    if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+    const int m = o.m > 0 ? o.m : (int)std::min<int64_t>(30, op->n);   // arnoldi(A, b; m = min(30, size(A,1)))
+    o.m = m;
+    int herm = o.ishermitian < 0 ? op->ishermitian : o.ishermitian;
+    expv_mi_ks_s ks;
+    ks_alloc(ks, ctx, op->dtype, herm ? EXPV_MI_F64 : op->dtype, op->n, m, 0);
+    DevBuf tmp;
+    const void *bd = stage_in(ctx, b, b_loc, (size_t)op->n * dtype_size(op->dtype), tmp);
+    const int mv = arnoldi_run(ks, *op, bd, o, nullptr, false);
+    expv_eval(ks, t_re, t_im, w, w_loc, w_dtype);
+    if (stats) {
+      stats->m_used = ks.m;
+      stats->wasbreakdown = ks.wasbreakdown;
+      stats->matvecs = mv;
+      stats->beta = ks.beta;
+      stats->reserved = 0;
+    }
+  });
+}
+
+int expv_mi_expv_error_estimate(expv_mi_ks_t ks, expv_mi_op_t op, double t_re, double t_im, const void *b, int b_loc,
+                                void *w, int w_loc, double atol, double rtol, int m, int ishermitian) {
+  return guarded(ks->ctx, [&] { expv_error_estimate_run(*ks, *op, t_re, t_im, b, b_loc, w, w_loc, atol, rtol, m, ishermitian); });
+}
+
+// ------------------------------------------------------------------ time stepping -----------
+void expv_mi_timestep_opts_default(expv_mi_timestep_opts *o) {
+  std::memset(o, 0, sizeof(*o));
+  o->tau = 0.0;
+  o->tol = 1.0e-7;
+  o->delta = 1.2;
+  o->gamma = 0.8;
+  o->ishermitian = -1;
+  o->ortho = EXPV_MI_ORTHO_AUTO;
+}
+int expv_mi_timestep_caches_create(expv_mi_ctx_t ctx, int dtype, int64_t n, int maxiter, int p, expv_mi_tscache_t *out) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    std::unique_ptr<expv_mi_tscache_s> c(new expv_mi_tscache_s());
+    const size_t esz = dtype_size(dtype);
+    c->ctx = ctx;
+    c->dtype = dtype;
+    c->n = n;
+    c->maxiter = maxiter;
+    c->p = p;
+    c->u.alloc(esz * std::max<int64_t>(n, 1));
+    c->W.alloc(esz * std::max<int64_t>(n, 1) * (p + 1));
+    c->P.alloc(esz * std::max<int64_t>(n, 1) * (p + 2));
+    c->ks = new expv_mi_ks_s();
+    ks_alloc(*c->ks, ctx, dtype, dtype, n, maxiter, 0);
+    *out = c.release();
+  });
+}
+int expv_mi_timestep_caches_destroy(expv_mi_tscache_t c) {
+  if (c) {
+    (void)hipSetDevice(c->ctx->device);
+    delete c->ks;
+    delete c;
+  }
+  return EXPV_MI_OK;
+}
+int expv_mi_phiv_timestep(expv_mi_ctx_t ctx, expv_mi_op_t op, int nts, double *ts, const void *B, int64_t ldb, int ncoef,
+                          int b_loc, void *U, int64_t ldu, int u_loc, const expv_mi_timestep_opts *opts,
+                          expv_mi_tscache_t caches, expv_mi_timestep_stats *stats) {
+  return guarded(ctx, [&] {
+    expv_mi_timestep_opts o;
+    if (opts) o = *opts; else expv_mi_timestep_opts_default(&o);
+    phiv_timestep_run(ctx, *op, nts, ts, B, ldb, ncoef, b_loc, U, ldu, u_loc, o, caches, stats);
+  });
+}
+
+void expv_mi_kiops_opts_default(expv_mi_kiops_opts *o) {
+  std::memset(o, 0, sizeof(*o));
+  o->mmin = 10;
+  o->mmax = 128;
+  o->m = 0;
+  o->iop = 2;
+  o->ishermitian = -1;
+  o->task1 = 0;
+  o->ortho = EXPV_MI_ORTHO_AUTO;
+  o->tol = 1.0e-7;
+}
+int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int ntau, int tau_ncols, const void *u,
+                  int64_t ldu, int ncols_u, int u_loc, void *w, int64_t ldw, int w_loc, const expv_mi_kiops_opts *opts,
+                  int64_t stats[5]) {
+  return guarded(ctx, [&] {
+    expv_mi_kiops_opts o;
+    if (opts) o = *opts; else expv_mi_kiops_opts_default(&o);
+    int64_t st[5];
+    kiops_run(ctx, *op, tau_out, ntau, tau_ncols, u, ldu, ncols_u, u_loc, w, ldw, w_loc, o, st);
+    if (stats) std::copy(st, st + 5, stats);
+  });
+}
+
+// ------------------------------------------------------------------ host diagnostics --------
+// exponential!(A, ExpMethodHigham2005Base()) on a host matrix, in place (exp_baseexp.jl:112-161)
+int expv_mi_host_expm(int dtype, int n, void *A, int lda) {
+  return guarded(nullptr, [&] {
+    if (dtype == EXPV_MI_C64) {
+      Mat<cd> M(n, n);
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) M(i, j) = reinterpret_cast<cd *>(A)[(size_t)j * lda + i];
+      dense::expm_higham2005base(M);
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) reinterpret_cast<cd *>(A)[(size_t)j * lda + i] = M(i, j);
+    } else {
+      Mat<double> M(n, n);
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) M(i, j) = reinterpret_cast<double *>(A)[(size_t)j * lda + i];
+      dense::expm_higham2005base(M);
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) reinterpret_cast<double *>(A)[(size_t)j * lda + i] = M(i, j);
+    }
+  });
+}
+// expHe = Z*(exp.(t*lambda).*Z[1,:]) for SymTridiagonal(d, e)  (krylov_phiv.jl:227-228); out is complex
+int expv_mi_host_symtridiag_expcol(int n, const double *d, const double *e, double t_re, double t_im, double *out_c64) {
+  return guarded(nullptr, [&] {
+    std::vector<double> dv(d, d + n), ev(e, e + (n > 1 ? n - 1 : 0));
+    std::vector<cd> r = dense::symtridiag_expcol<cd>(dv, ev, cd(t_re, t_im));
+    for (int i = 0; i < n; ++i) { out_c64[2 * i] = r[i].real(); out_c64[2 * i + 1] = r[i].imag(); }
+  });
+}
+// phiv_dense!(w, A, v, k)  (phi.jl:84-115); w is m x (k+1), ldw = m
+int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, const void *v, void *w) {
+  return guarded(nullptr, [&] {
+    if (dtype == EXPV_MI_C64) {
+      Mat<cd> M(m, m);
+      std::vector<cd> vv(m);
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) M(i, j) = reinterpret_cast<const cd *>(A)[(size_t)j * lda + i];
+      for (int i = 0; i < m; ++i) vv[i] = reinterpret_cast<const cd *>(v)[i];
+      Mat<cd> R = dense::phiv_dense(M, vv, k);
+      std::copy(R.a.begin(), R.a.end(), reinterpret_cast<cd *>(w));
+    } else {
+      Mat<double> M(m, m);
+      std::vector<double> vv(m);
+      for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) M(i, j) = reinterpret_cast<const double *>(A)[(size_t)j * lda + i];
+      for (int i = 0; i < m; ++i) vv[i] = reinterpret_cast<const double *>(v)[i];
+      Mat<double> R = dense::phiv_dense(M, vv, k);
+      std::copy(R.a.begin(), R.a.end(), reinterpret_cast<double *>(w));
+    }
+  });
+}
+
+int expv_mi_expv_batch(expv_mi_ctx_t ctx, int, int64_t, int, const int32_t *, const int32_t *, const void *, int64_t, int,
+                       const double *, const void *, int64_t, int, void *, int64_t, int, const expv_mi_arnoldi_opts *,
+                       int32_t *) {
+  return guarded(ctx, [&] { fail(EXPV_MI_UNSUPPORTED, "expv_batch: not built yet"); });
+}
+
+}  // extern "C"

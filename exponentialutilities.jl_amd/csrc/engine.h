@@ -1,0 +1,222 @@
+// engine.h -- internal C++ objects behind the opaque handles of include/expv_mi.h
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/expv_mi.h"
+#include "device_types.h"
+#include "host_dense.h"
+#include "kernels.h"
+
+namespace expv_mi {
+
+struct Err {
+  int code;
+  std::string msg;
+};
+[[noreturn]] inline void fail(int code, const std::string &m) { throw Err{code, m}; }
+
+#define HIPCHECK(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e__ = (expr);                                                                             \
+    if (e__ != hipSuccess)                                                                               \
+      ::expv_mi::fail(e__ == hipErrorOutOfMemory ? EXPV_MI_OUT_OF_MEMORY : EXPV_MI_HIP_ERROR,            \
+                      std::string(#expr) + ": " + hipGetErrorString(e__));                               \
+  } while (0)
+
+inline size_t dtype_size(int dt) { return dt == EXPV_MI_C64 ? 16 : 8; }
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int64_t launches = 0;
+  double total_ms = 0.0;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  std::string last_error;
+  bool prof_on = false;
+  ProfSlot prof[EXPV_MI_K_COUNT];
+  void use() const { HIPCHECK(hipSetDevice(device)); }
+};
+}  // namespace expv_mi
+struct expv_mi_ctx_s : expv_mi::Ctx {};
+namespace expv_mi {
+
+// RAII device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  explicit DevBuf(size_t b) { alloc(b); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  void alloc(size_t b) {
+    release();
+    bytes = b;
+    if (b) HIPCHECK(hipMalloc(&p, b));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  ~DevBuf() { release(); }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfScope {  // brackets one launch with events when profiling is on
+  Ctx *c;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(Ctx *c_, int id_) : c(c_), id(id_) {
+    if (c->prof_on) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (a) {
+      (void)hipEventRecord(b, c->stream);
+      c->prof[id].ev.emplace_back(a, b);
+    }
+    if (c->prof_on) c->prof[id].launches++;
+  }
+};
+
+enum OpKind { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2 };
+
+struct Op {
+  Ctx *ctx = nullptr;
+  int kind = OP_CSR, dtype = EXPV_MI_F64;
+  int64_t n = 0, nnz = 0;
+  int ishermitian = 0;
+  double opnorm_inf = 0.0;
+  DevBuf rowptr, col, val;   // CSR32
+  DevBuf dense;              // owned copy when created from host
+  const void *dense_ptr = nullptr;
+  int64_t lda = 0;
+  DevBuf gemv_scratch;
+  int gemv_split = 1;
+  expv_mi_matvec_fn fn = nullptr;
+  void *user = nullptr;
+};
+}  // namespace expv_mi
+struct expv_mi_op_s : expv_mi::Op {};
+namespace expv_mi {
+
+struct Ks {
+  Ctx *ctx = nullptr;
+  int dtypeT = EXPV_MI_F64, dtypeU = EXPV_MI_F64;
+  int64_t n = 0;       // operator size (rows of V minus augmented)
+  int maxiter = 30, augmented = 0;
+  int m = 30;
+  double beta = 0.0;
+  bool wasbreakdown = false;
+  int64_t ldv = 0;     // padded leading dimension of V (elements)
+  DevBuf V;            // (n+augmented) x (maxiter+1), dtype T
+  std::vector<char> H; // host, dtype U, (maxiter+1) x (maxiter + (augmented!=0))
+  int ldh = 0, hcols = 0;
+  DevBuf Hdev;         // device working copy, dtype T, (maxiter+2) x (maxiter+1)
+  int ldhd = 0;
+  DevBuf gram;         // LOWSYNC Gram rows, dtype T, (maxiter+1)^2
+  int ldg = 0;
+  int gram_rows = 0;   // leading basis vectors whose Gram rows are valid
+  DevBuf hcoef, part, state;
+  int64_t rows() const { return n + augmented; }
+};
+}  // namespace expv_mi
+struct expv_mi_ks_s : expv_mi::Ks {};
+namespace expv_mi {
+
+struct TsCache {
+  Ctx *ctx = nullptr;
+  int dtype = EXPV_MI_F64;
+  int64_t n = 0;
+  int maxiter = 0, p = 0;
+  DevBuf u, W, P;
+  expv_mi_ks_s *ks = nullptr;
+};
+}  // namespace expv_mi
+struct expv_mi_tscache_s : expv_mi::TsCache {};
+namespace expv_mi {
+
+// host H accessors (U-typed storage)
+inline dense::cd getH(const Ks &ks, int i, int j) {
+  if (ks.dtypeU == EXPV_MI_C64) {
+    const double *p = reinterpret_cast<const double *>(ks.H.data()) + 2 * ((size_t)j * ks.ldh + i);
+    return dense::cd(p[0], p[1]);
+  }
+  return dense::cd(reinterpret_cast<const double *>(ks.H.data())[(size_t)j * ks.ldh + i], 0.0);
+}
+inline void setH(Ks &ks, int i, int j, dense::cd v) {
+  if (ks.dtypeU == EXPV_MI_C64) {
+    double *p = reinterpret_cast<double *>(ks.H.data()) + 2 * ((size_t)j * ks.ldh + i);
+    p[0] = v.real();
+    p[1] = v.imag();
+  } else {
+    reinterpret_cast<double *>(ks.H.data())[(size_t)j * ks.ldh + i] = v.real();
+  }
+}
+inline void setH_realpart(Ks &ks, int i, int j, double v) {  // realview(...) write, arnoldi.jl:418-421
+  if (ks.dtypeU == EXPV_MI_C64) reinterpret_cast<double *>(ks.H.data())[2 * ((size_t)j * ks.ldh + i)] = v;
+  else reinterpret_cast<double *>(ks.H.data())[(size_t)j * ks.ldh + i] = v;
+}
+
+
+// ---- engine_core.hip -----------------------------------------------------------------------
+void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int augmented);
+void ks_resize(Ks &ks, int maxiter);
+void op_apply_dev(Op &op, const void *x_dev, void *y_dev, const StepState *st, int step, bool count = true);
+
+struct ArnoldiAug {  // augmented operator pieces (kiops)
+  const void *B = nullptr;  // device, n x p, dtype T
+  int64_t ldb = 0;
+  int p = 0;
+  const void *w = nullptr;  // device n-vector, dtype T
+  double *w_aug_host = nullptr;
+  double t = 0, mu = 0;
+};
+// returns the number of operator applications performed
+int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug,
+                bool force_lanczos);
+
+void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype);
+void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
+               double *errest);
+void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
+                       void *W, int64_t ldw, int w_loc, int w_dtype);
+
+// stage a caller buffer (host or device) as a device pointer; `tmp` owns the copy when one is made
+const void *stage_in(Ctx *ctx, const void *p, int loc, size_t bytes, DevBuf &tmp);
+// 2-D (column-major, ld in elements) variant producing a packed device matrix with ld = rows
+const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t cols, int64_t ld, size_t esz,
+                        DevBuf &tmp, int64_t *ld_out);
+void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_dev, int64_t ld_src, int64_t rows,
+                 int64_t cols, size_t esz);
+
+// ---- engine_drivers.hip --------------------------------------------------------------------
+void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int64_t ldb, int ncoef, int b_loc,
+                       void *U, int64_t ldu, int u_loc, const expv_mi_timestep_opts &o, TsCache *cache,
+                       expv_mi_timestep_stats *stats);
+void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols, const void *u, int64_t ldu,
+               int ncols_u, int u_loc, void *w, int64_t ldw, int w_loc, const expv_mi_kiops_opts &o, int64_t stats[5]);
+void expv_error_estimate_run(Ks &ks, Op &op, double t_re, double t_im, const void *b, int b_loc, void *w, int w_loc,
+                             double atol, double rtol, int m, int ishermitian);
+
+}  // namespace expv_mi

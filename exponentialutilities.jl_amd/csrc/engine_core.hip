@@ -1,0 +1,608 @@
+// engine_core.hip -- host drivers of the Krylov basis construction and evaluation.
+//
+//   arnoldi_run   = arnoldi! / lanczos!      /root/reference/src/arnoldi.jl:345-377, :456-490
+//   expv_eval     = expv!(w, t, Ks)          /root/reference/src/krylov_phiv.jl:200-280
+//   phiv_eval     = _phiv!(w, t, Ks, k, ..)  /root/reference/src/krylov_phiv.jl:620-653
+//
+// The whole Arnoldi loop is enqueued without a host round trip: projection coefficients, the
+// Hessenberg column and the happy-breakdown flag are produced on the device by the last workgroup
+// of each reduction kernel (kernels.hip); the host reads H and the flag once, after the loop.
+#include "engine.h"
+
+namespace expv_mi {
+
+using dense::cd;
+using dense::Mat;
+
+static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------
+// staging helpers
+// ------------------------------------------------------------------------------------------
+const void *stage_in(Ctx *ctx, const void *p, int loc, size_t bytes, DevBuf &tmp) {
+  if (loc == EXPV_MI_DEVICE || bytes == 0) return p;
+  tmp.alloc(bytes);
+  HIPCHECK(hipMemcpyAsync(tmp.p, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return tmp.p;
+}
+
+const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t cols, int64_t ld, size_t esz,
+                        DevBuf &tmp, int64_t *ld_out) {
+  if (loc == EXPV_MI_DEVICE) {
+    *ld_out = ld;
+    return p;
+  }
+  tmp.alloc((size_t)rows * cols * esz);
+  if (rows > 0 && cols > 0) {
+    HIPCHECK(hipMemcpy2DAsync(tmp.p, rows * esz, p, ld * esz, rows * esz, cols, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+  }
+  *ld_out = rows;
+  return tmp.p;
+}
+
+void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_dev, int64_t ld_src, int64_t rows,
+                 int64_t cols, size_t esz) {
+  if (rows <= 0 || cols <= 0) return;
+  const hipMemcpyKind kind = (loc == EXPV_MI_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIPCHECK(hipMemcpy2DAsync(dst, ld_dst * esz, src_dev, ld_src * esz, rows * esz, cols, kind, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// KrylovSubspace storage                                              arnoldi.jl:63-93
+// ------------------------------------------------------------------------------------------
+static void ks_alloc_aux(Ks &ks) {
+  const size_t esz = dtype_size(ks.dtypeT);
+  ks.ldhd = ks.maxiter + 2;
+  ks.Hdev.alloc((size_t)ks.ldhd * (ks.maxiter + 1) * esz);
+  HIPCHECK(hipMemsetAsync(ks.Hdev.p, 0, ks.Hdev.bytes, ks.ctx->stream));
+  ks.ldg = ks.maxiter + 1;
+  ks.gram.alloc((size_t)ks.ldg * ks.ldg * esz);
+  HIPCHECK(hipMemsetAsync(ks.gram.p, 0, ks.gram.bytes, ks.ctx->stream));
+  ks.hcoef.alloc((size_t)(ks.maxiter + 2) * esz);
+  if (!ks.part.p) ks.part.alloc((size_t)4 * dev::LOWSYNC_MAX * dev::MAX_GRID * sizeof(double));
+  if (!ks.state.p) {
+    ks.state.alloc(sizeof(StepState));
+    HIPCHECK(hipMemsetAsync(ks.state.p, 0, sizeof(StepState), ks.ctx->stream));
+  }
+}
+
+void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int augmented) {
+  if (n < 0 || maxiter < 1 || augmented < 0) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: bad n/maxiter/augmented");
+  if (dtT == EXPV_MI_F64 && dtU == EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: U complex with T real");
+  ctx->use();
+  ks.ctx = ctx;
+  ks.dtypeT = dtT;
+  ks.dtypeU = dtU;
+  ks.n = n;
+  ks.maxiter = ks.m = maxiter;
+  ks.augmented = augmented;
+  ks.beta = 0.0;
+  ks.wasbreakdown = false;
+  ks.ldv = round_up(ks.rows() > 0 ? ks.rows() : 1, 32);
+  const size_t esz = dtype_size(dtT);
+  ks.V.alloc((size_t)ks.ldv * (maxiter + 1) * esz);
+  HIPCHECK(hipMemsetAsync(ks.V.p, 0, ks.V.bytes, ctx->stream));  // padding rows must stay zero
+  ks.ldh = maxiter + 1;
+  ks.hcols = maxiter + (augmented != 0 ? 1 : 0);
+  ks.H.assign((size_t)ks.ldh * ks.hcols * dtype_size(dtU), 0);
+  ks.gram_rows = 0;
+  ks_alloc_aux(ks);
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+}
+
+void ks_resize(Ks &ks, int maxiter) {  // arnoldi.jl:80-93
+  ks.ctx->use();
+  const bool isaug = ks.augmented != 0;
+  const size_t esz = dtype_size(ks.dtypeT), usz = dtype_size(ks.dtypeU);
+  DevBuf Vn((size_t)ks.ldv * (maxiter + 1) * esz);
+  HIPCHECK(hipMemsetAsync(Vn.p, 0, Vn.bytes, ks.ctx->stream));
+  const int ldh_n = maxiter + 1, hcols_n = maxiter + (isaug ? 1 : 0);
+  std::vector<char> Hn((size_t)ldh_n * hcols_n * usz, 0);
+  DevBuf gram_old = std::move(ks.gram);
+  const int ldg_old = ks.ldg, mi_old = ks.maxiter;
+  if (isaug) {
+    const int ccopy = std::min(ks.maxiter + 1, maxiter + 1);
+    HIPCHECK(hipMemcpyAsync(Vn.p, ks.V.p, (size_t)ks.ldv * ccopy * esz, hipMemcpyDeviceToDevice, ks.ctx->stream));
+    const int rc = std::min(ks.ldh, ldh_n), cc = std::min(ks.hcols, hcols_n);
+    for (int j = 0; j < cc; ++j)
+      std::memcpy(&Hn[(size_t)j * ldh_n * usz], &ks.H[(size_t)j * ks.ldh * usz], (size_t)rc * usz);
+  }
+  HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
+  ks.V = std::move(Vn);
+  ks.H.swap(Hn);
+  ks.ldh = ldh_n;
+  ks.hcols = hcols_n;
+  ks.m = ks.maxiter = maxiter;
+  ks_alloc_aux(ks);
+  if (isaug) {
+    const int q = std::min(mi_old + 1, maxiter + 1);
+    HIPCHECK(hipMemcpy2DAsync(ks.gram.p, (size_t)ks.ldg * esz, gram_old.p, (size_t)ldg_old * esz, (size_t)q * esz, q,
+                              hipMemcpyDeviceToDevice, ks.ctx->stream));
+  } else {
+    ks.gram_rows = 0;
+  }
+  HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// operator application (mul!)                                          arnoldi.jl:185
+// ------------------------------------------------------------------------------------------
+template <class T>
+static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) {
+  Ctx *c = op.ctx;
+  ProfScope ps(c, EXPV_MI_K_MATVEC);
+  switch (op.kind) {
+    case OP_CSR:
+      dev::spmv_csr<T>(c->stream, op.n, op.rowptr.as<int32_t>(), op.col.as<int32_t>(), op.val.as<T>(), x, y, st, step);
+      break;
+    case OP_DENSE:
+      dev::gemv_dense<T>(c->stream, op.n, reinterpret_cast<const T *>(op.dense_ptr), op.lda, x, y,
+                         op.gemv_scratch.as<T>(), op.gemv_split, st, step);
+      break;
+    case OP_CALLBACK: {
+      const int rc = op.fn(op.user, x, y, (void *)c->stream);
+      if (rc != 0) fail(EXPV_MI_ARGUMENT_ERROR, "matrix-free operator callback returned an error");
+    } break;
+  }
+}
+void op_apply_dev(Op &op, const void *x, void *y, const StepState *st, int step, bool) {
+  if (op.dtype == EXPV_MI_C64) op_apply_T<cplx>(op, (const cplx *)x, (cplx *)y, st, step);
+  else op_apply_T<double>(op, (const double *)x, (double *)y, st, step);
+}
+
+// ------------------------------------------------------------------------------------------
+// arnoldi! / lanczos!
+// ------------------------------------------------------------------------------------------
+template <class T>
+static void read_state(Ks &ks, StepState *out) {
+  HIPCHECK(hipMemcpyAsync(out, ks.state.p, sizeof(StepState), hipMemcpyDeviceToHost, ks.ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
+}
+
+template <class T>
+static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos) {
+  Ctx *c = ks.ctx;
+  c->use();
+  hipStream_t s = c->stream;
+  const bool isaug = aug != nullptr;
+  int m = o.m > 0 ? o.m : (int)std::min<int64_t>(ks.maxiter, op.n);
+  const double tol = o.tol;
+  int init = o.init;
+  ks.wasbreakdown = false;
+  if (m > ks.maxiter) ks_resize(ks, m);
+  else ks.m = m;
+  // checkdims (arnoldi.jl:207-220)
+  const int p = isaug ? aug->p : 0;
+  if (op.n != ks.n || p != ks.augmented)
+    fail(EXPV_MI_DIMENSION_MISMATCH, "length(b') == size(A,1) == size(A,2) == size(V,1)-p doesn't hold");
+  if (op.dtype != ks.dtypeT) fail(EXPV_MI_ARGUMENT_ERROR, "operator dtype must equal the subspace dtype T");
+  const int64_t rows = ks.rows();
+  T *V = ks.V.as<T>();
+  StepState *st = ks.state.as<StepState>();
+  const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
+  const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
+
+  if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
+    for (int j = 0; j < hview_cols; ++j)
+      std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
+    StepState z;
+    std::memset(&z, 0, sizeof(z));
+    HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+    double extra = 0.0;
+    const T *src = b;
+    if (isaug) {
+      for (int k = 1; k <= p; ++k) {
+        if (k == p) aug->w_aug_host[k - 1] = aug->mu;
+        else {
+          const int i = p - k;
+          double f = 1.0;
+          for (int q = 2; q <= i; ++q) f *= q;
+          aug->w_aug_host[k - 1] = std::pow(aug->t, i) / f * aug->mu;
+        }
+        extra += aug->w_aug_host[k - 1] * aug->w_aug_host[k - 1];
+      }
+      src = reinterpret_cast<const T *>(aug->w);
+    }
+    {
+      ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
+      dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), st);
+    }
+    StepState h;
+    read_state<T>(ks, &h);
+    ks.beta = std::sqrt(h.sumsq + extra);
+    ks.gram_rows = 0;
+    if (ks.beta != 0.0) {
+      ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
+      if (isaug) {
+        dev::scale_copy<T>(s, V, src, ks.n, ks.beta, 1);  // @. V[1:n,1] = bl / beta
+        std::vector<T> tail(p);
+        for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k] / ks.beta);
+        HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));
+      } else {
+        dev::scale_copy<T>(s, V, src, ks.n, 1.0 / ks.beta, 0);  // V[i,1] = b[i] * inv(beta)
+      }
+      ks.gram_rows = 1;
+    }
+    init = 1;
+  }
+  if (ks.beta == 0.0) return 0;
+  int iop = o.iop;
+  if (iop == 0) iop = m;
+  const int jstart = lanczos ? 1 : init;     // lanczos!: loop is always 1:m (arnoldi.jl:480)
+  if (jstart > m) return 0;
+
+  // reset the device step state; zero the columns of Hdev this call will fill
+  {
+    StepState z;
+    std::memset(&z, 0, sizeof(z));
+    z.m_done = jstart - 1;
+    HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
+                            sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
+  }
+  T *Hd = ks.Hdev.as<T>();
+  T *hcoef = ks.hcoef.as<T>();
+  double *part = ks.part.as<double>();
+  const int ortho = o.ortho;
+
+  for (int j = jstart; j <= m; ++j) {
+    const T *x = V + (size_t)(j - 1) * ks.ldv;
+    T *y = V + (size_t)j * ks.ldv;
+    op_apply_T<T>(op, x, y, st, j);
+    if (isaug) {
+      ProfScope ps(c, EXPV_MI_K_AUG);
+      dev::aug_apply<T>(s, ks.n, p, reinterpret_cast<const T *>(aug->B), aug->ldb, x, y, st, j);
+    }
+    if (lanczos) {  // lanczos_step!  (arnoldi.jl:388-403)
+      dev::DotsArgs<T> d{};
+      d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
+      d.c0 = j - 1; d.dir = 1; d.nd = 1;
+      d.part = part; d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = real_coeff;
+      d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
+      { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
+      dev::UpdateArgs<T> u{};
+      u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
+      u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
+      u.tol = tol; u.step = j;
+      { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
+    } else {  // arnoldi_step!  (arnoldi.jl:289-308)
+      const int i0 = std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      bool lowsync = (ortho != EXPV_MI_ORTHO_MGS) && nd >= 2 && nd <= dev::LOWSYNC_MAX;
+      if (lowsync && nd >= 3 && ks.gram_rows < j - 1) lowsync = false;  // Gram rows of older vectors missing
+      if (lowsync) {
+        dev::DotsArgs<T> d{};
+        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = x;
+        d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+        d.part = part; d.st = st; d.mode = dev::DOTS_LOWSYNC; d.real_coeff = real_coeff;
+        d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
+        d.hcoef = hcoef;
+        { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
+        dev::UpdateArgs<T> u{};
+        u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i0 - 1; u.dir = 1; u.nd = nd;
+        u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
+        u.tol = tol; u.step = j;
+        { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
+        if (ks.gram_rows >= j - 1) ks.gram_rows = std::max(ks.gram_rows, j);
+      } else {  // literal MGS: dot -> axpy per column, then the norm
+        for (int i = i0; i <= j; ++i) {
+          dev::DotsArgs<T> d{};
+          d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
+          d.c0 = i - 1; d.dir = 1; d.nd = 1;
+          d.part = part; d.st = st; d.mode = dev::DOTS_STRICT; d.real_coeff = real_coeff;
+          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
+          { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
+          dev::UpdateArgs<T> u{};
+          u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i - 1; u.dir = 1; u.nd = 1;
+          u.hcoef = hcoef; u.do_norm = (i == j) ? 1 : 0; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+          u.jcol = j - 1; u.tol = tol; u.step = j;
+          { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
+        }
+      }
+    }
+    { ProfScope ps(c, EXPV_MI_K_SCALE); dev::scale_by_state<T>(s, y, rows, st, j); }
+  }
+
+  // ---- one host synchronisation per factorisation: state + Hessenberg --------------------
+  StepState h;
+  std::vector<T> Hh((size_t)ks.ldhd * (m + 1));
+  HIPCHECK(hipMemcpyAsync(Hh.data(), Hd, sizeof(T) * Hh.size(), hipMemcpyDeviceToHost, s));
+  read_state<T>(ks, &h);
+  const int jlast = h.breakdown ? h.m_done : m;
+  auto toc = [](const T &v) -> cd {
+    if constexpr (ST<T>::is_complex) return cd(v.re, v.im);
+    else return cd(v, 0.0);
+  };
+  if (lanczos) {
+    for (int j = 1; j <= jlast; ++j) {
+      setH(ks, j - 1, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + (j - 1)]));            // u[j] = alpha
+      setH_realpart(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]).real());       // v[j] = beta
+    }
+    // copyto!(@diagview(H, 1), v[1:end-1]) on the pre-breakdown view  (arnoldi.jl:488)
+    const int nsub = std::min(hview_rows - 1, hview_cols);
+    for (int i = 1; i < nsub; ++i)
+      if (i < hview_cols) setH(ks, i - 1, i, cd(getH(ks, i, i - 1).real(), 0.0));
+  } else {
+    const int iopw = iop;
+    for (int j = jstart; j <= jlast; ++j) {
+      const int i0 = std::max(1, j - iopw + 1);
+      for (int i = i0; i <= j; ++i) setH(ks, i - 1, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + (i - 1)]));
+      setH(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]));
+    }
+  }
+  if (h.breakdown) {
+    ks.m = h.m_done;
+    ks.wasbreakdown = true;
+  }
+  return jlast - jstart + 1;
+}
+
+int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug,
+                bool force_lanczos) {
+  int herm = o.ishermitian;
+  if (herm < 0) herm = op.ishermitian;
+  const bool lanczos = force_lanczos || herm != 0;
+  if (ks.dtypeT == EXPV_MI_C64) return arnoldi_T<cplx>(ks, op, (const cplx *)b_dev, o, aug, lanczos);
+  return arnoldi_T<double>(ks, op, (const double *)b_dev, o, aug, lanczos);
+}
+
+// ------------------------------------------------------------------------------------------
+// combine: W = scale * V[:, 0:mcols] * C                       krylov_phiv.jl:229-244, :641
+// ------------------------------------------------------------------------------------------
+void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
+                       void *W, int64_t ldw, int w_loc, int w_dtype) {
+  Ctx *c = ks.ctx;
+  c->use();
+  if (mcols < 0 || mcols > ks.maxiter + 1) fail(EXPV_MI_ASSERTION, "combine: more columns than the basis holds");
+  const bool Tc = ks.dtypeT == EXPV_MI_C64;
+  const bool Cc = (coef_dtype == EXPV_MI_C64) || Tc || (w_dtype == EXPV_MI_C64);
+  if (Cc && w_dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "InexactError: complex result into a real output");
+  const int64_t rows = ks.n;   // outputs cover the operator rows only (V[1:n, :] for augmented subspaces)
+  const size_t wsz = dtype_size(w_dtype);
+  // coefficient matrix, packed, in the compute type
+  std::vector<double> cbuf((size_t)mcols * ncols * (Cc ? 2 : 1));
+  for (int q = 0; q < ncols; ++q)
+    for (int i = 0; i < mcols; ++i) {
+      double re, im = 0.0;
+      if (coef_dtype == EXPV_MI_C64) {
+        const double *p = reinterpret_cast<const double *>(coef_host) + 2 * ((size_t)q * ldc + i);
+        re = p[0];
+        im = p[1];
+      } else {
+        re = reinterpret_cast<const double *>(coef_host)[(size_t)q * ldc + i];
+      }
+      if (Cc) {
+        cbuf[2 * ((size_t)q * mcols + i)] = re;
+        cbuf[2 * ((size_t)q * mcols + i) + 1] = im;
+      } else {
+        cbuf[(size_t)q * mcols + i] = re;
+      }
+    }
+  DevBuf cdev(cbuf.size() * sizeof(double) + 16);
+  HIPCHECK(hipMemcpyAsync(cdev.p, cbuf.data(), cbuf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  DevBuf wtmp;
+  void *Wd = W;
+  int64_t ldwd = ldw;
+  if (w_loc == EXPV_MI_HOST) {
+    wtmp.alloc((size_t)rows * ncols * wsz + 16);
+    Wd = wtmp.p;
+    ldwd = rows;
+  }
+  {
+    ProfScope ps(c, EXPV_MI_K_COMBINE);
+    const int mc = std::max(mcols, 0);
+    if (!Cc)
+      dev::combine<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cdev.as<double>(), mcols, ncols,
+                                   scale, (double *)Wd, ldwd);
+    else if (!Tc)
+      dev::combine<double, cplx>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cdev.as<cplx>(), mcols, ncols, scale,
+                                 (cplx *)Wd, ldwd);
+    else
+      dev::combine<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cdev.as<cplx>(), mcols, ncols, scale,
+                               (cplx *)Wd, ldwd);
+  }
+  if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
+  else HIPCHECK(hipStreamSynchronize(c->stream));
+}
+
+static void zero_output(Ctx *c, void *W, int64_t ldw, int w_loc, int64_t rows, int ncols, size_t esz) {
+  for (int q = 0; q < ncols; ++q) {
+    char *col = reinterpret_cast<char *>(W) + (size_t)q * ldw * esz;
+    if (w_loc == EXPV_MI_HOST) std::memset(col, 0, (size_t)rows * esz);
+    else HIPCHECK(hipMemsetAsync(col, 0, (size_t)rows * esz, c->stream));
+  }
+  if (w_loc != EXPV_MI_HOST) HIPCHECK(hipStreamSynchronize(c->stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// expv!(w, t, Ks)                                                krylov_phiv.jl:200-280
+// ------------------------------------------------------------------------------------------
+void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype) {
+  const int m = ks.m;
+  const bool tc = (t_im != 0.0);
+  if ((tc || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
+    fail(EXPV_MI_ARGUMENT_ERROR, "expv!: w must be complex when t or the basis is complex");
+  if (ks.beta == 0.0) {  // zero input: V was never initialised; the result is exactly zero (:206-213)
+    zero_output(ks.ctx, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
+    return;
+  }
+  // Hcopy = H[1:m, :]  (:223)
+  Mat<cd> Hc(m, m);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) Hc(i, j) = getH(ks, i, j);
+  bool herm = true, offreal = true;
+  for (int j = 0; j < m && herm; ++j)
+    for (int i = 0; i < m; ++i)
+      if (Hc(i, j) != std::conj(Hc(j, i))) { herm = false; break; }
+  for (int i = 0; i + 1 < m; ++i)
+    if (Hc(i, i + 1).imag() != 0.0) offreal = false;
+  const cd t(t_re, t_im);
+  if (herm && offreal) {  // eigen!(SymTridiagonal(Hcopy)) path  (:225-229, :270-273)
+    std::vector<double> d(m), e(m > 1 ? m - 1 : 0);
+    for (int i = 0; i < m; ++i) d[i] = Hc(i, i).real();
+    for (int i = 0; i + 1 < m; ++i) e[i] = Hc(i, i + 1).real();
+    if (tc) {
+      std::vector<cd> coef = dense::symtridiag_expcol<cd>(d, e, t);
+      combine_host_coef(ks, m, 1, coef.data(), m, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, w_dtype);
+    } else {
+      std::vector<double> coef = dense::symtridiag_expcol<double>(d, e, t_re);
+      combine_host_coef(ks, m, 1, coef.data(), m, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);
+    }
+    return;
+  }
+  const bool cplx_small = tc || ks.dtypeU == EXPV_MI_C64;
+  if (cplx_small) {  // lmul!(t, Hcopy); exponential!(Hcopy, ExpMethodHigham2005Base())  (:231-232)
+    for (auto &v : Hc.a) v *= t;
+    dense::expm_higham2005base(Hc);
+    combine_host_coef(ks, m, 1, Hc.data(), m, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, w_dtype);
+  } else {
+    Mat<double> Hr(m, m);
+    for (size_t i = 0; i < Hr.a.size(); ++i) Hr.a[i] = Hc.a[i].real() * t_re;
+    dense::expm_higham2005base(Hr);
+    combine_host_coef(ks, m, 1, Hr.data(), m, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// _phiv!(w, t, Ks, k, cache, correct, expmethod)                 krylov_phiv.jl:620-653
+// ------------------------------------------------------------------------------------------
+void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
+               double *errest) {
+  const int m = ks.m;
+  const bool tc = (t_im != 0.0);
+  if (k < 1) fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: k >= 1 required");
+  if ((tc || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
+    fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: w must be complex when t or the basis is complex");
+  const cd t(t_re, t_im);
+  const int hend_r = m, hend_c = m - 1 + (ks.augmented != 0 ? 1 : 0);   // H[end, end] of getH(Ks)
+  const cd hend = getH(ks, hend_r, hend_c);
+  const bool cplx_small = tc || ks.dtypeU == EXPV_MI_C64;
+  const int mext = m + (correct ? 1 : 0);
+  double err = 0.0;
+  if (cplx_small) {
+    Mat<cd> Hc(m, m);
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) Hc(i, j) = getH(ks, i, j) * t;
+    std::vector<cd> e(m, cd(0));
+    if (m > 0) e[0] = cd(1);
+    Mat<cd> C2 = dense::phiv_dense(Hc, e, k);
+    Mat<cd> Ce(mext, k + 1);
+    for (int q = 0; q <= k; ++q)
+      for (int i = 0; i < m; ++i) Ce(i, q) = C2(i, q);
+    if (correct)
+      for (int i = 1; i <= k; ++i) Ce(m, i - 1) = hend * t * C2(m - 1, i);   // betah*C2[end,i+1] / beta
+    err = std::abs(ks.beta * hend * t * C2(m - 1, k));
+    combine_host_coef(ks, mext, k + 1, Ce.data(), mext, EXPV_MI_C64, ks.beta, W, ldw, w_loc, w_dtype);
+  } else {
+    Mat<double> Hr(m, m);
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) Hr(i, j) = getH(ks, i, j).real() * t_re;
+    std::vector<double> e(m, 0.0);
+    if (m > 0) e[0] = 1.0;
+    Mat<double> C2 = dense::phiv_dense(Hr, e, k);
+    Mat<double> Ce(mext, k + 1);
+    for (int q = 0; q <= k; ++q)
+      for (int i = 0; i < m; ++i) Ce(i, q) = C2(i, q);
+    if (correct)
+      for (int i = 1; i <= k; ++i) Ce(m, i - 1) = hend.real() * t_re * C2(m - 1, i);
+    err = std::fabs(ks.beta * hend.real() * t_re * C2(m - 1, k));
+    combine_host_coef(ks, mext, k + 1, Ce.data(), mext, EXPV_MI_F64, ks.beta, W, ldw, w_loc, w_dtype);
+  }
+  if (errest) *errest = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// expv!(w, t, A, b, Ks, cache; atol, rtol, m)  -- error-estimate mode, Hermitian only
+//                                               krylov_phiv_error_estimate.jl:149-207
+// The stopping test needs alpha_j, beta_j on the host every step (eigen of the j x j tridiagonal,
+// :58-68), so this mode synchronises once per Lanczos step by construction.
+// ------------------------------------------------------------------------------------------
+template <class T>
+static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_loc, double atol, double rtol, int m) {
+  Ctx *c = ks.ctx;
+  c->use();
+  hipStream_t s = c->stream;
+  if (m <= 0) m = (int)std::min<int64_t>(ks.maxiter, op.n);
+  if (m > ks.maxiter) ks_resize(ks, m);
+  else ks.m = m;
+  if (op.n != ks.n || ks.augmented != 0) fail(EXPV_MI_DIMENSION_MISMATCH, "expv!: operator / subspace size mismatch");
+  if (op.dtype != ks.dtypeT) fail(EXPV_MI_ARGUMENT_ERROR, "operator dtype must equal the subspace dtype T");
+  T *V = ks.V.as<T>();
+  StepState *st = ks.state.as<StepState>();
+  StepState z;
+  std::memset(&z, 0, sizeof(z));
+  HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+  dev::sumsq<T>(s, b, ks.n, ks.part.as<double>(), st);
+  StepState h;
+  read_state<T>(ks, &h);
+  ks.beta = std::sqrt(h.sumsq);
+  const int w_dtype = EXPV_MI_C64 * ((ks.dtypeT == EXPV_MI_C64) || t.imag() != 0.0);
+  if (ks.beta == 0.0) {
+    ks.m = 0;
+    zero_output(c, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
+    return;
+  }
+  dev::scale_copy<T>(s, V, b, ks.n, ks.beta, 1);   // @. V[:, 1] = b / Ks.beta
+  ks.gram_rows = 0;
+  const double eps_stop = atol + rtol * ks.beta;
+  HIPCHECK(hipMemsetAsync(ks.Hdev.p, 0, ks.Hdev.bytes, s));
+  T *Hd = ks.Hdev.as<T>();
+  std::vector<double> alpha, betas;
+  std::vector<cd> cv;
+  std::vector<T> colbuf(ks.ldhd);
+  for (int j = 1; j <= m; ++j) {
+    const T *x = V + (size_t)(j - 1) * ks.ldv;
+    T *y = V + (size_t)j * ks.ldv;
+    op_apply_T<T>(op, x, y, nullptr, j);
+    dev::DotsArgs<T> d{};
+    d.V = V; d.ldv = ks.ldv; d.n = ks.n; d.y = y; d.x = nullptr; d.c0 = j - 1; d.dir = 1; d.nd = 1;
+    d.part = ks.part.as<double>(); d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = 1;
+    d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.hcoef = ks.hcoef.as<T>();
+    dev::dots<T>(s, d);
+    dev::UpdateArgs<T> u{};
+    u.V = V; u.ldv = ks.ldv; u.n = ks.n; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
+    u.hcoef = ks.hcoef.as<T>(); u.do_norm = 1; u.part = ks.part.as<double>(); u.st = st; u.Hdev = Hd;
+    u.ldh = ks.ldhd; u.jcol = j - 1; u.tol = -1.0; u.step = j;
+    dev::update<T>(s, u);
+    dev::scale_by_state<T>(s, y, ks.n, st, j);
+    HIPCHECK(hipMemcpyAsync(colbuf.data(), Hd + (size_t)(j - 1) * ks.ldhd, sizeof(T) * (j + 1), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    double aj, bj;
+    if constexpr (ST<T>::is_complex) { aj = colbuf[j - 1].re; bj = colbuf[j].re; }
+    else { aj = colbuf[j - 1]; bj = colbuf[j]; }
+    setH(ks, j - 1, j - 1, cd(aj, 0));
+    setH(ks, j, j - 1, cd(bj, 0));
+    alpha.push_back(aj);
+    betas.push_back(bj);
+    std::vector<double> off(betas.begin(), betas.begin() + (j - 1));   // SymTridiagonal(alpha, beta) uses beta[1:j-1]
+    cv = dense::symtridiag_expcol<cd>(alpha, off, t);                  // expT!  (:58-68)
+    const double sigma = bj * ks.beta * std::abs(cv[j - 1]);           // Saad's Er2  (:197)
+    if (sigma < eps_stop) { ks.m = j; break; }
+  }
+  const int mm = ks.m;
+  if (t.imag() == 0.0 && ks.dtypeT == EXPV_MI_F64) {
+    std::vector<double> cr(mm);
+    for (int i = 0; i < mm; ++i) cr[i] = cv[i].real();
+    combine_host_coef(ks, mm, 1, cr.data(), mm, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, EXPV_MI_F64);
+  } else {
+    combine_host_coef(ks, mm, 1, cv.data(), mm, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, EXPV_MI_C64);
+  }
+}
+
+void expv_error_estimate_run(Ks &ks, Op &op, double t_re, double t_im, const void *b, int b_loc, void *w, int w_loc,
+                             double atol, double rtol, int m, int ishermitian) {
+  int herm = ishermitian < 0 ? op.ishermitian : ishermitian;
+  if (!herm) fail(EXPV_MI_UNSUPPORTED, "Error estimation not yet available for non-Hermitian matrices.");
+  if (ks.dtypeU != EXPV_MI_F64)
+    fail(EXPV_MI_UNSUPPORTED, "Subspace exponential caches not yet available for non-Hermitian matrices.");
+  DevBuf tmp;
+  const void *bd = stage_in(ks.ctx, b, b_loc, (size_t)ks.n * dtype_size(ks.dtypeT), tmp);
+  if (ks.dtypeT == EXPV_MI_C64) error_estimate_T<cplx>(ks, op, cd(t_re, t_im), (const cplx *)bd, w, w_loc, atol, rtol, m);
+  else error_estimate_T<double>(ks, op, cd(t_re, t_im), (const double *)bd, w, w_loc, atol, rtol, m);
+}
+
+}  // namespace expv_mi

@@ -1,0 +1,539 @@
+// engine_drivers.hip -- host controllers that drive the device Krylov steps.
+//
+//   phiv_timestep_run = phiv_timestep!(U, ts, A, B; ...)   /root/reference/src/krylov_phiv_adaptive.jl:260-453
+//                       _phiv_timestep_adapt                :455-481
+//                       _phiv_timestep_estimate_flops       :482-501
+//   kiops_run         = kiops(tau_out, A, u; ...)           /root/reference/src/kiops.jl:57-281
+//                       kiops_update_solution!              :283-326
+// All O(n) work (W recurrence, u update, snapshots, solution update) runs in HBM through the
+// lincomb / combine kernels; only scalars and the (m+p)^2 matrices live on the host.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+
+#include "engine.h"
+
+namespace expv_mi {
+
+using dense::cd;
+using dense::Mat;
+
+template <class T>
+static inline T t_from_real(double r) { return ST<T>::from_real(r); }
+
+// out = sum_k coef[k] * in[k], any number of terms (chained in groups of 8)
+template <class T>
+static void lincomb_n(Ctx *c, T *out, int64_t n, std::vector<const T *> in, std::vector<double> coef) {
+  size_t k0 = 0;
+  bool first = true;
+  while (k0 < in.size() || first) {
+    dev::LincombArgs<T> a{};
+    a.out = out;
+    a.n = n;
+    int nt = 0;
+    if (!first) {
+      a.in[nt] = out;
+      a.coef[nt] = t_from_real<T>(1.0);
+      ++nt;
+    }
+    while (nt < 8 && k0 < in.size()) {
+      a.in[nt] = in[k0];
+      a.coef[nt] = t_from_real<T>(coef[k0]);
+      ++nt;
+      ++k0;
+    }
+    a.nterms = nt;
+    {
+      ProfScope ps(c, EXPV_MI_K_LINCOMB);
+      dev::lincomb<T>(c->stream, a);
+    }
+    first = false;
+    if (k0 >= in.size()) break;
+  }
+}
+
+static void emit(const expv_mi_timestep_opts &o, const std::string &line) {
+  if (!o.verbose) return;
+  if (o.print) o.print(line.c_str(), o.print_user);
+  else std::printf("%s\n", line.c_str());
+}
+static std::string fmt(const char *f, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, f);
+  std::vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+// krylov_phiv_adaptive.jl:482-501
+static double estimate_flops(int m, double tau, int64_t n, int p, int64_t NA, int iop, double Hnorm, double maxtau) {
+  const double flops_W = 2.0 * (p - 1) * (double)(NA + n);
+  const double flops_u = (2.0 * p + 1) * (double)n;
+  if (iop == 0) iop = m;
+  const double flops_matvec = 2.0 * m * (double)NA;
+  double flops_vecvec = 0;
+  for (int i = 1; i <= m; ++i) flops_vecvec += 3 * std::min(i, iop);
+  const double MH = 44.0 / 3.0 + 2.0 * std::ceil(std::max(0.0, std::log2(Hnorm / 5.37)));
+  const double flops_phiv = std::nearbyint(MH * std::pow((double)(m + p), 3));
+  const double onestep = flops_W + flops_u + flops_matvec + flops_vecvec + flops_phiv;
+  return onestep * std::ceil(maxtau / tau);
+}
+
+// opnorm(getH(Ks), 1)  (:372, :408)
+static double hnorm1(const Ks &ks) {
+  const int r = ks.m + 1, cdim = ks.m + (ks.augmented != 0 ? 1 : 0);
+  double best = 0;
+  for (int j = 0; j < cdim; ++j) {
+    double s = 0;
+    for (int i = 0; i < r; ++i) s += std::abs(getH(ks, i, j));
+    best = std::max(best, s);
+  }
+  return best;
+}
+
+template <class T>
+static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, int64_t ldb, int ncoef, T *Udev,
+                            int64_t ldu, const expv_mi_timestep_opts &o, TsCache *cache, const double *b0_host,
+                            expv_mi_timestep_stats *stats) {
+  const int64_t n = op.n;
+  const int dt = op.dtype;
+  int m = o.m > 0 ? o.m : (int)std::min<int64_t>(10, n);
+  const double tol = o.tol, delta = o.delta, gamma = o.gamma;
+  int iop = o.iop;
+  double tau = o.tau;
+  const bool arnoldi_scale = !o.has_opnorm;
+  bool have_abstol = false;
+  double abstol = 0.0, opn = 0.0;
+  auto b0norm = [&]() {
+    double v = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      double a;
+      if constexpr (ST<T>::is_complex) a = std::hypot(b0_host[2 * i], b0_host[2 * i + 1]);
+      else a = std::fabs(b0_host[i]);
+      v = std::max(v, a);
+    }
+    return v;
+  };
+  const double E = 2.718281828459045, PI = 3.141592653589793;
+  if (!arnoldi_scale) {
+    opn = o.opnorm;
+    abstol = tol * opn;
+    have_abstol = true;
+    if (tau == 0.0) {
+      tau = 10.0 / opn * std::pow(abstol * std::pow((m + 1) / E, m + 1) * std::sqrt(2 * PI * (m + 1)) /
+                                      (4 * opn * b0norm()), 1.0 / m);
+      emit(o, fmt("Initial time step unspecified, chosen to be %.17g", tau));
+    }
+  }
+  if (have_abstol) emit(o, fmt("Absolute tolerance: %.17g", abstol));
+  std::sort(ts, ts + nts);                       // sort!(ts)  (:297)
+  const double tend = ts[nts - 1];
+  const bool seed_arnoldi_tau = arnoldi_scale && tau == 0.0;
+  if (seed_arnoldi_tau) tau = tend;
+  const int p = ncoef - 1;
+  // work arrays (:309-325)
+  DevBuf ubuf, Wbuf, Pbuf;
+  std::unique_ptr<expv_mi_ks_s> ks_own;
+  T *u, *W, *P;
+  Ks *ks;
+  if (cache) {
+    if (cache->n != n || cache->dtype != dt || cache->p < p) fail(EXPV_MI_ASSERTION, "Dimension mismatch (caches)");
+    u = cache->u.as<T>();
+    W = cache->W.as<T>();
+    P = cache->P.as<T>();
+    ks = cache->ks;
+  } else {
+    ubuf.alloc(sizeof(T) * n);
+    Wbuf.alloc(sizeof(T) * n * (p + 1));
+    Pbuf.alloc(sizeof(T) * n * (p + 2));
+    u = ubuf.as<T>();
+    W = Wbuf.as<T>();
+    P = Pbuf.as<T>();
+    ks_own.reset(new expv_mi_ks_s());
+    ks_alloc(*ks_own, ctx, dt, dt, n, m, 0);      // U = T even when Hermitian (:315)
+    ks = ks_own.get();
+  }
+  hipStream_t s = ctx->stream;
+  HIPCHECK(hipMemcpyAsync(u, B, sizeof(T) * n, hipMemcpyDeviceToDevice, s));   // u(0) = b0
+  std::vector<double> coeffs(std::max(p, 1), 1.0);
+  int64_t NA = o.NA;
+  int herm = o.ishermitian < 0 ? op.ishermitian : o.ishermitian;
+  if (o.adaptive) {
+    if (herm) iop = 2;
+    if (NA == 0) NA = op.nnz;
+  }
+  expv_mi_arnoldi_opts ao;
+  expv_mi_arnoldi_opts_default(&ao);
+  ao.tol = tol;
+  ao.ishermitian = -1;          // arnoldi! evaluates LinearAlgebra.ishermitian(A) itself (:364)
+  ao.ortho = o.ortho;
+  double t = 0.0;
+  int snapshot = 1, num_timesteps = 0, matvecs = 0, arn_calls = 0;
+  while (t < tend) {
+    if (t + tau > tend) tau = tend - t;
+    // Part 1: w0..wp by recurrence (16)  (:353-362)
+    HIPCHECK(hipMemcpyAsync(W, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+    for (int l = 1; l <= p - 1; ++l) coeffs[l] = coeffs[l - 1] * t / l;
+    for (int j = 1; j <= p; ++j) {
+      T *wj = W + (size_t)j * n;
+      op_apply_dev(op, W + (size_t)(j - 1) * n, wj, nullptr, 0);
+      ++matvecs;
+      std::vector<const T *> in{wj};
+      std::vector<double> cf{1.0};
+      for (int l = 0; l <= p - j; ++l) {
+        in.push_back(B + (size_t)(j + l) * ldb);
+        cf.push_back(coeffs[l]);
+      }
+      lincomb_n<T>(ctx, wj, n, in, cf);
+    }
+    // Part 2: phi_p(tau A) w_p by Krylov (:364-423)
+    ao.m = m;
+    ao.iop = iop;
+    ao.init = 0;
+    matvecs += arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);
+    ++arn_calls;
+    if (!have_abstol) {
+      opn = hnorm1(*ks);
+      abstol = tol * opn;
+      have_abstol = true;
+      if (seed_arnoldi_tau) {
+        tau = std::min(tend - t, gamma * 10.0 / opn *
+                                     std::pow(abstol * std::pow((m + 1) / E, m + 1) * std::sqrt(2 * PI * (m + 1)) /
+                                                  (4 * opn * b0norm()), 1.0 / m));
+      }
+      emit(o, fmt("Absolute tolerance (Arnoldi estimate): %.17g", abstol));
+    }
+    if (ks->wasbreakdown) tau = tend - t;
+    double epsilon = 0.0;
+    phiv_eval(*ks, tau, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &epsilon);
+    emit(o, fmt("t = %.17g, m = %d, tau = %.17g, error estimate = %.17g", t, m, tau, epsilon));
+    if (o.adaptive) {
+      double omega = (tend / tau) * (epsilon / abstol);
+      double epsilon_old = epsilon, tau_old = tau, q = m / 4.0, kappa = 2.0;
+      int m_old = m;
+      const double maxtau = tend - t;
+      while (omega > delta) {  // inner loop of Algorithm 3
+        // _phiv_timestep_adapt (:455-481)
+        if (tau_old > tau) q = std::log(tau / tau_old) / std::log(epsilon / epsilon_old) - 1;
+        double tau_new = tau * std::pow(gamma / omega, 1.0 / (q + 1));
+        tau_new = std::min(std::min(std::max(tau_new, tau / 5), 2 * tau), maxtau);
+        if (m_old < m) kappa = std::pow(epsilon / epsilon_old, 1.0 / (m_old - m));
+        int m_new = m + (int)std::ceil(std::log(omega / gamma) / std::log(kappa));
+        m_new = std::min(std::max(std::max(m_new, (3 * m) / 4), 1), (int)std::ceil(4.0 * m / 3.0));
+        emit(o, fmt("  - Proposed new m: %d, new tau: %.17g", m_new, tau_new));
+        const double Hn = hnorm1(*ks);
+        const double cost_tau = estimate_flops(m, tau_new, n, p, NA, iop, Hn, maxtau);
+        const double cost_m = estimate_flops(m_new, tau, n, p, NA, iop, Hn, maxtau);
+        emit(o, fmt("  - Cost to use new m: %.0f flops, new tau: %.0f flops", cost_m, cost_tau));
+        if (cost_tau < cost_m) m_new = m;
+        else tau_new = tau;
+        m_old = m;
+        m = m_new;
+        tau_old = tau;
+        tau = tau_new;
+        ao.m = m;
+        matvecs += arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);   // from scratch, like :417
+        ++arn_calls;
+        double epsilon_new = 0.0;
+        phiv_eval(*ks, tau, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &epsilon_new);
+        epsilon_old = epsilon;
+        epsilon = epsilon_new;
+        omega = (tend / tau) * (epsilon / abstol);
+        emit(o, fmt("  * m = %d, tau = %.17g, error estimate = %.17g", m, tau, epsilon));
+      }
+    }
+    // Part 3: u update (15)  (:425-431)
+    auto u_update = [&](T *dst, double tt) {
+      for (int l = 1; l <= p - 1; ++l) coeffs[l] = coeffs[l - 1] * tt / l;
+      std::vector<const T *> in{P + (size_t)p * n};
+      std::vector<double> cf{std::pow(tt, p)};
+      for (int j = 0; j <= p - 1; ++j) {
+        in.push_back(W + (size_t)j * n);
+        cf.push_back(coeffs[j]);
+      }
+      lincomb_n<T>(ctx, dst, n, in, cf);
+    };
+    u_update(u, tau);
+    while (snapshot <= nts && t + tau >= ts[snapshot - 1]) {   // snapshots (:433-445)
+      const double tau_snapshot = ts[snapshot - 1] - t;
+      double dummy;
+      phiv_eval(*ks, tau_snapshot, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &dummy);
+      u_update(Udev + (size_t)(snapshot - 1) * ldu, tau_snapshot);
+      ++snapshot;
+    }
+    t += tau;
+    ++num_timesteps;
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  emit(o, fmt("Completed after %d time step(s)", num_timesteps));
+  if (stats) {
+    stats->num_timesteps = num_timesteps;
+    stats->matvecs = matvecs;
+    stats->m_final = m;
+    stats->arnoldi_calls = arn_calls;
+  }
+}
+
+void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int64_t ldb, int ncoef, int b_loc, void *U,
+                       int64_t ldu, int u_loc, const expv_mi_timestep_opts &o, TsCache *cache,
+                       expv_mi_timestep_stats *stats) {
+  ctx->use();
+  const int64_t n = op.n;
+  if (nts < 1) fail(EXPV_MI_ASSERTION, "Dimension mismatch: length(ts) == size(U,2)");
+  if (ncoef < 1) fail(EXPV_MI_ASSERTION, "Dimension mismatch: B needs at least one column");
+  const size_t esz = dtype_size(op.dtype);
+  DevBuf btmp, utmp;
+  int64_t ldbd = ldb;
+  const void *Bd = stage_in_2d(ctx, B, b_loc, n, ncoef, ldb, esz, btmp, &ldbd);
+  // ||b0||_inf is needed on the host only when tau is seeded (:285, :375)
+  std::vector<double> b0((size_t)n * (esz / 8));
+  const bool need_b0 = (o.tau == 0.0);
+  if (need_b0 && n > 0) {
+    if (b_loc == EXPV_MI_HOST) std::memcpy(b0.data(), B, (size_t)n * esz);
+    else {
+      HIPCHECK(hipMemcpyAsync(b0.data(), B, (size_t)n * esz, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  void *Ud = U;
+  int64_t ldud = ldu;
+  if (u_loc == EXPV_MI_HOST) {
+    utmp.alloc((size_t)n * nts * esz + 16);
+    Ud = utmp.p;
+    ldud = n;
+  }
+  if (op.dtype == EXPV_MI_C64)
+    phiv_timestep_T<cplx>(ctx, op, nts, ts, (const cplx *)Bd, ldbd, ncoef, (cplx *)Ud, ldud, o, cache, b0.data(), stats);
+  else
+    phiv_timestep_T<double>(ctx, op, nts, ts, (const double *)Bd, ldbd, ncoef, (double *)Ud, ldud, o, cache, b0.data(),
+                            stats);
+  if (u_loc == EXPV_MI_HOST) copy_out_2d(ctx, U, EXPV_MI_HOST, ldu, Ud, ldud, n, nts, esz);
+}
+
+// ------------------------------------------------------------------------------------------
+// KIOPS
+// ------------------------------------------------------------------------------------------
+template <class S>
+static Mat<S> hblock(const Ks &ks, int r, double scale) {   // scale * H[1:r, 1:r] in the small-exp type
+  Mat<S> F(r, r);
+  for (int j = 0; j < r; ++j)
+    for (int i = 0; i < r; ++i) {
+      const cd v = getH(ks, i, j) * scale;
+      if constexpr (std::is_same<S, cd>::value) F(i, j) = v;
+      else F(i, j) = v.real();
+    }
+  return F;
+}
+
+template <class T>
+static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols, const T *u, int64_t ldu, int ppo,
+                    const double *u_host_abs1, T *wdev, const expv_mi_kiops_opts &o, int64_t stats[5]) {
+  using S = typename std::conditional<ST<T>::is_complex, cd, double>::type;
+  const int64_t n = op.n;
+  const int dt = op.dtype;
+  hipStream_t s = ctx->stream;
+  int p = ppo - 1;
+  const bool padded = (p == 0);
+  if (padded) p = 1;            // "Add extra column of zeros" (kiops.jl:65-69)
+  int m = o.m > 0 ? o.m : std::min(o.mmin, o.mmax);
+  const int mmin = o.mmin, mmax = o.mmax;
+  const double tol = o.tol;
+  int herm = o.ishermitian < 0 ? op.ishermitian : o.ishermitian;
+  expv_mi_ks_s ks;
+  ks_alloc(ks, ctx, dt, (herm ? EXPV_MI_F64 : dt), n, m, p);       // KrylovSubspace{T, U}(n, m, p)  (:74)
+  int64_t step = 0, krystep = 0, ireject = 0, reject = 0, exps = 0;
+  const double tau_last = tau_out[ntau - 1];
+  const double sgn = (tau_last > 0) - (tau_last < 0);
+  double tau_now = 0.0;
+  const double tau_end = std::fabs(tau_last);
+  int j = 0;
+  const int numSteps = tau_ncols;                                  // size(tau_out, 2)  (:86)
+  if (numSteps != 1)
+    fail(EXPV_MI_DIMENSION_MISMATCH, "kiops: size(tau_out,2) > 1 fails checkdims in the reference (arnoldi.jl:217)");
+  std::vector<double> w_aug(p, 0.0);
+  HIPCHECK(hipMemcpyAsync(wdev, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));   // w[:,1] = u[:,1]
+  const double normU = *u_host_abs1;                               // norm(u[:, 2:end], 1), entrywise
+  double nu = 1, mu = 1;
+  if (ppo > 1 && normU > 0) {
+    const double ex = std::ceil(std::log2(normU));
+    nu = std::exp2(-ex);
+    mu = std::exp2(ex);
+  }
+  // u_flip = reverse(u[:, 2:end], dims = 2) * nu   (:105-106)
+  DevBuf uflip(sizeof(T) * n * p + 16);
+  T *uf = uflip.as<T>();
+  if (padded) {
+    HIPCHECK(hipMemsetAsync(uf, 0, sizeof(T) * n * p, s));
+  } else {
+    for (int k = 0; k < p; ++k) {
+      std::vector<const T *> in{u + (size_t)(p - k) * ldu};
+      std::vector<double> cf{nu};
+      lincomb_n<T>(ctx, uf + (size_t)k * n, n, in, cf);
+    }
+  }
+  double tau = tau_end;
+  double gamma, gamma_mmax;
+  if (tau_end > 1) { gamma = 0.2; gamma_mmax = 0.1; }
+  else { gamma = 0.9; gamma_mmax = 0.6; }
+  const double delta = 1.4;
+  int oldm = -1;
+  double oldtau = NAN, omega = NAN;
+  bool orderold = true, kestold = true;
+  double order = 0.0, kest = 2;
+  int l = 1;
+  expv_mi_arnoldi_opts ao;
+  expv_mi_arnoldi_opts_default(&ao);   // tol stays at arnoldi!'s own default 1e-7 (kiops.jl:138-141 passes none)
+  ao.iop = o.iop;
+  ao.ishermitian = herm;
+  ao.ortho = o.ortho;
+  ArnoldiAug aug;
+  aug.B = uf;
+  aug.ldb = n;
+  aug.p = p;
+  aug.w = wdev;
+  aug.w_aug_host = w_aug.data();
+  aug.mu = mu;
+  while (tau_now < tau_end) {
+    const int oldj = ks.m;
+    ao.m = m;
+    ao.init = j;
+    aug.t = tau_now;
+    arnoldi_run(ks, op, nullptr, ao, &aug, false);
+    j = ks.m;
+    bool happy = j < oldj;
+    const double beta = ks.beta;
+    setH(ks, 0, j, cd(1.0, 0.0));                  // H[1, j+1] = 1
+    const cd nrm = getH(ks, j, j - 1);             // save h_{j+1,j}
+    setH(ks, j, j - 1, cd(0.0, 0.0));
+    Mat<S> F = hblock<S>(ks, j + 1, sgn * tau);    // exp(sgn*tau*H[1:j+1, 1:j+1])
+    dense::expm_higham2005base(F);
+    ++exps;
+    setH(ks, j, j - 1, nrm);
+    double tau_new;
+    int m_new;
+    if (happy) {
+      omega = 0;
+      tau_new = std::min(tau_end - (tau_now + tau), tau);
+      m_new = m;
+      happy = false;
+    } else {
+      const double err = std::abs(beta * nrm * cd(F(j - 1, j)));
+      const double oldomega = omega;
+      omega = tau_end * err / (tau * tol);
+      if (m == oldm && tau != oldtau && ireject >= 1) {
+        order = std::max(1.0, std::log(omega / oldomega) / std::log(tau / oldtau));
+        orderold = false;
+      } else if (orderold || ireject == 0) {
+        orderold = true;
+        order = j / 4.0;
+      } else {
+        orderold = true;
+      }
+      if (m != oldm && tau == oldtau && ireject >= 1) {
+        kest = std::max(1.1, std::pow(omega / oldomega, 1.0 / (oldm - m)));
+        kestold = false;
+      } else if (kestold || ireject == 0) {
+        kestold = true;
+        kest = 2;
+      } else {
+        kestold = true;
+      }
+      const double remaining_time = (omega > delta) ? tau_end - tau_now : tau_end - (tau_now + tau);
+      const double same_tau = std::min(remaining_time, tau);
+      double tau_opt = tau * std::pow(gamma / omega, 1.0 / order);
+      tau_opt = std::min(remaining_time, std::max(tau / 5, std::min(5 * tau, tau_opt)));
+      const double mo = std::ceil(j + std::log(omega / gamma) / std::log(kest));
+      if (!std::isfinite(mo)) fail(EXPV_MI_ARGUMENT_ERROR, "kiops: InexactError in ceil(Int, ...) (omega == 0)");
+      int m_opt = (int)mo;
+      // kiops.jl:210:  `3 ÷ 4 * m` == 0 and `cld(4, 3) * m` == 2m
+      m_opt = std::max(mmin, std::min(mmax, std::max(0, std::min(m_opt, 2 * m))));
+      if (j == mmax) {
+        if (omega > delta) {
+          m_new = j;
+          tau_new = tau * std::pow(gamma_mmax / omega, 1.0 / order);
+          tau_new = std::min(tau_end - tau_now, std::max(tau / 5, tau_new));
+        } else {
+          tau_new = tau_opt;
+          m_new = m;
+        }
+      } else {
+        m_new = m_opt;
+        tau_new = same_tau;
+      }
+    }
+    if (omega <= delta) {  // kiops_update_solution!  (:283-326)
+      reject += ireject;
+      ++step;
+      int blownTs = 0;
+      const double nextT = tau_now + tau;
+      for (int k = l; k <= numSteps; ++k)
+        if (std::fabs(tau_out[k - 1]) < std::fabs(nextT)) ++blownTs;
+      if (blownTs != 0) fail(EXPV_MI_BOUNDS, "BoundsError: w[:, l + blownTs] (kiops.jl:303)");
+      std::vector<S> col(j);
+      for (int i = 0; i < j; ++i) col[i] = F(i, 0);
+      combine_host_coef(ks, j, 1, col.data(), j, std::is_same<S, cd>::value ? EXPV_MI_C64 : EXPV_MI_F64, beta, wdev, n,
+                        EXPV_MI_DEVICE, dt);
+      tau_now += tau;
+      j = 0;
+      ireject = 0;
+    } else {
+      ++ireject;
+      setH(ks, 0, j, cd(0.0, 0.0));
+    }
+    oldtau = tau;
+    tau = tau_new;
+    oldm = m;
+    m = m_new;
+  }
+  if (tau_out[0] != 1 && o.task1) {
+    if (ntau == 1) {
+      std::vector<const T *> in{wdev};
+      std::vector<double> cf{std::pow(1.0 / tau_out[l - 1], p)};
+      lincomb_n<T>(ctx, wdev, n, in, cf);
+    } else {
+      fail(EXPV_MI_UNSUPPORTED, "kiops task1 with several outputs is flagged FIXME in kiops.jl:255");
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  stats[0] = step; stats[1] = reject; stats[2] = krystep; stats[3] = exps; stats[4] = m;
+}
+
+void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols, const void *u, int64_t ldu, int ncols_u,
+               int u_loc, void *w, int64_t ldw, int w_loc, const expv_mi_kiops_opts &o, int64_t stats[5]) {
+  (void)ldw;
+  ctx->use();
+  const int64_t n = op.n;
+  if (ntau < 1 || ncols_u < 1) fail(EXPV_MI_ARGUMENT_ERROR, "kiops: empty tau_out or u");
+  const size_t esz = dtype_size(op.dtype);
+  DevBuf utmp, wtmp;
+  int64_t ldud = ldu;
+  const void *ud = stage_in_2d(ctx, u, u_loc, n, ncols_u, ldu, esz, utmp, &ldud);
+  // entrywise 1-norm of u[:, 2:end] on the host (setup cost, :94)
+  double normU = 0.0;
+  if (ncols_u > 1) {
+    std::vector<double> hb((size_t)n * (esz / 8));
+    for (int cidx = 1; cidx < ncols_u; ++cidx) {
+      const char *src = reinterpret_cast<const char *>(u) + (size_t)cidx * ldu * esz;
+      if (u_loc == EXPV_MI_HOST) std::memcpy(hb.data(), src, (size_t)n * esz);
+      else {
+        HIPCHECK(hipMemcpyAsync(hb.data(), src, (size_t)n * esz, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+      }
+      for (int64_t i = 0; i < n; ++i)
+        normU += (esz == 16) ? std::hypot(hb[2 * i], hb[2 * i + 1]) : std::fabs(hb[i]);
+    }
+  }
+  void *wd = w;
+  if (w_loc == EXPV_MI_HOST) {
+    wtmp.alloc((size_t)n * esz + 16);
+    wd = wtmp.p;
+  }
+  if (op.dtype == EXPV_MI_C64)
+    kiops_T<cplx>(ctx, op, tau_out, ntau, tau_ncols, (const cplx *)ud, ldud, ncols_u, &normU, (cplx *)wd, o, stats);
+  else
+    kiops_T<double>(ctx, op, tau_out, ntau, tau_ncols, (const double *)ud, ldud, ncols_u, &normU, (double *)wd, o, stats);
+  if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, n, wd, n, n, 1, esz);
+}
+
+}  // namespace expv_mi

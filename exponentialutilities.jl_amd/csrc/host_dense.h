@@ -1,0 +1,417 @@
+// host_dense.h -- small dense matrix functions that stay on the host (north_star: "the small
+// m x m Hessenberg exponential stays on the host").  Sizes are (m+p) <= ~140.
+//
+// Mirrors, with its own code:
+//   exponential!(A, ExpMethodHigham2005Base())      /root/reference/src/exp_baseexp.jl:112-161
+//   _pade_evaluate! (generic Horner in A^2)         exp_baseexp.jl:84-105
+//   PureGebal.balance!/unbalance! (xGEBAL job 'B')  exp_baseexp.jl:127,158
+//   LinearSolve LU solve of (V-U) X = (V+U)         exp_baseexp.jl:44-59  (SingularException)
+//   eigen!(SymTridiagonal) path of expv!            krylov_phiv.jl:227-228, :272-273
+//   phiv_dense!                                     phi.jl:84-115
+// All matrices column-major.  Header-only templates over S = double | std::complex<double>.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace expv_mi {
+namespace dense {
+
+using cd = std::complex<double>;
+
+struct SingularError : std::runtime_error {
+  SingularError() : std::runtime_error("SingularException(0): Pade denominator is singular") {}
+};
+
+inline double absv(double x) { return std::fabs(x); }
+inline double absv(const cd &x) { return std::abs(x); }
+inline double cabs1(double x) { return std::fabs(x); }
+inline double cabs1(const cd &x) { return std::fabs(x.real()) + std::fabs(x.imag()); }
+inline bool nonzero(double x) { return x != 0.0; }
+inline bool nonzero(const cd &x) { return x.real() != 0.0 || x.imag() != 0.0; }
+
+template <class S>
+struct Mat {  // tiny owning column-major matrix
+  int r = 0, c = 0;
+  std::vector<S> a;
+  Mat() {}
+  Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, S(0)) {}
+  S &operator()(int i, int j) { return a[(size_t)j * r + i]; }
+  const S &operator()(int i, int j) const { return a[(size_t)j * r + i]; }
+  S *data() { return a.data(); }
+  const S *data() const { return a.data(); }
+};
+
+template <class S>
+inline void matmul(Mat<S> &C, const Mat<S> &A, const Mat<S> &B) {  // C = A*B (C distinct)
+  const int n = A.r, k = A.c, m = B.c;
+  C = Mat<S>(n, m);
+  for (int j = 0; j < m; ++j)
+    for (int l = 0; l < k; ++l) {
+      const S b = B(l, j);
+      if (!nonzero(b)) continue;
+      const S *ac = &A.a[(size_t)l * n];
+      S *cc = &C.a[(size_t)j * n];
+      for (int i = 0; i < n; ++i) cc[i] += ac[i] * b;
+    }
+}
+
+template <class S>
+inline double opnorm1(const Mat<S> &A) {
+  double best = 0;
+  for (int j = 0; j < A.c; ++j) {
+    double s = 0;
+    for (int i = 0; i < A.r; ++i) s += absv(A(i, j));
+    best = std::max(best, s);
+  }
+  return best;
+}
+
+// opnorm(getH(Ks), 1) on a raw column-major block (krylov_phiv_adaptive.jl:372,408)
+template <class S>
+inline double opnorm1_raw(const S *H, int ld, int r, int c) {
+  double best = 0;
+  for (int j = 0; j < c; ++j) {
+    double s = 0;
+    for (int i = 0; i < r; ++i) s += absv(H[(size_t)j * ld + i]);
+    best = std::max(best, s);
+  }
+  return best;
+}
+
+// ---- balancing: LAPACK xGEBAL job='B' (2-norm variant) --------------------------------------
+template <class S>
+struct Balance {
+  int ilo = 1, ihi = 0;        // 1-based like LAPACK
+  std::vector<double> scale;   // permutation indices outside [ilo,ihi], scale factors inside
+};
+
+template <class S>
+inline double nrm2_strided(const S *x, int n, int inc) {
+  // scaled 2-norm (no overflow), like BLAS nrm2
+  double scale = 0, ssq = 1;
+  for (int i = 0; i < n; ++i) {
+    const S v = x[(size_t)i * inc];
+    const double parts[2] = {std::real(cd(v)), std::imag(cd(v))};
+    for (double p : parts) {
+      if (p != 0) {
+        const double a = std::fabs(p);
+        if (scale < a) {
+          ssq = 1 + ssq * (scale / a) * (scale / a);
+          scale = a;
+        } else {
+          ssq += (a / scale) * (a / scale);
+        }
+      }
+    }
+  }
+  return scale * std::sqrt(ssq);
+}
+
+template <class S>
+inline Balance<S> gebal(Mat<S> &A) {
+  const int n = A.r;
+  Balance<S> B;
+  B.scale.assign(n, 1.0);
+  if (n == 0) { B.ilo = 1; B.ihi = 0; return B; }
+  const double radix = 2.0, sclfac = 2.0, factor = 0.95;
+  auto swap_rc = [&](int j, int m, int k, int l) {  // 1-based j<->m; cols over rows 1..l, rows over cols k..n
+    B.scale[m - 1] = j;
+    if (j != m) {
+      for (int i = 0; i < l; ++i) std::swap(A(i, j - 1), A(i, m - 1));
+      for (int c = k - 1; c < n; ++c) std::swap(A(j - 1, c), A(m - 1, c));
+    }
+  };
+  int k = 1, l = n;
+  bool noconv = true;
+  while (noconv) {  // rows isolating an eigenvalue -> bottom
+    noconv = false;
+    for (int i = l; i >= 1; --i) {
+      bool canswap = true;
+      for (int j = 1; j <= l; ++j)
+        if (i != j && nonzero(A(i - 1, j - 1))) { canswap = false; break; }
+      if (canswap) {
+        swap_rc(i, l, k, l);
+        noconv = true;
+        if (l == 1) { B.ilo = 1; B.ihi = 1; return B; }
+        --l;
+      }
+    }
+  }
+  noconv = true;
+  while (noconv) {  // columns isolating an eigenvalue -> left
+    noconv = false;
+    for (int j = k; j <= l; ++j) {
+      bool canswap = true;
+      for (int i = k; i <= l; ++i)
+        if (i != j && nonzero(A(i - 1, j - 1))) { canswap = false; break; }
+      if (canswap) {
+        swap_rc(j, k, k, l);
+        noconv = true;
+        ++k;
+      }
+    }
+  }
+  for (int i = k; i <= l; ++i) B.scale[i - 1] = 1.0;
+  const double tiny = 2.2250738585072014e-308, eps = 2.220446049250313e-16;
+  const double sfmin1 = tiny / eps, sfmax1 = 1.0 / sfmin1;
+  const double sfmin2 = sfmin1 * sclfac, sfmax2 = 1.0 / sfmin2;
+  noconv = true;
+  while (noconv) {
+    noconv = false;
+    for (int i = k; i <= l; ++i) {
+      double c = nrm2_strided(&A(k - 1, i - 1), l - k + 1, 1);
+      double r = nrm2_strided(&A(i - 1, k - 1), l - k + 1, n);
+      int ica = 0;
+      double best = -1;
+      for (int q = 0; q < l; ++q) { double v = cabs1(A(q, i - 1)); if (v > best) { best = v; ica = q; } }
+      double ca = absv(A(ica, i - 1));
+      int ira = k - 1;
+      best = -1;
+      for (int q = k - 1; q < n; ++q) { double v = cabs1(A(i - 1, q)); if (v > best) { best = v; ira = q; } }
+      double ra = absv(A(i - 1, ira));
+      if (c == 0.0 || r == 0.0) continue;
+      double g = r / radix, f = 1.0;
+      const double s = c + r;
+      while (c < g && std::max(f, std::max(c, ca)) < sfmax2 && std::min(r, std::min(g, ra)) > sfmin2) {
+        f *= sclfac; c *= sclfac; ca *= sclfac; r /= sclfac; g /= sclfac; ra /= sclfac;
+      }
+      g = c / radix;
+      while (g >= r && std::max(r, ra) < sfmax2 && std::min(std::min(f, c), std::min(g, ca)) > sfmin2) {
+        f /= sclfac; c /= sclfac; g /= sclfac; ca /= sclfac; r *= sclfac; ra *= sclfac;
+      }
+      if ((c + r) >= factor * s) continue;
+      if (f < 1.0 && B.scale[i - 1] < 1.0 && f * B.scale[i - 1] <= sfmin1) continue;
+      if (f > 1.0 && B.scale[i - 1] > 1.0 && B.scale[i - 1] >= sfmax1 / f) continue;
+      g = 1.0 / f;
+      B.scale[i - 1] *= f;
+      noconv = true;
+      for (int cidx = k - 1; cidx < n; ++cidx) A(i - 1, cidx) *= g;
+      for (int ridx = 0; ridx < l; ++ridx) A(ridx, i - 1) *= f;
+    }
+  }
+  B.ilo = k;
+  B.ihi = l;
+  return B;
+}
+
+// inverse similarity for a matrix function: X <- D (P X P^T) D^-1 undone (exp_baseexp.jl:158)
+template <class S>
+inline void unbalance(Mat<S> &X, const Balance<S> &B) {
+  const int n = X.r;
+  for (int j = B.ilo; j <= B.ihi; ++j) {
+    const double sj = B.scale[j - 1];
+    for (int i = 0; i < n; ++i) X(j - 1, i) *= sj;
+    for (int i = 0; i < n; ++i) X(i, j - 1) /= sj;
+  }
+  auto rcswap = [&](int j, int k) {
+    if (j == k) return;
+    for (int i = 0; i < n; ++i) std::swap(X(j - 1, i), X(k - 1, i));
+    for (int i = 0; i < n; ++i) std::swap(X(i, j - 1), X(i, k - 1));
+  };
+  if (B.ilo > 1)
+    for (int j = B.ilo - 1; j >= 1; --j) rcswap(j, (int)B.scale[j - 1]);
+  if (B.ihi < n)
+    for (int j = B.ihi + 1; j <= n; ++j) rcswap(j, (int)B.scale[j - 1]);
+}
+
+// ---- LU with partial pivoting:  X <- M \ X  --------------------------------------------------
+template <class S>
+inline void lu_solve(Mat<S> &M, Mat<S> &X) {
+  const int n = M.r, nrhs = X.c;
+  std::vector<int> piv(n);
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double best = cabs1(M(k, k));
+    for (int i = k + 1; i < n; ++i) {
+      const double v = cabs1(M(i, k));
+      if (v > best) { best = v; p = i; }
+    }
+    piv[k] = p;
+    if (best == 0.0 || std::isnan(best)) throw SingularError();
+    if (p != k) {
+      for (int j = 0; j < n; ++j) std::swap(M(k, j), M(p, j));
+      for (int j = 0; j < nrhs; ++j) std::swap(X(k, j), X(p, j));
+    }
+    const S inv = S(1) / M(k, k);
+    for (int i = k + 1; i < n; ++i) M(i, k) *= inv;
+    for (int j = k + 1; j < n; ++j) {
+      const S mkj = M(k, j);
+      if (!nonzero(mkj)) continue;
+      for (int i = k + 1; i < n; ++i) M(i, j) -= M(i, k) * mkj;
+    }
+  }
+  for (int j = 0; j < nrhs; ++j) {
+    for (int k = 0; k < n; ++k) {  // forward (unit lower)
+      const S xk = X(k, j);
+      if (!nonzero(xk)) continue;
+      for (int i = k + 1; i < n; ++i) X(i, j) -= M(i, k) * xk;
+    }
+    for (int k = n - 1; k >= 0; --k) {  // backward
+      X(k, j) /= M(k, k);
+      const S xk = X(k, j);
+      for (int i = 0; i < k; ++i) X(i, j) -= M(i, k) * xk;
+    }
+  }
+}
+
+// ---- Pade evaluation, generic Horner in A^2 for every order (exp_baseexp.jl:84-105) ----------
+template <class S>
+inline Mat<S> pade_evaluate(const Mat<S> &A, const double *C, int N) {
+  const int n = A.r;
+  Mat<S> A2, P(n, n), U(n, n), V(n, n), tmp;
+  matmul(A2, A, A);
+  for (int i = 0; i < n; ++i) { P(i, i) = S(1); U(i, i) = S(C[1]); V(i, i) = S(C[0]); }
+  for (int k = 1; k <= N / 2 - 1; ++k) {
+    const int k2 = 2 * k;
+    matmul(tmp, P, A2);
+    std::swap(P.a, tmp.a);
+    const S cu = S(C[k2 + 1]), cv = S(C[k2]);
+    for (size_t i = 0; i < P.a.size(); ++i) { U.a[i] += cu * P.a[i]; V.a[i] += cv * P.a[i]; }
+  }
+  matmul(tmp, A, U);
+  std::swap(U.a, tmp.a);
+  Mat<S> X(n, n), D(n, n);
+  for (size_t i = 0; i < X.a.size(); ++i) { X.a[i] = V.a[i] + U.a[i]; D.a[i] = V.a[i] - U.a[i]; }
+  lu_solve(D, X);
+  return X;
+}
+
+static const double PADE_C3[] = {120.0, 60.0, 12.0, 1.0};
+static const double PADE_C5[] = {30240.0, 15120.0, 3360.0, 420.0, 30.0, 1.0};
+static const double PADE_C7[] = {17297280.0, 8648640.0, 1995840.0, 277200.0, 25200.0, 1512.0, 56.0, 1.0};
+static const double PADE_C9[] = {17643225600.0, 8821612800.0, 2075673600.0, 302702400.0, 30270240.0,
+                                 2162160.0,     110880.0,     3960.0,       90.0,        1.0};
+static const double PADE_C13[] = {64764752532480000.0, 32382376266240000.0, 7771770303897600.0,
+                                  1187353796428800.0,  129060195264000.0,   10559470521600.0,
+                                  670442572800.0,      33522128640.0,       1323241920.0,
+                                  40840800.0,          960960.0,            16380.0,
+                                  182.0,               1.0};
+
+// exponential!(A, ExpMethodHigham2005Base())  -- in place
+template <class S>
+inline void expm_higham2005base(Mat<S> &A) {
+  const int n = A.r;
+  if (n == 0) return;
+  Balance<S> bal = gebal(A);
+  const double nA = opnorm1(A);
+  Mat<S> X;
+  if (nA <= 2.1) {
+    if (nA > 0.95) X = pade_evaluate(A, PADE_C9, 10);
+    else if (nA > 0.25) X = pade_evaluate(A, PADE_C7, 8);
+    else if (nA > 0.015) X = pade_evaluate(A, PADE_C5, 6);
+    else X = pade_evaluate(A, PADE_C3, 4);
+  } else {
+    const double s = std::log2(nA / 5.4);
+    int si = 0;
+    if (s > 0) {
+      si = (int)std::ceil(s);
+      const double sc = std::ldexp(1.0, si);
+      for (auto &v : A.a) v /= sc;
+    }
+    X = pade_evaluate(A, PADE_C13, 14);
+    if (s > 0) {
+      Mat<S> tmp;
+      for (int t = 0; t < si; ++t) { matmul(tmp, X, X); std::swap(X.a, tmp.a); }
+    }
+  }
+  unbalance(X, bal);
+  A = X;
+}
+
+// ---- symmetric tridiagonal eigen-decomposition (implicit QL, EISPACK tql2 lineage) -----------
+// d[0..n) diagonal, e[0..n-1) off-diagonal; on return d = eigenvalues (ascending), Z = vectors.
+inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat<double> &Z) {
+  const int n = (int)d.size();
+  Z = Mat<double>(n, n);
+  for (int i = 0; i < n; ++i) Z(i, i) = 1.0;
+  if (n <= 1) return;
+  std::vector<double> e(n, 0.0);
+  for (int i = 0; i + 1 < n; ++i) e[i] = e_in[i];
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m + 1 < n; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m != l) {
+        if (++iter > 200) throw std::runtime_error("symtridiag_eig: no convergence");
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = Z(k, i + 1);
+            Z(k, i + 1) = s * Z(k, i) + c * f;
+            Z(k, i) = c * Z(k, i) - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  // sort ascending (LAPACK stegr order)
+  for (int i = 0; i + 1 < n; ++i) {
+    int k = i;
+    for (int j = i + 1; j < n; ++j) if (d[j] < d[k]) k = j;
+    if (k != i) {
+      std::swap(d[i], d[k]);
+      for (int r = 0; r < n; ++r) std::swap(Z(r, i), Z(r, k));
+    }
+  }
+}
+
+// expHe = Z * (exp.(t*lambda) .* Z[1,:])   (krylov_phiv.jl:227-228 real t, :272-273 complex t)
+template <class St>
+inline std::vector<St> symtridiag_expcol(const std::vector<double> &diag, const std::vector<double> &off, St t) {
+  std::vector<double> d = diag;
+  Mat<double> Z;
+  symtridiag_eig(d, off, Z);
+  const int n = (int)d.size();
+  std::vector<St> wv(n), out(n, St(0));
+  for (int i = 0; i < n; ++i) wv[i] = std::exp(t * d[i]) * Z(0, i);
+  for (int i = 0; i < n; ++i)
+    for (int r = 0; r < n; ++r) out[r] += Z(r, i) * wv[i];
+  return out;
+}
+
+// phiv_dense!(w, A, v, k)  (phi.jl:84-115): w is m x (k+1)
+template <class S>
+inline Mat<S> phiv_dense(const Mat<S> &A, const std::vector<S> &v, int k) {
+  const int m = A.r;
+  Mat<S> C(m + k, m + k);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) C(i, j) = A(i, j);
+  for (int i = 0; i < m; ++i) C(i, m) = v[i];
+  for (int i = m + 1; i <= m + k - 1; ++i) C(i - 1, i) = S(1);
+  expm_higham2005base(C);
+  Mat<S> w(m, k + 1);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) w(i, 0) += C(i, j) * v[j];
+  for (int i = 1; i <= k; ++i)
+    for (int j = 0; j < m; ++j) w(j, i) = C(j, m + i - 1);
+  return w;
+}
+
+}  // namespace dense
+}  // namespace expv_mi

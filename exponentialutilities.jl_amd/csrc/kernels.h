@@ -1,0 +1,76 @@
+// kernels.h -- launch interface of the gfx950 kernels (implemented in kernels.hip).
+#pragma once
+#include "device_types.h"
+
+namespace expv_mi {
+namespace dev {
+
+constexpr int BLOCK = 256;        // 4 wavefronts of 64
+constexpr int MAX_GRID = 1024;    // 4 workgroups per CU on 256 CUs; grid-stride beyond
+constexpr int LOWSYNC_MAX = 64;   // longest window the in-kernel triangular solve handles
+
+enum DotsMode { DOTS_STRICT = 0, DOTS_LOWSYNC = 1, DOTS_LANCZOS = 2 };
+
+template <class T>
+struct DotsArgs {
+  const T *V; int64_t ldv; int64_t n;  // basis, rows
+  const T *y;                          // vector being orthogonalised (A*v_j)
+  const T *x;                          // v_j, for the Gram row (LOWSYNC) -- may be null
+  int c0, dir, nd;                     // window columns c0 + dir*i, i < nd (0-based)
+  double *part;                        // partial sums, [value][MAX_GRID]
+  StepState *st;
+  int mode, real_coeff;
+  T *Hdev; int ldh; int jcol;          // coefficients go to Hdev[col, jcol]
+  T *gram; int ldg; int jrow;          // gram(i,k) = <v_i, v_k>, k < i ; jrow = index of v_j
+  T *hcoef;                            // coefficients for the update kernel, window order
+};
+
+template <class T>
+struct UpdateArgs {
+  const T *V; int64_t ldv; int64_t n;
+  T *y;                                // in/out
+  int c0, dir, nd;                     // y -= sum_i hcoef[i] * V[:, c0+dir*i]
+  const T *hcoef;
+  int do_norm;                         // also reduce ||y||^2 -> st->hnorm, Hdev[jcol+1, jcol], breakdown
+  double *part;
+  StepState *st;
+  T *Hdev; int ldh; int jcol;
+  double tol;
+  int step;                            // 1-based Krylov step, recorded in st->m_done
+};
+
+int grid_for(int64_t n, int rows_per_block);
+
+template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part, StepState *st);
+template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t n, double scal, int divide);
+template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);
+template <class T> void fill_zero(hipStream_t s, T *dst, int64_t n);
+
+template <class T>
+void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *col, const T *val, const T *x,
+              T *y, const StepState *st, int step);
+template <class T>
+void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
+                const StepState *st, int step);
+template <class T>
+void aug_apply(hipStream_t s, int64_t n, int p, const T *B, int64_t ldb, const T *x, T *y, const StepState *st,
+               int step);
+
+template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);
+template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);
+
+// W[:, q] = scale * sum_{i<m} V[:, i] * C[i, q]   (q < ncols <= 8); TV basis type, TC coefficient type
+template <class TV, class TC>
+void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC *C, int ldc, int ncols,
+             double scale, TC *W, int64_t ldw);
+
+// out = sum_k coef[k] * in[k]   (k < nterms <= 8); out may alias in[0]
+template <class T>
+struct LincombArgs { T *out; const T *in[8]; T coef[8]; int nterms; int64_t n; };
+template <class T> void lincomb(hipStream_t s, const LincombArgs<T> &a);
+
+// real -> complex widening copy, and strided gathers used by the host-language mirrors
+void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t n);
+
+}  // namespace dev
+}  // namespace expv_mi

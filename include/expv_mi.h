@@ -1,0 +1,254 @@
+/* expv_mi.h -- C ABI of libexpv_mi.so: MI355X-native Krylov exp(tA)v engine.
+ *
+ * Drop-in boundary for the Krylov path of SciML/ExponentialUtilities.jl (v1.35.0).
+ * The reference has no FFI for this path (it is pure Julia; its extension points are
+ * multiple dispatch on the operator / array types, docs/src/interfaces.md:7-36).  Each entry
+ * point below names the reference method a Julia shim forwards to it with `ccall`
+ * (INTEGRATION.md shows the binding).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns an expv_mi_status (0 = OK) and never throws / longjmps;
+ *     expv_mi_last_error(ctx) returns the message of the last failure on that context;
+ *   - all matrices are COLUMN-MAJOR with an explicit leading dimension (Julia layout);
+ *   - dtype: EXPV_MI_F64 = double, EXPV_MI_C64 = interleaved (re,im) double pairs;
+ *   - *_loc says where a caller buffer lives: EXPV_MI_HOST (library stages it through
+ *     HBM) or EXPV_MI_DEVICE (a HIP device pointer on the context's device);
+ *   - the caller owns every buffer it passes; the library owns what is behind handles;
+ *   - a handle is not thread-safe; distinct contexts are independent; calls are
+ *     synchronous on return (host-visible outputs are valid).
+ */
+#ifndef EXPV_MI_H
+#define EXPV_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct expv_mi_ctx_s *expv_mi_ctx_t;
+typedef struct expv_mi_op_s *expv_mi_op_t;
+typedef struct expv_mi_ks_s *expv_mi_ks_t;
+typedef struct expv_mi_tscache_s *expv_mi_tscache_t;
+
+typedef enum {
+  EXPV_MI_OK = 0,
+  EXPV_MI_DIMENSION_MISMATCH = 1, /* DimensionMismatch, arnoldi.jl:217-218                  */
+  EXPV_MI_ARGUMENT_ERROR = 2,     /* ArgumentError, krylov_phiv.jl:132,221                   */
+  EXPV_MI_ASSERTION = 3,          /* @assert "Dimension mismatch", krylov_phiv.jl:205,625    */
+  EXPV_MI_SINGULAR = 4,           /* SingularException, exp_baseexp.jl:54-56                 */
+  EXPV_MI_UNSUPPORTED = 5,        /* error(...), krylov_phiv_error_estimate.jl:97,164        */
+  EXPV_MI_OUT_OF_MEMORY = 6,
+  EXPV_MI_HIP_ERROR = 7,
+  EXPV_MI_BOUNDS = 8              /* BoundsError (kiops.jl:303 with several output times)    */
+} expv_mi_status;
+
+typedef enum { EXPV_MI_F64 = 0, EXPV_MI_C64 = 1 } expv_mi_dtype;
+typedef enum { EXPV_MI_HOST = 0, EXPV_MI_DEVICE = 1 } expv_mi_loc;
+
+/* Orthogonalisation arithmetic of arnoldi_step! (arnoldi.jl:301-304).
+ *   MGS    : the reference's literal sequence (dot -> axpy, one column at a time).
+ *   LOWSYNC: the same projection written as  h = (I + L)^-1 V^H y  (L = strict lower triangle
+ *            of V^H V), which is algebraically identical to MGS on the computed basis but needs
+ *            one grid-wide reduction per Krylov step instead of one per column.
+ *   AUTO   : LOWSYNC whenever the window holds at least 2 columns (a 1-column window is MGS). */
+typedef enum { EXPV_MI_ORTHO_AUTO = 0, EXPV_MI_ORTHO_MGS = 1, EXPV_MI_ORTHO_LOWSYNC = 2 } expv_mi_ortho;
+
+/* ------------------------------------------------------------------ context ---------- */
+/* One context = one GPU + one HIP stream.  `stream` may be NULL (library creates its own) or an
+ * existing hipStream_t (e.g. torch.cuda.Stream().cuda_stream) that the library launches on. */
+int expv_mi_ctx_create(int device_id, void *stream, expv_mi_ctx_t *ctx);
+int expv_mi_ctx_destroy(expv_mi_ctx_t ctx);
+int expv_mi_ctx_sync(expv_mi_ctx_t ctx);
+const char *expv_mi_last_error(expv_mi_ctx_t ctx);
+const char *expv_mi_version(void);
+
+/* raw device memory for host languages without a GPU array type (the Julia shim's MIVector) */
+int expv_mi_malloc(expv_mi_ctx_t ctx, size_t bytes, void **dptr);
+int expv_mi_free(expv_mi_ctx_t ctx, void *dptr);
+int expv_mi_memcpy_h2d(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes);
+int expv_mi_memcpy_d2h(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes);
+
+/* per-kernel timing (HIP events on the context's stream) for bench.py's roofline leg */
+enum {
+  EXPV_MI_K_FIRSTSTEP = 0, EXPV_MI_K_MATVEC = 1, EXPV_MI_K_DOTS = 2, EXPV_MI_K_UPDATE = 3,
+  EXPV_MI_K_SCALE = 4, EXPV_MI_K_COMBINE = 5, EXPV_MI_K_FUSED_A = 6, EXPV_MI_K_FUSED_B = 7,
+  EXPV_MI_K_LINCOMB = 8, EXPV_MI_K_AUG = 9, EXPV_MI_K_BATCH = 10, EXPV_MI_K_COUNT = 11
+};
+int expv_mi_prof_enable(expv_mi_ctx_t ctx, int on);
+int expv_mi_prof_reset(expv_mi_ctx_t ctx);
+int expv_mi_prof_get(expv_mi_ctx_t ctx, int kernel_id, int64_t *launches, double *total_ms);
+const char *expv_mi_prof_name(int kernel_id);
+
+/* ------------------------------------------------------------------ operators -------- */
+/* The operator contract of docs/src/interfaces.md:7-36 (eltype, size, mul!, ishermitian).
+ * Matrices are copied to HBM at create time (CSC is converted to CSR32 once; setup cost). */
+
+/* SparseArrays.SparseMatrixCSC{T,Int64} as Julia holds it: colptr[n+1], rowval[nnz], nzval[nnz];
+ * index_base = 1 for Julia arrays, 0 for scipy. */
+int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t *colptr,
+                          const int64_t *rowval, const void *nzval, int index_base, expv_mi_op_t *op);
+/* CSR (what test/gpu/gputests.jl:46 hands over as CuSparseMatrixCSR); idx_bytes = 4 or 8. */
+int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *rowptr, const void *colind,
+                          const void *vals, int idx_bytes, int index_base, expv_mi_op_t *op);
+/* Dense column-major n x n (Matrix{T}); `loc` = where A lives now. */
+int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *A, int64_t lda, int loc,
+                            expv_mi_op_t *op);
+/* Matrix-free operator: `matvec(user, x_dev, y_dev, hip_stream)` must enqueue y = A*x on the stream
+ * (basictests.jl:786-816 interface contract). */
+typedef int (*expv_mi_matvec_fn)(void *user, const void *x_dev, void *y_dev, void *hip_stream);
+int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_matvec_fn fn, void *user,
+                               int ishermitian, int64_t nnz_hint, expv_mi_op_t *op);
+int expv_mi_op_destroy(expv_mi_op_t op);
+/* size(A,1), nnz (NA of krylov_phiv_adaptive.jl:335-342), LinearAlgebra.ishermitian(A), opnorm(A,Inf) */
+int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian, double *opnorm_inf,
+                    int *dtype);
+/* mul!(y, A, x)  (arnoldi.jl:185) */
+int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc);
+
+/* ------------------------------------------------------------------ KrylovSubspace --- */
+/* KrylovSubspace{T,U}(n, maxiter, augmented)  (arnoldi.jl:63-76).  V lives in HBM,
+ * (n+augmented) x (maxiter+1); H is host-resident, (maxiter+1) x (maxiter + (augmented != 0)),
+ * element type U = dtype_U (EXPV_MI_F64 for a Hermitian problem). */
+int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, int maxiter, int augmented,
+                      expv_mi_ks_t *ks);
+int expv_mi_ks_destroy(expv_mi_ks_t ks);
+/* Base.resize!(Ks, maxiter)  (arnoldi.jl:80-93): contents survive only when augmented != 0 */
+int expv_mi_ks_resize(expv_mi_ks_t ks, int maxiter);
+/* fields m, maxiter, augmented, beta, wasbreakdown (arnoldi.jl:54-58) */
+int expv_mi_ks_get(expv_mi_ks_t ks, int *m, int *maxiter, int *augmented, double *beta, int *wasbreakdown);
+int expv_mi_ks_set_m(expv_mi_ks_t ks, int m);
+/* Ks.H: pointer to the host matrix (valid until resize/destroy), its leading dimension and shape */
+int expv_mi_ks_H(expv_mi_ks_t ks, void **H, int *ldh, int *nrows, int *ncols);
+/* copy columns [col0, col0+ncols) of Ks.V to / from the host (ld of the host array = ldh_host) */
+int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64_t ld_dst);
+int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, int64_t ld_src);
+int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv);
+
+/* arnoldi!(Ks, A, b; tol, m, ishermitian, iop, init)  (arnoldi.jl:345-377);
+ * ishermitian != 0 runs lanczos! (arnoldi.jl:456-490).  ishermitian < 0 = ask the operator. */
+typedef struct {
+  int32_t m;            /* requested Krylov dimension; <= 0 means min(maxiter, n)                  */
+  int32_t iop;          /* incomplete-orthogonalisation window; 0 = full Arnoldi                   */
+  int32_t init;         /* continue at step `init` (0 = fresh first step)                          */
+  int32_t ishermitian;  /* 1 Lanczos, 0 Arnoldi, -1 LinearAlgebra.ishermitian(A)                   */
+  int32_t ortho;        /* expv_mi_ortho                                                           */
+  int32_t reserved;
+  double tol;           /* happy-breakdown threshold (absolute), default 1e-7                      */
+} expv_mi_arnoldi_opts;
+void expv_mi_arnoldi_opts_default(expv_mi_arnoldi_opts *o);
+int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc,
+                    const expv_mi_arnoldi_opts *opts);
+/* lanczos!(Ks, A, b; ...) called directly (basictests.jl:746) */
+int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc,
+                    const expv_mi_arnoldi_opts *opts);
+/* augmented form used by kiops: arnoldi!(Ks, (A, B), (w, w_aug); init, t, mu, l, ...)
+ * (arnoldi.jl:191-205, :257-279).  B is n x p (dtype T), w is the n-vector column l of kiops' w,
+ * w_aug (host, p doubles) receives the t^i/i!*mu fill of firststep!. */
+int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t ldb, int p, int b_loc,
+                        const void *w, int w_loc, double *w_aug_host, double t, double mu,
+                        const expv_mi_arnoldi_opts *opts);
+
+/* ------------------------------------------------------------------ evaluation ------- */
+/* expv!(w, t, Ks)  (krylov_phiv.jl:200-280): w = beta * V[:,1:m] * exp(t*H[1:m,1:m]) e1.
+ * t = t_re + i t_im; w_dtype must be C64 when t or T is complex. */
+int expv_mi_expv_ks(expv_mi_ks_t ks, double t_re, double t_im, void *w, int w_loc, int w_dtype);
+/* phiv!(w, t, Ks, k; correct, errest)  (krylov_phiv.jl:607-653); W is n x (k+1); *errest always set */
+int expv_mi_phiv_ks(expv_mi_ks_t ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw,
+                    int w_loc, int w_dtype, double *errest);
+/* lmul!(beta_scale, mul!(w, V[:,1:m], coef))  (K10/K11 of SURVEY.md): coef is host, m x ncols */
+int expv_mi_combine(expv_mi_ks_t ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype,
+                    double beta_scale, void *W, int64_t ldw, int w_loc, int w_dtype);
+
+/* expv(t, A, b; m, tol, iop, ishermitian, mode)  (krylov_phiv.jl:125-160) in one call */
+typedef struct {
+  int32_t m_used;        /* Ks.m after the factorisation      */
+  int32_t wasbreakdown;
+  int32_t matvecs;       /* operator applications performed   */
+  int32_t reserved;
+  double beta;
+} expv_mi_expv_stats;
+int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, const void *b, int b_loc,
+                 void *w, int w_loc, int w_dtype, const expv_mi_arnoldi_opts *opts,
+                 expv_mi_expv_stats *stats);
+/* expv!(w, t, A, b, Ks, cache; atol, rtol, m)  error-estimate mode, Hermitian only
+ * (krylov_phiv_error_estimate.jl:149-207) */
+int expv_mi_expv_error_estimate(expv_mi_ks_t ks, expv_mi_op_t op, double t_re, double t_im, const void *b,
+                                int b_loc, void *w, int w_loc, double atol, double rtol, int m,
+                                int ishermitian);
+
+/* ------------------------------------------------------------------ time stepping ---- */
+typedef void (*expv_mi_print_fn)(const char *line, void *user);
+typedef struct {
+  double tau;          /* 0 = choose (krylov_phiv_adaptive.jl:284-292 / :374-383)   */
+  double tol;          /* 1e-7                                                      */
+  double delta;        /* 1.2                                                       */
+  double gamma;        /* 0.8                                                       */
+  double opnorm;       /* used iff has_opnorm                                       */
+  int32_t has_opnorm;  /* 0: estimate from the Arnoldi Hessenberg (default)         */
+  int32_t m;           /* <= 0: min(10, n)                                          */
+  int32_t iop;
+  int32_t correct;
+  int32_t adaptive;
+  int32_t ishermitian; /* -1 ask operator; only steers the flop model (see :332-334) */
+  int32_t verbose;
+  int32_t ortho;
+  int64_t NA;          /* 0: nnz of the operator                                    */
+  expv_mi_print_fn print;
+  void *print_user;
+} expv_mi_timestep_opts;
+typedef struct {
+  int32_t num_timesteps;
+  int32_t matvecs;
+  int32_t m_final;
+  int32_t arnoldi_calls;
+} expv_mi_timestep_stats;
+void expv_mi_timestep_opts_default(expv_mi_timestep_opts *o);
+/* _phiv_timestep_caches(u_prototype, maxiter, p)  (krylov_phiv_adaptive.jl:502-511) */
+int expv_mi_timestep_caches_create(expv_mi_ctx_t ctx, int dtype, int64_t n, int maxiter, int p,
+                                   expv_mi_tscache_t *cache);
+int expv_mi_timestep_caches_destroy(expv_mi_tscache_t cache);
+/* phiv_timestep!(U, ts, A, B; ...)  (krylov_phiv_adaptive.jl:260-453).  B is n x (p+1); U is n x nts;
+ * ts (host) is sorted in place like the reference (:297).  expv_timestep! is the p = 0 case. */
+int expv_mi_phiv_timestep(expv_mi_ctx_t ctx, expv_mi_op_t op, int nts, double *ts, const void *B,
+                          int64_t ldb, int ncoef, int b_loc, void *U, int64_t ldu, int u_loc,
+                          const expv_mi_timestep_opts *opts, expv_mi_tscache_t caches,
+                          expv_mi_timestep_stats *stats);
+
+/* kiops(tau_out, A, u; mmin, mmax, m, tol, iop, ishermitian, task1)  (kiops.jl:57-281).
+ * u is n x ncols_u; w is n x 1 (numSteps = size(tau_out,2) = 1 is the only reachable case, see
+ * DESIGN.md); stats = (step, reject, krystep, exps, m_ret).  For dtype C64 (no reference method)
+ * the mathematical extension is computed and w is complex. */
+typedef struct {
+  int32_t mmin, mmax, m, iop, ishermitian, task1, ortho, reserved;
+  double tol;
+} expv_mi_kiops_opts;
+void expv_mi_kiops_opts_default(expv_mi_kiops_opts *o);
+int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int ntau, int tau_ncols,
+                  const void *u, int64_t ldu, int ncols_u, int u_loc, void *w, int64_t ldw, int w_loc,
+                  const expv_mi_kiops_opts *opts, int64_t stats[5]);
+
+/* ------------------------------------------------------------------ batch ------------ */
+/* nprob independent expv problems of equal size n sharing one sparsity pattern family
+ * (BASELINE config 5): CSR arrays concatenated per problem; b and w are n x nprob. */
+int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr,
+                       const int32_t *colind, const void *vals, int64_t nnz_per_prob, int mat_loc,
+                       const double *t, const void *b, int64_t ldb, int b_loc, void *w, int64_t ldw,
+                       int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used);
+
+/* ------------------------------------------------------------------ host small-dense ---- */
+/* The m x m pieces that stay on the host (north_star); exported so a host language can reuse them
+ * and so they can be tested without a GPU.
+ * exponential!(A, ExpMethodHigham2005Base()), in place  (exp_baseexp.jl:112-161) */
+int expv_mi_host_expm(int dtype, int n, void *A, int lda);
+/* Z*(exp.(t*lambda).*Z[1,:]) of SymTridiagonal(d, e)  (krylov_phiv.jl:227-228); out: n complex */
+int expv_mi_host_symtridiag_expcol(int n, const double *d, const double *e, double t_re, double t_im,
+                                   double *out_c64);
+/* phiv_dense!(w, A, v, k)  (phi.jl:84-115); w is m x (k+1) packed */
+int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, const void *v, void *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXPV_MI_H */
