@@ -1,0 +1,192 @@
+"""bench.py -- headline benchmark: expv matvecs/s on BASELINE config 2
+(n = 1e6, 5-diagonal non-symmetric sparse fp64, m = 30, t = 1.0; SURVEY.md §8d inputs).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full expv(t, A, b): firststep + 30 Krylov steps (operator apply +
+orthogonalisation + normalisation) + host Pade of the 30x30 Hessenberg + the beta*V*coef combine,
+with A, b and w resident in HBM.  One unit of the metric = one Krylov step ("matvec"), so an expv
+at m = 30 is 30 units.  Every rank runs its own independent (A, b) problem (weak scaling, no
+data-path collective); value = N * K * 30 / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_ROWS = 1_000_000
+M_KRYLOV = 30
+T_FINAL = 1.0
+HBM_PEAK_GBS = 8000.0
+
+
+def c2_operator(n):
+    from tests._util import c2_operator as mk
+    return mk(n)
+
+
+def alg_bytes_expv(n, nnz, m, s=8):
+    """SURVEY.md §8d contract figure: m*A_B + s*n*(m(m+1)/2 + 3m + 3), A_B = nnz*(s+4) + 4(n+1)."""
+    a_b = nnz * (s + 4) + 4 * (n + 1)
+    return m * a_b + s * n * (m * (m + 1) // 2 + 3 * m + 3)
+
+
+def alg_bytes_kernel(name, n, nnz, m, s=8):
+    """Average algorithmic bytes of ONE launch of a kernel over the m steps of an expv."""
+    a_b = nnz * (s + 4) + 4 * (n + 1)
+    avg_j = (m + 1) / 2.0
+    return {
+        "matvec": a_b + 2 * s * n,                 # read A, read x, write y
+        "dots": s * n * (avg_j + 2),               # read V[:,1:j], y and v_j (Gram row)
+        "update": s * n * (avg_j + 2),             # read V[:,1:j] and y, write y
+        "scale": 2 * s * n,                        # read y, write v_{j+1}
+        "combine": s * n * (m + 1),                # read V[:,1:m], write w
+        "firststep": 3 * s * n / 2.0,              # sumsq reads b; scale_copy reads b, writes v_1 (2 launches)
+        "fused_a": a_b + s * n * (avg_j + 2),      # A + x + V[:,1:j-1] read, v_j and y written
+        "fused_b": s * n * (avg_j + 2),
+    }.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_ROWS, help="override problem size (debug only; invalidates the metric)")
+    ap.add_argument("--ortho", default="auto", choices=["auto", "mgs", "lowsync"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    import expv_mi_loader
+    eu = expv_mi_loader.load()
+    ctx = eu.Context(device=local_rank)
+    n, m = args.n, M_KRYLOV
+    A = c2_operator(n)
+    nnz = A.nnz
+    t_setup = time.perf_counter()
+    op = eu.MIOperator(A, ctx)                      # CSR32 upload + properties: setup, not timed
+    t_setup = time.perf_counter() - t_setup
+    b_host = np.random.default_rng(3 + rank).standard_normal(n)
+    b = torch.as_tensor(b_host, device="cuda")
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    Ks = eu.KrylovSubspace(np.float64, np.float64, n, m, 0, ctx)
+
+    def one_expv():
+        eu.arnoldi_(Ks, op, b, m=m, ishermitian=False, ortho=args.ortho)
+        eu.expv_(w, T_FINAL, Ks)
+        return Ks.m
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_expv()
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += one_expv()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        uu = torch.tensor([units], dtype=torch.float64, device="cuda")
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        units_total = float(uu.item())
+    else:
+        units_total = float(units)
+    value = units_total / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- per-kernel HIP-event timing of the same K steps (separate pass: events perturb the headline) ---
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(args.steps):
+        one_expv()
+    ctx.sync()
+    prof = ctx.prof_get()
+    ctx.prof_enable(False)
+    kern = {}
+    for name, p in prof.items():
+        ab = alg_bytes_kernel(name, n, nnz, m)
+        avg_ms = p["total_ms"] / p["launches"]
+        kern[name] = {"launches_per_expv": p["launches"] / args.steps, "avg_ms": avg_ms,
+                      "total_ms_per_expv": p["total_ms"] / args.steps,
+                      "alg_GBps": (ab / (avg_ms * 1e-3) / 1e9) if ab else None}
+    dom = max(kern, key=lambda k: kern[k]["total_ms_per_expv"]) if kern else None
+    b_alg = alg_bytes_expv(n, nnz, m)
+    expv_gbps = b_alg / (elapsed / args.steps) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom,
+        "achieved": kern[dom]["alg_GBps"] if dom else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (kern[dom]["alg_GBps"] / HBM_PEAK_GBS) if dom and kern[dom]["alg_GBps"] else None,
+        "traffic": None,
+        "avg_launch_ms": kern[dom]["avg_ms"] if dom else None,
+        "expv_alg_GBps": expv_gbps, "expv_frac": expv_gbps / HBM_PEAK_GBS,
+        "kernels": kern,
+    }
+
+    out = {
+        "metric": "expv matvecs/s (Krylov steps/s), n=1e6 5-diagonal sparse fp64, m=30",
+        "value": value, "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: expv(1.0, A, b), n=%d, offsets (-2..2) diagonals "
+                               "(0.3,1.2,-2.0,0.8,-0.1), nnz=%d, m=30, tol=1e-7, full Arnoldi (%s), "
+                               "one independent problem per GPU" % (n, nnz, args.ortho),
+                   "n": n, "m": m, "nnz": int(nnz), "ortho": args.ortho, "setup_s": t_setup},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the plain-C restatement of the reference loop (literal MGS), same workload
+        from oracle import c_oracle as co
+        threads = co.num_threads()
+        reps, tc = 0, 0.0
+        t_start = time.perf_counter()
+        while reps < 3 and (time.perf_counter() - t_start) < 25.0:
+            t1 = time.perf_counter()
+            wo, r = co.expv_csr(T_FINAL, A, b_host, m=m)
+            tc += time.perf_counter() - t1
+            reps += 1
+        cpu_val = reps * r["m"] / tc
+        err = float(np.linalg.norm(w.cpu().numpy() - wo) / np.linalg.norm(wo))
+        out["cpu_baseline"] = {"value": cpu_val, "unit": "matvecs/s", "cores": threads, "kind": "port",
+                               "sample": "%d full expv calls of the same workload (n=%d, m=30) through "
+                                         "oracle/expv_oracle.c, OpenMP threads=%d" % (reps, n, threads),
+                               "parity_rel_err_w": err}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

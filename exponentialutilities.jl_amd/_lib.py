@@ -130,6 +130,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    try:
+        # torch bundles its own libamdhip64.so.7; when tensors are shared with this library the
+        # runtime torch was built against must be the one in the process, so it has to load first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)           # AttributeError here = header/library mismatch

@@ -1,0 +1,373 @@
+"""GPU parity tests: the HIP path (through the C ABI of libexpv_mi.so) against the oracle on the
+same seeded inputs.  Tolerances (all fp64):
+    device vs oracle, same m:   |H_d - H_o| / |H| <= 1e-12,  |w_d - w_o| / |w_o| <= 1e-12
+    vs dense truth exp(tA)b in the converged regime: <= 1e-10 (the reference's own bar is sqrt(eps))
+They read like test/basictests.jl and test/gpu/gputests.jl (CPU result vs device result)."""
+import numpy as np
+import pytest
+import scipy.linalg as sl
+import scipy.sparse as sp
+
+from oracle import c_oracle as co
+from oracle import krylov_oracle as ko
+from tests._util import c2_operator, dense_phis, mkA, relerr, stencil2d
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+SQRT_EPS = float(np.sqrt(np.finfo(float).eps))
+
+
+@pytest.fixture(scope="module")
+def eu():
+    import expv_mi_loader
+    return expv_mi_loader.load()
+
+
+def herr(Hd, Ho):
+    return float(np.max(np.abs(Hd - Ho)) / max(np.max(np.abs(Ho)), 1e-300))
+
+
+# ------------------------------------------------------------------ Arnoldi / Lanczos --------
+@pytest.mark.parametrize("ortho", ["mgs", "lowsync"])
+@pytest.mark.parametrize("n,m,iop", [(20, 5, 0), (100, 30, 0), (513, 30, 0), (2000, 30, 0), (2000, 25, 2),
+                                     (2001, 17, 3), (4099, 40, 0)])
+def test_arnoldi_H_V_parity_sparse_real(eu, n, m, iop, ortho):
+    A = c2_operator(n)
+    b = np.random.default_rng(3).standard_normal(n)
+    Ks = eu.KrylovSubspace(np.float64, np.float64, n, m)
+    eu.arnoldi_(Ks, A, b, m=m, iop=iop, ishermitian=False, ortho=ortho)
+    Ko = ko.KrylovSubspace(float, float, n, m)
+    ko.arnoldi_(Ko, A, b, m=m, iop=iop, ishermitian=False)
+    assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
+    assert abs(Ks.beta - Ko.beta) <= 1e-14 * Ko.beta
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-11
+
+
+@pytest.mark.parametrize("ortho", ["mgs", "lowsync"])
+@pytest.mark.parametrize("kind", ["dense_real", "dense_complex", "sparse_complex"])
+def test_arnoldi_parity_other_operators(eu, kind, ortho):
+    rng = np.random.default_rng(12)
+    n, m = 300, 20
+    if kind == "dense_real":
+        A = rng.standard_normal((n, n)) / np.sqrt(n)
+        b = rng.standard_normal(n)
+    elif kind == "dense_complex":
+        A = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
+        b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    else:
+        A = (c2_operator(n) * (1 + 0.25j)).tocsc()
+        b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=False, ortho=ortho)
+    Ko = ko.arnoldi(A, b, m=m, ishermitian=False)
+    assert Ks.m == Ko.m
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-11
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_lanczos_parity(eu, cplx):
+    rng = np.random.default_rng(13)
+    n, m = 1500, 30
+    if cplx:
+        X = rng.standard_normal((200, 200)) + 1j * rng.standard_normal((200, 200))
+        A, n = (X + X.conj().T) / 2, 200
+        b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    else:
+        A = c2_operator(n, sym=True)
+        b = rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m)          # ishermitian(A) -> lanczos!
+    Ko = ko.arnoldi(A, b, m=m)
+    assert Ks.U == np.float64 and Ks.m == Ko.m
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-10
+
+
+def test_hermitian_H_real_arnoldi_vs_lanczos(eu):
+    """basictests.jl:731-754 on the device."""
+    rng = np.random.default_rng(7)
+    n, m = 100, 15
+    e = np.ones(n)
+    p = -1j * (np.diag(-e[1:], -1) + np.diag(e[1:], 1))
+    v = rng.random(n) + 1j * rng.random(n)
+    KsA = eu.KrylovSubspace(np.complex128, np.complex128, n, m)
+    KsL = eu.KrylovSubspace(np.complex128, np.float64, n, m)
+    eu.arnoldi_(KsA, p, v, ishermitian=False)
+    eu.lanczos_(KsL, p, v)
+    AH = KsA.H[: KsA.m, : KsA.m]
+    LH = KsL.H[: KsL.m, : KsL.m]
+    assert np.linalg.norm(AH - LH) / np.linalg.norm(AH) < 1e-14
+
+
+def test_happy_breakdown_and_zero_input(eu):
+    """basictests.jl:544-553, :565-566."""
+    rng = np.random.default_rng(5)
+    n = 20
+    v = rng.standard_normal(n)
+    v /= np.linalg.norm(v)
+    A = np.outer(v, v)
+    b = rng.standard_normal(n)
+    assert eu.arnoldi(A, b).m == 2
+    Ks = eu.arnoldi(A, b, ishermitian=False)
+    assert Ks.m == 2 and Ks.wasbreakdown
+    for herm in (False, True):
+        M = rng.standard_normal((n, n))
+        if herm:
+            M = (M + M.T) / 2
+        wz = eu.expv(1e-2, M, np.zeros(n), m=5)
+        assert np.linalg.norm(wz) == 0.0 and not np.any(np.isnan(wz))
+
+
+def test_dimension_mismatch(eu):
+    A = c2_operator(30)
+    Ks = eu.KrylovSubspace(np.float64, np.float64, 31, 5)
+    with pytest.raises(eu.DimensionMismatch):
+        eu.arnoldi_(Ks, A, np.ones(30))
+    with pytest.raises(eu.DimensionMismatch):
+        eu.arnoldi(A, np.ones(29))
+
+
+def test_resize_and_continuation(eu):
+    """arnoldi!(...; init=j) continues in place (arnoldi.jl:350,360-368)."""
+    n = 400
+    A = c2_operator(n)
+    b = np.random.default_rng(3).standard_normal(n)
+    Ks = eu.KrylovSubspace(np.float64, np.float64, n, 20)
+    eu.arnoldi_(Ks, A, b, m=8, ishermitian=False)
+    eu.arnoldi_(Ks, A, b, m=20, init=8, ishermitian=False)
+    Ko = ko.KrylovSubspace(float, float, n, 20)
+    ko.arnoldi_(Ko, A, b, m=20, ishermitian=False)
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    Ks.resize(25)
+    assert Ks.maxiter == 25 and Ks.m == 25 and np.all(Ks.H == 0)
+
+
+# ------------------------------------------------------------------ expv / phiv --------------
+@pytest.mark.parametrize("kindA", ["hc", "hr", "gc", "gr"])
+@pytest.mark.parametrize("cb", [True, False])
+@pytest.mark.parametrize("t", [1e-2, 1e-2j, 1e-2 + 1e-2j])
+def test_complex_value_matrix(eu, kindA, cb, t):
+    """basictests.jl:650-664 on the device, plus parity with the oracle."""
+    rng = np.random.default_rng(abs(hash((kindA, cb))) % 1000)
+    n, m = 20, 10
+    X = rng.random((n, n)) + (1j * rng.random((n, n)) if kindA[1] == "c" else 0)
+    A = (X + X.conj().T) / 2 if kindA[0] == "h" else X
+    b = rng.random(n) + (1j * rng.random(n) if cb else 0)
+    w = eu.expv(t, A, b, m=m)
+    assert relerr(w, sl.expm(t * A) @ b) < SQRT_EPS
+    assert relerr(w, ko.expv(t, A, b, m=m)) < TOL
+
+
+def test_arnoldi_krylov_testset(eu):
+    """basictests.jl:515-541."""
+    rng = np.random.default_rng(0)
+    n, m, K, t = 20, 5, 4, 1e-2
+    A = rng.standard_normal((n, n))
+    b = rng.standard_normal(n)
+    direct = sl.expm(t * A) @ b
+    assert relerr(eu.expv(t, A, b, m=m), direct) < SQRT_EPS
+    w, stats = eu.kiops(t, A, b)
+    assert relerr(w[:, 0], direct) < SQRT_EPS
+    P = dense_phis(t * A, K)
+    W = np.stack([P[i] @ b for i in range(K + 1)], axis=1)
+    Ks = eu.arnoldi(A, b, m=m)
+    assert relerr(eu.phiv(t, Ks, K), W) < SQRT_EPS
+    w3, st3 = eu.kiops(t, A, np.stack([b * (1 / t) ** i for i in range(K)], axis=1))
+    assert relerr(w3[:, 0], W[:, :K].sum(axis=1)) < SQRT_EPS
+    wo, so = ko.kiops(t, A, np.stack([b * (1 / t) ** i for i in range(K)], axis=1))
+    assert st3 == so and relerr(w3, wo) < 1e-10
+
+
+def test_phiv_matrix_kat(eu):
+    """basictests.jl:569-573 (m = n => exact)."""
+    n = 30
+    A = np.diag(np.ones(n - 1), -1) + 30 * np.eye(n) + np.diag(np.ones(n - 1), 1)
+    t = 0.1
+    Q = eu.phiv(t, A, np.ones(n), 10)
+    ref = np.linalg.solve(t * A, (sl.expm(t * A) - np.eye(n)) @ np.ones(n))
+    assert relerr(Q[:, 1], ref) < SQRT_EPS
+    np.testing.assert_allclose(Q[:3, 1], [6.85734928, 7.33460365, 7.3533841], rtol=1e-8)
+
+
+@pytest.mark.parametrize("correct", [False, True])
+def test_phiv_parity_and_errest(eu, correct):
+    n, m, k = 64, 30, 3
+    A = mkA(n)
+    b = 1.0 / np.arange(1, n + 1)
+    Ks = eu.arnoldi(A, b, m=m)
+    Ko = ko.arnoldi(A, b, m=m)
+    W, err = eu.phiv_(np.empty((n, k + 1), order="F"), 0.1, Ks, k, correct=correct, errest=True)
+    Wo, erro = ko.phiv_(np.empty((n, k + 1), order="F"), 0.1, Ko, k, correct=correct, errest=True)
+    assert relerr(W, Wo) < TOL
+    assert abs(err - erro) <= 1e-9 * max(erro, 1e-300) + 1e-25
+
+
+@pytest.mark.parametrize("herm", [False, True])
+def test_matrix_free_operator(eu, herm):
+    """basictests.jl:786-816: an operator with only eltype/size/mul!/ishermitian (device callback)."""
+    import torch
+    rng = np.random.default_rng(123)
+    n = 20
+    A = rng.random((n, n)) + 1j * rng.random((n, n))
+    M = A.conj().T @ A if herm else A
+    Md = torch.as_tensor(M, device="cuda")
+    Op = eu.MIOperator(None, matvec=lambda x: Md @ x, shape=(n, n), dtype=np.complex128, ishermitian=herm)
+    b = rng.random(n) + 1j * rng.random(n)
+    Ks = eu.arnoldi(Op, b, ishermitian=herm, tol=1e-12)
+    pv = eu.phiv(0.01, Ks, 2)
+    ref = np.stack([P @ b for P in dense_phis(0.01 * M, 2)], axis=1)
+    np.testing.assert_allclose(pv, ref, atol=1e-12, rtol=SQRT_EPS)
+    np.testing.assert_allclose(eu.expv(0.01, Op, b, m=n, ishermitian=herm), sl.expm(0.01 * M) @ b, atol=1e-12,
+                               rtol=SQRT_EPS)
+
+
+def test_error_estimate_mode(eu):
+    """basictests.jl:756-784."""
+    rng = np.random.default_rng(9)
+    n, m, dt = 300, 30, 0.1
+    A = rng.random((n, n))
+    A = (A + A.T) / 2
+    b = rng.random(n) + 1j * rng.random(n)
+    w = eu.expv(-1j, dt * A, b, m=m, tol=1e-10, rtol=1e-10, mode="error_estimate")
+    wp = sl.expm(-1j * dt * A) @ b
+    dw = np.linalg.norm(w - wp)
+    assert dw < 1e-10 and dw / abs(1e-16 + np.linalg.norm(w)) < 1e-10
+    wo = ko.expv(-1j, dt * A, b, m=m, tol=1e-10, rtol=1e-10, mode="error_estimate")
+    assert relerr(w, wo) < 1e-11
+    wz = eu.expv(-1j, dt * A, np.zeros(n, dtype=complex), m=m, tol=1e-10, rtol=1e-10, mode="error_estimate")
+    assert np.linalg.norm(wz) == 0
+    with pytest.raises(RuntimeError):
+        eu.expv(-1j, rng.random((5, 5)), np.ones(5, dtype=complex), mode="error_estimate", ishermitian=False)
+
+
+# ------------------------------------------------------------------ time stepping ------------
+def test_issue_143(eu):
+    """basictests.jl:193-205: 1x1 operator, breakdown => one step, stdout line."""
+    ts = np.arange(0, 1.0001, 0.1)
+    out = []
+    res = eu.expv_timestep(ts.copy(), np.array([[1.0]]), np.array([1.0]), verbose=True, out=out.append)
+    assert any("Completed after 1 time step(s)" in s for s in out)
+    np.testing.assert_allclose(np.asarray(res).ravel(), np.exp(ts), rtol=SQRT_EPS)
+
+
+def test_adaptive_krylov(eu):
+    """basictests.jl:666-691 and control-flow parity with the oracle (same steps, same matvecs)."""
+    n, K, t, tol = 100, 4, 5.0, 1e-7
+    A = sp.diags([np.ones(n - 1), -2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="csc")
+    B = np.random.default_rng(14).standard_normal((n, K + 1))
+    Ad = A.toarray()
+    Ph, Phh = dense_phis(t * Ad, K), dense_phis(t / 2 * Ad, K)
+    u_exact = sum(t ** i * Ph[i] @ B[:, i] for i in range(K + 1))
+    uhalf = sum((t / 2) ** i * Phh[i] @ B[:, i] for i in range(K + 1))
+    st, so = {}, {}
+    U = eu.phiv_timestep(np.array([t / 2, t]), A, B, adaptive=True, tol=tol, stats=st)
+    Uo = ko.phiv_timestep(np.array([t / 2, t]), A, B, adaptive=True, tol=tol, stats=so)
+    assert relerr(U[:, 0], uhalf) < tol and relerr(U[:, 1], u_exact) < tol
+    assert st["num_timesteps"] == so["num_timesteps"] and st["matvecs"] == so["matvecs"] and st["m"] == so["m"]
+    assert relerr(U, Uo) < 1e-10
+    u_exact0 = Ph[0] @ B[:, 0]
+    opn = lambda M, p: abs(M).sum(axis=1).max()
+    assert relerr(eu.expv_timestep(t, A, B[:, 0], adaptive=True, tol=tol, opnorm=opn), u_exact0) < tol
+    assert relerr(eu.expv_timestep(t, A, B[:, 0], adaptive=True, tol=tol, opnorm=opn(A, np.inf)), u_exact0) < tol
+
+
+def test_matrix_free_default_tolerance(eu):
+    """basictests.jl:693-729."""
+    n, t, tol = 50, 3.0, 1e-7
+    Ad = sp.diags([np.ones(n - 1), -2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="csc")
+    b = np.random.default_rng(8).standard_normal(n)
+    u_exact = sl.expm(t * Ad.toarray()) @ b
+    assert relerr(eu.expv_timestep(t, Ad, b, adaptive=True, tol=tol), u_exact) < 1e-5
+    assert relerr(eu.expv_timestep(t, Ad, b, adaptive=True, tol=tol, opnorm=4.0), u_exact) < 1e-5
+
+
+def test_expv_timestep_300_snapshots_complex_sparse(eu):
+    """test/gpu/gputests.jl:41-58: n=1000 complex upper-triangular-ish sparse, 300 snapshots, CPU vs device."""
+    rng = np.random.default_rng(0x0451)
+    n = 1000
+    A = sp.random(n, n, density=10 / n, random_state=rng, dtype=np.float64) \
+        + 1j * sp.random(n, n, density=10 / n, random_state=rng, dtype=np.float64)
+    A = (sp.triu(A, 1) + sp.random(n, n, density=1 / n, random_state=rng) * (1 + 1j)).tocsc()
+    b = rng.random(n) + 1j * rng.random(n)
+    t = 0.1
+    assert relerr(eu.expv(t, A, b), ko.expv(t, A, b)) < TOL
+    ts = np.linspace(0, 1, 300)
+    E1 = ko.expv_timestep(ts.copy(), A, b)
+    E2 = eu.expv_timestep(ts.copy(), A, b)
+    assert relerr(E2, E1) < SQRT_EPS
+
+
+def test_kiops_parity(eu):
+    rng = np.random.default_rng(11)
+    n = 400
+    A = c2_operator(n).tocsc()
+    u = rng.standard_normal((n, 3))
+    for herm_A in (A, c2_operator(n, sym=True).tocsc()):
+        w, st = eu.kiops(1.0, herm_A, u)
+        wo, so = ko.kiops(1.0, herm_A, u)
+        assert st == so
+        assert relerr(w, wo) < 1e-9
+    with pytest.raises(eu.DimensionMismatch):
+        eu.kiops(np.array([[0.5, 1.0]]), A, u[:, 0])
+    with pytest.raises(TypeError):
+        eu.kiops(1.0, A.astype(complex), u[:, 0])
+
+
+def test_kiops_complex_extension(eu):
+    """BASELINE config 4 shape at small n: no reference behaviour ("parity unpinned"); pinned by the
+    dense expm of the operator and by the oracle's same extension."""
+    rng = np.random.default_rng(6)
+    n = 300
+    A = (c2_operator(n) * (1 + 0.25j)).tocsc()
+    u = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    w, st = eu.kiops(1.0, A, u, allow_complex=True, ishermitian=False)
+    truth = sl.expm(A.toarray()) @ u
+    assert relerr(w[:, 0], truth) < 1e-6
+    wo, so = ko.kiops(1.0, A, u, allow_complex=True, ishermitian=False)
+    assert st == so and relerr(w, wo) < 1e-9
+
+
+# ------------------------------------------------------------------ full-size properties -----
+def test_c2_full_size_parity_with_c_oracle(eu):
+    """BASELINE config 2 at full size (n = 1e6, m = 30): H and w against the plain-C restatement."""
+    n, m = 1_000_000, 30
+    A = c2_operator(n)
+    b = np.random.default_rng(3).standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m)
+    r = co.arnoldi_csr(A, b, m=m)
+    assert Ks.m == r["m"] == m
+    assert herr(Ks.getH(), r["H"]) <= TOL
+    w = eu.expv_(np.empty(n), 1.0, Ks)
+    wo, _ = co.expv_csr(1.0, A, b, m=m)
+    assert relerr(w, wo) <= TOL
+    # size-independent properties: group property and linearity of exp(tA)
+    back = eu.expv(-1.0, A, w, m=m)
+    assert relerr(back, b) < 1e-9
+    w2 = eu.expv(1.0, A, 2.5 * b, m=m)
+    assert relerr(w2, 2.5 * w) < 1e-13
+
+
+def test_c2_symmetric_and_stencil_variants(eu):
+    n, m = 200_000, 30
+    b = np.random.default_rng(3).standard_normal(n)
+    As = c2_operator(n, sym=True)
+    w = eu.expv(1.0, As, b, m=m)
+    wo, r = co.expv_csr(1.0, As, b, m=m, hermitian=True)
+    assert relerr(w, wo) <= 1e-11
+    St = stencil2d(448)
+    bs = np.random.default_rng(4).standard_normal(St.shape[0])
+    ws = eu.expv(0.2, St, bs, m=m)
+    wso, _ = co.expv_csr(0.2, St, bs, m=m)
+    assert relerr(ws, wso) <= TOL
+
+
+def test_device_resident_vectors(eu):
+    """Inputs already in HBM (torch tensors): nothing is staged through the host."""
+    import torch
+    n, m = 50_000, 30
+    A = c2_operator(n)
+    b = np.random.default_rng(3).standard_normal(n)
+    bd = torch.as_tensor(b, device="cuda")
+    wd = eu.expv(1.0, A, bd, m=m)
+    assert wd.is_cuda
+    assert relerr(wd.cpu().numpy(), ko.expv(1.0, A, b, m=m, ishermitian=False)) < TOL
