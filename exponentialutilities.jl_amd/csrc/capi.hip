@@ -118,6 +118,45 @@ void upload_csr(Op &op, const std::vector<int32_t> &rp, const std::vector<int32_
   HIPCHECK(hipStreamSynchronize(c->stream));
 }
 
+// SELL-C-sigma (sigma = 1: no row sorting) with C = 128 rows (fp64) / 64 rows (complex): slot-major
+// inside a slice so one wave reads 1 KiB of values per slot.  Built only when padding stays small.
+template <class V>
+void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
+                const std::vector<V> &va) {
+  const int SH = 64 * (16 / (int)sizeof(V));
+  const int64_t nsl = (n + SH - 1) / SH;
+  std::vector<int64_t> off(nsl + 1, 0);
+  for (int64_t s = 0; s < nsl; ++s) {
+    int L = 0;
+    for (int64_t r = s * SH; r < std::min<int64_t>(n, (s + 1) * SH); ++r) L = std::max(L, rp[r + 1] - rp[r]);
+    off[s + 1] = off[s] + (int64_t)L * SH;
+  }
+  const int64_t padded = off[nsl];
+  op.sell_ok = false;
+  if (n == 0 || padded > (int64_t)(1.3 * (double)ci.size()) + 8 * SH) return;   // irregular rows: keep CSR
+  std::vector<V> sv((size_t)std::max<int64_t>(padded, 1), V(0));
+  std::vector<int32_t> sc((size_t)std::max<int64_t>(padded, 1), 0);
+  for (int64_t s = 0; s < nsl; ++s)
+    for (int64_t r = s * SH; r < std::min<int64_t>(n, (s + 1) * SH); ++r) {
+      const int q = (int)(r - s * SH);
+      int slot = 0;
+      for (int32_t k = rp[r]; k < rp[r + 1]; ++k, ++slot) {
+        sv[(size_t)(off[s] + (int64_t)slot * SH + q)] = va[k];
+        sc[(size_t)(off[s] + (int64_t)slot * SH + q)] = ci[k];
+      }
+    }
+  Ctx *c = op.ctx;
+  op.sell_off.alloc(sizeof(int64_t) * off.size());
+  op.sell_col.alloc(sizeof(int32_t) * sc.size() + 16);
+  op.sell_val.alloc(sizeof(V) * sv.size() + 16);
+  HIPCHECK(hipMemcpyAsync(op.sell_off.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(op.sell_col.p, sc.data(), sizeof(int32_t) * sc.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(op.sell_val.p, sv.data(), sizeof(V) * sv.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  op.nslices = nsl;
+  op.sell_ok = true;
+}
+
 template <class V>
 void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
   op.kind = OP_CSR;
@@ -125,6 +164,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.nnz = (int64_t)ci.size();
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
   upload_csr<V>(op, rp, ci, va);
+  build_sell<V>(op, n, rp, ci, va);
 }
 
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",

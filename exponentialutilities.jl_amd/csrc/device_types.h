@@ -76,8 +76,9 @@ struct StepState {
   double sumsq;          // scratch: last reduced sum of squares
   int32_t breakdown;     // set to 1 when beta_j < tol (arnoldi.jl:370-374)
   int32_t m_done;        // last step whose column of H is complete
-  uint32_t ticket;       // block-arrival counter for "last block reduces"
+  uint32_t ticket;       // arrival counter of the group reducers (stage 2 of the grid reduction)
   uint32_t pad;
+  uint32_t gticket[64];  // arrival counters of the workgroup groups (stage 1)
 };
 
 }  // namespace expv_mi

@@ -108,6 +108,9 @@ struct Op {
   int ishermitian = 0;
   double opnorm_inf = 0.0;
   DevBuf rowptr, col, val;   // CSR32
+  DevBuf sell_off, sell_col, sell_val;   // SELL-C (C = 128 rows fp64 / 64 complex), built when padding is small
+  int64_t nslices = 0;
+  bool sell_ok = false;
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;
@@ -137,7 +140,8 @@ struct Ks {
   DevBuf gram;         // LOWSYNC Gram rows, dtype T, (maxiter+1)^2
   int ldg = 0;
   int gram_rows = 0;   // leading basis vectors whose Gram rows are valid
-  DevBuf hcoef, part, state;
+  DevBuf hcoef, part, gpart, state;
+  DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
   int64_t rows() const { return n + augmented; }
 };
 }  // namespace expv_mi

@@ -7,6 +7,8 @@
 // The whole Arnoldi loop is enqueued without a host round trip: projection coefficients, the
 // Hessenberg column and the happy-breakdown flag are produced on the device by the last workgroup
 // of each reduction kernel (kernels.hip); the host reads H and the flag once, after the loop.
+#include <cstdlib>
+
 #include "engine.h"
 
 namespace expv_mi {
@@ -62,7 +64,8 @@ static void ks_alloc_aux(Ks &ks) {
   ks.gram.alloc((size_t)ks.ldg * ks.ldg * esz);
   HIPCHECK(hipMemsetAsync(ks.gram.p, 0, ks.gram.bytes, ks.ctx->stream));
   ks.hcoef.alloc((size_t)(ks.maxiter + 2) * esz);
-  if (!ks.part.p) ks.part.alloc((size_t)4 * dev::LOWSYNC_MAX * dev::MAX_GRID * sizeof(double));
+  if (!ks.part.p) ks.part.alloc((size_t)dev::MAX_RED_VALUES * dev::MAX_GRID * sizeof(double));
+  if (!ks.gpart.p) ks.gpart.alloc((size_t)dev::MAX_RED_VALUES * dev::MAX_GROUPS * sizeof(double));
   if (!ks.state.p) {
     ks.state.alloc(sizeof(StepState));
     HIPCHECK(hipMemsetAsync(ks.state.p, 0, sizeof(StepState), ks.ctx->stream));
@@ -81,7 +84,7 @@ void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int au
   ks.augmented = augmented;
   ks.beta = 0.0;
   ks.wasbreakdown = false;
-  ks.ldv = round_up(ks.rows() > 0 ? ks.rows() : 1, 32);
+  ks.ldv = round_up(ks.rows() > 0 ? ks.rows() : 1, 128);
   const size_t esz = dtype_size(dtT);
   ks.V.alloc((size_t)ks.ldv * (maxiter + 1) * esz);
   HIPCHECK(hipMemsetAsync(ks.V.p, 0, ks.V.bytes, ctx->stream));  // padding rows must stay zero
@@ -136,7 +139,12 @@ static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) 
   ProfScope ps(c, EXPV_MI_K_MATVEC);
   switch (op.kind) {
     case OP_CSR:
-      dev::spmv_csr<T>(c->stream, op.n, op.rowptr.as<int32_t>(), op.col.as<int32_t>(), op.val.as<T>(), x, y, st, step);
+      if (op.sell_ok) {
+        dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+        dev::spmv_sell<T>(c->stream, op.n, A, x, y, st, step);
+      } else {
+        dev::spmv_csr<T>(c->stream, op.n, op.rowptr.as<int32_t>(), op.col.as<int32_t>(), op.val.as<T>(), x, y, st, step);
+      }
       break;
     case OP_DENSE:
       dev::gemv_dense<T>(c->stream, op.n, reinterpret_cast<const T *>(op.dense_ptr), op.lda, x, y,
@@ -184,6 +192,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   StepState *st = ks.state.as<StepState>();
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
+  bool use_fused = false;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -208,13 +217,18 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     }
     {
       ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
-      dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), st);
+      dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
     }
     StepState h;
     read_state<T>(ks, &h);
     ks.beta = std::sqrt(h.sumsq + extra);
     ks.gram_rows = 0;
-    if (ks.beta != 0.0) {
+    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switch for profiling
+    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
+                (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+    if (ks.beta != 0.0 && use_fused) {
+      ks.gram_rows = 1;   // v_1 = b / beta is produced by the first fused half-step
+    } else if (ks.beta != 0.0) {
       ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
       if (isaug) {
         dev::scale_copy<T>(s, V, src, ks.n, ks.beta, 1);  // @. V[1:n,1] = bl / beta
@@ -240,6 +254,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     StepState z;
     std::memset(&z, 0, sizeof(z));
     z.m_done = jstart - 1;
+    z.hnorm = ks.beta;   // beta_0: the first fused half-step normalises b with it
     HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
                             sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
@@ -247,9 +262,44 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   T *Hd = ks.Hdev.as<T>();
   T *hcoef = ks.hcoef.as<T>();
   double *part = ks.part.as<double>();
+  double *gpart = ks.gpart.as<double>();
   const int ortho = o.ortho;
 
-  for (int j = jstart; j <= m; ++j) {
+  if (use_fused) {
+    // ---- fused path: 2 launches per Krylov step, lagged normalisation (fused.hip) ------------
+    const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
+    if (ks.ubuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
+    T *ub = ks.ubuf.as<T>(), *yb = ks.ybuf.as<T>();
+    dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+    for (int j = 1; j <= m; ++j) {
+      const int i0 = lanczos ? j : std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      dev::FusedAArgs<T> fa{};
+      fa.A = A;
+      fa.u = (j == 1) ? b : ub;
+      fa.ybuf = yb;
+      fa.step = j;
+      dev::DotsArgs<T> &d = fa.d;
+      d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = yb; d.x = V + (size_t)(j - 1) * ks.ldv;
+      d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+      d.part = part; d.gpart = gpart; d.st = st;
+      d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+      d.real_coeff = real_coeff;
+      d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
+      d.hcoef = hcoef;
+      { ProfScope ps(c, EXPV_MI_K_FUSED_A); dev::fused_a<T>(s, fa); }
+      dev::UpdateArgs<T> u{};
+      u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = ub; u.yin = yb;
+      if (lanczos) { u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1; }
+      else { u.c0 = i0 - 1; u.dir = 1; u.nd = nd; }
+      u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+      u.jcol = j - 1; u.tol = tol; u.step = j;
+      { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update<T>(s, u); }
+    }
+    { ProfScope ps(c, EXPV_MI_K_SCALE); dev::finalize_last<T>(s, V, ks.ldv, rows, ub, st); }
+    ks.gram_rows = lanczos ? 1 : m;
+  }
+  for (int j = jstart; j <= m && !use_fused; ++j) {
     const T *x = V + (size_t)(j - 1) * ks.ldv;
     T *y = V + (size_t)j * ks.ldv;
     op_apply_T<T>(op, x, y, st, j);
@@ -261,12 +311,12 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       dev::DotsArgs<T> d{};
       d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
       d.c0 = j - 1; d.dir = 1; d.nd = 1;
-      d.part = part; d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = real_coeff;
+      d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = real_coeff;
       d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
       { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
       dev::UpdateArgs<T> u{};
       u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
-      u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
+      u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
       u.tol = tol; u.step = j;
       { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
     } else {  // arnoldi_step!  (arnoldi.jl:289-308)
@@ -278,13 +328,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         dev::DotsArgs<T> d{};
         d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = x;
         d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
-        d.part = part; d.st = st; d.mode = dev::DOTS_LOWSYNC; d.real_coeff = real_coeff;
+        d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LOWSYNC; d.real_coeff = real_coeff;
         d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
         d.hcoef = hcoef;
         { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
         dev::UpdateArgs<T> u{};
         u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i0 - 1; u.dir = 1; u.nd = nd;
-        u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
+        u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
         u.tol = tol; u.step = j;
         { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
         if (ks.gram_rows >= j - 1) ks.gram_rows = std::max(ks.gram_rows, j);
@@ -293,12 +343,12 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           dev::DotsArgs<T> d{};
           d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
           d.c0 = i - 1; d.dir = 1; d.nd = 1;
-          d.part = part; d.st = st; d.mode = dev::DOTS_STRICT; d.real_coeff = real_coeff;
+          d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_STRICT; d.real_coeff = real_coeff;
           d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
           { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
           dev::UpdateArgs<T> u{};
           u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i - 1; u.dir = 1; u.nd = 1;
-          u.hcoef = hcoef; u.do_norm = (i == j) ? 1 : 0; u.part = part; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+          u.hcoef = hcoef; u.do_norm = (i == j) ? 1 : 0; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
           u.jcol = j - 1; u.tol = tol; u.step = j;
           { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
         }
@@ -536,7 +586,7 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
   StepState z;
   std::memset(&z, 0, sizeof(z));
   HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
-  dev::sumsq<T>(s, b, ks.n, ks.part.as<double>(), st);
+  dev::sumsq<T>(s, b, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
   StepState h;
   read_state<T>(ks, &h);
   ks.beta = std::sqrt(h.sumsq);
@@ -560,12 +610,12 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
     op_apply_T<T>(op, x, y, nullptr, j);
     dev::DotsArgs<T> d{};
     d.V = V; d.ldv = ks.ldv; d.n = ks.n; d.y = y; d.x = nullptr; d.c0 = j - 1; d.dir = 1; d.nd = 1;
-    d.part = ks.part.as<double>(); d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = 1;
+    d.part = ks.part.as<double>(); d.gpart = ks.gpart.as<double>(); d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = 1;
     d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.hcoef = ks.hcoef.as<T>();
     dev::dots<T>(s, d);
     dev::UpdateArgs<T> u{};
     u.V = V; u.ldv = ks.ldv; u.n = ks.n; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
-    u.hcoef = ks.hcoef.as<T>(); u.do_norm = 1; u.part = ks.part.as<double>(); u.st = st; u.Hdev = Hd;
+    u.hcoef = ks.hcoef.as<T>(); u.do_norm = 1; u.part = ks.part.as<double>(); u.gpart = ks.gpart.as<double>(); u.st = st; u.Hdev = Hd;
     u.ldh = ks.ldhd; u.jcol = j - 1; u.tol = -1.0; u.step = j;
     dev::update<T>(s, u);
     dev::scale_by_state<T>(s, y, ks.n, st, j);

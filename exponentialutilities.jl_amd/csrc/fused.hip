@@ -1,0 +1,191 @@
+// fused.hip -- the fused CSR/SELL Krylov half-steps (gfx950).
+//
+// One Krylov step of arnoldi_step! / lanczos_step! (/root/reference/src/arnoldi.jl:289-308, :388-403)
+// is two launches here:
+//   fused_a : v_j = u / beta_{j-1}   (the lagged `y ./= beta` of the PREVIOUS step, arnoldi.jl:306)
+//             y   = A v_j            (mul!, arnoldi.jl:185)        -- SELL-C-sigma SpMV
+//             d_i = <v_i, y>, g_i = <v_i, v_j>  for the window     (arnoldi.jl:302, all columns at once)
+//             last workgroup: Hessenberg column of the step
+//   update  : u   = y - sum_i h_i v_i ; beta_j = ||u||             (arnoldi.jl:303, :305) [kernels.hip]
+// HBM traffic per step (fp64, n rows, nnz entries, window w): A (12 B/entry) + gather of u +
+// 8n*(w-1) [V read] + 8n [v_j write] + 8n [y write]  |  8n*w [V read] + 8n [y read] + 8n [u write].
+#include "kernel_common.h"
+
+namespace expv_mi {
+namespace dev {
+
+template <class T>
+__device__ __forceinline__ void load_cols(const int32_t *p, int32_t *c);
+template <>
+__device__ __forceinline__ void load_cols<double>(const int32_t *p, int32_t *c) {
+  const int2 v = *reinterpret_cast<const int2 *>(p);
+  c[0] = v.x;
+  c[1] = v.y;
+}
+template <>
+__device__ __forceinline__ void load_cols<cplx>(const int32_t *p, int32_t *c) { c[0] = *p; }
+
+// y-rows of one slice for this lane: acc[k] = sum_slots val * x[col]
+template <class T>
+__device__ __forceinline__ void sell_rows(const SellView<T> &A, int64_t slice, int lane, const T *__restrict__ x,
+                                          T *acc) {
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  const int64_t off = A.slice_off[slice];
+  const int L = (int)((A.slice_off[slice + 1] - off) / SH);
+  const T *vp = A.val + off + (int64_t)lane * N;
+  const int32_t *cp = A.col + off + (int64_t)lane * N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = ST<T>::zero();
+  int s = 0;
+  for (; s + 4 <= L; s += 4) {  // 4 slots in flight: 4 x 16 B of values + indices, then 4N gathers
+    Pack<T> v[4];
+    int32_t c[4][N];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = *reinterpret_cast<const Pack<T> *>(vp + (int64_t)(s + q) * SH);
+      load_cols<T>(cp + (int64_t)(s + q) * SH, c[q]);
+    }
+    T xv[4][N];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < N; ++k) xv[q][k] = x[c[q][k]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::fma_(acc[k], v[q].v[k], xv[q][k]);
+  }
+  for (; s < L; ++s) {
+    const Pack<T> v = *reinterpret_cast<const Pack<T> *>(vp + (int64_t)s * SH);
+    int32_t c[N];
+    load_cols<T>(cp + (int64_t)s * SH, c);
+#pragma unroll
+    for (int k = 0; k < N; ++k) ST<T>::fma_(acc[k], v.v[k], x[c[k]]);
+  }
+}
+
+// ---- stand-alone SELL SpMV (mul!) ---------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_spmv_sell(int64_t n, SellView<T> A, const T *__restrict__ x,
+                                                     T *__restrict__ y, const StepState *st, int step) {
+  if (step_skipped(st, step)) return;
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool al = is_al16(y);
+  for (int64_t slice = (int64_t)blockIdx.x * (BLOCK / 64) + wave; slice < A.nslices;
+       slice += (int64_t)gridDim.x * (BLOCK / 64)) {
+    Pack<T> acc;
+    sell_rows<T>(A, slice, lane, x, acc.v);
+    st_pack(y, slice * SH + (int64_t)lane * N, n, al, acc);
+  }
+}
+template <class T>
+void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step) {
+  int64_t g = (A.nslices + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (g > MAX_GRID) g = MAX_GRID;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_spmv_sell<T>, dim3((int)g), dim3(BLOCK), 0, s, n, A, x, y, st, step);
+}
+
+// ---- fused half-step A ----------------------------------------------------------------------
+template <class T, bool GRAM>
+__global__ __launch_bounds__(BLOCK) void k_fused_a(FusedAArgs<T> fa) {
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  constexpr int CH = DotChunk<T>::CH;
+  constexpr int NR = ST<T>::nreal;
+  constexpr int NSETS = GRAM ? 2 : 1;
+  __shared__ double red_s[BLOCK / 64][CH * NR * NSETS];
+  __shared__ double vals_s[MAX_RED_VALUES];
+  __shared__ int flag_s;
+  __shared__ T gs_s[GRAM ? (LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2) : 1];
+  const DotsArgs<T> &a = fa.d;
+  if (step_skipped(a.st, fa.step)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double inv = 1.0 / a.st->hnorm;   // 1 / beta_{j-1}  (beta_0 = ||b|| on the first step)
+  T *vcol = const_cast<T *>(a.x);         // V[:, jcol]: written here, read back for the projections
+  const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(fa.ybuf);
+  const bool alu = is_al16(fa.u);
+
+  for (int cb = 0; cb < a.nd; cb += CH) {
+    T accd[CH], accg[GRAM ? CH : 1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) accd[c] = ST<T>::zero();
+    if (GRAM) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
+    }
+    for (int64_t sb = (int64_t)blockIdx.x * (BLOCK / 64); sb < fa.A.nslices; sb += (int64_t)gridDim.x * (BLOCK / 64)) {
+      const int64_t slice = sb + wave;
+      if (slice >= fa.A.nslices) continue;
+      const int64_t i = slice * SH + (int64_t)lane * N;
+      Pack<T> yv, xv;
+      if (cb == 0) {
+        sell_rows<T>(fa.A, slice, lane, fa.u, yv.v);          // A * u  (unnormalised)
+        const Pack<T> uo = ld_pack(fa.u, i, a.n, alu);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          yv.v[k] = ST<T>::mul_real(yv.v[k], inv);            // A * (u / beta) by linearity
+          xv.v[k] = ST<T>::mul_real(uo.v[k], inv);            // v_j
+        }
+        st_pack(fa.ybuf, i, a.n, al, yv);
+        st_pack(vcol, i, a.n, al, xv);
+        if (i + N > a.n) {                                    // rows past n must not enter the sums
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+            if (i + k >= a.n) { yv.v[k] = ST<T>::zero(); xv.v[k] = ST<T>::zero(); }
+        }
+      } else {
+        yv = ld_pack(fa.ybuf, i, a.n, al);
+        xv = ld_pack(vcol, i, a.n, al);
+      }
+      if (i < a.n) dots_accumulate<T, GRAM>(a.V, a.ldv, a.n, a.c0, a.dir, a.nd, cb, i, al, yv, xv, accd, accg);
+    }
+    dots_publish_chunk<T, GRAM>(accd, accg, cb, a.nd, a.part, red_s);
+  }
+  if (!hier_reduce(a.st, a.part, a.gpart, a.nd * NR * NSETS, vals_s, &flag_s)) return;
+  projection_epilogue<T>(a, vals_s, gs_s);
+}
+
+template <class T>
+void fused_a(hipStream_t s, const FusedAArgs<T> &a) {
+  int64_t g = (a.A.nslices + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (g > MAX_GRID) g = MAX_GRID;
+  if (g < 1) g = 1;
+  if (a.d.mode == DOTS_LOWSYNC)
+    hipLaunchKernelGGL((k_fused_a<T, true>), dim3((int)g), dim3(BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_fused_a<T, false>), dim3((int)g), dim3(BLOCK), 0, s, a);
+}
+
+// V[:, m_done] = u / beta_{m_done}: the normalisation of the LAST step of the call (arnoldi.jl:306)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int64_t n, const T *__restrict__ u,
+                                                         const StepState *st) {
+  constexpr int N = Pack<T>::N;
+  const double beta = st->hnorm;
+  T *dst = V + (int64_t)st->m_done * ldv;
+  const bool al = ((ldv * sizeof(T)) % 16 == 0) && is_al16(V) && is_al16(u);
+  for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
+    Pack<T> p = ld_pack(u, i, n, al);
+#pragma unroll
+    for (int k = 0; k < N; ++k) p.v[k] = ST<T>::div_real(p.v[k], beta);
+    st_pack(dst, i, n, al, p);
+  }
+}
+template <class T>
+void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st) {
+  hipLaunchKernelGGL(k_finalize_last<T>, dim3(grid_for(n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, V, ldv, n, u, st);
+}
+
+#define INSTF(T)                                                                                               \
+  template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int); \
+  template void fused_a<T>(hipStream_t, const FusedAArgs<T> &);                                                \
+  template void finalize_last<T>(hipStream_t, T *, int64_t, int64_t, const T *, const StepState *);
+INSTF(double)
+INSTF(cplx)
+
+}  // namespace dev
+}  // namespace expv_mi

@@ -296,6 +296,9 @@ template <class S>
 inline void expm_higham2005base(Mat<S> &A) {
   const int n = A.r;
   if (n == 0) return;
+  for (const auto &v : A.a)   // LAPACK.gebal!'s chkfinite: balancing never terminates on NaN input
+    if (!std::isfinite(std::real(cd(v))) || !std::isfinite(std::imag(cd(v))))
+      throw std::invalid_argument("ArgumentError: matrix contains Infs or NaNs");
   Balance<S> bal = gebal(A);
   const double nA = opnorm1(A);
   Mat<S> X;

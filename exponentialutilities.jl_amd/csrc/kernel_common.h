@@ -1,0 +1,267 @@
+// kernel_common.h -- device helpers shared by kernels.hip and fused.hip (gfx950 only).
+//
+// Grid-wide reductions never leave the device.  Protocol (cdna_hip_programming.md §6 Guideline 16,
+// write-through form R1 -- no fences on either side):
+//   1. every workgroup publishes its partial values with sc1 (write-through) 8-byte stores;
+//   2. all waves drain (s_waitcnt vmcnt(0)), barrier, one lane takes a ticket of its GROUP of GS
+//      consecutive workgroups; the group's last arriver reduces the group's partials with sc1 loads
+//      (L1-bypassing) in a fixed order and publishes one group partial per value;
+//   3. group reducers take a second, global ticket; the last one reduces the <= 32 group partials.
+// Two short, parallel stages instead of one workgroup reading ~1000 partials per value; the
+// summation order is fixed, so results are reproducible run to run and independent of dispatch
+// order and XCD placement.
+#pragma once
+#include "device_types.h"
+#include "kernels.h"
+
+namespace expv_mi {
+namespace dev {
+
+template <class T>
+struct __attribute__((aligned(16))) Pack {
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+
+template <class T>
+__device__ __forceinline__ Pack<T> ld_pack(const T *__restrict__ p, int64_t i, int64_t n, bool al) {
+  Pack<T> r;
+  if (al && i + Pack<T>::N <= n) {
+    r = *reinterpret_cast<const Pack<T> *>(p + i);
+  } else {
+#pragma unroll
+    for (int k = 0; k < Pack<T>::N; ++k) r.v[k] = (i + k < n) ? p[i + k] : ST<T>::zero();
+  }
+  return r;
+}
+template <class T>
+__device__ __forceinline__ void st_pack(T *__restrict__ p, int64_t i, int64_t n, bool al, const Pack<T> &r) {
+  if (al && i + Pack<T>::N <= n) {
+    *reinterpret_cast<Pack<T> *>(p + i) = r;
+  } else {
+#pragma unroll
+    for (int k = 0; k < Pack<T>::N; ++k)
+      if (i + k < n) p[i + k] = r.v[k];
+  }
+}
+__device__ __forceinline__ bool is_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ double wave_sum(double v) {  // total lands in lane 0
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void publish_f64(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double consume_f64(const double *p) {
+  unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+
+__device__ __forceinline__ bool step_skipped(const StepState *st, int step) {
+  // after a happy breakdown at step m_done the remaining launches of the call are no-ops
+  return st != nullptr && st->breakdown != 0 && step > st->m_done;
+}
+
+// one ticket per workgroup on `counter`; true in the workgroup that draws expected-1 (it also
+// re-arms the counter for the next launch).  Every storing wave drains before the ticket.
+__device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected, int *flag_s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == expected - 1);
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag_s = last;
+  }
+  __syncthreads();
+  return *flag_s != 0;
+}
+
+// sum of base[0..count) by a quad of lanes (q = lane & 3): each lane adds a contiguous quarter in
+// index order, then two butterfly steps -- a fixed summation tree.  All 4 lanes get the total.
+__device__ __forceinline__ double quad_sum(const double *base, int count, int q) {
+  const int per = (count + 3) >> 2;
+  const int b0 = q * per;
+  double s = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < per; ++i) {
+    const int b = b0 + i;
+    const double v = (b < count) ? consume_f64(base + b) : 0.0;
+    s += v;
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  return s;
+}
+
+// Hierarchical grid reduction of nvals values.  Precondition: this workgroup has published
+// part[v*MAX_GRID + blockIdx.x] for every v < nvals.  Returns true in exactly one workgroup, with
+// vals_s[v] = total (visible to all its threads).  Must be called by all threads of every workgroup.
+__device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double *gpart, int nvals, double *vals_s,
+                                            int *flag_s) {
+  const int nblk = gridDim.x;
+  const int g = blockIdx.x / GROUP_SIZE;
+  const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
+  const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
+  if (!take_ticket(&st->gticket[g], (uint32_t)gsize, flag_s)) return false;
+  for (int idx = threadIdx.x; idx < nvals * 4; idx += BLOCK) {
+    const int v = idx >> 2, q = idx & 3;
+    const double s = quad_sum(part + (size_t)v * MAX_GRID + (size_t)g * GROUP_SIZE, gsize, q);
+    if (q == 0) publish_f64(gpart + (size_t)v * MAX_GROUPS + g, s);
+  }
+  if (!take_ticket(&st->ticket, (uint32_t)ng, flag_s)) return false;
+  for (int idx = threadIdx.x; idx < nvals * 4; idx += BLOCK) {
+    const int v = idx >> 2, q = idx & 3;
+    const double s = quad_sum(gpart + (size_t)v * MAX_GROUPS, ng, q);
+    if (q == 0) vals_s[v] = s;
+  }
+  __syncthreads();
+  return true;
+}
+
+// block-level sum of one double per thread -> thread 0 (4 waves)
+__device__ __forceinline__ double block_sum(double v, double *red_s) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < BLOCK / 64; ++w) s += red_s[w];
+  return s;
+}
+
+template <class T> __device__ __forceinline__ void acc_to_vals(const T &a, double *out);
+template <> __device__ __forceinline__ void acc_to_vals<double>(const double &a, double *out) { out[0] = a; }
+template <> __device__ __forceinline__ void acc_to_vals<cplx>(const cplx &a, double *out) { out[0] = a.re; out[1] = a.im; }
+template <class T> __device__ __forceinline__ T vals_to_T(const double *v);
+template <> __device__ __forceinline__ double vals_to_T<double>(const double *v) { return v[0]; }
+template <> __device__ __forceinline__ cplx vals_to_T<cplx>(const double *v) { return make_cplx(v[0], v[1]); }
+template <class T> __device__ __forceinline__ T shfl_T(T v, int src);
+template <> __device__ __forceinline__ double shfl_T<double>(double v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) {
+  return make_cplx(__shfl(v.re, src, 64), __shfl(v.im, src, 64));
+}
+
+template <class T> struct DotChunk { static constexpr int CH = 16; };
+template <> struct DotChunk<cplx> { static constexpr int CH = 8; };
+
+// Accumulate one row pack into the chunk's projection sums; columns cb..cb+CH-1 of the window.
+template <class T, bool GRAM>
+__device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t n, int c0, int dir, int nd,
+                                                int cb, int64_t i, bool al, const Pack<T> &yv, const Pack<T> &xv,
+                                                T *accd, T *accg) {
+  constexpr int N = Pack<T>::N;
+  constexpr int CH = DotChunk<T>::CH;
+  Pack<T> vv[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (cb + c < nd) vv[c] = ld_pack(V + (int64_t)(c0 + dir * (cb + c)) * ldv, i, n, al);
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (cb + c < nd) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        ST<T>::cfma(accd[c], vv[c].v[k], yv.v[k]);
+        if (GRAM) ST<T>::cfma(accg[c], vv[c].v[k], xv.v[k]);
+      }
+    }
+}
+
+// workgroup reduction of a chunk's accumulators and publication of the per-workgroup partials
+template <class T, bool GRAM>
+__device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg, int cb, int nd, double *part,
+                                                   double (*red_s)[DotChunk<T>::CH * ST<T>::nreal * (GRAM ? 2 : 1)]) {
+  constexpr int CH = DotChunk<T>::CH;
+  constexpr int NR = ST<T>::nreal;
+  constexpr int NSETS = GRAM ? 2 : 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    double tmp[NR];
+    acc_to_vals<T>(accd[c], tmp);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const double s = wave_sum(tmp[r]);
+      if (lane == 0) red_s[wave][c * NR + r] = s;
+    }
+    if (GRAM) {
+      acc_to_vals<T>(accg[c], tmp);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const double s = wave_sum(tmp[r]);
+        if (lane == 0) red_s[wave][CH * NR + c * NR + r] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CH * NR * NSETS) {
+    const int set = threadIdx.x / (CH * NR), w = threadIdx.x % (CH * NR), c = w / NR, r = w % NR;
+    if (cb + c < nd) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < BLOCK / 64; ++q) s += red_s[q][threadIdx.x];
+      const int v = set * nd * NR + (cb + c) * NR + r;
+      publish_f64(part + (size_t)v * MAX_GRID + blockIdx.x, s);
+    }
+  }
+  __syncthreads();
+}
+
+// Epilogue of a projection pass, run by the last workgroup only (all BLOCK threads):
+// turns the reduced sums vals_s into the Hessenberg column of this step.
+//   STRICT / LANCZOS: one column, h = coeff(U, d)                       (arnoldi.jl:302, :397)
+//   LOWSYNC: h = (I + L)^-1 d, L = strict lower triangle of V^H V on the window -- algebraically
+//            the modified Gram-Schmidt coefficients  h_i = <v_i, y - sum_{k<i} h_k v_k>.
+template <class T>
+__device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s) {
+  constexpr int NR = ST<T>::nreal;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (a.mode != DOTS_LOWSYNC) {
+    if (threadIdx.x == 0) {
+      T h = vals_to_T<T>(vals_s);
+      if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
+      a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh] = h;
+      a.hcoef[0] = h;
+      if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
+        a.hcoef[1] = ST<T>::real_only(a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh]);
+    }
+    return;
+  }
+  const int nd = a.nd;  // <= LOWSYNC_MAX, dir == +1, newest column (v_j) is window index nd-1
+  for (int e = threadIdx.x; e < nd * (nd - 1) / 2; e += BLOCK) {
+    int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);   // unpack e -> (i, k), k < i
+    while (i * (i - 1) / 2 > e) --i;
+    while ((i + 1) * i / 2 <= e) ++i;
+    const int k = e - i * (i - 1) / 2;
+    T g;
+    if (i == nd - 1) {  // <v_j, v_ck> = conj(<v_ck, v_j>): the Gram row computed in this pass
+      g = ST<T>::conj(vals_to_T<T>(vals_s + nd * NR + k * NR));
+      a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg] = g;
+    } else {
+      g = a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg];
+    }
+    gs_s[e] = g;
+  }
+  __syncthreads();
+  if (wave == 0) {  // forward substitution, lane i owns row i
+    T sv = (lane < nd) ? vals_to_T<T>(vals_s + lane * NR) : ST<T>::zero();
+    for (int k = 0; k < nd; ++k) {
+      T hk = shfl_T<T>(sv, k);
+      if (a.real_coeff) hk = ST<T>::real_only(hk);
+      if (lane > k && lane < nd) ST<T>::nfma(sv, hk, gs_s[lane * (lane - 1) / 2 + k]);
+    }
+    if (a.real_coeff) sv = ST<T>::real_only(sv);
+    if (lane < nd) {
+      a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh] = sv;
+      a.hcoef[lane] = sv;
+    }
+  }
+}
+
+}  // namespace dev
+}  // namespace expv_mi

@@ -6,7 +6,10 @@ namespace expv_mi {
 namespace dev {
 
 constexpr int BLOCK = 256;        // 4 wavefronts of 64
-constexpr int MAX_GRID = 1024;    // 4 workgroups per CU on 256 CUs; grid-stride beyond
+constexpr int GROUP_SIZE = 64;    // workgroups per stage-1 reduction group
+constexpr int MAX_GROUPS = 32;    // stage-2 fan-in
+constexpr int MAX_GRID = GROUP_SIZE * MAX_GROUPS;   // 2048 workgroups = 8 per CU; grid-stride beyond
+constexpr int MAX_RED_VALUES = 4 * 64;              // LOWSYNC_MAX columns x (d, gram) x (re, im)
 constexpr int LOWSYNC_MAX = 64;   // longest window the in-kernel triangular solve handles
 
 enum DotsMode { DOTS_STRICT = 0, DOTS_LOWSYNC = 1, DOTS_LANCZOS = 2 };
@@ -17,7 +20,8 @@ struct DotsArgs {
   const T *y;                          // vector being orthogonalised (A*v_j)
   const T *x;                          // v_j, for the Gram row (LOWSYNC) -- may be null
   int c0, dir, nd;                     // window columns c0 + dir*i, i < nd (0-based)
-  double *part;                        // partial sums, [value][MAX_GRID]
+  double *part;                        // per-workgroup partial sums, [value][MAX_GRID]
+  double *gpart;                       // per-group partial sums, [value][MAX_GROUPS]
   StepState *st;
   int mode, real_coeff;
   T *Hdev; int ldh; int jcol;          // coefficients go to Hdev[col, jcol]
@@ -28,11 +32,12 @@ struct DotsArgs {
 template <class T>
 struct UpdateArgs {
   const T *V; int64_t ldv; int64_t n;
-  T *y;                                // in/out
-  int c0, dir, nd;                     // y -= sum_i hcoef[i] * V[:, c0+dir*i]
+  T *y;                                // out (and in, when yin is null)
+  const T *yin;                        // optional separate input vector
+  int c0, dir, nd;                     // y = yin - sum_i hcoef[i] * V[:, c0+dir*i]
   const T *hcoef;
   int do_norm;                         // also reduce ||y||^2 -> st->hnorm, Hdev[jcol+1, jcol], breakdown
-  double *part;
+  double *part, *gpart;
   StepState *st;
   T *Hdev; int ldh; int jcol;
   double tol;
@@ -41,7 +46,7 @@ struct UpdateArgs {
 
 int grid_for(int64_t n, int rows_per_block);
 
-template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part, StepState *st);
+template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st);
 template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t n, double scal, int divide);
 template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);
 template <class T> void fill_zero(hipStream_t s, T *dst, int64_t n);
@@ -55,6 +60,32 @@ void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T
 template <class T>
 void aug_apply(hipStream_t s, int64_t n, int p, const T *B, int64_t ldb, const T *x, T *y, const StepState *st,
                int step);
+
+// SELL-C-sigma storage (C = 64 * lanes-worth of 16 B: 128 rows for fp64, 64 for complex): slot-major
+// inside a slice, so lane l reads 16 B of values for ITS rows from one coalesced 1 KiB line per slot.
+template <class T>
+struct SellView {
+  const int64_t *slice_off;   // [nslices + 1], in entries
+  const int32_t *col;
+  const T *val;
+  int64_t nslices;
+};
+template <class T>
+void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step);
+
+// fused Krylov half-step A: v_j = u / beta_{j-1};  y = A v_j;  projection sums of y (and the Gram row
+// of v_j) against the window of V -- one pass, one grid reduction (arnoldi.jl:185, :302, :306 fused)
+template <class T>
+struct FusedAArgs {
+  SellView<T> A;
+  const T *u;        // unnormalised previous vector (b itself on the first step)
+  T *ybuf;           // out: A * v_j
+  DotsArgs<T> d;     // d.V/ldv/n, window, reduction buffers, epilogue targets; d.y = ybuf, d.x = V[:, jcol]
+  int step;
+};
+template <class T> void fused_a(hipStream_t s, const FusedAArgs<T> &a);
+// V[:, m_done] = u / beta_{m_done} after the loop (the column index comes from the device state)
+template <class T> void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);
 template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);

@@ -19,91 +19,10 @@
 //   K8  arnoldi.jl:195-202       aug_apply
 //   K10-K12 krylov_phiv.jl:229-244,641-649   combine
 //   K13-K14 krylov_phiv_adaptive.jl:353-362,425-443   lincomb
-#include "kernels.h"
+#include "kernel_common.h"
 
 namespace expv_mi {
 namespace dev {
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-template <class T>
-struct __attribute__((aligned(16))) Pack {
-  static constexpr int N = 16 / sizeof(T);
-  T v[N];
-};
-
-template <class T>
-__device__ __forceinline__ Pack<T> ld_pack(const T *__restrict__ p, int64_t i, int64_t n, bool al) {
-  Pack<T> r;
-  if (al && i + Pack<T>::N <= n) {
-    r = *reinterpret_cast<const Pack<T> *>(p + i);
-  } else {
-#pragma unroll
-    for (int k = 0; k < Pack<T>::N; ++k) r.v[k] = (i + k < n) ? p[i + k] : ST<T>::zero();
-  }
-  return r;
-}
-template <class T>
-__device__ __forceinline__ void st_pack(T *__restrict__ p, int64_t i, int64_t n, bool al, const Pack<T> &r) {
-  if (al && i + Pack<T>::N <= n) {
-    *reinterpret_cast<Pack<T> *>(p + i) = r;
-  } else {
-#pragma unroll
-    for (int k = 0; k < Pack<T>::N; ++k)
-      if (i + k < n) p[i + k] = r.v[k];
-  }
-}
-__device__ __forceinline__ bool is_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-__device__ __forceinline__ double wave_sum(double v) {  // total lands in lane 0
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-
-// write-through (sc1) publication / L1-bypassing read of one double: the inter-workgroup hand-off
-// form of cdna_hip_programming.md §6 Guideline 16 (R1) -- no fences needed on either side.
-__device__ __forceinline__ void publish_f64(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double consume_f64(const double *p) {
-  unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-  return __longlong_as_double((long long)u);
-}
-
-// After every wave has drained its stores: one ticket per workgroup; true in the last arriver.
-__device__ __forceinline__ bool last_block_arrives(StepState *st, int *flag_s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int last = (t == gridDim.x * gridDim.y - 1);
-    if (last) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag_s = last;
-  }
-  __syncthreads();
-  return *flag_s != 0;
-}
-
-__device__ __forceinline__ bool step_skipped(const StepState *st, int step) {
-  // after a happy breakdown at step m_done the remaining launches of the call are no-ops
-  return st != nullptr && st->breakdown != 0 && step > st->m_done;
-}
-
-// reduce `nvals` per-block partial values (layout part[v*MAX_GRID + b]) into vals_s[v]; all 256 threads
-__device__ __forceinline__ void reduce_partials(const double *part, int nblk, int nvals, double *vals_s) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int v = wave; v < nvals; v += BLOCK / 64) {
-    double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += consume_f64(part + (size_t)v * MAX_GRID + b);
-    s = wave_sum(s);
-    if (lane == 0) vals_s[v] = s;
-  }
-  __syncthreads();
-}
 
 int grid_for(int64_t n, int rows_per_block) {
   int64_t g = (n + rows_per_block - 1) / rows_per_block;
@@ -116,8 +35,10 @@ int grid_for(int64_t n, int rows_per_block) {
 // K1: sum of squares (norm(b), arnoldi.jl:233) and scaled copies
 // ------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(BLOCK) void k_sumsq(const T *__restrict__ x, int64_t n, double *part, StepState *st) {
+__global__ __launch_bounds__(BLOCK) void k_sumsq(const T *__restrict__ x, int64_t n, double *part, double *gpart,
+                                                 StepState *st) {
   __shared__ double red_s[BLOCK / 64];
+  __shared__ double vals_s[1];
   __shared__ int flag_s;
   constexpr int N = Pack<T>::N;
   const bool al = is_al16(x);
@@ -127,24 +48,19 @@ __global__ __launch_bounds__(BLOCK) void k_sumsq(const T *__restrict__ x, int64_
 #pragma unroll
     for (int k = 0; k < N; ++k) acc += ST<T>::abs2(p.v[k]);
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < BLOCK / 64; ++w) s += red_s[w];
-    publish_f64(part + blockIdx.x, s);
-  }
-  if (last_block_arrives(st, &flag_s)) {
-    __shared__ double vals_s[1];
-    reduce_partials(part, gridDim.x, 1, vals_s);
-    if (threadIdx.x == 0) st->sumsq = vals_s[0];
+  const double s = block_sum(acc, red_s);
+  if (threadIdx.x == 0) publish_f64(part + blockIdx.x, s);
+  if (hier_reduce(st, part, gpart, 1, vals_s, &flag_s)) {
+    if (threadIdx.x == 0) {
+      st->sumsq = vals_s[0];
+      st->hnorm = sqrt(vals_s[0]);    // beta_0: the fused first step normalises with it
+    }
   }
 }
 template <class T>
-void sumsq(hipStream_t s, const T *x, int64_t n, double *part, StepState *st) {
+void sumsq(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st) {
   const int g = grid_for(n, BLOCK * Pack<T>::N * 4);
-  hipLaunchKernelGGL(k_sumsq<T>, dim3(g), dim3(BLOCK), 0, s, x, n, part, st);
+  hipLaunchKernelGGL(k_sumsq<T>, dim3(g), dim3(BLOCK), 0, s, x, n, part, gpart, st);
 }
 
 template <class T>
@@ -316,31 +232,6 @@ void aug_apply(hipStream_t s, int64_t n, int p, const T *B, int64_t ldb, const T
 // ------------------------------------------------------------------------------------------
 // K3 (+K7): all projection coefficients of one Krylov step in ONE pass over the window of V.
 // ------------------------------------------------------------------------------------------
-template <class T> struct DotChunk { static constexpr int CH = 16; };
-template <> struct DotChunk<cplx> { static constexpr int CH = 8; };
-
-template <class T>
-__device__ __forceinline__ void acc_to_vals(const T &a, double *out);
-template <>
-__device__ __forceinline__ void acc_to_vals<double>(const double &a, double *out) { out[0] = a; }
-template <>
-__device__ __forceinline__ void acc_to_vals<cplx>(const cplx &a, double *out) { out[0] = a.re; out[1] = a.im; }
-template <class T>
-__device__ __forceinline__ T vals_to_T(const double *v);
-template <>
-__device__ __forceinline__ double vals_to_T<double>(const double *v) { return v[0]; }
-template <>
-__device__ __forceinline__ cplx vals_to_T<cplx>(const double *v) { return make_cplx(v[0], v[1]); }
-
-template <class T>
-__device__ __forceinline__ T shfl_T(T v, int src);
-template <>
-__device__ __forceinline__ double shfl_T<double>(double v, int src) { return __shfl(v, src, 64); }
-template <>
-__device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) {
-  return make_cplx(__shfl(v.re, src, 64), __shfl(v.im, src, 64));
-}
-
 template <class T, bool GRAM>
 __global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
   constexpr int N = Pack<T>::N;
@@ -348,15 +239,12 @@ __global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
   constexpr int NR = ST<T>::nreal;
   constexpr int NSETS = GRAM ? 2 : 1;
   __shared__ double red_s[BLOCK / 64][CH * NR * NSETS];
-  __shared__ double vals_s[2 * 128 * 2];
+  __shared__ double vals_s[MAX_RED_VALUES];
   __shared__ int flag_s;
   __shared__ T gs_s[GRAM ? (LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2) : 1];
   if (step_skipped(a.st, step)) return;
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y) && (!GRAM || is_al16(a.x));
   const int64_t tile = (int64_t)BLOCK * N;
-
   for (int cb = 0; cb < a.nd; cb += CH) {
     T accd[CH], accg[GRAM ? CH : 1];
 #pragma unroll
@@ -371,104 +259,13 @@ __global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
       const Pack<T> yv = ld_pack(a.y, i, a.n, al);
       Pack<T> xv;
       if (GRAM) xv = ld_pack(a.x, i, a.n, al);
-      Pack<T> vv[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (cb + c < a.nd) vv[c] = ld_pack(a.V + (int64_t)(a.c0 + a.dir * (cb + c)) * a.ldv, i, a.n, al);
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (cb + c < a.nd) {
-#pragma unroll
-          for (int k = 0; k < N; ++k) {
-            ST<T>::cfma(accd[c], vv[c].v[k], yv.v[k]);
-            if (GRAM) ST<T>::cfma(accg[c], vv[c].v[k], xv.v[k]);
-          }
-        }
+      else xv = yv;
+      dots_accumulate<T, GRAM>(a.V, a.ldv, a.n, a.c0, a.dir, a.nd, cb, i, al, yv, xv, accd, accg);
     }
-    // workgroup reduction of the chunk's CH (x2) values
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      double tmp[NR];
-      acc_to_vals<T>(accd[c], tmp);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const double s = wave_sum(tmp[r]);
-        if (lane == 0) red_s[wave][c * NR + r] = s;
-      }
-      if (GRAM) {
-        acc_to_vals<T>(accg[c], tmp);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const double s = wave_sum(tmp[r]);
-          if (lane == 0) red_s[wave][CH * NR + c * NR + r] = s;
-        }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < CH * NR * NSETS) {
-      const int set = threadIdx.x / (CH * NR), w = threadIdx.x % (CH * NR), c = w / NR, r = w % NR;
-      if (cb + c < a.nd) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < BLOCK / 64; ++q) s += red_s[q][threadIdx.x];
-        const int v = set * a.nd * NR + (cb + c) * NR + r;
-        publish_f64(a.part + (size_t)v * MAX_GRID + blockIdx.x, s);
-      }
-    }
-    __syncthreads();
+    dots_publish_chunk<T, GRAM>(accd, accg, cb, a.nd, a.part, red_s);
   }
-
-  if (!last_block_arrives(a.st, &flag_s)) return;
-
-  // ---- epilogue in the last workgroup: coefficients of this step ---------------------------
-  const int nvals = a.nd * NR * NSETS;
-  reduce_partials(a.part, gridDim.x, nvals, vals_s);
-  if (!GRAM) {
-    // STRICT / LANCZOS: nd == 1 (one column, arnoldi.jl:302 / :397)
-    if (threadIdx.x == 0) {
-      T h = vals_to_T<T>(vals_s);
-      if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
-      a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh] = h;
-      a.hcoef[0] = h;
-      if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
-        a.hcoef[1] = ST<T>::real_only(a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh]);
-    }
-    return;
-  }
-  if (GRAM) {
-    // LOWSYNC: h = (I + L)^-1 d over the window, L = strict lower triangle of V^H V.
-    const int nd = a.nd;  // <= LOWSYNC_MAX, dir == +1, newest column (v_j) is window index nd-1
-    for (int e = threadIdx.x; e < nd * (nd - 1) / 2; e += BLOCK) {
-      // unpack e -> (i, k), k < i, packed row-major lower triangle
-      int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);
-      while (i * (i - 1) / 2 > e) --i;
-      while ((i + 1) * i / 2 <= e) ++i;
-      const int k = e - i * (i - 1) / 2;
-      T g;
-      if (i == nd - 1) {
-        // <v_j, v_ck> = conj(<v_ck, v_j>) : the Gram row computed in this pass
-        g = ST<T>::conj(vals_to_T<T>(vals_s + nd * NR + k * NR));
-        a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg] = g;
-      } else {
-        g = a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg];
-      }
-      gs_s[e] = g;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      T sv = (lane < nd) ? vals_to_T<T>(vals_s + lane * NR) : ST<T>::zero();
-      for (int k = 0; k < nd; ++k) {
-        T hk = shfl_T<T>(sv, k);
-        if (a.real_coeff) hk = ST<T>::real_only(hk);
-        if (lane > k && lane < nd) ST<T>::nfma(sv, hk, gs_s[lane * (lane - 1) / 2 + k]);
-      }
-      if (a.real_coeff) sv = ST<T>::real_only(sv);
-      if (lane < nd) {
-        a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh] = sv;
-        a.hcoef[lane] = sv;
-      }
-    }
-  }
+  if (!hier_reduce(a.st, a.part, a.gpart, a.nd * NR * NSETS, vals_s, &flag_s)) return;
+  projection_epilogue<T>(a, vals_s, gs_s);
 }
 
 template <class T>
@@ -491,13 +288,14 @@ __global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a) {
   __shared__ double vals_s[1];
   __shared__ int flag_s;
   if (step_skipped(a.st, a.step)) return;
-  const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y);
+  const T *yin = a.yin ? a.yin : a.y;
+  const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y) && is_al16(yin);
   const int64_t tile = (int64_t)BLOCK * N;
   double nrm = 0.0;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < a.n; base += (int64_t)gridDim.x * tile) {
     const int64_t i = base + (int64_t)threadIdx.x * N;
     if (i >= a.n) break;
-    Pack<T> yv = ld_pack(a.y, i, a.n, al);
+    Pack<T> yv = ld_pack(yin, i, a.n, al);
     int c = 0;
     for (; c + UN <= a.nd; c += UN) {
       Pack<T> vv[UN];
@@ -516,23 +314,16 @@ __global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a) {
 #pragma unroll
       for (int k = 0; k < N; ++k) ST<T>::nfma(yv.v[k], h, vv.v[k]);
     }
-    if (a.nd > 0) st_pack(a.y, i, a.n, al, yv);
+    if (a.nd > 0 || yin != a.y) st_pack(a.y, i, a.n, al, yv);
     if (a.do_norm) {
 #pragma unroll
       for (int k = 0; k < N; ++k) nrm += ST<T>::abs2(yv.v[k]);
     }
   }
   if (!a.do_norm) return;
-  nrm = wave_sum(nrm);
-  if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = nrm;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < BLOCK / 64; ++w) s += red_s[w];
-    publish_f64(a.part + blockIdx.x, s);
-  }
-  if (!last_block_arrives(a.st, &flag_s)) return;
-  reduce_partials(a.part, gridDim.x, 1, vals_s);
+  const double bs = block_sum(nrm, red_s);
+  if (threadIdx.x == 0) publish_f64(a.part + blockIdx.x, bs);
+  if (!hier_reduce(a.st, a.part, a.gpart, 1, vals_s, &flag_s)) return;
   if (threadIdx.x == 0) {
     const double beta = sqrt(vals_s[0]);               // H[j+1, j] = norm(y), arnoldi.jl:305
     a.st->sumsq = vals_s[0];
@@ -677,7 +468,7 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
 // explicit instantiations
 // ------------------------------------------------------------------------------------------
 #define INST(T)                                                                                                    \
-  template void sumsq<T>(hipStream_t, const T *, int64_t, double *, StepState *);                                  \
+  template void sumsq<T>(hipStream_t, const T *, int64_t, double *, double *, StepState *);                        \
   template void scale_copy<T>(hipStream_t, T *, const T *, int64_t, double, int);                                  \
   template void scale_by_state<T>(hipStream_t, T *, int64_t, const StepState *, int);                              \
   template void fill_zero<T>(hipStream_t, T *, int64_t);                                                           \

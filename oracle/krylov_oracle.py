@@ -470,6 +470,8 @@ def exponential_(A: np.ndarray, balance: bool = True) -> np.ndarray:
     assert A.shape[0] == A.shape[1]
     if n == 0:
         return A
+    if not np.all(np.isfinite(A)):           # LAPACK.gebal!'s chkfinite; balancing never terminates on NaN
+        raise ValueError("ArgumentError: matrix contains Infs or NaNs")
     if balance:
         ilo, ihi, scale = gebal(A)
     nA = float(np.linalg.norm(A, 1))

@@ -94,3 +94,11 @@ def test_host_phiv_dense(eu, T):
     w = np.empty((9, 5), dtype=T, order="F")
     ko.phiv_dense_(w, A, v, 4)
     assert np.abs(eu.host_phiv_dense(A, v, 4) - w).max() < 1e-13
+
+
+def test_host_expm_rejects_nan(eu):
+    """Balancing never terminates on NaN input (LAPACK.gebal! guards with chkfinite): must raise, not hang."""
+    with pytest.raises(eu.ExpvMIError):
+        eu.host_expm(np.full((3, 3), np.nan))
+    with pytest.raises(ValueError):
+        ko.exponential_(np.full((3, 3), np.nan))
