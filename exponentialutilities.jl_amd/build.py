@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libexpv_mi.so")
 SOURCES = ["kernels.hip", "fused.hip", "engine_core.hip", "engine_drivers.hip", "capi.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma"]   # host small-dense exp: every MI355X host is x86-64-v3
 
 
 def _hipcc():

@@ -141,6 +141,9 @@ struct Ks {
   int ldg = 0;
   int gram_rows = 0;   // leading basis vectors whose Gram rows are valid
   DevBuf hcoef, part, gpart, state;
+  void *pin = nullptr;   // pinned host staging for the Hessenberg / step-state read-back
+  size_t pin_bytes = 0;
+  ~Ks() { if (pin) (void)hipHostFree(pin); }
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
   int64_t rows() const { return n + augmented; }
 };

@@ -215,17 +215,21 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       }
       src = reinterpret_cast<const T *>(aug->w);
     }
+    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switch for profiling
+    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
+                (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
     {
       ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
       dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
     }
-    StepState h;
-    read_state<T>(ks, &h);
-    ks.beta = std::sqrt(h.sumsq + extra);
     ks.gram_rows = 0;
-    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switch for profiling
-    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
-                (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+    if (use_fused) {
+      ks.beta = 1.0;   // placeholder: the true value is read back with H after the loop (no sync here)
+    } else {
+      StepState h;
+      read_state<T>(ks, &h);
+      ks.beta = std::sqrt(h.sumsq + extra);
+    }
     if (ks.beta != 0.0 && use_fused) {
       ks.gram_rows = 1;   // v_1 = b / beta is produced by the first fused half-step
     } else if (ks.beta != 0.0) {
@@ -251,11 +255,14 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
 
   // reset the device step state; zero the columns of Hdev this call will fill
   {
-    StepState z;
-    std::memset(&z, 0, sizeof(z));
-    z.m_done = jstart - 1;
-    z.hnorm = ks.beta;   // beta_0: the first fused half-step normalises b with it
-    HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+    if (!use_fused) {   // fused path: the sumsq epilogue left {hnorm = beta_0, m_done = 0} on the device
+      StepState z;
+      std::memset(&z, 0, sizeof(z));
+      z.m_done = jstart - 1;
+      z.hnorm = ks.beta;
+      z.beta0sq = ks.beta * ks.beta;
+      HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+    }
     HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
                             sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
   }
@@ -358,11 +365,23 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   }
 
   // ---- one host synchronisation per factorisation: state + Hessenberg --------------------
-  StepState h;
-  std::vector<T> Hh((size_t)ks.ldhd * (m + 1));
-  HIPCHECK(hipMemcpyAsync(Hh.data(), Hd, sizeof(T) * Hh.size(), hipMemcpyDeviceToHost, s));
-  read_state<T>(ks, &h);
-  const int jlast = h.breakdown ? h.m_done : m;
+  const size_t hbytes = sizeof(T) * (size_t)ks.ldhd * (m + 1);
+  if (ks.pin_bytes < hbytes + sizeof(StepState)) {
+    if (ks.pin) (void)hipHostFree(ks.pin);
+    ks.pin = nullptr;
+    ks.pin_bytes = sizeof(T) * (size_t)ks.ldhd * (ks.maxiter + 1) + sizeof(StepState);
+    HIPCHECK(hipHostMalloc(&ks.pin, ks.pin_bytes, hipHostMallocDefault));
+  }
+  const T *Hh = reinterpret_cast<const T *>(ks.pin);   // Hessenberg columns as the device left them
+  StepState &h = *reinterpret_cast<StepState *>(reinterpret_cast<char *>(ks.pin) + ks.pin_bytes - sizeof(StepState));
+  HIPCHECK(hipMemcpyAsync(ks.pin, Hd, hbytes, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(&h, st, sizeof(StepState), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  if (use_fused) {
+    ks.beta = std::sqrt(h.beta0sq);
+    if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
+  }
+  const int jlast = (h.breakdown == 1) ? h.m_done : m;
   auto toc = [](const T &v) -> cd {
     if constexpr (ST<T>::is_complex) return cd(v.re, v.im);
     else return cd(v, 0.0);
@@ -384,7 +403,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       setH(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]));
     }
   }
-  if (h.breakdown) {
+  if (h.breakdown == 1) {
     ks.m = h.m_done;
     ks.wasbreakdown = true;
   }
@@ -432,8 +451,12 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
         cbuf[(size_t)q * mcols + i] = re;
       }
     }
-  DevBuf cdev(cbuf.size() * sizeof(double) + 16);
-  HIPCHECK(hipMemcpyAsync(cdev.p, cbuf.data(), cbuf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const bool by_value = (ncols == 1 && mcols <= dev::COEF_BY_VALUE_MAX && (w_loc == EXPV_MI_HOST || ldw >= rows || true));
+  DevBuf cdev;
+  if (!by_value) {
+    cdev.alloc(cbuf.size() * sizeof(double) + 16);
+    HIPCHECK(hipMemcpyAsync(cdev.p, cbuf.data(), cbuf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
   DevBuf wtmp;
   void *Wd = W;
   int64_t ldwd = ldw;
@@ -445,7 +468,18 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   {
     ProfScope ps(c, EXPV_MI_K_COMBINE);
     const int mc = std::max(mcols, 0);
-    if (!Cc)
+    if (by_value) {
+      if (!Cc) {
+        dev::CoefVec<double> cv;
+        for (int i = 0; i < mc; ++i) cv.c[i] = cbuf[i];
+        dev::combine1<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, (double *)Wd);
+      } else {
+        dev::CoefVec<cplx> cv;
+        for (int i = 0; i < mc; ++i) cv.c[i] = make_cplx(cbuf[2 * i], cbuf[2 * i + 1]);
+        if (!Tc) dev::combine1<double, cplx>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, (cplx *)Wd);
+        else dev::combine1<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cv, scale, (cplx *)Wd);
+      }
+    } else if (!Cc)
       dev::combine<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cdev.as<double>(), mcols, ncols,
                                    scale, (double *)Wd, ldwd);
     else if (!Tc)

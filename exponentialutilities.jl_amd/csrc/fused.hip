@@ -91,7 +91,7 @@ void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y,
 
 // ---- fused half-step A ----------------------------------------------------------------------
 template <class T, bool GRAM>
-__global__ __launch_bounds__(BLOCK) void k_fused_a(FusedAArgs<T> fa) {
+__global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_fused_a(FusedAArgs<T> fa, int spw) {
   constexpr int N = Pack<T>::N;
   constexpr int SH = 64 * N;
   constexpr int CH = DotChunk<T>::CH;
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused_a(FusedAArgs<T> fa) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
     }
-    for (int64_t sb = (int64_t)blockIdx.x * (BLOCK / 64); sb < fa.A.nslices; sb += (int64_t)gridDim.x * (BLOCK / 64)) {
-      const int64_t slice = sb + wave;
-      if (slice >= fa.A.nslices) continue;
+    const int64_t s0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * spw;
+    const int64_t s1 = (s0 + spw < fa.A.nslices) ? s0 + spw : fa.A.nslices;
+    for (int64_t slice = s0; slice < s1; ++slice) {
       const int64_t i = slice * SH + (int64_t)lane * N;
       Pack<T> yv, xv;
       if (cb == 0) {
@@ -149,15 +149,28 @@ __global__ __launch_bounds__(BLOCK) void k_fused_a(FusedAArgs<T> fa) {
   projection_epilogue<T>(a, vals_s, gs_s);
 }
 
+// slices are handed out in contiguous, equal runs per WAVE so that every resident wave streams the
+// same number of bytes (a grid larger than the chip would run a second, partially filled round)
+static void plan_slices(int64_t nslices, int max_blocks, int *nblocks, int *spw) {
+  const int64_t nwaves = (int64_t)max_blocks * (BLOCK / 64);
+  int64_t per = (nslices + nwaves - 1) / nwaves;
+  if (per < 1) per = 1;
+  const int64_t waves = (nslices + per - 1) / per;
+  int64_t nb = (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (nb < 1) nb = 1;
+  *nblocks = (int)nb;
+  *spw = (int)per;
+}
 template <class T>
 void fused_a(hipStream_t s, const FusedAArgs<T> &a) {
-  int64_t g = (a.A.nslices + (BLOCK / 64) - 1) / (BLOCK / 64);
-  if (g > MAX_GRID) g = MAX_GRID;
-  if (g < 1) g = 1;
-  if (a.d.mode == DOTS_LOWSYNC)
-    hipLaunchKernelGGL((k_fused_a<T, true>), dim3((int)g), dim3(BLOCK), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_fused_a<T, false>), dim3((int)g), dim3(BLOCK), 0, s, a);
+  int nb, spw;
+  if (a.d.mode == DOTS_LOWSYNC) {
+    plan_slices(a.A.nslices, resident_blocks((const void *)k_fused_a<T, true>), &nb, &spw);
+    hipLaunchKernelGGL((k_fused_a<T, true>), dim3(nb), dim3(BLOCK), 0, s, a, spw);
+  } else {
+    plan_slices(a.A.nslices, resident_blocks((const void *)k_fused_a<T, false>), &nb, &spw);
+    hipLaunchKernelGGL((k_fused_a<T, false>), dim3(nb), dim3(BLOCK), 0, s, a, spw);
+  }
 }
 
 // V[:, m_done] = u / beta_{m_done}: the normalisation of the LAST step of the call (arnoldi.jl:306)
@@ -165,6 +178,7 @@ template <class T>
 __global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int64_t n, const T *__restrict__ u,
                                                          const StepState *st) {
   constexpr int N = Pack<T>::N;
+  if (st->breakdown == 2) return;   // zero starting vector: V stays untouched (arnoldi.jl:366)
   const double beta = st->hnorm;
   T *dst = V + (int64_t)st->m_done * ldv;
   const bool al = ((ldv * sizeof(T)) % 16 == 0) && is_al16(V) && is_al16(u);

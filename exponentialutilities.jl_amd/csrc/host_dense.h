@@ -89,13 +89,25 @@ struct Balance {
   std::vector<double> scale;   // permutation indices outside [ilo,ihi], scale factors inside
 };
 
+inline double re_of(double x) { return x; }
+inline double im_of(double) { return 0.0; }
+inline double re_of(const cd &x) { return x.real(); }
+inline double im_of(const cd &x) { return x.imag(); }
+
 template <class S>
 inline double nrm2_strided(const S *x, int n, int inc) {
-  // scaled 2-norm (no overflow), like BLAS nrm2
+  // plain sum of squares first (what balancing sees is O(|H|)); the scaled BLAS-style form only
+  // when that over/underflows
+  double ss = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const S v = x[(size_t)i * inc];
+    ss += re_of(v) * re_of(v) + im_of(v) * im_of(v);
+  }
+  if (ss > 1e-280 && ss < 1e280) return std::sqrt(ss);
   double scale = 0, ssq = 1;
   for (int i = 0; i < n; ++i) {
     const S v = x[(size_t)i * inc];
-    const double parts[2] = {std::real(cd(v)), std::imag(cd(v))};
+    const double parts[2] = {re_of(v), im_of(v)};
     for (double p : parts) {
       if (p != 0) {
         const double a = std::fabs(p);

@@ -82,46 +82,98 @@ __device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected
   return *flag_s != 0;
 }
 
-// sum of base[0..count) by a quad of lanes (q = lane & 3): each lane adds a contiguous quarter in
-// index order, then two butterfly steps -- a fixed summation tree.  All 4 lanes get the total.
-__device__ __forceinline__ double quad_sum(const double *base, int count, int q) {
-  const int per = (count + 3) >> 2;
-  const int b0 = q * per;
-  double s = 0.0;
-#pragma unroll 8
-  for (int i = 0; i < per; ++i) {
-    const int b = b0 + i;
-    const double v = (b < count) ? consume_f64(base + b) : 0.0;
-    s += v;
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  return s;
-}
-
 // Hierarchical grid reduction of nvals values.  Precondition: this workgroup has published
 // part[v*MAX_GRID + blockIdx.x] for every v < nvals.  Returns true in exactly one workgroup, with
 // vals_s[v] = total (visible to all its threads).  Must be called by all threads of every workgroup.
+// Each stage reads one partial per LANE (all loads of a round independent, 4 values in flight per
+// wave) and sums them with the fixed wave_sum tree: reproducible, and no serial chain of L2 misses.
+__device__ __forceinline__ void reduce_stage(const double *src, size_t vstride, int count, int nvals, double *dst,
+                                             size_t dstride, bool to_lds) {
+  // `count` <= 64 partials per value, one per lane; RB values per wave in flight at once
+  constexpr int RB = 8;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v0 = wave * RB; v0 < nvals; v0 += RB * (BLOCK / 64)) {
+    double x[RB];
+#pragma unroll
+    for (int k = 0; k < RB; ++k)
+      x[k] = (v0 + k < nvals && lane < count) ? consume_f64(src + (size_t)(v0 + k) * vstride + lane) : 0.0;
+#pragma unroll
+    for (int k = 0; k < RB; ++k) {
+      const double s = wave_sum(x[k]);
+      if (lane == 0 && v0 + k < nvals) {
+        if (to_lds) dst[(size_t)(v0 + k) * dstride] = s;
+        else publish_f64(dst + (size_t)(v0 + k) * dstride, s);
+      }
+    }
+  }
+}
+// single-stage form for few values: every thread of the last workgroup sums a strided slice of the
+// nblk partials of each value (independent loads), then a workgroup reduction -- one ticket, one
+// round trip.  Fixed order: thread t adds partials t, t+256, ...; then the wave/block tree.
+__device__ __forceinline__ void reduce_flat(const double *part, int nblk, int nvals, double *vals_s, double *red_s) {
+  for (int v = 0; v < nvals; ++v) {
+    double x = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += BLOCK) x += consume_f64(part + (size_t)v * MAX_GRID + b);
+    x = wave_sum(x);
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLOCK / 64; ++w) t += red_s[w];
+      vals_s[v] = t;
+    }
+    __syncthreads();
+  }
+}
 __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double *gpart, int nvals, double *vals_s,
                                             int *flag_s) {
   const int nblk = gridDim.x;
+  if (nvals <= 2) {   // norms: 1 ticket + 1 round of loads
+    __shared__ double red2_s[BLOCK / 64];
+    if (!take_ticket(&st->ticket, (uint32_t)nblk, flag_s)) return false;
+    reduce_flat(part, nblk, nvals, vals_s, red2_s);
+    return true;
+  }
   const int g = blockIdx.x / GROUP_SIZE;
   const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
   const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
   if (!take_ticket(&st->gticket[g], (uint32_t)gsize, flag_s)) return false;
-  for (int idx = threadIdx.x; idx < nvals * 4; idx += BLOCK) {
-    const int v = idx >> 2, q = idx & 3;
-    const double s = quad_sum(part + (size_t)v * MAX_GRID + (size_t)g * GROUP_SIZE, gsize, q);
-    if (q == 0) publish_f64(gpart + (size_t)v * MAX_GROUPS + g, s);
-  }
+  reduce_stage(part + (size_t)g * GROUP_SIZE, MAX_GRID, gsize, nvals, gpart + g, MAX_GROUPS, false);
   if (!take_ticket(&st->ticket, (uint32_t)ng, flag_s)) return false;
-  for (int idx = threadIdx.x; idx < nvals * 4; idx += BLOCK) {
-    const int v = idx >> 2, q = idx & 3;
-    const double s = quad_sum(gpart + (size_t)v * MAX_GROUPS, ng, q);
-    if (q == 0) vals_s[v] = s;
-  }
+  reduce_stage(gpart, MAX_GROUPS, ng, nvals, vals_s, 1, true);
   __syncthreads();
   return true;
+}
+
+// Sum K (power of two, <= 32) per-lane values across the wave by recursive halving: at each step a
+// lane keeps one half of its values and trades the other half with lane^offset, so K values cost
+// K-1 (+ log2(64/K)) exchanges instead of 6K.  On return a[0] holds, in every lane, the wave total of
+// value index ((lane >> (6 - log2 K)) ... ) -- see wave_multi_index.
+template <int HALF, int OFF, int K>
+__device__ __forceinline__ void wave_halve(double (&a)[K], int lane) {
+  const bool hi = (lane & OFF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const double send = hi ? a[i] : a[i + HALF];
+    const double keep = hi ? a[i + HALF] : a[i];
+    a[i] = keep + __shfl_xor(send, OFF, 64);
+  }
+  if constexpr (HALF > 1) wave_halve<HALF / 2, OFF / 2, K>(a, lane);
+  else {
+#pragma unroll
+    for (int off = OFF / 2; off >= 1; off >>= 1) a[0] += __shfl_xor(a[0], off, 64);
+  }
+}
+template <int K>
+__device__ __forceinline__ void wave_reduce_multi(double (&a)[K]) {
+  wave_halve<K / 2, 32, K>(a, threadIdx.x & 63);
+}
+// index of the value whose wave total a lane holds after wave_reduce_multi<K>
+template <int K>
+__device__ __forceinline__ int wave_multi_index(int lane) {
+  int bits = 0;
+  for (int k = K; k > 1; k >>= 1) ++bits;      // log2 K
+  return (lane >> (6 - bits)) & (K - 1);
 }
 
 // block-level sum of one double per thread -> thread 0 (4 waves)
@@ -147,6 +199,11 @@ template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) {
   return make_cplx(__shfl(v.re, src, 64), __shfl(v.im, src, 64));
 }
 
+// minimum waves/SIMD requested for the projection kernels (= workgroups/CU at 256 threads): 3 keeps
+// them spill-free at <= 168 VGPRs; the balanced row partition makes the grid exactly one resident round
+#ifndef DOTS_WAVES
+#define DOTS_WAVES 3
+#endif
 template <class T> struct DotChunk { static constexpr int CH = 16; };
 template <> struct DotChunk<cplx> { static constexpr int CH = 8; };
 
@@ -157,19 +214,23 @@ __device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t
                                                 T *accd, T *accg) {
   constexpr int N = Pack<T>::N;
   constexpr int CH = DotChunk<T>::CH;
-  Pack<T> vv[CH];
+  constexpr int LB = 8;   // loads in flight per lane: 8 x 16 B; keeps the kernel at <= 128 VGPRs (4 workgroups/CU)
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
-    if (cb + c < nd) vv[c] = ld_pack(V + (int64_t)(c0 + dir * (cb + c)) * ldv, i, n, al);
+  for (int h = 0; h < CH; h += LB) {
+    Pack<T> vv[LB];
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
-    if (cb + c < nd) {
+    for (int c = 0; c < LB; ++c)
+      if (cb + h + c < nd) vv[c] = ld_pack(V + (int64_t)(c0 + dir * (cb + h + c)) * ldv, i, n, al);
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        ST<T>::cfma(accd[c], vv[c].v[k], yv.v[k]);
-        if (GRAM) ST<T>::cfma(accg[c], vv[c].v[k], xv.v[k]);
+    for (int c = 0; c < LB; ++c)
+      if (cb + h + c < nd) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          ST<T>::cfma(accd[h + c], vv[c].v[k], yv.v[k]);
+          if (GRAM) ST<T>::cfma(accg[h + c], vv[c].v[k], xv.v[k]);
+        }
       }
-    }
+  }
 }
 
 // workgroup reduction of a chunk's accumulators and publication of the per-workgroup partials
@@ -179,27 +240,18 @@ __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg,
   constexpr int CH = DotChunk<T>::CH;
   constexpr int NR = ST<T>::nreal;
   constexpr int NSETS = GRAM ? 2 : 1;
+  constexpr int K = CH * NR * NSETS;            // 16 or 32 values per lane
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double a[K];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    double tmp[NR];
-    acc_to_vals<T>(accd[c], tmp);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const double s = wave_sum(tmp[r]);
-      if (lane == 0) red_s[wave][c * NR + r] = s;
-    }
-    if (GRAM) {
-      acc_to_vals<T>(accg[c], tmp);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const double s = wave_sum(tmp[r]);
-        if (lane == 0) red_s[wave][CH * NR + c * NR + r] = s;
-      }
-    }
+    acc_to_vals<T>(accd[c], &a[c * NR]);
+    if (GRAM) acc_to_vals<T>(accg[c], &a[CH * NR + c * NR]);
   }
+  wave_reduce_multi<K>(a);
+  if ((lane & ((64 / K) - 1)) == 0) red_s[wave][wave_multi_index<K>(lane)] = a[0];
   __syncthreads();
-  if (threadIdx.x < CH * NR * NSETS) {
+  if (threadIdx.x < K) {
     const int set = threadIdx.x / (CH * NR), w = threadIdx.x % (CH * NR), c = w / NR, r = w % NR;
     if (cb + c < nd) {
       double s = 0.0;

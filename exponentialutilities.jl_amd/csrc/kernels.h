@@ -46,6 +46,14 @@ struct UpdateArgs {
 
 int grid_for(int64_t n, int rows_per_block);
 
+// Balanced contiguous partition of n rows over at most max_blocks workgroups, in units of `unit`
+// rows: every workgroup streams the same number of bytes (no second, partially filled round).
+struct RowPlan { int nblocks; int64_t rows_per_block; };
+RowPlan plan_rows(int64_t n, int unit, int max_blocks);
+int device_cus();
+// workgroups of BLOCK threads of `kernel` that fit on the chip at once (occupancy query, cached)
+int resident_blocks(const void *kernel);
+
 template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st);
 template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t n, double scal, int divide);
 template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);
@@ -94,6 +102,11 @@ template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);
 template <class TV, class TC>
 void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC *C, int ldc, int ncols,
              double scale, TC *W, int64_t ldw);
+
+constexpr int COEF_BY_VALUE_MAX = 64;
+template <class TC> struct CoefVec { TC c[COEF_BY_VALUE_MAX]; };
+template <class TV, class TC>
+void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W);
 
 // out = sum_k coef[k] * in[k]   (k < nterms <= 8); out may alias in[0]
 template <class T>

@@ -19,10 +19,44 @@
 //   K8  arnoldi.jl:195-202       aug_apply
 //   K10-K12 krylov_phiv.jl:229-244,641-649   combine
 //   K13-K14 krylov_phiv_adaptive.jl:353-362,425-443   lincomb
+#include <map>
+#include <mutex>
+
 #include "kernel_common.h"
 
 namespace expv_mi {
 namespace dev {
+
+int device_cus() {
+  static int cus = [] {
+    int d = 0, v = 256;
+    (void)hipGetDevice(&d);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return cus;
+}
+int resident_blocks(const void *kernel) {
+  static std::mutex mu;
+  static std::map<const void *, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(kernel);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb <= 0) nb = 2;
+  int total = nb * device_cus();
+  if (total > MAX_GRID) total = MAX_GRID;
+  cache[kernel] = total;
+  return total;
+}
+RowPlan plan_rows(int64_t n, int unit, int max_blocks) {
+  int64_t units = (n + unit - 1) / unit;
+  if (units < 1) units = 1;
+  int64_t nb = units < max_blocks ? units : max_blocks;
+  const int64_t upb = (units + nb - 1) / nb;
+  nb = (units + upb - 1) / upb;
+  return RowPlan{(int)nb, upb * unit};
+}
 
 int grid_for(int64_t n, int rows_per_block) {
   int64_t g = (n + rows_per_block - 1) / rows_per_block;
@@ -53,7 +87,12 @@ __global__ __launch_bounds__(BLOCK) void k_sumsq(const T *__restrict__ x, int64_
   if (hier_reduce(st, part, gpart, 1, vals_s, &flag_s)) {
     if (threadIdx.x == 0) {
       st->sumsq = vals_s[0];
+      st->beta0sq = vals_s[0];
       st->hnorm = sqrt(vals_s[0]);    // beta_0: the fused first step normalises with it
+      if (vals_s[0] == 0.0) {         // iszero(Ks.beta) && return  (arnoldi.jl:366): later launches are no-ops
+        st->breakdown = 2;
+        st->m_done = 0;
+      }
     }
   }
 }
@@ -233,7 +272,7 @@ void aug_apply(hipStream_t s, int64_t n, int p, const T *B, int64_t ldb, const T
 // K3 (+K7): all projection coefficients of one Krylov step in ONE pass over the window of V.
 // ------------------------------------------------------------------------------------------
 template <class T, bool GRAM>
-__global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
+__global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_dots(DotsArgs<T> a, int step, int64_t rpb) {
   constexpr int N = Pack<T>::N;
   constexpr int CH = DotChunk<T>::CH;
   constexpr int NR = ST<T>::nreal;
@@ -253,9 +292,8 @@ __global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
     }
-    for (int64_t base = (int64_t)blockIdx.x * tile; base < a.n; base += (int64_t)gridDim.x * tile) {
-      const int64_t i = base + (int64_t)threadIdx.x * N;
-      if (i >= a.n) break;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < a.n) ? r0 + rpb : a.n;
+    for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += tile) {
       const Pack<T> yv = ld_pack(a.y, i, a.n, al);
       Pack<T> xv;
       if (GRAM) xv = ld_pack(a.x, i, a.n, al);
@@ -270,18 +308,20 @@ __global__ __launch_bounds__(BLOCK) void k_dots(DotsArgs<T> a, int step) {
 
 template <class T>
 void dots(hipStream_t s, const DotsArgs<T> &a) {
-  const int g = grid_for(a.n, BLOCK * Pack<T>::N * 2);
-  if (a.mode == DOTS_LOWSYNC)
-    hipLaunchKernelGGL((k_dots<T, true>), dim3(g), dim3(BLOCK), 0, s, a, a.jcol + 1);
-  else
-    hipLaunchKernelGGL((k_dots<T, false>), dim3(g), dim3(BLOCK), 0, s, a, a.jcol + 1);
+  if (a.mode == DOTS_LOWSYNC) {
+    const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, resident_blocks((const void *)k_dots<T, true>));
+    hipLaunchKernelGGL((k_dots<T, true>), dim3(p.nblocks), dim3(BLOCK), 0, s, a, a.jcol + 1, p.rows_per_block);
+  } else {
+    const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, resident_blocks((const void *)k_dots<T, false>));
+    hipLaunchKernelGGL((k_dots<T, false>), dim3(p.nblocks), dim3(BLOCK), 0, s, a, a.jcol + 1, p.rows_per_block);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // K4 + K5: y -= sum_i h_i V[:, c_i]  in window order (the MGS axpy order), then ||y||
 // ------------------------------------------------------------------------------------------
 template <class T>
-__global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a) {
+__global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a, int64_t rpb) {
   constexpr int N = Pack<T>::N;
   constexpr int UN = 8;
   __shared__ double red_s[BLOCK / 64];
@@ -292,9 +332,8 @@ __global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a) {
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y) && is_al16(yin);
   const int64_t tile = (int64_t)BLOCK * N;
   double nrm = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * tile; base < a.n; base += (int64_t)gridDim.x * tile) {
-    const int64_t i = base + (int64_t)threadIdx.x * N;
-    if (i >= a.n) break;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < a.n) ? r0 + rpb : a.n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += tile) {
     Pack<T> yv = ld_pack(yin, i, a.n, al);
     int c = 0;
     for (; c + UN <= a.nd; c += UN) {
@@ -335,8 +374,8 @@ __global__ __launch_bounds__(BLOCK) void k_update(UpdateArgs<T> a) {
 }
 template <class T>
 void update(hipStream_t s, const UpdateArgs<T> &a) {
-  const int g = grid_for(a.n, BLOCK * Pack<T>::N * 2);
-  hipLaunchKernelGGL(k_update<T>, dim3(g), dim3(BLOCK), 0, s, a);
+  const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, resident_blocks((const void *)k_update<T>));
+  hipLaunchKernelGGL(k_update<T>, dim3(p.nblocks), dim3(BLOCK), 0, s, a, p.rows_per_block);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -404,6 +443,45 @@ __global__ __launch_bounds__(BLOCK) void k_combine(int64_t n, const TV *__restri
       }
   }
 }
+// single output column with the coefficients passed BY VALUE in the kernel arguments: no H2D copy
+// between the host Pade and the launch (expv!: w = beta * V[:, 1:m] * expHe, krylov_phiv.jl:229,242)
+template <class TV, class TC>
+__global__ __launch_bounds__(BLOCK) void k_combine1(int64_t n, const TV *__restrict__ V, int64_t ldv, int m,
+                                                    CoefVec<TC> cv, double scale, TC *__restrict__ W, int64_t rpb) {
+  constexpr int N = Pack<TV>::N;
+  const bool al = ((ldv * sizeof(TV)) % 16 == 0) && is_al16(V);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+    TC acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = ST<TC>::zero();
+    int c = 0;
+    for (; c + 8 <= m; c += 8) {
+      Pack<TV> vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[u] = ld_pack(V + (int64_t)(c + u) * ldv, i, n, al);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) mulacc<TV, TC>(acc[k], vv[u].v[k], cv.c[c + u]);
+    }
+    for (; c < m; ++c) {
+      const Pack<TV> vv = ld_pack(V + (int64_t)c * ldv, i, n, al);
+#pragma unroll
+      for (int k = 0; k < N; ++k) mulacc<TV, TC>(acc[k], vv.v[k], cv.c[c]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (i + k < n) W[i + k] = ST<TC>::mul_real(acc[k], scale);
+  }
+}
+template <class TV, class TC>
+void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W) {
+  const RowPlan p = plan_rows(n, 64 * Pack<TV>::N, resident_blocks((const void *)k_combine1<TV, TC>));
+  hipLaunchKernelGGL((k_combine1<TV, TC>), dim3(p.nblocks), dim3(BLOCK), 0, s, n, V, ldv, m, cv, scale, W,
+                     p.rows_per_block);
+}
+
 template <class TV, class TC>
 void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC *C, int ldc, int ncols, double scale,
              TC *W, int64_t ldw) {
@@ -483,6 +561,12 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void lincomb<T>(hipStream_t, const LincombArgs<T> &);
 INST(double)
 INST(cplx)
+template void combine1<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<double> &,
+                                       double, double *);
+template void combine1<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<cplx> &, double,
+                                     cplx *);
+template void combine1<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefVec<cplx> &, double,
+                                   cplx *);
 template void combine<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const double *, int, int,
                                       double, double *, int64_t);
 template void combine<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const cplx *, int, int, double,
