@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libexpv_mi.so")
+LIB_PATH = os.environ.get("EXPV_MI_LIB") or os.path.join(HERE, "libexpv_mi.so")   # EXPV_MI_LIB: A/B builds when profiling
 
 F64, C64 = 0, 1
 HOST, DEVICE = 0, 1

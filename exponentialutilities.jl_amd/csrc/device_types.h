@@ -75,6 +75,7 @@ struct StepState {
   double hnorm;          // beta_j of the last finished step (H[j+1,j])
   double sumsq;          // scratch: last reduced sum of squares
   double beta0sq;        // ||b||^2 of the first step (Ks.beta^2), kept for the host
+  double inv;            // 1 / beta of the vector being normalised lazily (single-reduction path)
   int32_t breakdown;     // 1: beta_j < tol (arnoldi.jl:370-374); 2: zero starting vector (arnoldi.jl:366)
   int32_t m_done;        // last step whose column of H is complete
   uint32_t ticket;       // arrival counter of the group reducers (stage 2 of the grid reduction)

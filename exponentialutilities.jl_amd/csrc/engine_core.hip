@@ -64,8 +64,8 @@ static void ks_alloc_aux(Ks &ks) {
   ks.gram.alloc((size_t)ks.ldg * ks.ldg * esz);
   HIPCHECK(hipMemsetAsync(ks.gram.p, 0, ks.gram.bytes, ks.ctx->stream));
   ks.hcoef.alloc((size_t)(ks.maxiter + 2) * esz);
-  if (!ks.part.p) ks.part.alloc((size_t)dev::MAX_RED_VALUES * dev::MAX_GRID * sizeof(double));
-  if (!ks.gpart.p) ks.gpart.alloc((size_t)dev::MAX_RED_VALUES * dev::MAX_GROUPS * sizeof(double));
+  if (!ks.part.p) ks.part.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GRID * sizeof(double));
+  if (!ks.gpart.p) ks.gpart.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GROUPS * sizeof(double));
   if (!ks.state.p) {
     ks.state.alloc(sizeof(StepState));
     HIPCHECK(hipMemsetAsync(ks.state.p, 0, sizeof(StepState), ks.ctx->stream));
@@ -192,7 +192,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   StepState *st = ks.state.as<StepState>();
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
-  bool use_fused = false;
+  bool use_fused = false, single_red = false;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -215,10 +215,15 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       }
       src = reinterpret_cast<const T *>(aug->w);
     }
-    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switch for profiling
+    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
+    static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
+    single_red = !fused_v1;
     use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
                 (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
-    {
+    if (use_fused && single_red) {
+      // u_1 = b goes to V[:, 0] unnormalised; ||b|| comes out of the first fused half-step's reduction
+      HIPCHECK(hipMemcpyAsync(V, src, sizeof(T) * (size_t)ks.n, hipMemcpyDeviceToDevice, s));
+    } else {
       ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
       dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
     }
@@ -272,7 +277,44 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   double *gpart = ks.gpart.as<double>();
   const int ortho = o.ortho;
 
-  if (use_fused) {
+  if (use_fused && single_red) {
+    // ---- single-reduction path: 2 launches and ONE grid reduction per Krylov step (fused.hip) --
+    const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
+    if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
+    T *yb = ks.ybuf.as<T>();
+    dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+    for (int j = 1; j <= m; ++j) {
+      const int i0 = lanczos ? j : std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      dev::FusedAArgs<T> fa{};
+      fa.A = A;
+      fa.u = V + (size_t)(j - 1) * ks.ldv;
+      fa.ybuf = yb;
+      fa.step = j;
+      dev::DotsArgs<T> &d = fa.d;
+      d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = yb; d.x = fa.u;
+      d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+      d.part = part; d.gpart = gpart; d.st = st;
+      d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+      d.real_coeff = real_coeff;
+      d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
+      d.hcoef = hcoef;
+      { ProfScope ps(c, EXPV_MI_K_FUSED_A); dev::fused_a2<T>(s, fa, tol); }
+      dev::UpdateArgs<T> u{};
+      u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)j * ks.ldv; u.yin = yb;
+      if (lanczos) { u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1; }
+      else { u.c0 = i0 - 1; u.dir = 1; u.nd = nd; }
+      u.hcoef = hcoef; u.do_norm = 0; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+      u.jcol = j - 1; u.tol = tol; u.step = j;
+      { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, j - 1); }
+    }
+    {
+      ProfScope ps(c, EXPV_MI_K_SCALE);
+      dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol);
+      dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
+    }
+    ks.gram_rows = lanczos ? 1 : m;
+  } else if (use_fused) {
     // ---- fused path: 2 launches per Krylov step, lagged normalisation (fused.hip) ------------
     const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
     if (ks.ubuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }

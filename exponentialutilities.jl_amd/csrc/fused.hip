@@ -9,6 +9,8 @@
 //   update  : u   = y - sum_i h_i v_i ; beta_j = ||u||             (arnoldi.jl:303, :305) [kernels.hip]
 // HBM traffic per step (fp64, n rows, nnz entries, window w): A (12 B/entry) + gather of u +
 // 8n*(w-1) [V read] + 8n [v_j write] + 8n [y write]  |  8n*w [V read] + 8n [y read] + 8n [u write].
+#include <cstdlib>
+
 #include "kernel_common.h"
 
 namespace expv_mi {
@@ -175,12 +177,13 @@ void fused_a(hipStream_t s, const FusedAArgs<T> &a) {
 
 // V[:, m_done] = u / beta_{m_done}: the normalisation of the LAST step of the call (arnoldi.jl:306)
 template <class T>
-__global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int64_t n, const T *__restrict__ u,
+__global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int64_t n, const T *u,
                                                          const StepState *st) {
   constexpr int N = Pack<T>::N;
   if (st->breakdown == 2) return;   // zero starting vector: V stays untouched (arnoldi.jl:366)
   const double beta = st->hnorm;
   T *dst = V + (int64_t)st->m_done * ldv;
+  if (u == nullptr) u = dst;   // single-reduction path: the unnormalised vector already sits in its column
   const bool al = ((ldv * sizeof(T)) % 16 == 0) && is_al16(V) && is_al16(u);
   for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
     Pack<T> p = ld_pack(u, i, n, al);
@@ -194,9 +197,211 @@ void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, cons
   hipLaunchKernelGGL(k_finalize_last<T>, dim3(grid_for(n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, V, ldv, n, u, st);
 }
 
+// ---- single-reduction step --------------------------------------------------------------------
+template <class T, bool GRAM, int CH, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int spw, double tol) {
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  constexpr int NR = ST<T>::nreal;
+  constexpr int NSETS = GRAM ? 2 : 1;
+  __shared__ double red_s[BLOCK / 64][CH * NR * NSETS];
+  __shared__ double vals_s[MAX_RED_VALUES + 1];
+  __shared__ double nrm_s[BLOCK / 64];
+  __shared__ int flag_s;
+  __shared__ T gs_s[GRAM ? (LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2) : 1];
+  const DotsArgs<T> &a = fa.d;
+  if (step_skipped(a.st, fa.step)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const T *u = fa.u;                       // V[:, jcol], unnormalised
+  const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(fa.ybuf) && is_al16(u);
+  double nrm = 0.0;
+  for (int cb = 0; cb < a.nd; cb += CH) {
+    T accd[CH], accg[GRAM ? CH : 1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) accd[c] = ST<T>::zero();
+    if (GRAM) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
+    }
+    const int64_t s0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * spw;
+    const int64_t s1 = (s0 + spw < fa.A.nslices) ? s0 + spw : fa.A.nslices;
+    for (int64_t slice = s0; slice < s1; ++slice) {
+      const int64_t i = slice * SH + (int64_t)lane * N;
+      Pack<T> yv;
+      const Pack<T> xv = ld_pack(u, i, a.n, al);
+      if (cb == 0) {
+        sell_rows<T>(fa.A, slice, lane, u, yv.v);             // y~ = A u_j
+        st_pack(fa.ybuf, i, a.n, al, yv);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          if (i + k >= a.n) yv.v[k] = ST<T>::zero();
+          nrm += ST<T>::abs2(xv.v[k]);
+        }
+      } else {
+        yv = ld_pack(fa.ybuf, i, a.n, al);
+      }
+      if (i < a.n) dots_accumulate<T, GRAM, CH>(a.V, a.ldv, a.n, a.c0, a.dir, a.nd, cb, i, al, yv, xv, accd, accg);
+    }
+    dots_publish_chunk<T, GRAM, CH>(accd, accg, cb, a.nd, a.part, red_s);
+  }
+  const int NV = a.nd * NR * NSETS;        // index of the extra value ||u_j||^2
+  const double bs = block_sum(nrm, nrm_s);
+  if (threadIdx.x == 0) publish_f64(a.part + (size_t)NV * MAX_GRID + blockIdx.x, bs);
+  if (!hier_reduce(a.st, a.part, a.gpart, NV + 1, vals_s, &flag_s)) return;
+
+  // ---- last workgroup: finish step j-1 (norm, breakdown) and produce the column of step j -------
+  const double beta = sqrt(vals_s[NV]);
+  const double inv = 1.0 / beta;
+  const int jcol = a.jcol;
+  bool stop = false;
+  if (fa.step == 1) stop = (beta == 0.0);                  // iszero(Ks.beta) && return  (arnoldi.jl:366)
+  else stop = (beta < tol);                                // happy breakdown of step j-1  (arnoldi.jl:370)
+  if (threadIdx.x == 0) {
+    a.st->hnorm = beta;
+    a.st->inv = inv;
+    a.st->m_done = fa.step - 1;
+    if (fa.step == 1) a.st->beta0sq = vals_s[NV];
+    else a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh] = ST<T>::from_real(beta);   // H[j, j-1] = ||u_j||
+    if (stop) a.st->breakdown = (fa.step == 1) ? 2 : 1;
+  }
+  if (stop) return;
+  // sums were taken against the unnormalised u_j:  <v_i, A v_j> = inv <v_i, A u_j>,  <v_j, A v_j> = inv^2 <u_j, A u_j>,
+  // <v_i, v_j> = inv <v_i, u_j>
+  for (int e = threadIdx.x; e < NV; e += BLOCK) {
+    const int set = e / (a.nd * NR), col = (e % (a.nd * NR)) / NR;
+    const double f = (set == 0 && col == a.nd - 1) ? inv * inv : inv;
+    vals_s[e] *= f;
+  }
+  __syncthreads();
+  projection_epilogue<T>(a, vals_s, gs_s, inv);
+}
+
+static void plan_slices2(int64_t nslices, int max_blocks, int *nblocks, int *spw) { plan_slices(nslices, max_blocks, nblocks, spw); }
+template <class T>
+void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol) {
+  constexpr int CH = DotChunk<T>::CH;
+  // measured on C2 (profiles/r01_ab_variants.txt): the 2x-accumulator variant is slower (56 vs 48 us per launch),
+  // so it is opt-in for experiments only
+  static const bool wide_ok = std::getenv("EXPV_MI_WIDE") != nullptr;
+  int nb, spw;
+  if (a.d.mode == DOTS_LOWSYNC) {
+    if (wide_ok && a.d.nd > CH && a.d.nd <= 2 * CH) {
+      // windows of 17..32 columns (fp64): one pass with twice the accumulators (2 workgroups/CU)
+      // instead of a second sweep over y, v_j and a second workgroup reduction
+      auto k = k_fused_a2<T, true, 2 * CH, 2>;
+      plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+    } else {
+      auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
+      plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+    }
+  } else {
+    auto k = k_fused_a2<T, false, CH, DOTS_WAVES>;
+    plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
+    hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+  }
+}
+
+// u_{j+1} = y~ * inv - sum_i c_i V_i  ->  out;  V[:, newest] <- V[:, newest] * inv   (pure streaming, no reduction)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_update2(UpdateArgs<T> a, int newest_col, int64_t rpb) {
+  constexpr int N = Pack<T>::N;
+  constexpr int UN = 8;
+  if (step_skipped(a.st, a.step)) return;
+  const double inv = a.st->inv;
+  T *Vw = const_cast<T *>(a.V);
+  const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y) && is_al16(a.yin);
+  // rows are walked in the REVERSE order of the projection pass that just ran: the tiles it touched
+  // last are the ones still resident in L2 / Infinity Cache
+  const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * rpb, r1 = (r0 + rpb < a.n) ? r0 + rpb : a.n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+    Pack<T> yv = ld_pack(a.yin, i, a.n, al);
+#pragma unroll
+    for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::mul_real(yv.v[k], inv);
+    int c = 0;
+    for (; c + UN <= a.nd; c += UN) {
+      Pack<T> vv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) vv[u] = ld_pack(a.V + (int64_t)(a.c0 + a.dir * (c + u)) * a.ldv, i, a.n, al);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int col = a.c0 + a.dir * (c + u);
+        const T h = a.hcoef[c + u];
+#pragma unroll
+        for (int k = 0; k < N; ++k) ST<T>::nfma(yv.v[k], h, vv[u].v[k]);
+        if (col == newest_col) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) vv[u].v[k] = ST<T>::mul_real(vv[u].v[k], inv);
+          st_pack(Vw + (int64_t)col * a.ldv, i, a.n, al, vv[u]);
+        }
+      }
+    }
+    for (; c < a.nd; ++c) {
+      const int col = a.c0 + a.dir * c;
+      Pack<T> vv = ld_pack(a.V + (int64_t)col * a.ldv, i, a.n, al);
+      const T h = a.hcoef[c];
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::nfma(yv.v[k], h, vv.v[k]);
+      if (col == newest_col) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) vv.v[k] = ST<T>::mul_real(vv.v[k], inv);
+        st_pack(Vw + (int64_t)col * a.ldv, i, a.n, al, vv);
+      }
+    }
+    st_pack(a.y, i, a.n, al, yv);
+  }
+}
+template <class T>
+void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col) {
+  const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, resident_blocks((const void *)k_update2<T>));
+  hipLaunchKernelGGL(k_update2<T>, dim3(p.nblocks), dim3(BLOCK), 0, s, a, newest_col, p.rows_per_block);
+}
+
+// norm of the last vector of the call: beta_m = ||u_{m+1}||, H[m+1, m], breakdown test of step m
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, int64_t n, double *part, double *gpart,
+                                                      StepState *st, T *Hdev, int ldh, int m, double tol, int64_t rpb) {
+  __shared__ double red_s[BLOCK / 64];
+  __shared__ double vals_s[1];
+  __shared__ int flag_s;
+  if (st->breakdown != 0) return;   // an earlier step already ended the factorisation
+  constexpr int N = Pack<T>::N;
+  const bool al = is_al16(x);
+  double acc = 0.0;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+    const Pack<T> p = ld_pack(x, i, n, al);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc += ST<T>::abs2(p.v[k]);
+  }
+  const double bs = block_sum(acc, red_s);
+  if (threadIdx.x == 0) publish_f64(part + blockIdx.x, bs);
+  if (!hier_reduce(st, part, gpart, 1, vals_s, &flag_s)) return;
+  if (threadIdx.x == 0) {
+    const double beta = sqrt(vals_s[0]);
+    st->hnorm = beta;
+    st->inv = 1.0 / beta;
+    st->m_done = m;
+    Hdev[m + (int64_t)(m - 1) * ldh] = ST<T>::from_real(beta);
+    if (beta < tol) st->breakdown = 1;
+  }
+}
+template <class T>
+void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh, int m,
+                double tol) {
+  const RowPlan p = plan_rows(n, 64 * Pack<T>::N, resident_blocks((const void *)k_norm_final<T>));
+  hipLaunchKernelGGL(k_norm_final<T>, dim3(p.nblocks), dim3(BLOCK), 0, s, x, n, part, gpart, st, Hdev, ldh, m, tol,
+                     p.rows_per_block);
+}
+
 #define INSTF(T)                                                                                               \
   template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int); \
   template void fused_a<T>(hipStream_t, const FusedAArgs<T> &);                                                \
+  template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double);                                       \
+  template void update2<T>(hipStream_t, const UpdateArgs<T> &, int);                                           \
+  template void norm_final<T>(hipStream_t, const T *, int64_t, double *, double *, StepState *, T *, int, int,  \
+                              double);                                                                         \
   template void finalize_last<T>(hipStream_t, T *, int64_t, int64_t, const T *, const StepState *);
 INSTF(double)
 INSTF(cplx)

@@ -128,7 +128,7 @@ __device__ __forceinline__ void reduce_flat(const double *part, int nblk, int nv
 __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double *gpart, int nvals, double *vals_s,
                                             int *flag_s) {
   const int nblk = gridDim.x;
-  if (nvals <= 2) {   // norms: 1 ticket + 1 round of loads
+  if (nvals <= 2 && nblk <= 2 * GROUP_SIZE) {   // few workgroups: 1 ticket + 1 round of loads
     __shared__ double red2_s[BLOCK / 64];
     if (!take_ticket(&st->ticket, (uint32_t)nblk, flag_s)) return false;
     reduce_flat(part, nblk, nvals, vals_s, red2_s);
@@ -208,19 +208,34 @@ template <class T> struct DotChunk { static constexpr int CH = 16; };
 template <> struct DotChunk<cplx> { static constexpr int CH = 8; };
 
 // Accumulate one row pack into the chunk's projection sums; columns cb..cb+CH-1 of the window.
-template <class T, bool GRAM>
+template <class T, bool GRAM, int CH = DotChunk<T>::CH>
 __device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t n, int c0, int dir, int nd,
                                                 int cb, int64_t i, bool al, const Pack<T> &yv, const Pack<T> &xv,
                                                 T *accd, T *accg) {
   constexpr int N = Pack<T>::N;
-  constexpr int CH = DotChunk<T>::CH;
   constexpr int LB = 8;   // loads in flight per lane: 8 x 16 B; keeps the kernel at <= 128 VGPRs (4 workgroups/CU)
+#ifndef DOTS_PTR_STEP
+#define DOTS_PTR_STEP 0
+#endif
+#if DOTS_PTR_STEP
+  // one running per-lane pointer stepped by ldv per column (a 64-bit VALU add) instead of CH
+  // loop-invariant scalar base addresses
+  const T *vp = V + (int64_t)(c0 + dir * cb) * ldv + i;
+  const int64_t step = (int64_t)dir * ldv;
+#endif
 #pragma unroll
   for (int h = 0; h < CH; h += LB) {
     Pack<T> vv[LB];
 #pragma unroll
     for (int c = 0; c < LB; ++c)
-      if (cb + h + c < nd) vv[c] = ld_pack(V + (int64_t)(c0 + dir * (cb + h + c)) * ldv, i, n, al);
+      if (cb + h + c < nd) {
+#if DOTS_PTR_STEP
+        vv[c] = ld_pack(vp, 0, n - i, al);
+        vp += step;
+#else
+        vv[c] = ld_pack(V + (int64_t)(c0 + dir * (cb + h + c)) * ldv, i, n, al);
+#endif
+      }
 #pragma unroll
     for (int c = 0; c < LB; ++c)
       if (cb + h + c < nd) {
@@ -234,22 +249,28 @@ __device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t
 }
 
 // workgroup reduction of a chunk's accumulators and publication of the per-workgroup partials
-template <class T, bool GRAM>
+template <class T, bool GRAM, int CH = DotChunk<T>::CH>
 __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg, int cb, int nd, double *part,
-                                                   double (*red_s)[DotChunk<T>::CH * ST<T>::nreal * (GRAM ? 2 : 1)]) {
-  constexpr int CH = DotChunk<T>::CH;
+                                                   double (*red_s)[CH * ST<T>::nreal * (GRAM ? 2 : 1)]) {
   constexpr int NR = ST<T>::nreal;
   constexpr int NSETS = GRAM ? 2 : 1;
-  constexpr int K = CH * NR * NSETS;            // 16 or 32 values per lane
+  constexpr int K = CH * NR * NSETS;            // values per workgroup and chunk
+  constexpr int K1 = CH * NR;                   // reduced one set at a time (keeps the register peak low)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double a[K];
+  {
+    double a[K1];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    acc_to_vals<T>(accd[c], &a[c * NR]);
-    if (GRAM) acc_to_vals<T>(accg[c], &a[CH * NR + c * NR]);
+    for (int c = 0; c < CH; ++c) acc_to_vals<T>(accd[c], &a[c * NR]);
+    wave_reduce_multi<K1>(a);
+    if (K1 >= 64 || (lane & ((64 / K1) - 1)) == 0) red_s[wave][wave_multi_index<K1>(lane)] = a[0];
   }
-  wave_reduce_multi<K>(a);
-  if ((lane & ((64 / K) - 1)) == 0) red_s[wave][wave_multi_index<K>(lane)] = a[0];
+  if (GRAM) {
+    double a[K1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc_to_vals<T>(accg[c], &a[c * NR]);
+    wave_reduce_multi<K1>(a);
+    if (K1 >= 64 || (lane & ((64 / K1) - 1)) == 0) red_s[wave][K1 + wave_multi_index<K1>(lane)] = a[0];
+  }
   __syncthreads();
   if (threadIdx.x < K) {
     const int set = threadIdx.x / (CH * NR), w = threadIdx.x % (CH * NR), c = w / NR, r = w % NR;
@@ -270,7 +291,8 @@ __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg,
 //   LOWSYNC: h = (I + L)^-1 d, L = strict lower triangle of V^H V on the window -- algebraically
 //            the modified Gram-Schmidt coefficients  h_i = <v_i, y - sum_{k<i} h_k v_k>.
 template <class T>
-__device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s) {
+__device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s,
+                                                    double newest_scale = 1.0) {
   constexpr int NR = ST<T>::nreal;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (a.mode != DOTS_LOWSYNC) {
@@ -278,7 +300,7 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
       T h = vals_to_T<T>(vals_s);
       if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
       a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh] = h;
-      a.hcoef[0] = h;
+      a.hcoef[0] = ST<T>::mul_real(h, newest_scale);
       if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
         a.hcoef[1] = ST<T>::real_only(a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh]);
     }
@@ -310,7 +332,7 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     if (a.real_coeff) sv = ST<T>::real_only(sv);
     if (lane < nd) {
       a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh] = sv;
-      a.hcoef[lane] = sv;
+      a.hcoef[lane] = (lane == nd - 1) ? ST<T>::mul_real(sv, newest_scale) : sv;
     }
   }
 }

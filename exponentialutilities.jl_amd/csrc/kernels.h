@@ -92,6 +92,18 @@ struct FusedAArgs {
   int step;
 };
 template <class T> void fused_a(hipStream_t s, const FusedAArgs<T> &a);
+
+// ---- single-reduction step (one grid reduction per Krylov step) ------------------------------
+// step j:  fused_a2: y~ = A u_j (u_j = V[:, j-1], still UNNORMALISED), window sums of y~ and u_j, ||u_j||^2;
+//                    last workgroup: beta_{j-1} = ||u_j||, H[j, j-1], breakdown test of step j-1, then the
+//                    Hessenberg column of step j from the rescaled sums
+//          update2 : u_{j+1} = y~/beta - sum_i c_i V_i  -> V[:, j];  V[:, j-1] <- u_j / beta   (no reduction)
+// after the loop: norm_final (beta_m, H[m+1, m], breakdown test) + finalize_last.
+template <class T> void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol);
+template <class T> void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col);
+template <class T>
+void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh,
+                int m, double tol);
 // V[:, m_done] = u / beta_{m_done} after the loop (the column index comes from the device state)
 template <class T> void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st);
 

@@ -26,7 +26,9 @@ print("%-62s %8s %12s %10s" % ("kernel", "calls", "total_us", "avg_us"))
 for k, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print("%-62s %8d %12.1f %10.2f" % (k, c, us, us / c))
 # last expv: from the last k_sumsq to the end
-idx = max(i for i, r in enumerate(rows) if "k_sumsq" in r[2])
+starts = [i for i, r in enumerate(rows) if "k_sumsq" in r[2] or "k_fused_a2<double, false>" in r[2]
+          or "k_fused_a2<expv_mi::cplx, false>" in r[2]]
+idx = max(starts) if starts else 0
 seq = rows[idx:]
 print("\nlast expv: %d launches, span %.1f us, busy %.1f us" % (
     len(seq), (seq[-1][1] - seq[0][0]) / 1e3, sum(e - s for s, e, _ in seq) / 1e3))
