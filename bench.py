@@ -55,6 +55,28 @@ def alg_bytes_kernel(name, n, nnz, m, s=8):
     }.get(name)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, gfx950 x2 read correction applied: tools/pmc_summary.py).  PMC collection
+    cannot run inside this process, so the per-launch figure measured on the same command is read from
+    profiles/; None when no pass has been recorded for this kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files or kernel is None:
+        return None
+    data = json.load(open(files[-1]))
+    key = {"fused_a": "k_fused_a", "fused_b": "k_update2", "dots": "k_dots", "update": "k_update<",
+           "matvec": "k_spmv", "combine": "k_combine"}.get(kernel)
+    if key is None:
+        return None
+    tot_b = tot_n = 0.0
+    for name, v in data.items():
+        if name.startswith(key):
+            tot_b += v["hbm_bytes_per_launch"] * v["launches"]
+            tot_n += v["launches"]
+    return (tot_b / tot_n) if tot_n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,13 +163,14 @@ def main():
                       "total_ms_per_expv": p["total_ms"] / args.steps,
                       "alg_GBps": (ab / (avg_ms * 1e-3) / 1e9) if ab else None}
     dom = max(kern, key=lambda k: kern[k]["total_ms_per_expv"]) if kern else None
+    traffic = pmc_traffic(dom) if n == N_ROWS else None
     b_alg = alg_bytes_expv(n, nnz, m)
     expv_gbps = b_alg / (elapsed / args.steps) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom,
         "achieved": kern[dom]["alg_GBps"] if dom else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (kern[dom]["alg_GBps"] / HBM_PEAK_GBS) if dom and kern[dom]["alg_GBps"] else None,
-        "traffic": None,
+        "traffic": traffic,
         "avg_launch_ms": kern[dom]["avg_ms"] if dom else None,
         "expv_alg_GBps": expv_gbps, "expv_frac": expv_gbps / HBM_PEAK_GBS,
         "kernels": kern,
