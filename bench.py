@@ -77,6 +77,54 @@ def pmc_traffic(kernel):
     return (tot_b / tot_n) if tot_n else None
 
 
+def run_c5(args, eu, ctx, world, rank, dist, torch):
+    """BASELINE configs[4]: nprob independent expv problems (n = 1e5, C2 diagonals scaled per problem,
+    m = 30), problems sharded over the ranks, one final gather of the results."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(ROOT, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    n, m, nprob = 100_000, M_KRYLOV, args.nprob
+    A0 = c2_operator(n).tocsr()
+    A0.sort_indices()
+    nnz = A0.nnz
+    lo, hi = D.shard_range(nprob, world, rank)
+    rng = np.random.default_rng(7)
+    scales = 1 + 0.1 * rng.random(nprob)
+    vals = torch.as_tensor(np.stack([A0.data * s for s in scales[lo:hi]]), device="cuda")
+    B = torch.as_tensor(np.random.default_rng(100 + rank).standard_normal((hi - lo, n)), device="cuda").t()
+    def step():
+        W = eu.expv_batch(T_FINAL, A0, vals, B, m=m, ctx=ctx)
+        return D.gather_columns(W, nprob) if world > 1 else W
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); ctx.sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        W = step()
+    torch.cuda.synchronize(); ctx.sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    units, elapsed = D.aggregate_throughput((hi - lo) * m * args.steps, elapsed, device="cuda")
+    b_alg = alg_bytes_expv(n, nnz, m) * nprob
+    out = {"metric": "expv matvecs/s, batch of independent problems n=1e5 sparse fp64 m=30", "value": units / elapsed,
+           "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: %d independent expv, n=1e5, 5-diagonal, m=30, sharded over %d "
+                                  "GPU(s), final gather" % (nprob, world), "nprob": nprob, "n": n, "m": m},
+           "roofline": {"bound": "hbm", "achieved": b_alg / (elapsed / args.steps) / 1e9 / world, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": b_alg / (elapsed / args.steps) / 1e9 / world / HBM_PEAK_GBS,
+                        "traffic": None, "note": "whole-call algorithmic GB/s per GPU (V of a problem is cache-resident)"}}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +133,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_ROWS, help="override problem size (debug only; invalidates the metric)")
     ap.add_argument("--ortho", default="auto", choices=["auto", "mgs", "lowsync"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
+                    help="c2 (default, the headline metric) or c5: batch of --nprob independent n=1e5 problems")
+    ap.add_argument("--nprob", type=int, default=1024, help="c5: total number of problems over all GPUs")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +155,8 @@ def main():
     import expv_mi_loader
     eu = expv_mi_loader.load()
     ctx = eu.Context(device=local_rank)
+    if args.config == "c5":
+        return run_c5(args, eu, ctx, world, rank, dist, torch)
     n, m = args.n, M_KRYLOV
     A = c2_operator(n)
     nnz = A.nnz

@@ -29,7 +29,7 @@ from . import _lib as L
 __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
-    "phiv_timestep_", "kiops", "timestep_caches", "ExpvMIError", "DimensionMismatch", "host_expm",
+    "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "ExpvMIError", "DimensionMismatch", "host_expm",
     "host_phiv_dense", "host_symtridiag_expcol",
 ]
 
@@ -710,6 +710,59 @@ def kiops(tau_out, A, u, *, mmin=10, mmax=128, m=None, tol=1e-7, opnorm=None, io
            op.ctx._h)
     wa.finish()
     return w, tuple(int(x) for x in st)
+
+
+# ---------------------------------------------------------------------------------------------
+# batch of independent problems (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------
+def expv_batch(ts, pattern, vals, B, *, m=None, tol=1e-7, iop=0, ishermitian=False, ctx=None, return_m=False):
+    """W[:, p] = expv(ts[p], A_p, B[:, p]; m, tol, iop, ishermitian) for nprob operators A_p that share
+    the sparsity pattern of the scipy matrix ``pattern`` (CSR order) and have values ``vals[p, :]``.
+
+    Equivalent to a host loop over the reference's ``expv`` (the reference has no batching); all problems
+    advance in lock step inside the library.  ``vals``/``B`` may be numpy arrays or torch CUDA tensors
+    (B as an (n, nprob) column-major view, e.g. ``torch.empty(nprob, n).t()``)."""
+    ctx = ctx or default_context()
+    P = pattern.tocsr()
+    P.sort_indices()
+    n = P.shape[0]
+    nnz = int(P.nnz)
+    vdt, bdt = _np_dtype_of(vals), _np_dtype_of(B)
+    T = _work_dtype(vdt, bdt)
+    class _Raw:          # problem-major (nprob, nnz) values: row-major is the wanted layout here
+        pass
+    va = _Raw()
+    if _is_torch(vals):
+        import torch
+        want = torch.complex128 if T.kind == "c" else torch.float64
+        vt = vals.to(want).contiguous()
+        if not vt.is_cuda:
+            raise TypeError("torch tensors must live on the GPU (or pass a numpy array)")
+        va.ptr, va.loc, va.keep, nprob = vt.data_ptr(), L.DEVICE, vt, int(vt.shape[0])
+        if vt.numel() != nprob * nnz:
+            raise DimensionMismatch("vals must hold nprob x nnz values")
+    else:
+        vh = np.ascontiguousarray(np.asarray(vals, dtype=T))
+        nprob = int(vh.shape[0])
+        if vh.size != nprob * nnz:
+            raise DimensionMismatch("vals must hold nprob x nnz values")
+        va.ptr, va.loc, va.keep = vh.ctypes.data, L.HOST, vh
+    Ba = _Arg(B, T)
+    if Ba.shape[0] != n or (len(Ba.shape) == 2 and Ba.shape[1] != nprob):
+        raise DimensionMismatch("B must be n x nprob")
+    W = _empty_like(B, (n, nprob), T)
+    Wa = _Arg(W, T, writable=True)
+    rp = np.ascontiguousarray(P.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(P.indices, dtype=np.int32)
+    tarr = np.ascontiguousarray(np.broadcast_to(np.asarray(ts, dtype=np.float64), (nprob,)))
+    o = _opts(m, tol, iop, 0, ishermitian, "auto")
+    mu = np.zeros(nprob, dtype=np.int32)
+    _check(L.load().expv_mi_expv_batch(ctx._h, _code(T), n, int(nprob), rp.ctypes.data, ci.ctypes.data, va.ptr, nnz,
+                                       L.HOST if va.loc == L.HOST else L.DEVICE, tarr.ctypes.data_as(L._pd), Ba.ptr, Ba.ld,
+                                       Ba.loc, Wa.ptr, Wa.ld, Wa.loc, C.byref(o), mu.ctypes.data_as(C.POINTER(C.c_int32))),
+           ctx._h)
+    Wa.finish()
+    return (W, mu) if return_m else W
 
 
 # ---------------------------------------------------------------------------------------------

@@ -718,10 +718,15 @@ int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, con
   });
 }
 
-int expv_mi_expv_batch(expv_mi_ctx_t ctx, int, int64_t, int, const int32_t *, const int32_t *, const void *, int64_t, int,
-                       const double *, const void *, int64_t, int, void *, int64_t, int, const expv_mi_arnoldi_opts *,
-                       int32_t *) {
-  return guarded(ctx, [&] { fail(EXPV_MI_UNSUPPORTED, "expv_batch: not built yet"); });
+int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr, const int32_t *colind,
+                       const void *vals, int64_t nnz_per_prob, int mat_loc, const double *t, const void *b, int64_t ldb,
+                       int b_loc, void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used) {
+  return guarded(ctx, [&] {
+    expv_mi_arnoldi_opts o;
+    if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+    expv_batch_run(ctx, dtype, n, nprob, rowptr, colind, vals, nnz_per_prob, mat_loc, t, b, ldb, b_loc, w, ldw, w_loc, o,
+                   m_used);
+  });
 }
 
 }  // extern "C"

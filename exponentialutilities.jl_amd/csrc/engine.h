@@ -217,6 +217,11 @@ const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t 
 void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_dev, int64_t ld_src, int64_t rows,
                  int64_t cols, size_t esz);
 
+// ---- engine_batch.hip ---------------------------------------------------------------------
+void expv_batch_run(Ctx *ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr, const int32_t *colind,
+                    const void *vals, int64_t nnz, int mat_loc, const double *t, const void *b, int64_t ldb, int b_loc,
+                    void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts &o, int32_t *m_used);
+
 // ---- engine_drivers.hip --------------------------------------------------------------------
 void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int64_t ldb, int ncoef, int b_loc,
                        void *U, int64_t ldu, int u_loc, const expv_mi_timestep_opts &o, TsCache *cache,

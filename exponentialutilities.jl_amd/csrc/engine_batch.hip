@@ -1,0 +1,228 @@
+// engine_batch.hip -- nprob independent expv problems of equal size sharing one sparsity pattern
+// (BASELINE config 5: 1024 x (n = 1e5, m = 30), sharded over the GPUs of a node by the caller).
+//
+// Each problem is exactly expv(t_p, A_p, b_p; m, tol, iop, ishermitian) of the reference
+// (/root/reference/src/krylov_phiv.jl:125-144 -> arnoldi.jl:345-377 -> krylov_phiv.jl:200-247); the
+// problems of a chunk advance in lock step, one launch per half-step for ALL of them (problem index
+// in blockIdx.y), so the per-launch fixed costs (boundaries, reduction epilogues) are paid once per
+// chunk instead of once per problem.  Every problem keeps its own step state, Hessenberg matrix,
+// breakdown flag and reduction buffers; nothing is shared between problems but the pattern of A.
+#include <algorithm>
+#include <cmath>
+#include <thread>
+
+#include "engine.h"
+
+namespace expv_mi {
+
+using dense::cd;
+using dense::Mat;
+
+template <class T>
+static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h, const int32_t *colind_h,
+                         const T *vals_dev, int64_t nnz, const double *t, const T *b_dev, int64_t ldb, T *w_dev,
+                         int64_t ldw, const expv_mi_arnoldi_opts &o, int32_t *m_used) {
+  ctx->use();
+  hipStream_t s = ctx->stream;
+  const int m = o.m > 0 ? o.m : (int)std::min<int64_t>(30, n);
+  const int herm = o.ishermitian > 0;
+  const int iop = (o.iop == 0) ? m : o.iop;
+  if (!herm && std::min(iop, m) > dev::LOWSYNC_MAX) fail(EXPV_MI_UNSUPPORTED, "expv_batch: window longer than 64 columns");
+  if (m > dev::LOWSYNC_MAX * 2) fail(EXPV_MI_UNSUPPORTED, "expv_batch: m > 128");
+  // ---- pattern -> SELL (once, shared by every problem) + the CSR->SELL value permutation ----------
+  constexpr int N = 16 / (int)sizeof(T);
+  const int SH = 64 * N;
+  const int64_t nsl = (n + SH - 1) / SH;
+  std::vector<int64_t> off(nsl + 1, 0);
+  for (int64_t sl = 0; sl < nsl; ++sl) {
+    int L = 0;
+    for (int64_t r = sl * SH; r < std::min<int64_t>(n, (sl + 1) * SH); ++r) L = std::max(L, rowptr_h[r + 1] - rowptr_h[r]);
+    off[sl + 1] = off[sl] + (int64_t)L * SH;
+  }
+  const int64_t padded = std::max<int64_t>(off[nsl], 1);
+  std::vector<int32_t> perm((size_t)padded, -1), scol((size_t)padded, 0);
+  for (int64_t sl = 0; sl < nsl; ++sl)
+    for (int64_t r = sl * SH; r < std::min<int64_t>(n, (sl + 1) * SH); ++r) {
+      const int q = (int)(r - sl * SH);
+      int slot = 0;
+      for (int32_t k = rowptr_h[r]; k < rowptr_h[r + 1]; ++k, ++slot) {
+        perm[(size_t)(off[sl] + (int64_t)slot * SH + q)] = k;
+        scol[(size_t)(off[sl] + (int64_t)slot * SH + q)] = colind_h[k];
+      }
+    }
+  DevBuf d_off(sizeof(int64_t) * off.size()), d_col(sizeof(int32_t) * scol.size() + 16), d_perm(sizeof(int32_t) * perm.size());
+  HIPCHECK(hipMemcpyAsync(d_off.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(d_col.p, scol.data(), sizeof(int32_t) * scol.size(), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(d_perm.p, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
+
+  // ---- per-chunk storage ---------------------------------------------------------------------------
+  const int64_t ldv = (n + 127) / 128 * 128;
+  const int64_t strideV = ldv * (m + 1);
+  const int ldhd = m + 2;
+  const int64_t strideH = (int64_t)ldhd * (m + 1);
+  const int ldg = m + 1;
+  const size_t per_prob = sizeof(T) * (size_t)(strideV + ldv + padded);
+  size_t free_b = 0, total_b = 0;
+  HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+  int PC = (int)std::min<size_t>((size_t)nprob, std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / std::max<size_t>(per_prob, 1)));
+  PC = std::min(PC, 256);
+  const int64_t npart = (int64_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GRID, ngpart = (int64_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GROUPS;
+  // partial buffers are sized for the largest per-problem grid only: grids shrink with the batch, so cap rows
+  DevBuf dV(sizeof(T) * (size_t)strideV * PC), dY(sizeof(T) * (size_t)ldv * PC), dAval(sizeof(T) * (size_t)padded * PC + 16);
+  DevBuf dH(sizeof(T) * (size_t)strideH * PC), dG(sizeof(T) * (size_t)ldg * ldg * PC), dhc(sizeof(T) * (size_t)(m + 2) * PC);
+  DevBuf dpart(sizeof(double) * (size_t)npart * PC), dgpart(sizeof(double) * (size_t)ngpart * PC), dst(sizeof(StepState) * (size_t)PC);
+  DevBuf dcoef(sizeof(T) * (size_t)(m + 1) * PC), dbeta(sizeof(double) * PC), dmcols(sizeof(int32_t) * PC);
+  HIPCHECK(hipMemsetAsync(dV.p, 0, dV.bytes, s));
+  std::vector<T> Hh((size_t)strideH * PC);
+  std::vector<StepState> sth(PC);
+  std::vector<T> coefh((size_t)(m + 1) * PC);
+  std::vector<double> betah(PC);
+  std::vector<int32_t> mch(PC);
+  const bool real_coeff = false;
+  const double tol = o.tol;
+
+  dev::BatchStrides bs{};
+  bs.V = strideV; bs.ybuf = ldv; bs.part = npart; bs.gpart = ngpart; bs.Hdev = strideH; bs.gram = (int64_t)ldg * ldg;
+  bs.hcoef = m + 2; bs.Aval = padded; bs.st = 1;
+
+  for (int p0 = 0; p0 < nprob; p0 += PC) {
+    const int pc = std::min(PC, nprob - p0);
+    // values of this chunk into SELL order; b columns into V[:, 0] of each problem
+    dev::permute_values<T>(s, dAval.as<T>(), padded, vals_dev + (int64_t)p0 * nnz, nnz, d_perm.as<int32_t>(), padded, pc);
+    HIPCHECK(hipMemcpy2DAsync(dV.p, sizeof(T) * (size_t)strideV, b_dev + (int64_t)p0 * ldb, sizeof(T) * (size_t)ldb,
+                              sizeof(T) * (size_t)n, pc, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemsetAsync(dst.p, 0, sizeof(StepState) * (size_t)pc, s));
+    HIPCHECK(hipMemsetAsync(dH.p, 0, sizeof(T) * (size_t)strideH * pc, s));
+    T *V = dV.as<T>();
+    dev::SellView<T> A{d_off.as<int64_t>(), d_col.as<int32_t>(), dAval.as<T>(), nsl};
+    for (int j = 1; j <= m; ++j) {
+      const int i0 = herm ? j : std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      dev::FusedAArgs<T> fa{};
+      fa.A = A;
+      fa.u = V + (size_t)(j - 1) * ldv;
+      fa.ybuf = dY.as<T>();
+      fa.step = j;
+      dev::DotsArgs<T> &d = fa.d;
+      d.V = V; d.ldv = ldv; d.n = n; d.y = dY.as<T>(); d.x = fa.u;
+      d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+      d.part = dpart.as<double>(); d.gpart = dgpart.as<double>(); d.st = dst.as<StepState>();
+      d.mode = herm ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+      d.real_coeff = real_coeff;
+      d.Hdev = dH.as<T>(); d.ldh = ldhd; d.jcol = j - 1; d.gram = dG.as<T>(); d.ldg = ldg; d.jrow = j - 1;
+      d.hcoef = dhc.as<T>();
+      d.bs = bs;
+      { ProfScope ps(ctx, EXPV_MI_K_BATCH); dev::fused_a2<T>(s, fa, tol, pc); }
+      dev::UpdateArgs<T> u{};
+      u.V = V; u.ldv = ldv; u.n = n; u.y = V + (size_t)j * ldv; u.yin = dY.as<T>();
+      if (herm) { u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1; }
+      else { u.c0 = i0 - 1; u.dir = 1; u.nd = nd; }
+      u.hcoef = dhc.as<T>(); u.do_norm = 0; u.st = dst.as<StepState>(); u.Hdev = dH.as<T>(); u.ldh = ldhd;
+      u.jcol = j - 1; u.tol = tol; u.step = j;
+      u.bs = bs;
+      { ProfScope ps(ctx, EXPV_MI_K_BATCH); dev::update2<T>(s, u, j - 1, pc); }
+    }
+    {
+      ProfScope ps(ctx, EXPV_MI_K_BATCH);
+      dev::norm_final<T>(s, V + (size_t)m * ldv, n, dpart.as<double>(), dgpart.as<double>(), dst.as<StepState>(), dH.as<T>(),
+                         ldhd, m, tol, bs, pc);
+      dev::finalize_last<T>(s, V, ldv, n, nullptr, dst.as<StepState>(), strideV, pc);
+    }
+    HIPCHECK(hipMemcpyAsync(Hh.data(), dH.p, sizeof(T) * (size_t)strideH * pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(sth.data(), dst.p, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    // ---- host: the m x m exponentials of the chunk, on all cores -------------------------------------
+    auto solve_one = [&](int q) {
+      const StepState &h = sth[q];
+      const double beta = std::sqrt(h.beta0sq);
+      int mm = (h.breakdown == 1) ? h.m_done : m;
+      betah[q] = beta;
+      mch[q] = (beta == 0.0) ? 0 : mm;
+      if (m_used) m_used[p0 + q] = mm;
+      if (beta == 0.0) return;
+      const T *Hq = Hh.data() + (size_t)q * strideH;
+      auto at = [&](int i, int jj) -> cd {
+        if constexpr (ST<T>::is_complex) return cd(Hq[(size_t)jj * ldhd + i].re, Hq[(size_t)jj * ldhd + i].im);
+        else return cd(Hq[(size_t)jj * ldhd + i], 0.0);
+      };
+      T *cq = coefh.data() + (size_t)q * (m + 1);
+      const double tq = t[p0 + q];
+      if (herm) {   // lanczos!: symmetric tridiagonal -> eigen path of expv!  (krylov_phiv.jl:225-229)
+        std::vector<double> dd(mm), ee(mm > 1 ? mm - 1 : 0);
+        for (int i = 0; i < mm; ++i) dd[i] = at(i, i).real();
+        for (int i = 0; i + 1 < mm; ++i) ee[i] = at(i + 1, i).real();
+        std::vector<double> cf = dense::symtridiag_expcol<double>(dd, ee, tq);
+        for (int i = 0; i < mm; ++i) cq[i] = ST<T>::from_real(cf[i]);
+      } else if constexpr (ST<T>::is_complex) {
+        Mat<cd> Hm(mm, mm);
+        for (int jj = 0; jj < mm; ++jj)
+          for (int i = 0; i < mm; ++i) Hm(i, jj) = at(i, jj) * tq;
+        dense::expm_higham2005base(Hm);
+        for (int i = 0; i < mm; ++i) cq[i] = make_cplx(Hm(i, 0).real(), Hm(i, 0).imag());
+      } else {
+        Mat<double> Hm(mm, mm);
+        for (int jj = 0; jj < mm; ++jj)
+          for (int i = 0; i < mm; ++i) Hm(i, jj) = at(i, jj).real() * tq;
+        dense::expm_higham2005base(Hm);
+        for (int i = 0; i < mm; ++i) cq[i] = Hm(i, 0);
+      }
+    };
+    {
+      const int nth = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+      std::vector<std::thread> th;
+      std::vector<std::string> errs(nth);
+      for (int w = 0; w < nth; ++w)
+        th.emplace_back([&, w] {
+          try {
+            for (int q = w; q < pc; q += nth) solve_one(q);
+          } catch (const std::exception &e) { errs[w] = e.what(); }
+        });
+      for (auto &x : th) x.join();
+      for (auto &e : errs)
+        if (!e.empty()) fail(EXPV_MI_SINGULAR, e);
+    }
+    HIPCHECK(hipMemcpyAsync(dcoef.p, coefh.data(), sizeof(T) * (size_t)(m + 1) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dbeta.p, betah.data(), sizeof(double) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dmcols.p, mch.data(), sizeof(int32_t) * pc, hipMemcpyHostToDevice, s));
+    {
+      ProfScope ps(ctx, EXPV_MI_K_COMBINE);
+      dev::combine_batch<T>(s, n, V, ldv, strideV, dcoef.as<T>(), m + 1, dbeta.as<double>(), dmcols.as<int32_t>(),
+                            w_dev + (int64_t)p0 * ldw, ldw, pc);
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+}
+
+void expv_batch_run(Ctx *ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr, const int32_t *colind,
+                    const void *vals, int64_t nnz, int mat_loc, const double *t, const void *b, int64_t ldb, int b_loc,
+                    void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts &o, int32_t *m_used) {
+  ctx->use();
+  if (nprob <= 0 || n <= 0) return;
+  const size_t esz = dtype_size(dtype);
+  // the pattern is needed on the host (SELL layout); values, b and w on the device
+  std::vector<int32_t> rp(n + 1), ci((size_t)nnz);
+  // rowptr / colind are HOST arrays (the pattern is small and is re-laid out on the host); mat_loc
+  // says where the VALUES live
+  std::copy(rowptr, rowptr + n + 1, rp.begin());
+  std::copy(colind, colind + nnz, ci.begin());
+  if (rp[n] != nnz) fail(EXPV_MI_ARGUMENT_ERROR, "expv_batch: rowptr[n] != nnz_per_prob");
+  DevBuf vt, bt, wt;
+  const void *vd = stage_in(ctx, vals, mat_loc, (size_t)nnz * nprob * esz, vt);
+  int64_t ldbd = ldb;
+  const void *bd = stage_in_2d(ctx, b, b_loc, n, nprob, ldb, esz, bt, &ldbd);
+  void *wd = w;
+  int64_t ldwd = ldw;
+  if (w_loc == EXPV_MI_HOST) {
+    wt.alloc((size_t)n * nprob * esz + 16);
+    wd = wt.p;
+    ldwd = n;
+  }
+  if (dtype == EXPV_MI_C64)
+    expv_batch_T<cplx>(ctx, n, nprob, rp.data(), ci.data(), (const cplx *)vd, nnz, t, (const cplx *)bd, ldbd, (cplx *)wd, ldwd, o, m_used);
+  else
+    expv_batch_T<double>(ctx, n, nprob, rp.data(), ci.data(), (const double *)vd, nnz, t, (const double *)bd, ldbd, (double *)wd,
+                         ldwd, o, m_used);
+  if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, ldw, wd, ldwd, n, nprob, esz);
+}
+
+}  // namespace expv_mi

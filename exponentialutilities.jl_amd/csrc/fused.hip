@@ -9,6 +9,7 @@
 //   update  : u   = y - sum_i h_i v_i ; beta_j = ||u||             (arnoldi.jl:303, :305) [kernels.hip]
 // HBM traffic per step (fp64, n rows, nnz entries, window w): A (12 B/entry) + gather of u +
 // 8n*(w-1) [V read] + 8n [v_j write] + 8n [y write]  |  8n*w [V read] + 8n [y read] + 8n [u write].
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernel_common.h"
@@ -178,8 +179,9 @@ void fused_a(hipStream_t s, const FusedAArgs<T> &a) {
 // V[:, m_done] = u / beta_{m_done}: the normalisation of the LAST step of the call (arnoldi.jl:306)
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int64_t n, const T *u,
-                                                         const StepState *st) {
+                                                         const StepState *st, int64_t strideV) {
   constexpr int N = Pack<T>::N;
+  if (blockIdx.y != 0) { V += (int64_t)blockIdx.y * strideV; st += blockIdx.y; }
   if (st->breakdown == 2) return;   // zero starting vector: V stays untouched (arnoldi.jl:366)
   const double beta = st->hnorm;
   T *dst = V + (int64_t)st->m_done * ldv;
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int6
   }
 }
 template <class T>
-void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st) {
-  hipLaunchKernelGGL(k_finalize_last<T>, dim3(grid_for(n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, V, ldv, n, u, st);
+void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st, int64_t strideV,
+                   int nbatch) {
+  const int g = std::max(1, grid_for(n, BLOCK * Pack<T>::N * 2) / (nbatch > 8 ? 8 : nbatch));
+  hipLaunchKernelGGL(k_finalize_last<T>, dim3(g, nbatch), dim3(BLOCK), 0, s, V, ldv, n, u, st, strideV);
 }
 
 // ---- single-reduction step --------------------------------------------------------------------
@@ -209,10 +213,19 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
   __shared__ double nrm_s[BLOCK / 64];
   __shared__ int flag_s;
   __shared__ T gs_s[GRAM ? (LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2) : 1];
-  const DotsArgs<T> &a = fa.d;
+  DotsArgs<T> a = fa.d;
+  const T *u = fa.u;                       // V[:, jcol], unnormalised
+  if (blockIdx.y != 0) {                   // batched launch: this workgroup works on problem blockIdx.y
+    const int64_t pb = blockIdx.y;
+    a.V += pb * a.bs.V; a.y += pb * a.bs.ybuf; a.x += pb * a.bs.V;
+    a.part += pb * a.bs.part; a.gpart += pb * a.bs.gpart; a.st += pb * a.bs.st;
+    a.Hdev += pb * a.bs.Hdev; a.gram += pb * a.bs.gram; a.hcoef += pb * a.bs.hcoef;
+    u += pb * a.bs.V;
+    fa.ybuf += pb * a.bs.ybuf;
+    fa.A.val += pb * a.bs.Aval;
+  }
   if (step_skipped(a.st, fa.step)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const T *u = fa.u;                       // V[:, jcol], unnormalised
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(fa.ybuf) && is_al16(u);
   double nrm = 0.0;
   for (int cb = 0; cb < a.nd; cb += CH) {
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
 
 static void plan_slices2(int64_t nslices, int max_blocks, int *nblocks, int *spw) { plan_slices(nslices, max_blocks, nblocks, spw); }
 template <class T>
-void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol) {
+void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
   constexpr int CH = DotChunk<T>::CH;
   // measured on C2 (profiles/r01_ab_variants.txt): the 2x-accumulator variant is slower (56 vs 48 us per launch),
   // so it is opt-in for experiments only
@@ -289,17 +302,17 @@ void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol) {
       // windows of 17..32 columns (fp64): one pass with twice the accumulators (2 workgroups/CU)
       // instead of a second sweep over y, v_j and a second workgroup reduction
       auto k = k_fused_a2<T, true, 2 * CH, 2>;
-      plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
-      hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+      plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
     } else {
       auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
-      plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
-      hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+      plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
     }
   } else {
     auto k = k_fused_a2<T, false, CH, DOTS_WAVES>;
-    plan_slices2(a.A.nslices, resident_blocks((const void *)k), &nb, &spw);
-    hipLaunchKernelGGL(k, dim3(nb), dim3(BLOCK), 0, s, a, spw, tol);
+    plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+    hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
   }
 }
 
@@ -308,6 +321,10 @@ template <class T>
 __global__ __launch_bounds__(BLOCK) void k_update2(UpdateArgs<T> a, int newest_col, int64_t rpb) {
   constexpr int N = Pack<T>::N;
   constexpr int UN = 8;
+  if (blockIdx.y != 0) {
+    const int64_t pb = blockIdx.y;
+    a.V += pb * a.bs.V; a.y += pb * a.bs.V; a.yin += pb * a.bs.ybuf; a.hcoef += pb * a.bs.hcoef; a.st += pb * a.bs.st;
+  }
   if (step_skipped(a.st, a.step)) return;
   const double inv = a.st->inv;
   T *Vw = const_cast<T *>(a.V);
@@ -353,18 +370,23 @@ __global__ __launch_bounds__(BLOCK) void k_update2(UpdateArgs<T> a, int newest_c
   }
 }
 template <class T>
-void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col) {
-  const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, resident_blocks((const void *)k_update2<T>));
-  hipLaunchKernelGGL(k_update2<T>, dim3(p.nblocks), dim3(BLOCK), 0, s, a, newest_col, p.rows_per_block);
+void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col, int nbatch) {
+  const RowPlan p = plan_rows(a.n, 64 * Pack<T>::N, std::max(1, resident_blocks((const void *)k_update2<T>) / nbatch));
+  hipLaunchKernelGGL(k_update2<T>, dim3(p.nblocks, nbatch), dim3(BLOCK), 0, s, a, newest_col, p.rows_per_block);
 }
 
 // norm of the last vector of the call: beta_m = ||u_{m+1}||, H[m+1, m], breakdown test of step m
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, int64_t n, double *part, double *gpart,
-                                                      StepState *st, T *Hdev, int ldh, int m, double tol, int64_t rpb) {
+                                                      StepState *st, T *Hdev, int ldh, int m, double tol, int64_t rpb,
+                                                      BatchStrides bs) {
   __shared__ double red_s[BLOCK / 64];
   __shared__ double vals_s[1];
   __shared__ int flag_s;
+  if (blockIdx.y != 0) {
+    const int64_t pb = blockIdx.y;
+    x += pb * bs.V; part += pb * bs.part; gpart += pb * bs.gpart; st += pb * bs.st; Hdev += pb * bs.Hdev;
+  }
   if (st->breakdown != 0) return;   // an earlier step already ended the factorisation
   constexpr int N = Pack<T>::N;
   const bool al = is_al16(x);
@@ -375,8 +397,8 @@ __global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, i
 #pragma unroll
     for (int k = 0; k < N; ++k) acc += ST<T>::abs2(p.v[k]);
   }
-  const double bs = block_sum(acc, red_s);
-  if (threadIdx.x == 0) publish_f64(part + blockIdx.x, bs);
+  const double bsum = block_sum(acc, red_s);
+  if (threadIdx.x == 0) publish_f64(part + blockIdx.x, bsum);
   if (!hier_reduce(st, part, gpart, 1, vals_s, &flag_s)) return;
   if (threadIdx.x == 0) {
     const double beta = sqrt(vals_s[0]);
@@ -389,20 +411,88 @@ __global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, i
 }
 template <class T>
 void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh, int m,
-                double tol) {
-  const RowPlan p = plan_rows(n, 64 * Pack<T>::N, resident_blocks((const void *)k_norm_final<T>));
-  hipLaunchKernelGGL(k_norm_final<T>, dim3(p.nblocks), dim3(BLOCK), 0, s, x, n, part, gpart, st, Hdev, ldh, m, tol,
-                     p.rows_per_block);
+                double tol, const BatchStrides &bs, int nbatch) {
+  const RowPlan p = plan_rows(n, 64 * Pack<T>::N, std::max(1, resident_blocks((const void *)k_norm_final<T>) / nbatch));
+  hipLaunchKernelGGL(k_norm_final<T>, dim3(p.nblocks, nbatch), dim3(BLOCK), 0, s, x, n, part, gpart, st, Hdev, ldh, m, tol,
+                     p.rows_per_block, bs);
+}
+
+// ---- batch helpers --------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_combine_batch(int64_t n, const T *__restrict__ V, int64_t ldv, int64_t strideV,
+                                                         const T *__restrict__ coef, int ldc, const double *beta,
+                                                         const int32_t *mcols, T *__restrict__ W, int64_t ldw, int64_t rpb) {
+  constexpr int N = Pack<T>::N;
+  __shared__ T cs[256];
+  const int64_t pb = blockIdx.y;
+  V += pb * strideV;
+  W += pb * ldw;
+  const int m = mcols[pb];
+  const double scale = beta[pb];
+  for (int e = threadIdx.x; e < m; e += BLOCK) cs[e] = coef[pb * ldc + e];
+  __syncthreads();
+  const bool al = ((ldv * sizeof(T)) % 16 == 0) && is_al16(V);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+    T acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = ST<T>::zero();
+    int c = 0;
+    for (; c + 8 <= m; c += 8) {
+      Pack<T> vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[u] = ld_pack(V + (int64_t)(c + u) * ldv, i, n, al);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) ST<T>::fma_(acc[k], vv[u].v[k], cs[c + u]);
+    }
+    for (; c < m; ++c) {
+      const Pack<T> vv = ld_pack(V + (int64_t)c * ldv, i, n, al);
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::fma_(acc[k], vv.v[k], cs[c]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (i + k < n) W[i + k] = ST<T>::mul_real(acc[k], scale);
+  }
+}
+template <class T>
+void combine_batch(hipStream_t s, int64_t n, const T *V, int64_t ldv, int64_t strideV, const T *coef, int ldc,
+                   const double *beta, const int32_t *mcols, T *W, int64_t ldw, int nbatch) {
+  const RowPlan p = plan_rows(n, 64 * Pack<T>::N, std::max(1, resident_blocks((const void *)k_combine_batch<T>) / nbatch));
+  hipLaunchKernelGGL(k_combine_batch<T>, dim3(p.nblocks, nbatch), dim3(BLOCK), 0, s, n, V, ldv, strideV, coef, ldc, beta,
+                     mcols, W, ldw, p.rows_per_block);
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_permute_values(T *__restrict__ sell_val, int64_t sell_stride,
+                                                          const T *__restrict__ csr_val, int64_t csr_stride,
+                                                          const int32_t *__restrict__ perm, int64_t padded) {
+  const int64_t pb = blockIdx.y;
+  for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < padded; e += (int64_t)gridDim.x * BLOCK) {
+    const int32_t src = perm[e];
+    sell_val[pb * sell_stride + e] = (src >= 0) ? csr_val[pb * csr_stride + src] : ST<T>::zero();
+  }
+}
+template <class T>
+void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *csr_val, int64_t csr_stride,
+                    const int32_t *perm, int64_t padded, int nbatch) {
+  hipLaunchKernelGGL(k_permute_values<T>, dim3(grid_for(padded, BLOCK * 4), nbatch), dim3(BLOCK), 0, s, sell_val,
+                     sell_stride, csr_val, csr_stride, perm, padded);
 }
 
 #define INSTF(T)                                                                                               \
   template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int); \
   template void fused_a<T>(hipStream_t, const FusedAArgs<T> &);                                                \
-  template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double);                                       \
-  template void update2<T>(hipStream_t, const UpdateArgs<T> &, int);                                           \
+  template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double, int);                                  \
+  template void update2<T>(hipStream_t, const UpdateArgs<T> &, int, int);                                      \
   template void norm_final<T>(hipStream_t, const T *, int64_t, double *, double *, StepState *, T *, int, int,  \
-                              double);                                                                         \
-  template void finalize_last<T>(hipStream_t, T *, int64_t, int64_t, const T *, const StepState *);
+                              double, const BatchStrides &, int);                                              \
+  template void combine_batch<T>(hipStream_t, int64_t, const T *, int64_t, int64_t, const T *, int, const double *, \
+                                 const int32_t *, T *, int64_t, int);                                          \
+  template void permute_values<T>(hipStream_t, T *, int64_t, const T *, int64_t, const int32_t *, int64_t, int);  \
+  template void finalize_last<T>(hipStream_t, T *, int64_t, int64_t, const T *, const StepState *, int64_t, int);
 INSTF(double)
 INSTF(cplx)
 

@@ -14,6 +14,12 @@ constexpr int LOWSYNC_MAX = 64;   // longest window the in-kernel triangular sol
 
 enum DotsMode { DOTS_STRICT = 0, DOTS_LOWSYNC = 1, DOTS_LANCZOS = 2 };
 
+// Independent problems of equal shape run side by side in blockIdx.y; every per-problem array is
+// the problem-0 pointer plus blockIdx.y times one of these strides (all zero for a single problem).
+struct BatchStrides {
+  int64_t V, ybuf, part, gpart, Hdev, gram, hcoef, Aval, st;
+};
+
 template <class T>
 struct DotsArgs {
   const T *V; int64_t ldv; int64_t n;  // basis, rows
@@ -27,6 +33,7 @@ struct DotsArgs {
   T *Hdev; int ldh; int jcol;          // coefficients go to Hdev[col, jcol]
   T *gram; int ldg; int jrow;          // gram(i,k) = <v_i, v_k>, k < i ; jrow = index of v_j
   T *hcoef;                            // coefficients for the update kernel, window order
+  BatchStrides bs;                     // batched launches only (zero otherwise)
 };
 
 template <class T>
@@ -42,6 +49,7 @@ struct UpdateArgs {
   T *Hdev; int ldh; int jcol;
   double tol;
   int step;                            // 1-based Krylov step, recorded in st->m_done
+  BatchStrides bs;
 };
 
 int grid_for(int64_t n, int rows_per_block);
@@ -99,13 +107,23 @@ template <class T> void fused_a(hipStream_t s, const FusedAArgs<T> &a);
 //                    Hessenberg column of step j from the rescaled sums
 //          update2 : u_{j+1} = y~/beta - sum_i c_i V_i  -> V[:, j];  V[:, j-1] <- u_j / beta   (no reduction)
 // after the loop: norm_final (beta_m, H[m+1, m], breakdown test) + finalize_last.
-template <class T> void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol);
-template <class T> void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col);
+template <class T> void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch = 1);
+template <class T> void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col, int nbatch = 1);
 template <class T>
 void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh,
-                int m, double tol);
+                int m, double tol, const BatchStrides &bs = BatchStrides{}, int nbatch = 1);
+// batched combine: W_p[:, 0] = beta_p * V_p[:, 0:m_p] * coef_p, with beta_p and m_p taken from per-problem arrays
+template <class T>
+void combine_batch(hipStream_t s, int64_t n, const T *V, int64_t ldv, int64_t strideV, const T *coef, int ldc,
+                   const double *beta, const int32_t *mcols, T *W, int64_t ldw, int nbatch);
+// sell_val[p][e] = perm[e] >= 0 ? csr_val[p][perm[e]] : 0   (values of every problem into SELL order)
+template <class T>
+void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *csr_val, int64_t csr_stride,
+                    const int32_t *perm, int64_t padded, int nbatch);
 // V[:, m_done] = u / beta_{m_done} after the loop (the column index comes from the device state)
-template <class T> void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st);
+template <class T>
+void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st, int64_t strideV = 0,
+                   int nbatch = 1);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);
 template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);

@@ -230,8 +230,12 @@ int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int
                   const expv_mi_kiops_opts *opts, int64_t stats[5]);
 
 /* ------------------------------------------------------------------ batch ------------ */
-/* nprob independent expv problems of equal size n sharing one sparsity pattern family
- * (BASELINE config 5): CSR arrays concatenated per problem; b and w are n x nprob. */
+/* nprob independent problems expv(t[p], A_p, b[:, p]; m, tol, iop, ishermitian) of equal size n whose
+ * operators share ONE sparsity pattern (BASELINE config 5): rowptr[n+1] / colind[nnz_per_prob] (CSR32,
+ * 0-based) once, vals = nnz_per_prob values per problem, problem-major; b and w are n x nprob.
+ * The problems advance in lock step (problem index in blockIdx.y of every launch); each keeps its own
+ * Hessenberg matrix and happy-breakdown state, m_used[p] = Ks.m of problem p.  ishermitian applies to all.
+ * rowptr / colind are host arrays; mat_loc says where `vals` lives. */
 int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr,
                        const int32_t *colind, const void *vals, int64_t nnz_per_prob, int mat_loc,
                        const double *t, const void *b, int64_t ldb, int b_loc, void *w, int64_t ldw,

@@ -371,3 +371,39 @@ def test_device_resident_vectors(eu):
     wd = eu.expv(1.0, A, bd, m=m)
     assert wd.is_cuda
     assert relerr(wd.cpu().numpy(), ko.expv(1.0, A, b, m=m, ishermitian=False)) < TOL
+
+
+# ------------------------------------------------------------------ batch (config 5) ---------
+@pytest.mark.parametrize("sym", [False, True])
+def test_expv_batch_matches_single_problem_loop(eu, sym):
+    """BASELINE config 5 at small size: nprob operators with one pattern, values scaled per problem."""
+    rng = np.random.default_rng(7)
+    n, nprob, m = 3000, 9, 30
+    A0 = c2_operator(n, sym=sym).tocsr()
+    A0.sort_indices()
+    scales = 1 + 0.1 * rng.random(nprob)
+    vals = np.stack([A0.data * s for s in scales])
+    B = np.asfortranarray(rng.standard_normal((n, nprob)))
+    ts = np.linspace(0.5, 1.0, nprob)
+    W, mu = eu.expv_batch(ts, A0, vals, B, m=m, ishermitian=sym, return_m=True)
+    for p in range(nprob):
+        Ap = A0.copy()
+        Ap.data = vals[p].copy()
+        wo = ko.expv(ts[p], Ap, B[:, p], m=m, ishermitian=sym)
+        assert relerr(W[:, p], wo) < TOL
+        assert mu[p] == m
+
+
+def test_expv_batch_breakdown_and_zero_columns(eu):
+    """Per-problem state: one problem breaks down early, one has a zero right-hand side."""
+    n, m = 256, 20
+    A0 = sp.identity(n, format="csr") * 2.0          # A = 2I: Krylov space has dimension 1 -> breakdown at j = 1
+    vals = np.stack([A0.data, A0.data * 0.5, A0.data])
+    rng = np.random.default_rng(1)
+    B = np.asfortranarray(rng.standard_normal((n, 3)))
+    B[:, 2] = 0.0
+    W, mu = eu.expv_batch(0.3, A0, vals, B, m=m, return_m=True)
+    np.testing.assert_allclose(W[:, 0], np.exp(0.6) * B[:, 0], rtol=1e-13)
+    np.testing.assert_allclose(W[:, 1], np.exp(0.3) * B[:, 1], rtol=1e-13)
+    assert np.all(W[:, 2] == 0.0)
+    assert mu[0] == 1 and mu[1] == 1
