@@ -163,6 +163,10 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.n = n;
   op.nnz = (int64_t)ci.size();
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
+  int64_t bw = 0;
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) bw = std::max<int64_t>(bw, std::llabs((long long)ci[k] - (long long)r));
+  op.bandwidth = bw;
   upload_csr<V>(op, rp, ci, va);
   build_sell<V>(op, n, rp, ci, va);
 }
@@ -478,6 +482,7 @@ int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
     copy_out_2d(ks->ctx, dst, EXPV_MI_HOST, ld_dst, ks->V.as<char>() + (size_t)col0 * ks->ldv * esz, ks->ldv,
                 ks->rows(), ncols, esz);
@@ -487,6 +492,7 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
     if (ncols > 0 && ks->rows() > 0)
       HIPCHECK(hipMemcpy2DAsync(ks->V.as<char>() + (size_t)col0 * ks->ldv * esz, ks->ldv * esz, src, ld_src * esz,
@@ -497,6 +503,8 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
 }
 int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv) {
   if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  const int rc = guarded(ks->ctx, [&] { ks_materialize(*ks); });
+  if (rc != EXPV_MI_OK) return rc;
   if (V) *V = ks->V.p;
   if (ldv) *ldv = ks->ldv;
   return EXPV_MI_OK;

@@ -111,6 +111,7 @@ struct Op {
   DevBuf sell_off, sell_col, sell_val;   // SELL-C (C = 128 rows fp64 / 64 complex), built when padding is small
   int64_t nslices = 0;
   bool sell_ok = false;
+  int64_t bandwidth = -1;   // max |col - row| (CSR operators)
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;
@@ -144,6 +145,10 @@ struct Ks {
   void *pin = nullptr;   // pinned host staging for the Hessenberg / step-state read-back
   size_t pin_bytes = 0;
   ~Ks() { if (pin) (void)hipHostFree(pin); }
+  DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
+  std::vector<double> colscale_host; // ... and their host copy
+  bool scale_pending = false;        // stored columns are v_c / s_c until materialised
+  int scale_cols = 0;
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
   int64_t rows() const { return n + augmented; }
 };
@@ -189,6 +194,7 @@ inline void setH_realpart(Ks &ks, int i, int j, double v) {  // realview(...) wr
 // ---- engine_core.hip -----------------------------------------------------------------------
 void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int augmented);
 void ks_resize(Ks &ks, int maxiter);
+void ks_materialize(Ks &ks);   // apply pending column scales (pipelined factorisation) so that V is orthonormal in HBM
 void op_apply_dev(Op &op, const void *x_dev, void *y_dev, const StepState *st, int step, bool count = true);
 
 struct ArnoldiAug {  // augmented operator pieces (kiops)

@@ -98,6 +98,7 @@ void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int au
 
 void ks_resize(Ks &ks, int maxiter) {  // arnoldi.jl:80-93
   ks.ctx->use();
+  ks_materialize(ks);
   const bool isaug = ks.augmented != 0;
   const size_t esz = dtype_size(ks.dtypeT), usz = dtype_size(ks.dtypeU);
   DevBuf Vn((size_t)ks.ldv * (maxiter + 1) * esz);
@@ -128,6 +129,16 @@ void ks_resize(Ks &ks, int maxiter) {  // arnoldi.jl:80-93
     ks.gram_rows = 0;
   }
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
+}
+
+void ks_materialize(Ks &ks) {
+  if (!ks.scale_pending) return;
+  ks.ctx->use();
+  if (ks.dtypeT == EXPV_MI_F64 && ks.scale_cols > 0)
+    dev::scale_columns(ks.ctx->stream, ks.V.as<double>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+  HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
+  ks.scale_pending = false;
+  ks.scale_cols = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,6 +191,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   const double tol = o.tol;
   int init = o.init;
   ks.wasbreakdown = false;
+  if (init != 0) ks_materialize(ks);        // a continuation reads the stored basis
+  else { ks.scale_pending = false; ks.scale_cols = 0; }   // a fresh factorisation overwrites it
   if (m > ks.maxiter) ks_resize(ks, m);
   else ks.m = m;
   // checkdims (arnoldi.jl:207-220)
@@ -192,7 +205,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   StepState *st = ks.state.as<StepState>();
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
-  bool use_fused = false, single_red = false;
+  bool use_fused = false, single_red = false, use_pipe = false;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -218,9 +231,17 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
     static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
     single_red = !fused_v1;
+    // The single-pass banded pipeline (pipe.hip) is CORRECT (parity-green) but measured slower than the two-kernel
+    // step on C2 (profiles/r01_ab_variants.txt: 94.6 us vs 47.9 + 25.7 us per step): opt-in for experiments.
+    static const bool no_pipe = std::getenv("EXPV_MI_PIPE") == nullptr;
     use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
                 (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
-    if (use_fused && single_red) {
+    if constexpr (!ST<T>::is_complex)
+      use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+                 m <= dev::PIPE_CH && !real_coeff;
+    if (use_pipe) {
+      // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
+    } else if (use_fused && single_red) {
       // u_1 = b goes to V[:, 0] unnormalised; ||b|| comes out of the first fused half-step's reduction
       HIPCHECK(hipMemcpyAsync(V, src, sizeof(T) * (size_t)ks.n, hipMemcpyDeviceToDevice, s));
     } else {
@@ -277,7 +298,58 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   double *gpart = ks.gpart.as<double>();
   const int ortho = o.ortho;
 
-  if (use_fused && single_red) {
+  if (use_pipe) {
+    if constexpr (!ST<T>::is_complex) {
+      // ---- single-pass banded pipeline: ONE launch, ONE reduction, ONE read of V per step (pipe.hip) --
+      const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
+      if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
+      if (ks.hcoef2.bytes < ks.hcoef.bytes) ks.hcoef2.alloc(ks.hcoef.bytes);
+      if (ks.colscale.bytes < sizeof(double) * (size_t)(ks.maxiter + 2)) ks.colscale.alloc(sizeof(double) * (size_t)(ks.maxiter + 2));
+      double *ya = ks.ybuf.as<double>(), *yb2 = ks.ubuf.as<double>();
+      double *hca = ks.hcoef.as<double>(), *hcb = ks.hcoef2.as<double>();
+      dev::SellView<double> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<double>(), op.nslices};
+      for (int j = 1; j <= m; ++j) {
+        const int i0 = lanczos ? j : std::max(1, j - iop + 1);
+        const int nd = j - i0 + 1;
+        dev::PipeArgs pa{};
+        pa.A = A;
+        pa.w = (int)op.bandwidth;
+        pa.yprev = (j & 1) ? yb2 : ya;
+        pa.ybuf = (j & 1) ? ya : yb2;
+        pa.u0 = (j == 1) ? reinterpret_cast<const double *>(b) : nullptr;
+        dev::DotsArgs<double> &d = pa.d;
+        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
+        d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+        d.part = part; d.gpart = gpart; d.st = st;
+        d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+        d.real_coeff = 0;
+        d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.jrow = j - 1;
+        d.hcoef = nullptr;
+        if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
+        else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+        else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
+        pa.hcoef_in = (j & 1) ? hcb : hca;
+        pa.hcoef_out = (j & 1) ? hca : hcb;
+        pa.scales = ks.colscale.as<double>();
+        pa.step = j;
+        pa.tol = tol;
+        { ProfScope ps(c, EXPV_MI_K_FUSED_A); dev::pipe_step(s, pa); }
+      }
+      {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
+        dev::UpdateArgs<double> u{};
+        u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
+        if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }
+        else { const int i0 = std::max(1, m - iop + 1); u.c0 = i0 - 1; u.dir = 1; u.nd = m - i0 + 1; }
+        u.hcoef = (m & 1) ? hca : hcb; u.do_norm = 0; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+        u.jcol = m - 1; u.tol = tol; u.step = m + 1;
+        { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<double>(s, u, -1); }
+        ProfScope ps(c, EXPV_MI_K_SCALE);
+        dev::norm_final<double>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol, dev::BatchStrides{}, 1,
+                                ks.colscale.as<double>() + m);
+      }
+      ks.gram_rows = lanczos ? 1 : m;
+    }
+  } else if (use_fused && single_red) {
     // ---- single-reduction path: 2 launches and ONE grid reduction per Krylov step (fused.hip) --
     const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
     if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
@@ -423,6 +495,14 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     ks.beta = std::sqrt(h.beta0sq);
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
   }
+  if (use_pipe) {   // the stored columns are v_c / s_c: keep the scales for the combine / a later materialisation
+    const int ncol = ((h.breakdown == 1) ? h.m_done : m) + 1;
+    ks.colscale_host.assign(ks.maxiter + 2, 1.0);
+    HIPCHECK(hipMemcpyAsync(ks.colscale_host.data(), ks.colscale.p, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    ks.scale_pending = true;
+    ks.scale_cols = ncol;
+  }
   const int jlast = (h.breakdown == 1) ? h.m_done : m;
   auto toc = [](const T &v) -> cd {
     if constexpr (ST<T>::is_complex) return cd(v.re, v.im);
@@ -493,6 +573,14 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
         cbuf[(size_t)q * mcols + i] = re;
       }
     }
+  if (ks.scale_pending) {   // W = V_stored * diag(s) * C
+    for (int q = 0; q < ncols; ++q)
+      for (int i = 0; i < mcols && i < ks.scale_cols; ++i) {
+        const double sc = ks.colscale_host[i];
+        if (Cc) { cbuf[2 * ((size_t)q * mcols + i)] *= sc; cbuf[2 * ((size_t)q * mcols + i) + 1] *= sc; }
+        else cbuf[(size_t)q * mcols + i] *= sc;
+      }
+  }
   const bool by_value = (ncols == 1 && mcols <= dev::COEF_BY_VALUE_MAX && (w_loc == EXPV_MI_HOST || ldw >= rows || true));
   DevBuf cdev;
   if (!by_value) {

@@ -379,7 +379,7 @@ void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col, int nbatch) 
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, int64_t n, double *part, double *gpart,
                                                       StepState *st, T *Hdev, int ldh, int m, double tol, int64_t rpb,
-                                                      BatchStrides bs) {
+                                                      BatchStrides bs, double *scale_out) {
   __shared__ double red_s[BLOCK / 64];
   __shared__ double vals_s[1];
   __shared__ int flag_s;
@@ -406,15 +406,16 @@ __global__ __launch_bounds__(BLOCK) void k_norm_final(const T *__restrict__ x, i
     st->inv = 1.0 / beta;
     st->m_done = m;
     Hdev[m + (int64_t)(m - 1) * ldh] = ST<T>::from_real(beta);
+    if (scale_out) *scale_out = 1.0 / beta;
     if (beta < tol) st->breakdown = 1;
   }
 }
 template <class T>
 void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh, int m,
-                double tol, const BatchStrides &bs, int nbatch) {
+                double tol, const BatchStrides &bs, int nbatch, double *scale_out) {
   const RowPlan p = plan_rows(n, 64 * Pack<T>::N, std::max(1, resident_blocks((const void *)k_norm_final<T>) / nbatch));
   hipLaunchKernelGGL(k_norm_final<T>, dim3(p.nblocks, nbatch), dim3(BLOCK), 0, s, x, n, part, gpart, st, Hdev, ldh, m, tol,
-                     p.rows_per_block, bs);
+                     p.rows_per_block, bs, scale_out);
 }
 
 // ---- batch helpers --------------------------------------------------------------------------
@@ -488,7 +489,7 @@ void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *cs
   template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double, int);                                  \
   template void update2<T>(hipStream_t, const UpdateArgs<T> &, int, int);                                      \
   template void norm_final<T>(hipStream_t, const T *, int64_t, double *, double *, StepState *, T *, int, int,  \
-                              double, const BatchStrides &, int);                                              \
+                              double, const BatchStrides &, int, double *);                                    \
   template void combine_batch<T>(hipStream_t, int64_t, const T *, int64_t, int64_t, const T *, int, const double *, \
                                  const int32_t *, T *, int64_t, int);                                          \
   template void permute_values<T>(hipStream_t, T *, int64_t, const T *, int64_t, const int32_t *, int64_t, int);  \

@@ -111,7 +111,7 @@ template <class T> void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double t
 template <class T> void update2(hipStream_t s, const UpdateArgs<T> &a, int newest_col, int nbatch = 1);
 template <class T>
 void norm_final(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st, T *Hdev, int ldh,
-                int m, double tol, const BatchStrides &bs = BatchStrides{}, int nbatch = 1);
+                int m, double tol, const BatchStrides &bs = BatchStrides{}, int nbatch = 1, double *scale_out = nullptr);
 // batched combine: W_p[:, 0] = beta_p * V_p[:, 0:m_p] * coef_p, with beta_p and m_p taken from per-problem arrays
 template <class T>
 void combine_batch(hipStream_t s, int64_t n, const T *V, int64_t ldv, int64_t strideV, const T *coef, int ldc,
@@ -124,6 +124,27 @@ void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *cs
 template <class T>
 void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st, int64_t strideV = 0,
                    int nbatch = 1);
+
+// ---- single-pass step for narrow-banded operators (pipe.hip, fp64) -------------------------
+constexpr int PIPE_CH = 32;       // longest window (m <= 32)
+constexpr int PIPE_TILE = BLOCK;  // rows per workgroup pass, one row per lane
+constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 256-row tile)
+struct PipeArgs {
+  SellView<double> A;
+  int w;                       // half-bandwidth of A
+  const double *yprev;         // y~_{j-1} = A u_{j-1}
+  double *ybuf;                // out: y~_j
+  const double *u0;            // step 1: the starting vector b (u_1 = b)
+  DotsArgs<double> d;          // basis, projection window of step j, reduction buffers, epilogue targets
+  int uc0, udir, und;          // update window of step j-1: columns uc0 + udir*i, i < und
+  const double *hcoef_in;      // its coefficients (h_i * s_i), produced by the previous pass
+  double *hcoef_out;           // coefficients for the next pass
+  double *scales;              // s_c: stored column c = v_{c+1} / s_c
+  int step;
+  double tol;
+};
+void pipe_step(hipStream_t s, const PipeArgs &pa);
+void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *scales, int ncols);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);
 template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);
