@@ -407,3 +407,102 @@ def test_expv_batch_breakdown_and_zero_columns(eu):
     np.testing.assert_allclose(W[:, 1], np.exp(0.3) * B[:, 1], rtol=1e-13)
     assert np.all(W[:, 2] == 0.0)
     assert mu[0] == 1 and mu[1] == 1
+
+
+# ------------------------------------------------------------------ edge cases ---------------
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 513, 1023, 1025])
+def test_sizes_around_tile_boundaries(eu, n):
+    """Ragged sizes: one row, odd lengths (16-byte packs), wave (128) and tile boundaries."""
+    rng = np.random.default_rng(n)
+    A = c2_operator(n) if n > 2 else sp.csr_matrix(np.array([[-2.0]]) if n == 1 else np.array([[-2.0, 0.8], [1.2, -2.0]]))
+    b = rng.standard_normal(n)
+    m = min(30, n)
+    for ortho in ("auto", "mgs"):
+        Ks = eu.arnoldi(A, b, m=m, ishermitian=False, ortho=ortho)
+        Ko = ko.arnoldi(A, b, m=m, ishermitian=False)
+        assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
+        mm = Ks.m
+        assert herr(Ks.H[: mm + 1, :mm], Ko.H[: mm + 1, :mm]) <= 1e-10      # near-breakdown columns amplify rounding
+        w = eu.expv_(np.empty(n), 0.7, Ks)
+        assert relerr(w, sl.expm(0.7 * A.toarray()) @ b) < 1e-9
+
+
+def test_m_larger_than_n_breaks_down(eu):
+    n = 4
+    A = c2_operator(8)[:n, :n].tocsr()
+    b = np.random.default_rng(2).standard_normal(n)
+    Ks = eu.KrylovSubspace(np.float64, np.float64, n, 8)
+    eu.arnoldi_(Ks, A, b, m=8, ishermitian=False)
+    Ko = ko.KrylovSubspace(float, float, n, 8)
+    ko.arnoldi_(Ko, A, b, m=8, ishermitian=False)
+    assert Ks.m == Ko.m <= n and Ks.wasbreakdown and Ko.wasbreakdown
+
+
+def test_irregular_rows_fall_back_to_csr_and_empty_rows(eu):
+    """A dense row makes SELL padding explode (kept as CSR, one row per lane); empty rows are legal."""
+    rng = np.random.default_rng(21)
+    n = 700
+    A = sp.random(n, n, density=0.01, random_state=rng, format="lil")
+    A[5, :] = rng.standard_normal(n)          # one dense row
+    A[17, :] = 0                              # empty rows
+    A[n - 1, :] = 0
+    A = (A.tocsr() * 0.3).tocsc()
+    b = rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=25, ishermitian=False)
+    Ko = ko.arnoldi(A, b, m=25, ishermitian=False)
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    assert relerr(eu.expv(1.0, A, b, m=25), ko.expv(1.0, A, b, m=25)) < TOL
+
+
+def test_sparse_complex_fused_full_arnoldi(eu):
+    rng = np.random.default_rng(31)
+    n, m = 5000, 30
+    A = (c2_operator(n) * (1 + 0.25j)).tocsc()
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=False)
+    Ko = ko.arnoldi(A, b, m=m, ishermitian=False)
+    assert herr(Ks.getH(), Ko.getH()) <= TOL
+    for t in (0.4, 0.4j, -0.2 + 0.1j):
+        w = eu.expv_(np.empty(n, dtype=complex), t, Ks)
+        assert relerr(w, ko.expv_(np.empty(n, dtype=complex), t, Ko)) < TOL
+
+
+def test_window_longer_than_one_chunk_and_iop(eu):
+    """m = 48 (> 32): three projection chunks; iop windows of 5 and 20."""
+    n = 3000
+    A = stencil2d(55)[:n, :n].tocsr()
+    b = np.random.default_rng(4).standard_normal(n)
+    for m, iop in ((48, 0), (40, 5), (40, 20)):
+        Ks = eu.KrylovSubspace(np.float64, np.float64, n, m)
+        eu.arnoldi_(Ks, A, b, m=m, iop=iop, ishermitian=False)
+        Ko = ko.KrylovSubspace(float, float, n, m)
+        ko.arnoldi_(Ko, A, b, m=m, iop=iop, ishermitian=False)
+        assert Ks.m == Ko.m
+        assert herr(Ks.getH(), Ko.getH()) <= 1e-11
+
+
+def test_timestep_sorts_ts_in_place_and_matrix_output(eu):
+    """krylov_phiv_adaptive.jl:297: ts is sorted in place; U[:, j] follows the sorted order."""
+    n = 60
+    A = c2_operator(n).tocsc()
+    b = np.random.default_rng(5).standard_normal(n)
+    ts = np.array([0.9, 0.1, 0.5])
+    U = eu.expv_timestep(ts, A, b, tol=1e-9)
+    Uo = ko.expv_timestep(np.array([0.9, 0.1, 0.5]), A, b, tol=1e-9)
+    assert relerr(U, Uo) < 1e-10
+    for j, t in enumerate(sorted([0.9, 0.1, 0.5])):       # non-adaptive, m = 10: the method's own accuracy
+        assert relerr(U[:, j], sl.expm(t * A.toarray()) @ b) < 1e-5
+
+
+def test_pipelined_path_when_enabled_is_lazy_and_consistent(eu):
+    """Ks.V is orthonormal whenever it is observed, whatever path produced it."""
+    n, m = 4000, 20
+    A = c2_operator(n)
+    b = np.random.default_rng(6).standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=False)
+    w1 = eu.expv_(np.empty(n), 1.0, Ks)          # combine before V is observed
+    V = Ks.getV()
+    G = V.T @ V
+    assert np.max(np.abs(G - np.eye(m + 1))) < 1e-12
+    w2 = eu.expv_(np.empty(n), 1.0, Ks)          # and after
+    assert relerr(w2, w1) < 1e-14
