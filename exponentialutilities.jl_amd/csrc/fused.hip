@@ -81,7 +81,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int64_t n, SellView<T> A, c
        slice += (int64_t)gridDim.x * (BLOCK / 64)) {
     Pack<T> acc;
     sell_rows<T>(A, slice, lane, x, acc.v);
-    st_pack(y, slice * SH + (int64_t)lane * N, n, al, acc);
+    st_pack_user(y, slice * SH + (int64_t)lane * N, n, al, acc);
   }
 }
 template <class T>
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_fused_a(FusedAArgs<T> fa,
       Pack<T> yv, xv;
       if (cb == 0) {
         sell_rows<T>(fa.A, slice, lane, fa.u, yv.v);          // A * u  (unnormalised)
-        const Pack<T> uo = ld_pack(fa.u, i, a.n, alu);
+        const Pack<T> uo = ld_pack_user(fa.u, i, a.n, alu);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
           yv.v[k] = ST<T>::mul_real(yv.v[k], inv);            // A * (u / beta) by linearity

@@ -23,8 +23,15 @@ struct __attribute__((aligned(16))) Pack {
   T v[N];
 };
 
+// Two flavours of 16-byte row-pack access.
+//  * ld_pack / st_pack: LIBRARY-OWNED vectors (columns of V, y/u scratch): their allocation is padded to a
+//    multiple of 128 rows and the padding rows are kept at zero, so a pack that starts at a valid row may
+//    always be moved whole.  The only test is the wave-uniform alignment flag: no per-lane exec masking,
+//    no scalar tail path in the hot loops.
+//  * ld_pack_user / st_pack_user: CALLER vectors of exactly n elements (b, w, operator outputs): the last
+//    pack is handled element-wise.
 template <class T>
-__device__ __forceinline__ Pack<T> ld_pack(const T *__restrict__ p, int64_t i, int64_t n, bool al) {
+__device__ __forceinline__ Pack<T> ld_pack_user(const T *__restrict__ p, int64_t i, int64_t n, bool al) {
   Pack<T> r;
   if (al && i + Pack<T>::N <= n) {
     r = *reinterpret_cast<const Pack<T> *>(p + i);
@@ -35,7 +42,7 @@ __device__ __forceinline__ Pack<T> ld_pack(const T *__restrict__ p, int64_t i, i
   return r;
 }
 template <class T>
-__device__ __forceinline__ void st_pack(T *__restrict__ p, int64_t i, int64_t n, bool al, const Pack<T> &r) {
+__device__ __forceinline__ void st_pack_user(T *__restrict__ p, int64_t i, int64_t n, bool al, const Pack<T> &r) {
   if (al && i + Pack<T>::N <= n) {
     *reinterpret_cast<Pack<T> *>(p + i) = r;
   } else {
@@ -43,6 +50,24 @@ __device__ __forceinline__ void st_pack(T *__restrict__ p, int64_t i, int64_t n,
     for (int k = 0; k < Pack<T>::N; ++k)
       if (i + k < n) p[i + k] = r.v[k];
   }
+}
+template <class T>
+__device__ __forceinline__ Pack<T> ld_pack(const T *p, int64_t i, int64_t n, bool al) {
+  if (al) return *reinterpret_cast<const Pack<T> *>(p + i);
+  Pack<T> r;
+#pragma unroll
+  for (int k = 0; k < Pack<T>::N; ++k) r.v[k] = (i + k < n) ? p[i + k] : ST<T>::zero();
+  return r;
+}
+template <class T>
+__device__ __forceinline__ void st_pack(T *p, int64_t i, int64_t n, bool al, const Pack<T> &r) {
+  if (al) {
+    *reinterpret_cast<Pack<T> *>(p + i) = r;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < Pack<T>::N; ++k)
+    if (i + k < n) p[i + k] = r.v[k];
 }
 __device__ __forceinline__ bool is_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k_sumsq(const T *__restrict__ x, int64_
   const bool al = is_al16(x);
   double acc = 0.0;
   for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
-    Pack<T> p = ld_pack(x, i, n, al);
+    Pack<T> p = ld_pack_user(x, i, n, al);
 #pragma unroll
     for (int k = 0; k < N; ++k) acc += ST<T>::abs2(p.v[k]);
   }
@@ -108,10 +108,10 @@ __global__ __launch_bounds__(BLOCK) void k_scale_copy(T *__restrict__ dst, const
   constexpr int N = Pack<T>::N;
   const bool al = is_al16(dst) && is_al16(src);
   for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
-    Pack<T> p = ld_pack(src, i, n, al);
+    Pack<T> p = ld_pack_user(src, i, n, al);
 #pragma unroll
     for (int k = 0; k < N; ++k) p.v[k] = divide ? ST<T>::div_real(p.v[k], scal) : ST<T>::mul_real(p.v[k], scal);
-    st_pack(dst, i, n, al, p);
+    st_pack_user(dst, i, n, al, p);
   }
 }
 template <class T>
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemv_dense(int64_t n, const T *__rest
     for (; c + 8 <= cend; c += 8) {
       Pack<T> a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = ld_pack(A + (c + u) * lda, i, n, al);
+      for (int u = 0; u < 8; ++u) a[u] = ld_pack_user(A + (c + u) * lda, i, n, al);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const T xc = x[c + u];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemv_dense(int64_t n, const T *__rest
       }
     }
     for (; c < cend; ++c) {
-      Pack<T> a = ld_pack(A + c * lda, i, n, al);
+      Pack<T> a = ld_pack_user(A + c * lda, i, n, al);
       const T xc = x[c];
 #pragma unroll
       for (int k = 0; k < N; ++k) ST<T>::fma_(acc.v[k], a.v[k], xc);
@@ -518,14 +518,14 @@ __global__ __launch_bounds__(BLOCK) void k_lincomb(LincombArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < N; ++k) acc.v[k] = ST<T>::zero();
     for (int t = 0; t < a.nterms; ++t) {
-      const Pack<T> v = ld_pack(a.in[t], i, a.n, al);
+      const Pack<T> v = ld_pack_user(a.in[t], i, a.n, al);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         if (t == 0) acc.v[k] = ST<T>::mul(a.coef[0], v.v[k]);
         else ST<T>::fma_(acc.v[k], a.coef[t], v.v[k]);
       }
     }
-    st_pack(a.out, i, a.n, al, acc);
+    st_pack_user(a.out, i, a.n, al, acc);
   }
 }
 template <class T>

@@ -63,11 +63,24 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
   for (int64_t tile = t0; tile < t1; ++tile) {
     const int64_t r0 = tile * TR, i = r0 + 2 * (int64_t)tid;
+    // ---- halo rows (w above, w below the tile), same MGS order as the tile rows ------------------------
+    if (tid < 2 * w) {
+      const int64_t hr = (tid < w) ? r0 - w + tid : r0 + TR + (tid - w);
+      double uh = 0.0;
+      if (hr >= 0 && hr < a.n) {
+        if (first) uh = pa.u0[hr];
+        else {
+          uh = pa.yprev[hr] * inv;
+          for (int k = 0; k < und; ++k) uh = fma(-pa.hcoef_in[k], a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv], uh);
+        }
+      }
+      us[(tid < w) ? tid : TR + tid] = uh;
+    }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
     Pack<double> vreg[CH - 1];
     Pack<double> u;
     if (first) {
-      u = ld_pack(pa.u0, i, a.n, al);
+      u = ld_pack_user(pa.u0, i, a.n, al);
     } else {
       u = ld_pack(pa.yprev, i, a.n, al);
       u.v[0] *= inv;
@@ -82,18 +95,6 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
           u.v[0] = fma(-h, vreg[k].v[0], u.v[0]);
           u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
         }
-    }
-    if (tid < 2 * w) {                          // halo rows: w above and w below the tile
-      const int64_t hr = (tid < w) ? r0 - w + tid : r0 + TR + (tid - w);
-      double uh = 0.0;
-      if (hr >= 0 && hr < a.n) {
-        if (first) uh = pa.u0[hr];
-        else {
-          uh = pa.yprev[hr] * inv;
-          for (int k = 0; k < und; ++k) uh = fma(-pa.hcoef_in[k], a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv], uh);
-        }
-      }
-      us[(tid < w) ? tid : TR + tid] = uh;
     }
     us[w + 2 * tid] = u.v[0];
     us[w + 2 * tid + 1] = u.v[1];
