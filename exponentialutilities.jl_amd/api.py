@@ -527,9 +527,26 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
     bdt = _np_dtype_of(b)
     n = b.shape[0]
     if mode == "happy_breakdown":
-        Ks = arnoldi(op, b, **kw)
-        w = _empty_like(b, (n,), _work_dtype(tdt, op.dtype, bdt))
-        return expv_(w, t, Ks)
+        # expv(t, A, b) = arnoldi + expv! (krylov_phiv.jl:135-144) as ONE library call: the subspace is
+        # private to the call, so the library reuses its workspace and skips v_{m+1} / H[m+1, m]
+        T = _work_dtype(op.dtype, bdt)
+        opT = _as_operator(op, T)
+        extra = set(kw) - {"m", "tol", "iop", "ishermitian", "ortho", "opnorm"}
+        if extra:
+            raise TypeError(f"unexpected keyword(s) {sorted(extra)}")
+        ish = kw.get("ishermitian")
+        o = _opts(kw.get("m", min(30, op.shape[0])), kw.get("tol", 1e-7), kw.get("iop", 0), 0,
+                  opT.ishermitian if ish is None else ish, kw.get("ortho", "auto"))
+        w = _empty_like(b, (n,), _work_dtype(tdt, T))
+        ba, wa = _Arg(b, T), _Arg(w, _work_dtype(tdt, T), writable=True)
+        if int(np.prod(ba.shape)) != op.shape[0]:
+            raise DimensionMismatch(f"length(b) [{int(np.prod(ba.shape))}] == size(A,1) [{op.shape[0]}] doesn't hold")
+        st = L.ExpvStats()
+        _check(L.load().expv_mi_expv(opT.ctx._h, opT._h, tr, ti, ba.ptr, ba.loc, wa.ptr, wa.loc, _code(wa.dtype),
+                                     C.byref(o), C.byref(st)), opT.ctx._h)
+        wa.finish()
+        expv.last_stats = {"m": st.m_used, "wasbreakdown": bool(st.wasbreakdown), "matvecs": st.matvecs, "beta": st.beta}
+        return w
     if mode == "error_estimate":        # _expv_ee  (:145-160)
         m = kw.pop("m", min(30, op.shape[0]))
         tol = kw.pop("tol", 1e-7)

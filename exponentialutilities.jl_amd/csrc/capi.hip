@@ -205,6 +205,7 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &p : ctx->prof)
     for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return EXPV_MI_OK;
@@ -584,8 +585,19 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     const int m = o.m > 0 ? o.m : (int)std::min<int64_t>(30, op->n);   // arnoldi(A, b; m = min(30, size(A,1)))
     o.m = m;
     int herm = o.ishermitian < 0 ? op->ishermitian : o.ishermitian;
-    expv_mi_ks_s ks;
-    ks_alloc(ks, ctx, op->dtype, herm ? EXPV_MI_F64 : op->dtype, op->n, m, 0);
+    // the internal subspace is private to this call: reuse it across calls of the same shape, and skip what
+    // expv never reads (v_{m+1}, H[m+1, m])
+    const int dtU = herm ? EXPV_MI_F64 : op->dtype;
+    expv_mi_ks_s *kp = reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
+    if (!kp || kp->dtypeT != op->dtype || kp->dtypeU != dtU || kp->n != op->n || kp->maxiter != m || kp->augmented != 0) {
+      delete kp;
+      ctx->ws_ks = nullptr;
+      kp = new expv_mi_ks_s();
+      ctx->ws_ks = kp;
+      ks_alloc(*kp, ctx, op->dtype, dtU, op->n, m, 0);
+    }
+    expv_mi_ks_s &ks = *kp;
+    ks.skip_tail = true;
     DevBuf tmp;
     const void *bd = stage_in(ctx, b, b_loc, (size_t)op->n * dtype_size(op->dtype), tmp);
     const int mv = arnoldi_run(ks, *op, bd, o, nullptr, false);

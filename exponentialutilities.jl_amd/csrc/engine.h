@@ -46,6 +46,7 @@ struct Ctx {
   std::string last_error;
   bool prof_on = false;
   ProfSlot prof[EXPV_MI_K_COUNT];
+  void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
   void use() const { HIPCHECK(hipSetDevice(device)); }
 };
 }  // namespace expv_mi
@@ -148,6 +149,7 @@ struct Ks {
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
   std::vector<double> colscale_host; // ... and their host copy
   bool scale_pending = false;        // stored columns are v_c / s_c until materialised
+  bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed
   int scale_cols = 0;
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
   int64_t rows() const { return n + augmented; }

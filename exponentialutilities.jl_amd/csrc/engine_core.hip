@@ -231,11 +231,10 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
     static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
     single_red = !fused_v1;
-    // The single-pass banded pipeline (pipe.hip) is CORRECT (parity-green) but measured slower than the two-kernel
-    // step on C2 (profiles/r01_ab_variants.txt: 94.6 us vs 47.9 + 25.7 us per step): opt-in for experiments.
-    static const bool no_pipe = std::getenv("EXPV_MI_PIPE") == nullptr;
     use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
                 (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+    // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
+    static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
     if constexpr (!ST<T>::is_complex)
       use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  m <= dev::PIPE_CH && !real_coeff;
@@ -335,7 +334,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         pa.tol = tol;
         { ProfScope ps(c, EXPV_MI_K_FUSED_A); dev::pipe_step(s, pa); }
       }
-      {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
+      if (!ks.skip_tail) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
         dev::UpdateArgs<double> u{};
         u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
         if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }
@@ -380,7 +379,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       u.jcol = j - 1; u.tol = tol; u.step = j;
       { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, j - 1); }
     }
-    {
+    if (!ks.skip_tail) {
       ProfScope ps(c, EXPV_MI_K_SCALE);
       dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol);
       dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
@@ -496,7 +495,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
   }
   if (use_pipe) {   // the stored columns are v_c / s_c: keep the scales for the combine / a later materialisation
-    const int ncol = ((h.breakdown == 1) ? h.m_done : m) + 1;
+    const int ncol = ((h.breakdown == 1) ? h.m_done + 1 : (ks.skip_tail ? m : m + 1));
     ks.colscale_host.assign(ks.maxiter + 2, 1.0);
     HIPCHECK(hipMemcpyAsync(ks.colscale_host.data(), ks.colscale.p, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));

@@ -48,13 +48,33 @@ struct Mat {  // tiny owning column-major matrix
 template <class S>
 inline void matmul(Mat<S> &C, const Mat<S> &A, const Mat<S> &B) {  // C = A*B (C distinct)
   const int n = A.r, k = A.c, m = B.c;
-  C = Mat<S>(n, m);
-  for (int j = 0; j < m; ++j)
+  if (C.r != n || C.c != m) C = Mat<S>(n, m);
+  else std::fill(C.a.begin(), C.a.end(), S(0));
+  int j = 0;
+  for (; j + 4 <= m; j += 4) {   // four columns of C per sweep over A: each column of A is loaded once per four FMAs
+    S *__restrict__ c0 = &C.a[(size_t)j * n];
+    S *__restrict__ c1 = c0 + n;
+    S *__restrict__ c2 = c1 + n;
+    S *__restrict__ c3 = c2 + n;
+    for (int l = 0; l < k; ++l) {
+      const S b0 = B(l, j), b1 = B(l, j + 1), b2 = B(l, j + 2), b3 = B(l, j + 3);
+      if (!nonzero(b0) && !nonzero(b1) && !nonzero(b2) && !nonzero(b3)) continue;
+      const S *__restrict__ ac = &A.a[(size_t)l * n];
+      for (int i = 0; i < n; ++i) {
+        const S a = ac[i];
+        c0[i] += a * b0;
+        c1[i] += a * b1;
+        c2[i] += a * b2;
+        c3[i] += a * b3;
+      }
+    }
+  }
+  for (; j < m; ++j)
     for (int l = 0; l < k; ++l) {
       const S b = B(l, j);
       if (!nonzero(b)) continue;
-      const S *ac = &A.a[(size_t)l * n];
-      S *cc = &C.a[(size_t)j * n];
+      const S *__restrict__ ac = &A.a[(size_t)l * n];
+      S *__restrict__ cc = &C.a[(size_t)j * n];
       for (int i = 0; i < n; ++i) cc[i] += ac[i] * b;
     }
 }
@@ -249,23 +269,28 @@ inline void lu_solve(Mat<S> &M, Mat<S> &X) {
       for (int j = 0; j < nrhs; ++j) std::swap(X(k, j), X(p, j));
     }
     const S inv = S(1) / M(k, k);
-    for (int i = k + 1; i < n; ++i) M(i, k) *= inv;
+    S *__restrict__ mk = &M.a[(size_t)k * n];
+    for (int i = k + 1; i < n; ++i) mk[i] *= inv;
     for (int j = k + 1; j < n; ++j) {
-      const S mkj = M(k, j);
+      S *__restrict__ mj = &M.a[(size_t)j * n];
+      const S mkj = mj[k];
       if (!nonzero(mkj)) continue;
-      for (int i = k + 1; i < n; ++i) M(i, j) -= M(i, k) * mkj;
+      for (int i = k + 1; i < n; ++i) mj[i] -= mk[i] * mkj;
     }
   }
   for (int j = 0; j < nrhs; ++j) {
+    S *__restrict__ xj = &X.a[(size_t)j * n];
     for (int k = 0; k < n; ++k) {  // forward (unit lower)
-      const S xk = X(k, j);
+      const S xk = xj[k];
       if (!nonzero(xk)) continue;
-      for (int i = k + 1; i < n; ++i) X(i, j) -= M(i, k) * xk;
+      const S *__restrict__ mk = &M.a[(size_t)k * n];
+      for (int i = k + 1; i < n; ++i) xj[i] -= mk[i] * xk;
     }
     for (int k = n - 1; k >= 0; --k) {  // backward
-      X(k, j) /= M(k, k);
-      const S xk = X(k, j);
-      for (int i = 0; i < k; ++i) X(i, j) -= M(i, k) * xk;
+      const S *__restrict__ mk = &M.a[(size_t)k * n];
+      xj[k] /= mk[k];
+      const S xk = xj[k];
+      for (int i = 0; i < k; ++i) xj[i] -= mk[i] * xk;
     }
   }
 }
@@ -279,8 +304,12 @@ inline Mat<S> pade_evaluate(const Mat<S> &A, const double *C, int N) {
   for (int i = 0; i < n; ++i) { P(i, i) = S(1); U(i, i) = S(C[1]); V(i, i) = S(C[0]); }
   for (int k = 1; k <= N / 2 - 1; ++k) {
     const int k2 = 2 * k;
-    matmul(tmp, P, A2);
-    std::swap(P.a, tmp.a);
+    if (k == 1) {
+      P = A2;   // I * A2, exactly
+    } else {
+      matmul(tmp, P, A2);
+      std::swap(P.a, tmp.a);
+    }
     const S cu = S(C[k2 + 1]), cv = S(C[k2]);
     for (size_t i = 0; i < P.a.size(); ++i) { U.a[i] += cu * P.a[i]; V.a[i] += cv * P.a[i]; }
   }

@@ -107,6 +107,37 @@ __device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected
   return *flag_s != 0;
 }
 
+// Sum K (power of two, <= 32) per-lane values across the wave by recursive halving: at each step a
+// lane keeps one half of its values and trades the other half with lane^offset, so K values cost
+// K-1 (+ log2(64/K)) exchanges instead of 6K.  On return a[0] holds, in every lane, the wave total of
+// value index ((lane >> (6 - log2 K)) ... ) -- see wave_multi_index.
+template <int HALF, int OFF, int K>
+__device__ __forceinline__ void wave_halve(double (&a)[K], int lane) {
+  const bool hi = (lane & OFF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const double send = hi ? a[i] : a[i + HALF];
+    const double keep = hi ? a[i + HALF] : a[i];
+    a[i] = keep + __shfl_xor(send, OFF, 64);
+  }
+  if constexpr (HALF > 1) wave_halve<HALF / 2, OFF / 2, K>(a, lane);
+  else {
+#pragma unroll
+    for (int off = OFF / 2; off >= 1; off >>= 1) a[0] += __shfl_xor(a[0], off, 64);
+  }
+}
+template <int K>
+__device__ __forceinline__ void wave_reduce_multi(double (&a)[K]) {
+  wave_halve<K / 2, 32, K>(a, threadIdx.x & 63);
+}
+// index of the value whose wave total a lane holds after wave_reduce_multi<K>
+template <int K>
+__device__ __forceinline__ int wave_multi_index(int lane) {
+  int bits = 0;
+  for (int k = K; k > 1; k >>= 1) ++bits;      // log2 K
+  return (lane >> (6 - bits)) & (K - 1);
+}
+
 // Hierarchical grid reduction of nvals values.  Precondition: this workgroup has published
 // part[v*MAX_GRID + blockIdx.x] for every v < nvals.  Returns true in exactly one workgroup, with
 // vals_s[v] = total (visible to all its threads).  Must be called by all threads of every workgroup.
@@ -114,21 +145,20 @@ __device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected
 // wave) and sums them with the fixed wave_sum tree: reproducible, and no serial chain of L2 misses.
 __device__ __forceinline__ void reduce_stage(const double *src, size_t vstride, int count, int nvals, double *dst,
                                              size_t dstride, bool to_lds) {
-  // `count` <= 64 partials per value, one per lane; RB values per wave in flight at once
-  constexpr int RB = 8;
+  // `count` <= 64 partials per value, one per lane; a wave takes 16 values per round: 16 independent
+  // loads per lane, then ONE recursive-halving reduction (15 exchanges + 2) instead of 16 x 6 shuffles
+  constexpr int RB = 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int v0 = wave * RB; v0 < nvals; v0 += RB * (BLOCK / 64)) {
     double x[RB];
 #pragma unroll
     for (int k = 0; k < RB; ++k)
       x[k] = (v0 + k < nvals && lane < count) ? consume_f64(src + (size_t)(v0 + k) * vstride + lane) : 0.0;
-#pragma unroll
-    for (int k = 0; k < RB; ++k) {
-      const double s = wave_sum(x[k]);
-      if (lane == 0 && v0 + k < nvals) {
-        if (to_lds) dst[(size_t)(v0 + k) * dstride] = s;
-        else publish_f64(dst + (size_t)(v0 + k) * dstride, s);
-      }
+    wave_reduce_multi<RB>(x);
+    const int v = v0 + wave_multi_index<RB>(lane);
+    if ((lane & (64 / RB - 1)) == 0 && v < nvals) {
+      if (to_lds) dst[(size_t)v * dstride] = x[0];
+      else publish_f64(dst + (size_t)v * dstride, x[0]);
     }
   }
 }
@@ -168,37 +198,6 @@ __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double 
   reduce_stage(gpart, MAX_GROUPS, ng, nvals, vals_s, 1, true);
   __syncthreads();
   return true;
-}
-
-// Sum K (power of two, <= 32) per-lane values across the wave by recursive halving: at each step a
-// lane keeps one half of its values and trades the other half with lane^offset, so K values cost
-// K-1 (+ log2(64/K)) exchanges instead of 6K.  On return a[0] holds, in every lane, the wave total of
-// value index ((lane >> (6 - log2 K)) ... ) -- see wave_multi_index.
-template <int HALF, int OFF, int K>
-__device__ __forceinline__ void wave_halve(double (&a)[K], int lane) {
-  const bool hi = (lane & OFF) != 0;
-#pragma unroll
-  for (int i = 0; i < HALF; ++i) {
-    const double send = hi ? a[i] : a[i + HALF];
-    const double keep = hi ? a[i + HALF] : a[i];
-    a[i] = keep + __shfl_xor(send, OFF, 64);
-  }
-  if constexpr (HALF > 1) wave_halve<HALF / 2, OFF / 2, K>(a, lane);
-  else {
-#pragma unroll
-    for (int off = OFF / 2; off >= 1; off >>= 1) a[0] += __shfl_xor(a[0], off, 64);
-  }
-}
-template <int K>
-__device__ __forceinline__ void wave_reduce_multi(double (&a)[K]) {
-  wave_halve<K / 2, 32, K>(a, threadIdx.x & 63);
-}
-// index of the value whose wave total a lane holds after wave_reduce_multi<K>
-template <int K>
-__device__ __forceinline__ int wave_multi_index(int lane) {
-  int bits = 0;
-  for (int k = K; k > 1; k >>= 1) ++bits;      // log2 K
-  return (lane >> (6 - bits)) & (K - 1);
 }
 
 // block-level sum of one double per thread -> thread 0 (4 waves)

@@ -38,10 +38,17 @@ namespace dev {
 // Every 512-row tile's 64 per-lane products are summed across the wave at once by recursive halving
 // (63 exchanges), so a lane carries ONE running sum instead of 62 -- that is what lets the pass use
 // 16-byte loads with the whole window (<= 31 columns) of a tile in flight.
-__global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
-  constexpr int CH = PIPE_CH;                 // 32
+// CH = window capacity (update window <= CH-1 columns), K = CH sums per set; WAVES = workgroups per CU the
+// register budget allows; PS = SELL slots prefetched into registers before the barrier.
+template <int CH, int WAVES, int PS>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
   constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
+  constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
+  constexpr int P = (CH + K - 1) / K;         // parts per set
+  constexpr int NSETS = 2 * P;                // d~ and g~ sets
+  static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
   __shared__ double us[TR + 2 * PIPE_WMAX];
+  __shared__ double hs[32];                   // update coefficients (h_i s_i): LDS broadcast, no SGPRs
   __shared__ double red_s[BLOCK / 64][64];
   __shared__ double vals_s[64];
   __shared__ double std_s[MAX_RED_VALUES];
@@ -54,105 +61,149 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
   const bool first = (pa.step == 1);
   const double inv = first ? 1.0 : a.st->inv;
   const bool slot_dots = (a.mode != DOTS_LANCZOS) && !first;
-  const bool al = (a.ldv % 2 == 0) && is_al16(a.V) && is_al16(pa.ybuf) && (first ? is_al16(pa.u0) : is_al16(pa.yprev));
   double *Vw = const_cast<double *>(a.V);
-  double acc = 0.0;                           // running total of value `lane` over this wave's tiles
+  if (tid < 32) hs[tid] = (tid < und) ? pa.hcoef_in[tid] : 0.0;
+  __syncthreads();
+  const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
+  const int64_t nb = (a.n + 127) & ~(int64_t)127;        // library vectors are padded (zeros) up to here
+  double acc = 0.0;                           // running total of one value of one set (see below)
 
   const int64_t ntiles = (a.n + TR - 1) / TR;
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
   for (int64_t tile = t0; tile < t1; ++tile) {
     const int64_t r0 = tile * TR, i = r0 + 2 * (int64_t)tid;
-    // ---- halo rows (w above, w below the tile), same MGS order as the tile rows ------------------------
-    if (tid < 2 * w) {
-      const int64_t hr = (tid < w) ? r0 - w + tid : r0 + TR + (tid - w);
-      double uh = 0.0;
+    const bool act = i < nb;   // whole waves: nb is a multiple of the 128 rows a wave owns
+    // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
+    for (int e = tid; e < 2 * w * 32; e += BLOCK) {
+      const int hrow = e >> 5, k = e & 31;
+      const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
+      double val = 0.0;
       if (hr >= 0 && hr < a.n) {
-        if (first) uh = pa.u0[hr];
-        else {
-          uh = pa.yprev[hr] * inv;
-          for (int k = 0; k < und; ++k) uh = fma(-pa.hcoef_in[k], a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv], uh);
-        }
+        if (k == 31) val = first ? pa.u0[hr] : pa.yprev[hr] * inv;
+        else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
-      us[(tid < w) ? tid : TR + tid] = uh;
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+      if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
+    }
+    // ---- operator slots of this lane's two rows: issued now, consumed after the barrier ------------
+    Pack<double> av[PS > 0 ? PS : 1];
+    int2 aci[PS > 0 ? PS : 1];
+    int L = 0;
+    const double *avp = nullptr;
+    const int32_t *acp = nullptr;
+    if (i < a.n) {
+      const int64_t slice = i >> 7;
+      const int64_t off = pa.A.slice_off[slice];
+      L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
+      avp = pa.A.val + off + 2 * lane;
+      acp = pa.A.col + off + 2 * lane;
+#pragma unroll
+      for (int sl = 0; sl < PS; ++sl)
+        if (sl < L) {
+          av[sl] = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
+          aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
+        }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
     Pack<double> vreg[CH - 1];
+#pragma unroll
+    for (int k = 0; k < CH - 1; ++k) { vreg[k].v[0] = 0.0; vreg[k].v[1] = 0.0; }
     Pack<double> u;
+    u.v[0] = 0.0;
+    u.v[1] = 0.0;
     if (first) {
-      u = ld_pack_user(pa.u0, i, a.n, al);
-    } else {
-      u = ld_pack(pa.yprev, i, a.n, al);
+      u = ld_pack_user(pa.u0, i, a.n, is_al16(pa.u0));
+    } else if (act) {
+      u = *reinterpret_cast<const Pack<double> *>(pa.yprev + i);
       u.v[0] *= inv;
       u.v[1] *= inv;
+      const double *vp = a.V + (int64_t)pa.uc0 * a.ldv + i;    // one running pointer, stepped per column
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
-        if (k < und) vreg[k] = ld_pack(a.V + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv, i, a.n, al);
+        if (k < und) {
+          vreg[k] = *reinterpret_cast<const Pack<double> *>(vp);
+          vp += cstep;
+        }
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
         if (k < und) {                          // MGS axpy order
-          const double h = pa.hcoef_in[k];
+          const double h = hs[k];
           u.v[0] = fma(-h, vreg[k].v[0], u.v[0]);
           u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
         }
     }
     us[w + 2 * tid] = u.v[0];
     us[w + 2 * tid + 1] = u.v[1];
-    st_pack(Vw + (int64_t)jcol * a.ldv, i, a.n, al, u);      // raw u_j -> column j-1
+    if (act) *reinterpret_cast<Pack<double> *>(Vw + (int64_t)jcol * a.ldv + i) = u;      // raw u_j -> column j-1
     __syncthreads();
     // ---- phase 2: y~ = A u_j for this lane's two rows (SELL-128: one slice per wave), u from LDS ----
     Pack<double> y;
     y.v[0] = 0.0;
     y.v[1] = 0.0;
     if (i < a.n) {
-      const int64_t slice = i >> 7;
-      const int64_t off = pa.A.slice_off[slice];
-      const int L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
-      const double *vp = pa.A.val + off + 2 * lane;
-      const int32_t *cp = pa.A.col + off + 2 * lane;
       const int lim = TR + 2 * w, shift = (int)(w - r0);
-      for (int sl = 0; sl < L; ++sl) {
-        const Pack<double> av = *reinterpret_cast<const Pack<double> *>(vp + (int64_t)sl * 128);
-        const int2 ci = *reinterpret_cast<const int2 *>(cp + (int64_t)sl * 128);
+#pragma unroll
+      for (int sl = 0; sl < PS; ++sl)
+        if (sl < L) {
+          const int i0 = aci[sl].x + shift, i1 = aci[sl].y + shift;
+          y.v[0] = fma(av[sl].v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);   // padding entries carry value 0
+          y.v[1] = fma(av[sl].v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
+        }
+      for (int sl = PS; sl < L; ++sl) {
+        const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
+        const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
         const int i0 = ci.x + shift, i1 = ci.y + shift;
-        y.v[0] = fma(av.v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);   // padding entries carry value 0
-        y.v[1] = fma(av.v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
+        y.v[0] = fma(v2.v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);
+        y.v[1] = fma(v2.v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
       }
-      st_pack(pa.ybuf, i, a.n, al, y);
       if (i + 1 >= a.n) y.v[1] = 0.0;
     }
-    // ---- phase 3: this tile's products, summed across the wave at once (two sets of 32 values) -------
-    // after wave_reduce_multi<32>, lane l holds the wave total of value (l >> 1); even lanes keep the
-    // d~ set, odd lanes the g~ set, so that one per-lane accumulator serves all 64 values
-    {
-      double arr[32];
+    if (act) *reinterpret_cast<Pack<double> *>(pa.ybuf + i) = y;
+    // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
+    // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
+    // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
+    // COPIES = 64/K lanes hold the same one, so lane (l & (NSETS-1)) == s keeps the running sum of
+    // set s = part + P*t (t = 0: d~ against y~, t = 1: g~ against u): ONE accumulator per lane.
 #pragma unroll
-      for (int k = 0; k < CH - 1; ++k)
-        arr[k] = (slot_dots && k < und) ? fma(vreg[k].v[0], y.v[0], vreg[k].v[1] * y.v[1]) : 0.0;
-      arr[31] = fma(u.v[0], y.v[0], u.v[1] * y.v[1]);
-      wave_reduce_multi<32>(arr);
-      if ((lane & 1) == 0) acc += arr[0];
-    }
-    {
-      double arr[32];
+    for (int sidx = 0; sidx < NSETS; ++sidx) {
+      const int part = sidx % P, t = sidx / P;
+      const double o0 = t ? u.v[0] : y.v[0], o1 = t ? u.v[1] : y.v[1];
+      double arr[K];
 #pragma unroll
-      for (int k = 0; k < CH - 1; ++k)
-        arr[k] = (slot_dots && k < und) ? fma(vreg[k].v[0], u.v[0], vreg[k].v[1] * u.v[1]) : 0.0;
-      arr[31] = fma(u.v[0], u.v[0], u.v[1] * u.v[1]);
-      wave_reduce_multi<32>(arr);
-      if ((lane & 1) == 1) acc += arr[0];
+      for (int k = 0; k < K; ++k) {
+        const int q = part * K + k;                 // position in the CH-long vector of the set
+        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? fma(vreg[q < CH - 1 ? q : 0].v[0], o0, vreg[q < CH - 1 ? q : 0].v[1] * o1) : 0.0;
+        else if (q == CH - 1) arr[k] = fma(u.v[0], o0, u.v[1] * o1);
+        else arr[k] = 0.0;
+      }
+      wave_reduce_multi<K>(arr);
+      if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
     }
     __syncthreads();   // us is rewritten by the next tile
   }
 
-  // ---- workgroup: 4 waves -> one partial per value; publish all 64 ---------------------------------
-  red_s[wave][(lane >> 1) + 32 * (lane & 1)] = acc;
+  // ---- workgroup: 4 waves -> one partial per value ------------------------------------------------------
+  // compact value layout: [0,und) d~ slots, [und,2und) g~ slots, 2und: <u,y~>, 2und+1: ||u||^2
+  {
+    constexpr int COPIES = 64 / K;             // lanes holding the same value index after the reduction
+    const int idx = wave_multi_index<K>(lane);
+    const int sidx = lane & (NSETS - 1);
+    if ((lane & (COPIES - 1)) == sidx) {
+      const int part = sidx % P, t = sidx / P;
+      const int q = part * K + idx;
+      if (q == CH - 1) red_s[wave][2 * und + t] = acc;
+      else if (q < und) red_s[wave][t * und + q] = acc;
+    }
+  }
   __syncthreads();
-  if (tid < 64) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
-  if (!hier_reduce(a.st, a.part, a.gpart, 64, vals_s, &flag_s)) return;
+  const int nvals = 2 * und + 2;
+  if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
+  if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s)) return;
 
   // ---- last workgroup: finish step j-1, produce the Hessenberg column of step j ------------------
-  const double beta = sqrt(vals_s[63]);
+  const double beta = sqrt(vals_s[2 * und + 1]);
   const double invj = 1.0 / beta;
   const bool stop = first ? (beta == 0.0) : (beta < pa.tol);
   if (threadIdx.x == 0) {
@@ -160,7 +211,7 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
     a.st->inv = invj;
     a.st->m_done = pa.step - 1;
     pa.scales[jcol] = invj;                                       // s_j: column j-1 holds u_j = beta * v_j
-    if (first) a.st->beta0sq = vals_s[63];
+    if (first) a.st->beta0sq = vals_s[2 * und + 1];
     else a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh] = beta;        // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = first ? 2 : 1;
   }
@@ -173,12 +224,12 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
     double dv, gv = 0.0, f;
     if (col == jcol) {
       f = invj * invj;
-      dv = vals_s[31];
+      dv = vals_s[2 * und];
     } else {
       const int slot = (col - pa.uc0) * pa.udir;
       f = pa.scales[col] * invj;
       dv = vals_s[slot];
-      gv = vals_s[32 + slot] * f;
+      gv = vals_s[und + slot] * f;
     }
     std_s[k] = dv * f;
     std_s[nd + k] = gv;
@@ -201,13 +252,21 @@ __global__ __launch_bounds__(BLOCK, PIPE_WAVES) void k_pipe(PipeArgs pa, int til
   }
 }
 
-void pipe_step(hipStream_t s, const PipeArgs &pa) {
+template <int CH, int WAVES, int PS>
+static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe);
+  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  hipLaunchKernelGGL(k_pipe, dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+}
+void pipe_step(hipStream_t s, const PipeArgs &pa) {
+  // the register budget follows the window: short windows run with more workgroups per CU
+  if (pa.und <= 7) pipe_launch<8, 4, 6>(s, pa);
+  else if (pa.und <= 15) pipe_launch<16, 3, 6>(s, pa);
+  else if (pa.und <= 23) pipe_launch<24, 3, 0>(s, pa);
+  else pipe_launch<32, 2, 5>(s, pa);
 }
 
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation
