@@ -81,6 +81,10 @@ struct StepState {
   uint32_t ticket;       // arrival counter of the group reducers (stage 2 of the grid reduction)
   uint32_t pad;
   uint32_t gticket[64];  // arrival counters of the workgroup groups (stage 1)
+  uint32_t pad2[20];     // -> 384: the polled flag below sits alone in its 128-byte line
+  uint32_t step_done;    // persistent pipeline: last step whose epilogue results are published (grid-wide flag)
+  uint32_t pad3[31];
 };
+static_assert(sizeof(StepState) == 512, "StepState layout");
 
 }  // namespace expv_mi

@@ -147,6 +147,8 @@ struct Ks {
   size_t pin_bytes = 0;
   ~Ks() { if (pin) (void)hipHostFree(pin); }
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
+  DevBuf flags;                      // ... its grid-wide step flags (persistent launches)
+  uint32_t pipe_seq = 0;
   std::vector<double> colscale_host; // ... and their host copy
   bool scale_pending = false;        // stored columns are v_c / s_c until materialised
   bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed

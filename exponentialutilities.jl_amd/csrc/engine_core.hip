@@ -307,7 +307,40 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       double *ya = ks.ybuf.as<double>(), *yb2 = ks.ubuf.as<double>();
       double *hca = ks.hcoef.as<double>(), *hcb = ks.hcoef2.as<double>();
       dev::SellView<double> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<double>(), op.nslices};
-      for (int j = 1; j <= m; ++j) {
+      // EXPV_MI_PIPE_PERSIST=1: persistent launches (one per window-size variant, grid-wide step flags).  Parity-green
+      // but measured slower on C2 (profiles/r01_ab_variants.txt: the in-kernel step synchronisation costs more than
+      // the launch boundary it replaces), so the step-wise launches stay the default.
+      static const bool persist = std::getenv("EXPV_MI_PIPE_PERSIST") != nullptr;
+      bool ran = false;
+      if (persist) {
+        dev::PipeRun pr{};
+        dev::PipeArgs &pa = pr.base;
+        pa.A = A;
+        pa.w = (int)op.bandwidth;
+        pa.u0 = reinterpret_cast<const double *>(b);
+        dev::DotsArgs<double> &d = pa.d;
+        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr; d.dir = 1;
+        d.part = part; d.gpart = gpart; d.st = st; d.real_coeff = 0;
+        d.Hdev = Hd; d.ldh = ks.ldhd; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.hcoef = nullptr;
+        pa.scales = ks.colscale.as<double>();
+        pa.tol = tol;
+        pr.ya = ya; pr.yb = yb2; pr.hca = hca; pr.hcb = hcb;
+        pr.iop = iop; pr.lanczos = lanczos ? 1 : 0;
+        pr.j0 = 1; pr.j1 = m;
+        if (!ks.flags.p) {
+          ks.flags.alloc(sizeof(uint32_t) * (size_t)dev::PIPE_FLAG_COPIES * dev::PIPE_FLAG_STRIDE);
+          HIPCHECK(hipMemsetAsync(ks.flags.p, 0, ks.flags.bytes, s));
+        }
+        pr.flags = ks.flags.as<uint32_t>();
+        ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+        if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+        pr.seq = ks.pipe_seq;
+        ProfScope ps(c, EXPV_MI_K_FUSED_A);
+        const int err = dev::pipe_run(s, pr);
+        if (err != 0) fail(EXPV_MI_HIP_ERROR, "cooperative launch of the pipelined factorisation was refused");
+        ran = true;
+      }
+      for (int j = 1; j <= m && !ran; ++j) {
         const int i0 = lanczos ? j : std::max(1, j - iop + 1);
         const int nd = j - i0 + 1;
         dev::PipeArgs pa{};
@@ -490,6 +523,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   HIPCHECK(hipMemcpyAsync(ks.pin, Hd, hbytes, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipMemcpyAsync(&h, st, sizeof(StepState), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
+  if (h.breakdown == 99) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: the grid stopped making progress (bounded wait expired)");
   if (use_fused) {
     ks.beta = std::sqrt(h.beta0sq);
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)

@@ -314,19 +314,32 @@ __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg,
 //   STRICT / LANCZOS: one column, h = coeff(U, d)                       (arnoldi.jl:302, :397)
 //   LOWSYNC: h = (I + L)^-1 d, L = strict lower triangle of V^H V on the window -- algebraically
 //            the modified Gram-Schmidt coefficients  h_i = <v_i, y - sum_{k<i} h_k v_k>.
-template <class T>
+// SHARED (fp64 only): the step results are read by OTHER workgroups of the same launch (persistent pipeline), and
+// the Gram rows / H were written by other workgroups earlier in it: every global access goes through to memory
+// (sc1) instead of relying on a kernel boundary.  slot_scale_s (LDS, optional): factor folded into hcoef[k].
+template <class T, bool SHARED = false>
 __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s,
-                                                    double newest_scale = 1.0) {
+                                                    double newest_scale = 1.0, const double *slot_scale_s = nullptr) {
   constexpr int NR = ST<T>::nreal;
+  static_assert(!SHARED || NR == 1, "the write-through epilogue is fp64 only");
+  auto ldg = [](const T *p) -> T {
+    if constexpr (SHARED) return consume_f64(reinterpret_cast<const double *>(p));
+    else return *p;
+  };
+  auto stg = [](T *p, T v) {
+    if constexpr (SHARED) publish_f64(reinterpret_cast<double *>(p), *reinterpret_cast<const double *>(&v));
+    else *p = v;
+  };
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (a.mode != DOTS_LOWSYNC) {
     if (threadIdx.x == 0) {
       T h = vals_to_T<T>(vals_s);
       if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
-      a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh] = h;
-      a.hcoef[0] = ST<T>::mul_real(h, newest_scale);
+      stg(&a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh], h);
+      stg(&a.hcoef[0], ST<T>::mul_real(h, slot_scale_s ? slot_scale_s[0] : newest_scale));
       if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
-        a.hcoef[1] = ST<T>::real_only(a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh]);
+        stg(&a.hcoef[1], ST<T>::mul_real(ST<T>::real_only(ldg(&a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh])),
+                                         slot_scale_s ? slot_scale_s[1] : 1.0));
     }
     return;
   }
@@ -339,9 +352,9 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     T g;
     if (i == nd - 1) {  // <v_j, v_ck> = conj(<v_ck, v_j>): the Gram row computed in this pass
       g = ST<T>::conj(vals_to_T<T>(vals_s + nd * NR + k * NR));
-      a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg] = g;
+      stg(&a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg], g);
     } else {
-      g = a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg];
+      g = ldg(&a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg]);
     }
     gs_s[e] = g;
   }
@@ -355,8 +368,9 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     }
     if (a.real_coeff) sv = ST<T>::real_only(sv);
     if (lane < nd) {
-      a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh] = sv;
-      a.hcoef[lane] = (lane == nd - 1) ? ST<T>::mul_real(sv, newest_scale) : sv;
+      stg(&a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh], sv);
+      const double f = slot_scale_s ? slot_scale_s[lane] : ((lane == nd - 1) ? newest_scale : 1.0);
+      stg(&a.hcoef[lane], (slot_scale_s || lane == nd - 1) ? ST<T>::mul_real(sv, f) : sv);
     }
   }
 }

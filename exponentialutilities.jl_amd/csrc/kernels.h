@@ -142,8 +142,23 @@ struct PipeArgs {
   double *scales;              // s_c: stored column c = v_{c+1} / s_c
   int step;
   double tol;
+  unsigned long long stamp;    // persistent launch: validity stamp of this step's partials
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa);
+// Steps j0..j1 of one factorisation in persistent launches (one per window-size variant): the step-independent
+// fields of `base` are used as they are, the per-step ones are derived on the device exactly as the host loop
+// derives them for pipe_step.
+struct PipeRun {
+  PipeArgs base;
+  double *ya, *yb;             // y~ ping-pong: step j reads (j odd ? yb : ya), writes the other
+  double *hca, *hcb;           // coefficient ping-pong: step j reads (j odd ? hcb : hca), writes the other
+  int iop, lanczos;
+  int j0, j1;
+  uint32_t *flags;             // PIPE_FLAG_COPIES words, PIPE_FLAG_STRIDE apart
+  uint32_t seq;                // sequence number of this factorisation (stamps the flags)
+};
+constexpr int PIPE_FLAG_COPIES = 16, PIPE_FLAG_STRIDE = 1024;
+int pipe_run(hipStream_t s, const PipeRun &pr);   // 0, or the hipError_t of a refused cooperative launch
 void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *scales, int ncols);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);

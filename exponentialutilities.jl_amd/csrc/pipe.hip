@@ -29,6 +29,10 @@
 #define PIPE_WAVES 2
 #endif
 
+#ifndef PIPE_SPIN_LIMIT
+#define PIPE_SPIN_LIMIT 400000   // polls before a persistent launch gives up (status) instead of hanging
+#endif
+
 namespace expv_mi {
 namespace dev {
 
@@ -40,29 +44,136 @@ namespace dev {
 // 16-byte loads with the whole window (<= 31 columns) of a tile in flight.
 // CH = window capacity (update window <= CH-1 columns), K = CH sums per set; WAVES = workgroups per CU the
 // register budget allows; PS = SELL slots prefetched into registers before the barrier.
-template <int CH, int WAVES, int PS>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
+// 16-byte store that goes through to memory (sc0 sc1): no dirty line stays in this XCD's L2, so a later reader on
+// another XCD needs no L2 write-back from us (persistent launch: no kernel boundary between writer and reader)
+__device__ __forceinline__ void st_pack_wt(double *p, const Pack<double> &v) {
+  typedef double vec2d __attribute__((ext_vector_type(2)));
+  vec2d d;
+  d.x = v.v[0];
+  d.y = v.v[1];
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+}
+template <bool WT>
+__device__ __forceinline__ void st_tile(double *p, const Pack<double> &v) {
+  if constexpr (WT) st_pack_wt(p, v);
+  else *reinterpret_cast<Pack<double> *>(p) = v;
+}
+template <bool FRESH>
+__device__ __forceinline__ double ld_shared_f64(const double *p) {   // value another workgroup wrote during this launch
+  if constexpr (FRESH) return consume_f64(p);
+  else return *p;
+}
+#ifdef PIPE_TRACE
+// build-time tracing (tools/pipe_trace.py): per step and workgroup {pass begin, main loop end, reduced, published}
+__device__ unsigned long long g_pipe_trace[33][1024][6];
+#define PIPE_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 33 && blockIdx.x < 1024) g_pipe_trace[step][blockIdx.x][slot] = wall_clock64(); } while (0)
+#else
+#define PIPE_STAMP(step, slot) do { } while (0)
+#endif
+// ---- grid reduction of the persistent launch: stamped partials, designated reducers, no atomics -------
+// A partial is published as two 8-byte words {bits(v), bits(v) ^ H}, H = hash(call sequence, step): a reader
+// accepts the pair only if w0 ^ w1 == H, so a slot needs no reset and no ticket, and a reader that races the
+// writer (or still sees the pair of an earlier step) simply polls again.  The first workgroup of each group of
+// 64 reduces its group, workgroup 0 reduces the groups -- the same fixed tree as hier_reduce, so the sums are
+// bit-identical to the step-wise kernel's; the waits are bounded like wait_step's.
+__device__ __forceinline__ unsigned long long stamp_hash(uint32_t seq, int step) {
+  return ((unsigned long long)seq * 256ull + (unsigned long long)step + 1ull) * 0x9E3779B97F4A7C15ull;
+}
+__device__ __forceinline__ void publish_stamped(double *slot, double v, unsigned long long h) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + 1, b ^ h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one stage: `count` <= 64 stamped partials per value (lane = partial), 16 values per wave and round
+template <bool TO_LDS>
+__device__ __forceinline__ bool stamped_stage(const double *src, size_t vstride, int count, int nvals, double *dst,
+                                              size_t dstride, unsigned long long h, int *budget) {
+  constexpr int RB = 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v0 = wave * RB; v0 < nvals; v0 += RB * (BLOCK / 64)) {
+    double x[RB];
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        x[k] = 0.0;
+        if (v0 + k < nvals && lane < count) {
+          const unsigned long long *q = reinterpret_cast<const unsigned long long *>(src + 2 * ((size_t)(v0 + k) * vstride + lane));
+          const unsigned long long w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((w0 ^ w1) == h);
+          x[k] = __longlong_as_double((long long)w0);
+        }
+      }
+      if (__all(ok)) break;
+      if (--(*budget) < 0) return false;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    wave_reduce_multi<RB>(x);
+    const int v = v0 + wave_multi_index<RB>(lane);
+    if ((lane & (64 / RB - 1)) == 0 && v < nvals) {
+      if constexpr (TO_LDS) dst[(size_t)v * dstride] = x[0];
+      else publish_stamped(dst + 2 * (size_t)v * dstride, x[0], h);
+    }
+  }
+  return true;
+}
+// precondition: this workgroup has published its stamped partials part[2*(v*MAX_GRID + blockIdx.x)].
+// Returns 1 in workgroup 0 with vals_s filled, 0 elsewhere, -1 if a wait expired.
+__device__ __forceinline__ int stamped_reduce(double *part, double *gpart, int nvals, double *vals_s, unsigned long long h,
+                                              int *flag_s, int step) {
+  const int nblk = gridDim.x, b = blockIdx.x;
+  if (b % GROUP_SIZE != 0) return 0;
+  const int g = b / GROUP_SIZE;
+  const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
+  const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
+  int budget = PIPE_SPIN_LIMIT;
+  bool ok = stamped_stage<false>(part + 2 * (size_t)g * GROUP_SIZE, MAX_GRID, gsize, nvals, gpart + 2 * g, MAX_GROUPS, h, &budget);
+  PIPE_STAMP(step, 4);
+  if (ok && b == 0) ok = stamped_stage<true>(gpart, MAX_GROUPS, ng, nvals, vals_s, 1, h, &budget);
+  if (threadIdx.x == 0) *flag_s = 1;
+  __syncthreads();
+  if (!ok) *flag_s = 0;          // any wave whose wait expired
+  __syncthreads();
+  if (*flag_s == 0) return -1;
+  return b == 0 ? 1 : 0;
+}
+
+struct PipeShared {
+  double us[2 * BLOCK + 2 * PIPE_WMAX];
+  double hs[32];                   // update coefficients (h_i s_i): LDS broadcast, no SGPRs
+  double red_s[BLOCK / 64][64];
+  double vals_s[64];
+  double std_s[MAX_RED_VALUES];
+  int flag_s;
+  double gs_s[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2];
+  double cs_s[64];                 // per-slot factors folded into the next pass's coefficients
+};
+// one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
+// last one found the breakdown / zero-vector condition
+template <int CH, int PS, bool PERSIST>
+__device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block, PipeShared &sh) {
   constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
   constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
   constexpr int P = (CH + K - 1) / K;         // parts per set
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
-  __shared__ double us[TR + 2 * PIPE_WMAX];
-  __shared__ double hs[32];                   // update coefficients (h_i s_i): LDS broadcast, no SGPRs
-  __shared__ double red_s[BLOCK / 64][64];
-  __shared__ double vals_s[64];
-  __shared__ double std_s[MAX_RED_VALUES];
-  __shared__ int flag_s;
-  __shared__ double gs_s[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2];
+  double(&us)[2 * BLOCK + 2 * PIPE_WMAX] = sh.us;
+  double(&hs)[32] = sh.hs;
+  double(&red_s)[BLOCK / 64][64] = sh.red_s;
+  double(&vals_s)[64] = sh.vals_s;
+  double(&std_s)[MAX_RED_VALUES] = sh.std_s;
+  int &flag_s = sh.flag_s;
+  double(&gs_s)[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2] = sh.gs_s;
   DotsArgs<double> a = pa.d;
-  if (step_skipped(a.st, pa.step)) return;
+  PIPE_STAMP(pa.step, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = pa.w, jcol = a.jcol, und = pa.und;
   const bool first = (pa.step == 1);
-  const double inv = first ? 1.0 : a.st->inv;
+  const double inv = first ? 1.0 : ld_shared_f64<PERSIST>(&a.st->inv);
   const bool slot_dots = (a.mode != DOTS_LANCZOS) && !first;
   double *Vw = const_cast<double *>(a.V);
-  if (tid < 32) hs[tid] = (tid < und) ? pa.hcoef_in[tid] : 0.0;
+  if (tid < 32) hs[tid] = (tid < und) ? ld_shared_f64<PERSIST>(pa.hcoef_in + tid) : 0.0;
   __syncthreads();
   const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
   const int64_t nb = (a.n + 127) & ~(int64_t)127;        // library vectors are padded (zeros) up to here
@@ -80,7 +191,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
       const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
       double val = 0.0;
       if (hr >= 0 && hr < a.n) {
-        if (k == 31) val = first ? pa.u0[hr] : pa.yprev[hr] * inv;
+        if (k == 31) val = first ? pa.u0[hr] : ld_shared_f64<PERSIST>(pa.yprev + hr) * inv;
         else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
 #pragma unroll
@@ -136,7 +247,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
     }
     us[w + 2 * tid] = u.v[0];
     us[w + 2 * tid + 1] = u.v[1];
-    if (act) *reinterpret_cast<Pack<double> *>(Vw + (int64_t)jcol * a.ldv + i) = u;      // raw u_j -> column j-1
+    if (act) st_tile<PERSIST>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
     __syncthreads();
     // ---- phase 2: y~ = A u_j for this lane's two rows (SELL-128: one slice per wave), u from LDS ----
     Pack<double> y;
@@ -160,7 +271,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
       }
       if (i + 1 >= a.n) y.v[1] = 0.0;
     }
-    if (act) *reinterpret_cast<Pack<double> *>(pa.ybuf + i) = y;
+    if (act) st_tile<PERSIST>(pa.ybuf + i, y);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -184,6 +295,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
     __syncthreads();   // us is rewritten by the next tile
   }
 
+  PIPE_STAMP(pa.step, 1);
   // ---- workgroup: 4 waves -> one partial per value ------------------------------------------------------
   // compact value layout: [0,und) d~ slots, [und,2und) g~ slots, 2und: <u,y~>, 2und+1: ||u||^2
   {
@@ -197,61 +309,154 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
       else if (q < und) red_s[wave][t * und + q] = acc;
     }
   }
+  // persistent launch: this wave's write-through y~ / u_j stores are complete before the partials that
+  // announce the workgroup (the step-wise kernel drains them in take_ticket)
+  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int nvals = 2 * und + 2;
-  if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
-  if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s)) return;
+  const double mine = (tid < nvals) ? red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid] : 0.0;
+  if constexpr (PERSIST) {
+    if (tid < nvals) publish_stamped(a.part + 2 * ((size_t)tid * MAX_GRID + blockIdx.x), mine, pa.stamp);
+    const int r = stamped_reduce(a.part, a.gpart, nvals, vals_s, pa.stamp, &flag_s, pa.step);
+    if (r < 0) {
+      if (threadIdx.x == 0) __hip_atomic_store(&a.st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 3;
+    }
+    if (r == 0) return 0;
+    __syncthreads();
+  } else {
+    if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, mine);
+    if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s)) return 0;
+  }
+  PIPE_STAMP(pa.step, 2);
 
   // ---- last workgroup: finish step j-1, produce the Hessenberg column of step j ------------------
+  // (persistent launch: what earlier last workgroups wrote -- scales, Gram rows, H -- is read through to
+  // memory, and everything written here is stored through: no kernel boundary separates the steps)
+  auto put = [](double *p, double v) {
+    if constexpr (PERSIST) publish_f64(p, v);
+    else *p = v;
+  };
   const double beta = sqrt(vals_s[2 * und + 1]);
   const double invj = 1.0 / beta;
   const bool stop = first ? (beta == 0.0) : (beta < pa.tol);
   if (threadIdx.x == 0) {
-    a.st->hnorm = beta;
-    a.st->inv = invj;
+    put(&a.st->hnorm, beta);
+    put(&a.st->inv, invj);
     a.st->m_done = pa.step - 1;
-    pa.scales[jcol] = invj;                                       // s_j: column j-1 holds u_j = beta * v_j
+    put(&pa.scales[jcol], invj);                                  // s_j: column j-1 holds u_j = beta * v_j
     if (first) a.st->beta0sq = vals_s[2 * und + 1];
-    else a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh] = beta;        // H[j, j-1] = ||u_j||
+    else put(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);   // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = first ? 2 : 1;
   }
-  if (stop) return;
-  __syncthreads();
-  // sums against the stored (raw) columns -> sums against the orthonormal basis, standard layout
+  if (stop) return 2;
+  // sums against the stored (raw) columns -> sums against the orthonormal basis, standard layout;
+  // the next pass subtracts h_i * v_i = (h_i s_i) * raw_i: s_i goes into cs_s
   const int nd = a.nd;
   for (int k = threadIdx.x; k < nd; k += BLOCK) {
     const int col = a.c0 + k;
-    double dv, gv = 0.0, f;
+    double dv, gv = 0.0, f, sc;
     if (col == jcol) {
       f = invj * invj;
       dv = vals_s[2 * und];
+      sc = invj;
     } else {
       const int slot = (col - pa.uc0) * pa.udir;
-      f = pa.scales[col] * invj;
+      sc = ld_shared_f64<PERSIST>(pa.scales + col);
+      f = sc * invj;
       dv = vals_s[slot];
       gv = vals_s[und + slot] * f;
     }
     std_s[k] = dv * f;
     std_s[nd + k] = gv;
+    sh.cs_s[k] = sc;
+  }
+  if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) {
+    sh.cs_s[0] = invj;
+    sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<PERSIST>(pa.scales + jcol - 1) : 1.0;
   }
   __syncthreads();
   a.hcoef = pa.hcoef_out;
-  projection_epilogue<double>(a, std_s, gs_s, 1.0);
-  __syncthreads();
-  // the next pass subtracts h_i * v_i = (h_i s_i) * raw_i
-  if (a.mode == DOTS_LANCZOS) {
-    if (threadIdx.x == 0) {
-      pa.hcoef_out[0] *= invj;
-      if (jcol >= 1) pa.hcoef_out[1] *= pa.scales[jcol - 1];
+  projection_epilogue<double, PERSIST>(a, std_s, gs_s, 1.0, sh.cs_s);
+  return 1;
+}
+
+template <int CH, int WAVES, int PS>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
+  __shared__ PipeShared sh;
+  if (step_skipped(pa.d.st, pa.step)) return;
+  (void)pipe_pass<CH, PS, false>(pa, tiles_per_block, sh);
+}
+
+// ---- persistent form: steps j0..j1 in ONE cooperative launch -------------------------------------------
+// Every workgroup keeps its tiles for all the steps of the launch; between steps the grid synchronises on
+// StepState::step_done, which the last workgroup of a step publishes after its epilogue.  That removes the
+// launch boundary per step and lets the wait overlap with whatever does not depend on the reduction.
+// Waiting is bounded (PIPE_SPIN_LIMIT polls): a launch that cannot make progress reports breakdown = 99
+// instead of hanging the device.
+// The grid-wide flag: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels); workgroup b polls copy
+// b % COPIES.  A word holds (call sequence << 8) | stop << 7 | step, so it never needs a reset between calls.
+constexpr uint32_t PIPE_STOP_BIT = 0x80u;
+__device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s) {
+  if (threadIdx.x == 0) {
+    const uint32_t *f = flags + (size_t)(blockIdx.x % PIPE_FLAG_COPIES) * PIPE_FLAG_STRIDE;
+    int res = 0, it = 0;
+    for (;;) {
+      const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 8) == seq && (int)(v & 0x7fu) >= step) { res = (v & PIPE_STOP_BIT) ? 1 : 0; break; }
+      if (++it > PIPE_SPIN_LIMIT) {
+        __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res = 99;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
     }
-  } else {
-    for (int k = threadIdx.x; k < nd; k += BLOCK) {
-      const int col = a.c0 + k;
-      pa.hcoef_out[k] *= (col == jcol) ? invj : pa.scales[col];
+    *flag_s = res;
+  }
+  __syncthreads();
+  const int bd = *flag_s;
+  __syncthreads();
+  return bd;
+}
+template <int CH, int WAVES, int PS>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_run(PipeRun pr, int tiles_per_block) {
+  __shared__ PipeShared sh;
+  StepState *st = pr.base.d.st;
+  if (step_skipped(st, pr.j0)) return;
+  for (int j = pr.j0; j <= pr.j1; ++j) {
+    if (j > pr.j0 && wait_step(st, pr.flags, pr.seq, j - 1, &sh.flag_s) != 0) return;   // breakdown (or a stuck grid): all leave
+    PipeArgs pa = pr.base;
+    const int iop = pr.iop, lanczos = pr.lanczos;
+    const int i0 = lanczos ? j : (j - iop + 1 > 1 ? j - iop + 1 : 1);
+    const int nd = j - i0 + 1;
+    pa.yprev = (j & 1) ? pr.yb : pr.ya;
+    pa.ybuf = (j & 1) ? pr.ya : pr.yb;
+    if (j != 1) pa.u0 = nullptr;
+    pa.d.c0 = i0 - 1;
+    pa.d.nd = nd;
+    pa.d.mode = lanczos ? DOTS_LANCZOS : (nd >= 2 ? DOTS_LOWSYNC : DOTS_STRICT);
+    pa.d.jcol = j - 1;
+    pa.d.jrow = j - 1;
+    if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
+    else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+    else { const int i0p = (j - 1) - iop + 1 > 1 ? (j - 1) - iop + 1 : 1; pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
+    pa.hcoef_in = (j & 1) ? pr.hcb : pr.hca;
+    pa.hcoef_out = (j & 1) ? pr.hca : pr.hcb;
+    pa.step = j;
+    pa.stamp = stamp_hash(pr.seq, j);
+    const int r = pipe_pass<CH, PS, true>(pa, tiles_per_block, sh);
+    if (r == 3) return;
+    if (r != 0) {   // last workgroup: publish the step (its results, stored through, first)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x < PIPE_FLAG_COPIES)
+        __hip_atomic_store(pr.flags + (size_t)threadIdx.x * PIPE_FLAG_STRIDE,
+                           (pr.seq << 8) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      PIPE_STAMP(j, 3);
+      if (r == 2) return;
     }
   }
 }
-
 template <int CH, int WAVES, int PS>
 static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
@@ -261,12 +466,59 @@ static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
   const int nb = (int)((ntiles + tpb - 1) / tpb);
   hipLaunchKernelGGL((k_pipe<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
+static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
 void pipe_step(hipStream_t s, const PipeArgs &pa) {
   // the register budget follows the window: short windows run with more workgroups per CU
-  if (pa.und <= 7) pipe_launch<8, 4, 6>(s, pa);
-  else if (pa.und <= 15) pipe_launch<16, 3, 6>(s, pa);
-  else if (pa.und <= 23) pipe_launch<24, 3, 0>(s, pa);
-  else pipe_launch<32, 2, 5>(s, pa);
+  switch (pipe_variant(pa.und)) {
+    case 0: pipe_launch<8, 4, 6>(s, pa); break;
+    case 1: pipe_launch<16, 3, 6>(s, pa); break;
+    case 2: pipe_launch<24, 3, 0>(s, pa); break;
+    default: pipe_launch<32, 2, 5>(s, pa); break;
+  }
+}
+
+template <int CH, int WAVES, int PS>
+static hipError_t pipe_run_launch(hipStream_t s, PipeRun pr) {
+  const int64_t ntiles = (pr.base.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
+  const int maxb = resident_blocks((const void *)k_pipe_run<CH, WAVES, PS>);
+  int64_t tpb = (ntiles + maxb - 1) / maxb;
+  if (tpb < 1) tpb = 1;
+  const int nb = (int)((ntiles + tpb - 1) / tpb);
+  int tpb_i = (int)tpb;
+  void *args[] = {&pr, &tpb_i};
+  // cooperative: the runtime guarantees that all nb workgroups are resident together (the grid waits on itself)
+  // every workgroup must be resident (the grid waits on itself): nb <= the occupancy bound, and the wait is
+  // bounded, so a launch that shares the device with something else fails (status) instead of hanging
+  (void)args;
+  hipLaunchKernelGGL((k_pipe_run<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pr, tpb_i);
+  return hipGetLastError();
+}
+static int update_window(int j, int iop, int lanczos) {   // columns the update of step j-1 subtracts (pipe_step's und)
+  if (j == 1) return 0;
+  if (lanczos) return (j - 1 > 1) ? 2 : 1;
+  const int i0p = std::max(1, (j - 1) - iop + 1);
+  return (j - 1) - i0p + 1;
+}
+int pipe_run(hipStream_t s, const PipeRun &pr_in) {
+  int j = pr_in.j0;
+  while (j <= pr_in.j1) {
+    const int v = pipe_variant(update_window(j, pr_in.iop, pr_in.lanczos));
+    int e = j;
+    while (e + 1 <= pr_in.j1 && pipe_variant(update_window(e + 1, pr_in.iop, pr_in.lanczos)) == v) ++e;
+    PipeRun pr = pr_in;
+    pr.j0 = j;
+    pr.j1 = e;
+    hipError_t err;
+    switch (v) {
+      case 0: err = pipe_run_launch<8, 4, 6>(s, pr); break;
+      case 1: err = pipe_run_launch<16, 3, 6>(s, pr); break;
+      case 2: err = pipe_run_launch<24, 3, 0>(s, pr); break;
+      default: err = pipe_run_launch<32, 2, 5>(s, pr); break;
+    }
+    if (err != hipSuccess) return (int)err;
+    j = e + 1;
+  }
+  return 0;
 }
 
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation
@@ -293,3 +545,22 @@ void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const doubl
 
 }  // namespace dev
 }  // namespace expv_mi
+
+#ifdef PIPE_TRACE
+#include <cstdio>
+#include <vector>
+extern "C" void expv_mi_pipe_trace_dump(const char *path) {
+  using namespace expv_mi::dev;
+  std::vector<unsigned long long> h((size_t)33 * 1024 * 6);
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pipe_trace), h.size() * 8);
+  FILE *f = std::fopen(path, "w");
+  if (!f) return;
+  for (int st = 1; st < 33; ++st)
+    for (int b = 0; b < 1024; ++b) {
+      const unsigned long long *r = &h[((size_t)st * 1024 + b) * 6];
+      if (r[0]) std::fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu\n", st, b, r[0], r[1], r[2], r[3], r[4], r[5]);
+    }
+  std::fclose(f);
+}
+#endif
