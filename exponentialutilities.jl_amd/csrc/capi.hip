@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 
 #include "engine.h"
 
@@ -157,6 +158,48 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
   op.sell_ok = true;
 }
 
+// DIA form for the banded pipeline (fp64): the distinct offsets col-row, ascending; built when there are at most
+// PIPE_DIA_MAX of them, rows are free of duplicate entries and the zero fill stays below 30 %.  Absent entries are
+// explicit zeros, so a row's sum runs over the same terms, in ascending-column order, plus exact zeros.
+inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
+                      const std::vector<double> &va) {
+  op.ndiag = 0;
+  if (n == 0 || op.bandwidth < 0 || op.bandwidth > dev::PIPE_WMAX) return;
+  const int W = dev::PIPE_WMAX;
+  std::vector<int64_t> cnt(2 * W + 1, 0);
+  for (int64_t r = 0; r < n; ++r) {
+    int32_t prev = -1;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      if (ci[k] <= prev) return;   // unsorted or duplicate entries: keep the row order SELL preserves
+      prev = ci[k];
+      ++cnt[(size_t)(ci[k] - r + W)];
+    }
+  }
+  int nd = 0;
+  int offs[2 * dev::PIPE_WMAX + 1];
+  for (int o = 0; o <= 2 * W; ++o)
+    if (cnt[o] > 0) offs[nd++] = o - W;
+  if (nd == 0 || nd > dev::PIPE_DIA_MAX) return;
+  if ((double)nd * (double)n > 1.3 * (double)ci.size() + 1024.0) return;
+  const int64_t ld = (n + 511) / 512 * 512;
+  int slot_of[2 * dev::PIPE_WMAX + 1];
+  for (int d = 0; d < nd; ++d) slot_of[offs[d] + W] = d;
+  std::vector<double> dv((size_t)nd * (size_t)ld, 0.0);
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) dv[(size_t)slot_of[ci[k] - r + W] * (size_t)ld + (size_t)r] = va[k];
+  op.dia_val.alloc(sizeof(double) * dv.size());
+  HIPCHECK(hipMemcpyAsync(op.dia_val.p, dv.data(), sizeof(double) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipStreamSynchronize(op.ctx->stream));
+  op.ndiag = nd;
+  op.dia_ld = ld;
+  for (int d = 0; d < nd; ++d) op.dia_off[d] = offs[d];
+}
+template <class V>
+inline void maybe_build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
+                            const std::vector<V> &va) {
+  if constexpr (std::is_same<V, double>::value) build_dia(op, n, rp, ci, va);
+}
+
 template <class V>
 void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
   op.kind = OP_CSR;
@@ -169,6 +212,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.bandwidth = bw;
   upload_csr<V>(op, rp, ci, va);
   build_sell<V>(op, n, rp, ci, va);
+  if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va);
 }
 
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",

@@ -113,6 +113,10 @@ struct Op {
   int64_t nslices = 0;
   bool sell_ok = false;
   int64_t bandwidth = -1;   // max |col - row| (CSR operators)
+  DevBuf dia_val;           // DIA form of a narrow-banded fp64 operator (pipe.hip): [ndiag][dia_ld], ascending offsets
+  int ndiag = 0;
+  int64_t dia_ld = 0;
+  int dia_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;

@@ -316,6 +316,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         dev::PipeRun pr{};
         dev::PipeArgs &pa = pr.base;
         pa.A = A;
+        static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
+        if (op.ndiag > 0 && !no_dia) {
+          pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
+          for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+        }
         pa.w = (int)op.bandwidth;
         pa.u0 = reinterpret_cast<const double *>(b);
         dev::DotsArgs<double> &d = pa.d;
@@ -345,6 +350,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         const int nd = j - i0 + 1;
         dev::PipeArgs pa{};
         pa.A = A;
+        static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
+        if (op.ndiag > 0 && !no_dia) {
+          pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
+          for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+        }
         pa.w = (int)op.bandwidth;
         pa.yprev = (j & 1) ? yb2 : ya;
         pa.ybuf = (j & 1) ? ya : yb2;

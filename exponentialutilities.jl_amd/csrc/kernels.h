@@ -129,8 +129,15 @@ void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, cons
 constexpr int PIPE_CH = 32;       // longest window (m <= 32)
 constexpr int PIPE_TILE = BLOCK;  // rows per workgroup pass, one row per lane
 constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 256-row tile)
+constexpr int PIPE_DIA_MAX = 8;       // diagonals of the DIA form of a narrow-banded operator
 struct PipeArgs {
   SellView<double> A;
+  // DIA form (built when the pattern is a few full diagonals): value d of row r at dia_val[d*dia_ld + r],
+  // column r + dia_off[d]; no column indices are read.  ndiag == 0: use the SELL view.
+  const double *dia_val;
+  int64_t dia_ld;
+  int ndiag;
+  int dia_off[PIPE_DIA_MAX];
   int w;                       // half-bandwidth of A
   const double *yprev;         // y~_{j-1} = A u_{j-1}
   double *ybuf;                // out: y~_j

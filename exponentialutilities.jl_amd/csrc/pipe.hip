@@ -151,7 +151,7 @@ struct PipeShared {
 };
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition
-template <int CH, int PS, bool PERSIST>
+template <int CH, int PS, bool PERSIST, bool DIA>
 __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block, PipeShared &sh) {
   constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
   constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
@@ -204,7 +204,15 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     int L = 0;
     const double *avp = nullptr;
     const int32_t *acp = nullptr;
-    if (i < a.n) {
+    if constexpr (DIA) {   // diagonal d of these two rows: one aligned 16-byte load, no column indices
+      if (act) {
+        L = pa.ndiag;
+        avp = pa.dia_val + i;
+#pragma unroll
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) av[sl] = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld);
+      }
+    } else if (i < a.n) {
       const int64_t slice = i >> 7;
       const int64_t off = pa.A.slice_off[slice];
       L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
@@ -253,7 +261,24 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     Pack<double> y;
     y.v[0] = 0.0;
     y.v[1] = 0.0;
-    if (i < a.n) {
+    if constexpr (DIA) {
+      if (act) {
+        const int base = w + 2 * tid;             // LDS index of this lane's first row
+#pragma unroll
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) {
+            const int o = base + pa.dia_off[sl];
+            y.v[0] = fma(av[sl].v[0], us[o], y.v[0]);     // rows beyond n and absent entries carry value 0
+            y.v[1] = fma(av[sl].v[1], us[o + 1], y.v[1]);
+          }
+        for (int sl = PS; sl < L; ++sl) {
+          const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld);
+          const int o = base + pa.dia_off[sl];
+          y.v[0] = fma(v2.v[0], us[o], y.v[0]);
+          y.v[1] = fma(v2.v[1], us[o + 1], y.v[1]);
+        }
+      }
+    } else if (i < a.n) {
       const int lim = TR + 2 * w, shift = (int)(w - r0);
 #pragma unroll
       for (int sl = 0; sl < PS; ++sl)
@@ -381,11 +406,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   return 1;
 }
 
-template <int CH, int WAVES, int PS>
+template <int CH, int WAVES, int PS, bool DIA>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
   if (step_skipped(pa.d.st, pa.step)) return;
-  (void)pipe_pass<CH, PS, false>(pa, tiles_per_block, sh);
+  (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
 }
 
 // ---- persistent form: steps j0..j1 in ONE cooperative launch -------------------------------------------
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_run(PipeRun pr, int tiles
     pa.hcoef_out = (j & 1) ? pr.hca : pr.hcb;
     pa.step = j;
     pa.stamp = stamp_hash(pr.seq, j);
-    const int r = pipe_pass<CH, PS, true>(pa, tiles_per_block, sh);
+    const int r = pipe_pass<CH, PS, true, false>(pa, tiles_per_block, sh);
     if (r == 3) return;
     if (r != 0) {   // last workgroup: publish the step (its results, stored through, first)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,23 +482,33 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_run(PipeRun pr, int tiles
     }
   }
 }
-template <int CH, int WAVES, int PS>
+template <int CH, int WAVES, int PS, bool DIA>
 static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS>);
+  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
 static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
 void pipe_step(hipStream_t s, const PipeArgs &pa) {
   // the register budget follows the window: short windows run with more workgroups per CU
-  switch (pipe_variant(pa.und)) {
-    case 0: pipe_launch<8, 4, 6>(s, pa); break;
-    case 1: pipe_launch<16, 3, 6>(s, pa); break;
-    case 2: pipe_launch<24, 3, 0>(s, pa); break;
-    default: pipe_launch<32, 2, 5>(s, pa); break;
+  const int v = pipe_variant(pa.und);
+  if (pa.ndiag > 0) {
+    switch (v) {
+      case 0: pipe_launch<8, 4, 6, true>(s, pa); break;
+      case 1: pipe_launch<16, 3, 6, true>(s, pa); break;
+      case 2: pipe_launch<24, 3, 0, true>(s, pa); break;
+      default: pipe_launch<32, 2, 5, true>(s, pa); break;
+    }
+    return;
+  }
+  switch (v) {
+    case 0: pipe_launch<8, 4, 6, false>(s, pa); break;
+    case 1: pipe_launch<16, 3, 6, false>(s, pa); break;
+    case 2: pipe_launch<24, 3, 0, false>(s, pa); break;
+    default: pipe_launch<32, 2, 5, false>(s, pa); break;
   }
 }
 

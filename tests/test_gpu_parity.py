@@ -506,3 +506,43 @@ def test_pipelined_path_when_enabled_is_lazy_and_consistent(eu):
     assert np.max(np.abs(G - np.eye(m + 1))) < 1e-12
     w2 = eu.expv_(np.empty(n), 1.0, Ks)          # and after
     assert relerr(w2, w1) < 1e-14
+
+
+@pytest.mark.parametrize("case", ["gappy_diagonals", "nine_offsets", "dropped_entries", "lanczos_tridiag"])
+def test_banded_operator_forms(eu, case):
+    """Narrow-banded operators take the single-pass pipeline; their diagonals are read in DIA form when there are
+    at most 8 distinct offsets and little zero fill, in SELL form otherwise.  Same H, V and expv either way."""
+    rng = np.random.default_rng(11)
+    n, m = 3001, 24
+    herm = False
+    if case == "gappy_diagonals":        # offsets with holes, all diagonals full
+        offs = [-5, -1, 0, 3, 8]
+    elif case == "nine_offsets":         # more distinct offsets than the DIA form takes -> SELL slots
+        offs = [-4, -3, -2, -1, 0, 1, 2, 3, 4]
+    elif case == "dropped_entries":      # ~10 % of the entries absent: explicit zeros in the DIA form
+        offs = [-2, -1, 0, 1, 2]
+    else:
+        offs = [-1, 0, 1]
+        herm = True
+    diags = [rng.standard_normal(n - abs(o)) * 0.4 - (2.0 if o == 0 else 0.0) for o in offs]
+    A = sp.diags(diags, offs, shape=(n, n), format="csr")
+    if case == "dropped_entries":
+        A = A.tocoo()
+        keep = rng.random(A.nnz) > 0.1
+        A = sp.csr_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=(n, n))
+    if herm:
+        A = ((A + A.T) * 0.5).tocsr()
+    b = rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=herm)
+    Ko = ko.arnoldi(A, b, m=m, ishermitian=herm)
+    assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
+    # the random bands make the basis lose orthogonality (the reference's MGS does too): rounding differences
+    # between two correct orthogonalisations are amplified by that loss, so the bar scales with it
+    Vo = Ko.V[:, : m + 1]
+    loss = float(np.max(np.abs(Vo.T @ Vo - np.eye(m + 1))))
+    assert herr(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m]) <= max(TOL, 10 * loss)
+    w = eu.expv_(np.empty(n), 0.5, Ks)
+    wo = ko.expv_(np.empty(n), 0.5, Ko)
+    assert relerr(w, wo) < max(1e-11, 10 * loss)
+    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= max(1e-10, 100 * loss)
+    assert relerr(eu.expv(0.5, A, b, m=m, ishermitian=herm), wo) < max(1e-11, 10 * loss)     # whole-call form
