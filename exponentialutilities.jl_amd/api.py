@@ -61,7 +61,8 @@ def _check(code, ctx=None):
 class Context:
     """One GPU + one HIP stream (expv_mi_ctx_create).  ``stream`` may be a torch.cuda.Stream."""
 
-    def __init__(self, device=None, stream=None):
+
+    def __init__(self, device=None, stream=None, async_outputs=False):
         lib = L.load()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,6 +75,10 @@ class Context:
         self.device = int(device)
         self._stream_keepalive = stream
         self._finalizer = weakref.finalize(self, lib.expv_mi_ctx_destroy, h)
+        # async_outputs: device-resident results are stream-ordered (valid after ctx.sync() or for later work on
+        # the context's stream) instead of complete when a call returns
+        if async_outputs:
+            _check(lib.expv_mi_ctx_set_async_outputs(h, 1))
 
     def sync(self):
         _check(L.load().expv_mi_ctx_sync(self._h), self._h)
@@ -531,13 +536,15 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
         # private to the call, so the library reuses its workspace and skips v_{m+1} / H[m+1, m]
         T = _work_dtype(op.dtype, bdt)
         opT = _as_operator(op, T)
-        extra = set(kw) - {"m", "tol", "iop", "ishermitian", "ortho", "opnorm"}
+        extra = set(kw) - {"m", "tol", "iop", "ishermitian", "ortho", "opnorm", "out"}
         if extra:
             raise TypeError(f"unexpected keyword(s) {sorted(extra)}")
         ish = kw.get("ishermitian")
         o = _opts(kw.get("m", min(30, op.shape[0])), kw.get("tol", 1e-7), kw.get("iop", 0), 0,
                   opT.ishermitian if ish is None else ish, kw.get("ortho", "auto"))
-        w = _empty_like(b, (n,), _work_dtype(tdt, T))
+        w = kw.get("out")           # optional preallocated result (not in the reference: saves the allocation)
+        if w is None:
+            w = _empty_like(b, (n,), _work_dtype(tdt, T))
         ba, wa = _Arg(b, T), _Arg(w, _work_dtype(tdt, T), writable=True)
         if int(np.prod(ba.shape)) != op.shape[0]:
             raise DimensionMismatch(f"length(b) [{int(np.prod(ba.shape))}] == size(A,1) [{op.shape[0]}] doesn't hold")

@@ -249,9 +249,18 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto &p : ctx->prof)
     for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  ht_report();
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return EXPV_MI_OK;
+}
+int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on) {
+  if (!ctx) return EXPV_MI_ARGUMENT_ERROR;
+  ctx->async_out = (on != 0);
   return EXPV_MI_OK;
 }
 int expv_mi_ctx_sync(expv_mi_ctx_t ctx) {
@@ -631,6 +640,7 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     int herm = o.ishermitian < 0 ? op->ishermitian : o.ishermitian;
     // the internal subspace is private to this call: reuse it across calls of the same shape, and skip what
     // expv never reads (v_{m+1}, H[m+1, m])
+    ht_mark(0);
     const int dtU = herm ? EXPV_MI_F64 : op->dtype;
     expv_mi_ks_s *kp = reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
     if (!kp || kp->dtypeT != op->dtype || kp->dtypeU != dtU || kp->n != op->n || kp->maxiter != m || kp->augmented != 0) {

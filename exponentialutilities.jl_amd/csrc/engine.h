@@ -33,6 +33,11 @@ struct Err {
 
 inline size_t dtype_size(int dt) { return dt == EXPV_MI_C64 ? 16 : 8; }
 
+// host-side phase timing (EXPV_MI_HOST_TIMING=1): wall time between consecutive marks, summed per mark id and
+// printed when the context is destroyed
+void ht_mark(int id);
+void ht_report();
+
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int64_t launches = 0;
@@ -45,8 +50,17 @@ struct Ctx {
   bool owns_stream = false;
   std::string last_error;
   bool prof_on = false;
+  bool async_out = false;   // device outputs are stream-ordered instead of complete on return
   ProfSlot prof[EXPV_MI_K_COUNT];
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
+  hipStream_t stream2 = nullptr;          // second stream + fork/join events of the overlapped pipeline
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void ensure_aux() {
+    if (stream2) return;
+    HIPCHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   void use() const { HIPCHECK(hipSetDevice(device)); }
 };
 }  // namespace expv_mi
@@ -84,7 +98,8 @@ struct ProfScope {  // brackets one launch with events when profiling is on
   Ctx *c;
   int id;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(Ctx *c_, int id_) : c(c_), id(id_) {
+  int nl;
+  ProfScope(Ctx *c_, int id_, int nlaunch = 1) : c(c_), id(id_), nl(nlaunch) {
     if (c->prof_on) {
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
@@ -96,7 +111,7 @@ struct ProfScope {  // brackets one launch with events when profiling is on
       (void)hipEventRecord(b, c->stream);
       c->prof[id].ev.emplace_back(a, b);
     }
-    if (c->prof_on) c->prof[id].launches++;
+    if (c->prof_on) c->prof[id].launches += nl;
   }
 };
 
@@ -149,10 +164,17 @@ struct Ks {
   DevBuf hcoef, part, gpart, state;
   void *pin = nullptr;   // pinned host staging for the Hessenberg / step-state read-back
   size_t pin_bytes = 0;
-  ~Ks() { if (pin) (void)hipHostFree(pin); }
+  ~Ks() {
+    if (pin) (void)hipHostFree(pin);
+    if (mbox) (void)hipHostFree(mbox);
+  }
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
-  DevBuf flags;                      // ... its grid-wide step flags (persistent launches)
+  DevBuf flags, arrive;              // ... the step flags and arrival counters of its overlapped form
   uint32_t pipe_seq = 0;
+  bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait
+  void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv
+  size_t mbox_bytes = 0;
+  bool mbox_armed = false;
   std::vector<double> colscale_host; // ... and their host copy
   bool scale_pending = false;        // stored columns are v_c / s_c until materialised
   bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed

@@ -9,6 +9,10 @@
 // of each reduction kernel (kernels.hip); the host reads H and the flag once, after the loop.
 #include <cstdlib>
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+
 #include "engine.h"
 
 namespace expv_mi {
@@ -181,6 +185,23 @@ static void read_state(Ks &ks, StepState *out) {
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
 }
 
+static const bool g_ht_on = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
+static double g_ht_sum[16];
+static long g_ht_cnt[16];
+static std::chrono::steady_clock::time_point g_ht_last;
+void ht_mark(int id) {
+  if (!g_ht_on) return;
+  const auto now = std::chrono::steady_clock::now();
+  if (id > 0) { g_ht_sum[id] += std::chrono::duration<double, std::micro>(now - g_ht_last).count(); g_ht_cnt[id]++; }
+  g_ht_last = now;
+}
+void ht_report() {
+  if (!g_ht_on) return;
+  static const char *names[16] = {"", "front (reset, fork)", "step launches + join", "H/state read-back + sync", "scales read-back + sync",
+                                  "host exp(tH)", "combine launch", "", "", "", "", "", "", "", "", ""};
+  for (int i = 1; i < 16; ++i)
+    if (g_ht_cnt[i]) std::fprintf(stderr, "[host timing] %-28s %8.2f us avg over %ld\n", names[i], g_ht_sum[i] / g_ht_cnt[i], g_ht_cnt[i]);
+}
 template <class T>
 static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos) {
   Ctx *c = ks.ctx;
@@ -307,76 +328,109 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       double *ya = ks.ybuf.as<double>(), *yb2 = ks.ubuf.as<double>();
       double *hca = ks.hcoef.as<double>(), *hcb = ks.hcoef2.as<double>();
       dev::SellView<double> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<double>(), op.nslices};
-      // EXPV_MI_PIPE_PERSIST=1: persistent launches (one per window-size variant, grid-wide step flags).  Parity-green
-      // but measured slower on C2 (profiles/r01_ab_variants.txt: the in-kernel step synchronisation costs more than
-      // the launch boundary it replaces), so the step-wise launches stay the default.
-      static const bool persist = std::getenv("EXPV_MI_PIPE_PERSIST") != nullptr;
-      bool ran = false;
-      if (persist) {
-        dev::PipeRun pr{};
-        dev::PipeArgs &pa = pr.base;
-        pa.A = A;
-        static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
-        if (op.ndiag > 0 && !no_dia) {
-          pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
-          for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
-        }
-        pa.w = (int)op.bandwidth;
-        pa.u0 = reinterpret_cast<const double *>(b);
-        dev::DotsArgs<double> &d = pa.d;
-        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr; d.dir = 1;
-        d.part = part; d.gpart = gpart; d.st = st; d.real_coeff = 0;
-        d.Hdev = Hd; d.ldh = ks.ldhd; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.hcoef = nullptr;
-        pa.scales = ks.colscale.as<double>();
-        pa.tol = tol;
-        pr.ya = ya; pr.yb = yb2; pr.hca = hca; pr.hcb = hcb;
-        pr.iop = iop; pr.lanczos = lanczos ? 1 : 0;
-        pr.j0 = 1; pr.j1 = m;
+      // Overlapped form (default): consecutive steps on two streams, the next step's kernel starts while this one
+      // finishes (pipe.hip).  EXPV_MI_PIPE_SERIAL=1 / profiling / a previous expired wait: one stream, one launch
+      // after the other.
+      ht_mark(1);
+      static const bool serial_env = std::getenv("EXPV_MI_PIPE_SERIAL") != nullptr;
+      static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
+      const bool live = !serial_env && !ks.pipe_serial && m >= 2;
+      hipStream_t s2 = nullptr;
+      if (live) {
+        c->ensure_aux();
+        s2 = c->stream2;
         if (!ks.flags.p) {
           ks.flags.alloc(sizeof(uint32_t) * (size_t)dev::PIPE_FLAG_COPIES * dev::PIPE_FLAG_STRIDE);
           HIPCHECK(hipMemsetAsync(ks.flags.p, 0, ks.flags.bytes, s));
         }
-        pr.flags = ks.flags.as<uint32_t>();
         ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
         if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-        pr.seq = ks.pipe_seq;
-        ProfScope ps(c, EXPV_MI_K_FUSED_A);
-        const int err = dev::pipe_run(s, pr);
-        if (err != 0) fail(EXPV_MI_HIP_ERROR, "cooperative launch of the pipelined factorisation was refused");
-        ran = true;
-      }
-      for (int j = 1; j <= m && !ran; ++j) {
-        const int i0 = lanczos ? j : std::max(1, j - iop + 1);
-        const int nd = j - i0 + 1;
-        dev::PipeArgs pa{};
-        pa.A = A;
-        static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
-        if (op.ndiag > 0 && !no_dia) {
-          pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
-          for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+        const size_t abytes = sizeof(uint32_t) * (size_t)dev::PIPE_ARRIVE_STEP * (dev::PIPE_CH + 2);
+        if (!ks.arrive.p) ks.arrive.alloc(abytes);
+        HIPCHECK(hipMemsetAsync(ks.arrive.p, 0, abytes, s));
+        // whole-call expv: the kernels mirror H, the scales and the final state into host-mapped memory and raise a
+        // flag there, so the host continues the moment the last step is done (no copy engine, no stream sync)
+        static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
+        ks.mbox_armed = false;
+        if (ks.skip_tail && !no_mbox) {
+          const size_t need = sizeof(double) * ((size_t)ks.ldhd * (ks.maxiter + 1) + (size_t)(ks.maxiter + 2) + 8);
+          if (ks.mbox_bytes < need) {
+            if (ks.mbox) (void)hipHostFree(ks.mbox);
+            ks.mbox = nullptr;
+            HIPCHECK(hipHostMalloc(&ks.mbox, need, hipHostMallocMapped | hipHostMallocCoherent));
+            HIPCHECK(hipHostGetDevicePointer(&ks.mbox_dev, ks.mbox, 0));
+            ks.mbox_bytes = need;
+            std::memset(ks.mbox, 0, need);
+          }
+          double *mh = reinterpret_cast<double *>(ks.mbox);
+          const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
+          std::memset(mh, 0, sizeof(double) * (size_t)ks.ldhd * (m + 1));       // columns this call fills
+          std::memset(mh + hwords + swords, 0, sizeof(double) * 4);            // state
+          ks.mbox_armed = true;
         }
-        pa.w = (int)op.bandwidth;
-        pa.yprev = (j & 1) ? yb2 : ya;
-        pa.ybuf = (j & 1) ? ya : yb2;
-        pa.u0 = (j == 1) ? reinterpret_cast<const double *>(b) : nullptr;
-        dev::DotsArgs<double> &d = pa.d;
-        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
-        d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
-        d.part = part; d.gpart = gpart; d.st = st;
-        d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
-        d.real_coeff = 0;
-        d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.jrow = j - 1;
-        d.hcoef = nullptr;
-        if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
-        else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
-        else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
-        pa.hcoef_in = (j & 1) ? hcb : hca;
-        pa.hcoef_out = (j & 1) ? hca : hcb;
-        pa.scales = ks.colscale.as<double>();
-        pa.step = j;
-        pa.tol = tol;
-        { ProfScope ps(c, EXPV_MI_K_FUSED_A); dev::pipe_step(s, pa); }
+        HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
+        HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
       }
+      {
+        ProfScope ps(c, EXPV_MI_K_FUSED_A, m);   // the whole sequence: overlapped kernels have no separate durations
+        int prev_grid = 0;
+        for (int j = 1; j <= m; ++j) {
+          const int i0 = lanczos ? j : std::max(1, j - iop + 1);
+          const int nd = j - i0 + 1;
+          dev::PipeArgs pa{};
+          pa.A = A;
+          if (op.ndiag > 0 && !no_dia) {
+            pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
+            for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+          }
+          pa.w = (int)op.bandwidth;
+          pa.yprev = (j & 1) ? yb2 : ya;
+          pa.ybuf = (j & 1) ? ya : yb2;
+          pa.u0 = (j == 1) ? reinterpret_cast<const double *>(b) : nullptr;
+          dev::DotsArgs<double> &d = pa.d;
+          d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
+          d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+          d.part = part; d.gpart = gpart; d.st = st;
+          d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+          d.real_coeff = 0;
+          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.jrow = j - 1;
+          d.hcoef = nullptr;
+          if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
+          else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+          else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
+          pa.hcoef_in = (j & 1) ? hcb : hca;
+          pa.hcoef_out = (j & 1) ? hca : hcb;
+          pa.scales = ks.colscale.as<double>();
+          pa.step = j;
+          pa.tol = tol;
+          if (live) {
+            hipStream_t sj = (j & 1) ? s : s2;
+            uint32_t *arr = ks.arrive.as<uint32_t>();
+            pa.flags = ks.flags.as<uint32_t>();
+            pa.seq = ks.pipe_seq;
+            pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
+            if (ks.mbox_armed) {
+              double *md = reinterpret_cast<double *>(ks.mbox_dev);
+              const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
+              d.Hhost = md;
+              pa.mb_scales = md + hwords;
+              pa.mb_state = md + hwords + swords;
+              pa.mb_done = reinterpret_cast<unsigned long long *>(md + hwords + swords + 4);
+              pa.last_step = m;
+            }
+            if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st);
+            prev_grid = dev::pipe_step_live(sj, pa);
+          } else {
+            dev::pipe_step(s, pa);
+          }
+        }
+        if (live) {
+          HIPCHECK(hipEventRecord(c->ev_join, s2));
+          HIPCHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+        }
+      }
+      ks.pipe_live_used = live;
+      ht_mark(2);
       if (!ks.skip_tail) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
         dev::UpdateArgs<double> u{};
         u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
@@ -530,10 +584,43 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   }
   const T *Hh = reinterpret_cast<const T *>(ks.pin);   // Hessenberg columns as the device left them
   StepState &h = *reinterpret_cast<StepState *>(reinterpret_cast<char *>(ks.pin) + ks.pin_bytes - sizeof(StepState));
-  HIPCHECK(hipMemcpyAsync(ks.pin, Hd, hbytes, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipMemcpyAsync(&h, st, sizeof(StepState), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  if (h.breakdown == 99) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: the grid stopped making progress (bounded wait expired)");
+  bool from_mbox = false;
+  if (use_pipe && ks.pipe_live_used && ks.mbox_armed) {
+    // wait on the mailbox flag; the stream is queried now and then so a factorisation that ended without raising
+    // it (expired wait) falls through to the copy path below
+    const double *mh = reinterpret_cast<const double *>(ks.mbox);
+    const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
+    const volatile unsigned long long *done = reinterpret_cast<const volatile unsigned long long *>(mh + hwords + swords + 4);
+    for (long it = 1;; ++it) {
+      if (*done == (unsigned long long)ks.pipe_seq) { from_mbox = true; break; }
+      __builtin_ia32_pause();
+      if ((it & 0xfff) == 0 && hipStreamQuery(s) == hipSuccess) {
+        from_mbox = (*done == (unsigned long long)ks.pipe_seq);
+        break;
+      }
+    }
+    if (from_mbox) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      Hh = reinterpret_cast<const T *>(mh);
+      std::memset(&h, 0, sizeof(h));
+      h.beta0sq = mh[hwords + swords];
+      h.breakdown = (int32_t)mh[hwords + swords + 1];
+      h.m_done = (int32_t)mh[hwords + swords + 2];
+    }
+  }
+  if (!from_mbox) {
+    HIPCHECK(hipMemcpyAsync(ks.pin, Hd, hbytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&h, st, sizeof(StepState), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+  ht_mark(3);
+  if (h.breakdown == 99) {
+    // a kernel of the overlapped form waited in vain (its predecessor could not become resident: the device is
+    // shared with other work).  Nothing is lost: redo the factorisation with one launch after the other.
+    if (!ks.pipe_live_used || ks.pipe_serial) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: bounded wait expired");
+    ks.pipe_serial = true;
+    return arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+  }
   if (use_fused) {
     ks.beta = std::sqrt(h.beta0sq);
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
@@ -541,8 +628,14 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   if (use_pipe) {   // the stored columns are v_c / s_c: keep the scales for the combine / a later materialisation
     const int ncol = ((h.breakdown == 1) ? h.m_done + 1 : (ks.skip_tail ? m : m + 1));
     ks.colscale_host.assign(ks.maxiter + 2, 1.0);
-    HIPCHECK(hipMemcpyAsync(ks.colscale_host.data(), ks.colscale.p, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    if (from_mbox) {
+      const double *ms = reinterpret_cast<const double *>(ks.mbox) + (size_t)ks.ldhd * (ks.maxiter + 1);
+      for (int q = 0; q < ncol; ++q) ks.colscale_host[q] = ms[q];
+    } else {
+      HIPCHECK(hipMemcpyAsync(ks.colscale_host.data(), ks.colscale.p, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    }
+    ht_mark(4);
     ks.scale_pending = true;
     ks.scale_cols = ncol;
   }
@@ -663,7 +756,7 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
                                (cplx *)Wd, ldwd);
   }
   if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
-  else HIPCHECK(hipStreamSynchronize(c->stream));
+  else if (!c->async_out) HIPCHECK(hipStreamSynchronize(c->stream));
 }
 
 static void zero_output(Ctx *c, void *W, int64_t ldw, int w_loc, int64_t rows, int ncols, size_t esz) {
@@ -672,7 +765,7 @@ static void zero_output(Ctx *c, void *W, int64_t ldw, int w_loc, int64_t rows, i
     if (w_loc == EXPV_MI_HOST) std::memset(col, 0, (size_t)rows * esz);
     else HIPCHECK(hipMemsetAsync(col, 0, (size_t)rows * esz, c->stream));
   }
-  if (w_loc != EXPV_MI_HOST) HIPCHECK(hipStreamSynchronize(c->stream));
+  if (w_loc != EXPV_MI_HOST && !c->async_out) HIPCHECK(hipStreamSynchronize(c->stream));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -720,7 +813,9 @@ void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype
     Mat<double> Hr(m, m);
     for (size_t i = 0; i < Hr.a.size(); ++i) Hr.a[i] = Hc.a[i].real() * t_re;
     dense::expm_higham2005base(Hr);
+    ht_mark(5);
     combine_host_coef(ks, m, 1, Hr.data(), m, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);
+    ht_mark(6);
   }
 }
 

@@ -81,6 +81,11 @@ __device__ __forceinline__ void publish_f64(double *p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// store to host-mapped (fine-grained) memory, system scope
+__device__ __forceinline__ void publish_host_f64(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ double consume_f64(const double *p) {
   unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -180,11 +185,16 @@ __device__ __forceinline__ void reduce_flat(const double *part, int nblk, int nv
     __syncthreads();
   }
 }
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// `pf` runs in the workgroups that finished a stage-1 group, right before they queue for the final ticket: loads it
+// issues (e.g. the Gram rows the epilogue needs) complete together with the ticket's round trip.
+template <class PF = NoPrefetch>
 __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double *gpart, int nvals, double *vals_s,
-                                            int *flag_s) {
+                                            int *flag_s, PF pf = PF()) {
   const int nblk = gridDim.x;
   if (nvals <= 2 && nblk <= 2 * GROUP_SIZE) {   // few workgroups: 1 ticket + 1 round of loads
     __shared__ double red2_s[BLOCK / 64];
+    pf();
     if (!take_ticket(&st->ticket, (uint32_t)nblk, flag_s)) return false;
     reduce_flat(part, nblk, nvals, vals_s, red2_s);
     return true;
@@ -194,6 +204,7 @@ __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double 
   const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
   if (!take_ticket(&st->gticket[g], (uint32_t)gsize, flag_s)) return false;
   reduce_stage(part + (size_t)g * GROUP_SIZE, MAX_GRID, gsize, nvals, gpart + g, MAX_GROUPS, false);
+  pf();
   if (!take_ticket(&st->ticket, (uint32_t)ng, flag_s)) return false;
   reduce_stage(gpart, MAX_GROUPS, ng, nvals, vals_s, 1, true);
   __syncthreads();
@@ -314,12 +325,28 @@ __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg,
 //   STRICT / LANCZOS: one column, h = coeff(U, d)                       (arnoldi.jl:302, :397)
 //   LOWSYNC: h = (I + L)^-1 d, L = strict lower triangle of V^H V on the window -- algebraically
 //            the modified Gram-Schmidt coefficients  h_i = <v_i, y - sum_{k<i} h_k v_k>.
+// the earlier Gram rows of the window (everything but the row this pass computes) -> gs_s, same packing as below
+template <class T, bool SHARED>
+__device__ __forceinline__ void gram_prefetch(const DotsArgs<T> &a, T *gs_s) {
+  const int nd = a.nd;
+  const int nold = (nd - 1) * (nd - 2) / 2;      // entries (i, k) with k < i < nd-1 come first in the packing
+  for (int e = threadIdx.x; e < nold; e += BLOCK) {
+    int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);
+    while (i * (i - 1) / 2 > e) --i;
+    while ((i + 1) * i / 2 <= e) ++i;
+    const int k = e - i * (i - 1) / 2;
+    const T *p = &a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg];
+    if constexpr (SHARED) gs_s[e] = consume_f64(reinterpret_cast<const double *>(p));
+    else gs_s[e] = *p;
+  }
+}
 // SHARED (fp64 only): the step results are read by OTHER workgroups of the same launch (persistent pipeline), and
 // the Gram rows / H were written by other workgroups earlier in it: every global access goes through to memory
 // (sc1) instead of relying on a kernel boundary.  slot_scale_s (LDS, optional): factor folded into hcoef[k].
 template <class T, bool SHARED = false>
 __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s,
-                                                    double newest_scale = 1.0, const double *slot_scale_s = nullptr) {
+                                                    double newest_scale = 1.0, const double *slot_scale_s = nullptr,
+                                                    bool gram_ready = false) {
   constexpr int NR = ST<T>::nreal;
   static_assert(!SHARED || NR == 1, "the write-through epilogue is fp64 only");
   auto ldg = [](const T *p) -> T {
@@ -330,12 +357,18 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     if constexpr (SHARED) publish_f64(reinterpret_cast<double *>(p), *reinterpret_cast<const double *>(&v));
     else *p = v;
   };
+  auto sth = [&](int64_t idx, T v) {   // an entry of H: device copy, and the host mirror if there is one
+    stg(&a.Hdev[idx], v);
+    if constexpr (SHARED) {
+      if (a.Hhost) publish_host_f64(reinterpret_cast<double *>(&a.Hhost[idx]), *reinterpret_cast<const double *>(&v));
+    }
+  };
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (a.mode != DOTS_LOWSYNC) {
     if (threadIdx.x == 0) {
       T h = vals_to_T<T>(vals_s);
       if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
-      stg(&a.Hdev[a.c0 + (int64_t)a.jcol * a.ldh], h);
+      sth(a.c0 + (int64_t)a.jcol * a.ldh, h);
       stg(&a.hcoef[0], ST<T>::mul_real(h, slot_scale_s ? slot_scale_s[0] : newest_scale));
       if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
         stg(&a.hcoef[1], ST<T>::mul_real(ST<T>::real_only(ldg(&a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh])),
@@ -353,6 +386,8 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     if (i == nd - 1) {  // <v_j, v_ck> = conj(<v_ck, v_j>): the Gram row computed in this pass
       g = ST<T>::conj(vals_to_T<T>(vals_s + nd * NR + k * NR));
       stg(&a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg], g);
+    } else if (gram_ready) {
+      continue;           // gs_s[e] was filled by gram_prefetch before the final ticket
     } else {
       g = ldg(&a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg]);
     }
@@ -368,7 +403,7 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     }
     if (a.real_coeff) sv = ST<T>::real_only(sv);
     if (lane < nd) {
-      stg(&a.Hdev[(a.c0 + lane) + (int64_t)a.jcol * a.ldh], sv);
+      sth((a.c0 + lane) + (int64_t)a.jcol * a.ldh, sv);
       const double f = slot_scale_s ? slot_scale_s[lane] : ((lane == nd - 1) ? newest_scale : 1.0);
       stg(&a.hcoef[lane], (slot_scale_s || lane == nd - 1) ? ST<T>::mul_real(sv, f) : sv);
     }

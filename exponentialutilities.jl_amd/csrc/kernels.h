@@ -34,6 +34,7 @@ struct DotsArgs {
   T *gram; int ldg; int jrow;          // gram(i,k) = <v_i, v_k>, k < i ; jrow = index of v_j
   T *hcoef;                            // coefficients for the update kernel, window order
   BatchStrides bs;                     // batched launches only (zero otherwise)
+  T *Hhost;                            // optional mirror of Hdev in host-mapped memory (overlapped pipeline), or null
 };
 
 template <class T>
@@ -149,23 +150,23 @@ struct PipeArgs {
   double *scales;              // s_c: stored column c = v_{c+1} / s_c
   int step;
   double tol;
-  unsigned long long stamp;    // persistent launch: validity stamp of this step's partials
+  uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
+  uint32_t seq;                // ... and the sequence number of this factorisation that stamps them
+  uint32_t *arrive;            // ... and this step's arrival counters (residency gate)
+  // result mailbox in host-mapped memory (null: none): the last workgroup of each step mirrors what the host
+  // reads after the factorisation, and the final one raises mb_done -- the host needs no copy and no stream sync
+  double *mb_scales;           // s_c
+  double *mb_state;            // {beta_0^2, breakdown, m_done}
+  unsigned long long *mb_done; // = seq when everything above is complete
+  int last_step;
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa);
-// Steps j0..j1 of one factorisation in persistent launches (one per window-size variant): the step-independent
-// fields of `base` are used as they are, the per-step ones are derived on the device exactly as the host loop
-// derives them for pipe_step.
-struct PipeRun {
-  PipeArgs base;
-  double *ya, *yb;             // y~ ping-pong: step j reads (j odd ? yb : ya), writes the other
-  double *hca, *hcb;           // coefficient ping-pong: step j reads (j odd ? hcb : hca), writes the other
-  int iop, lanczos;
-  int j0, j1;
-  uint32_t *flags;             // PIPE_FLAG_COPIES words, PIPE_FLAG_STRIDE apart
-  uint32_t seq;                // sequence number of this factorisation (stamps the flags)
-};
+// the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
+int pipe_step_live(hipStream_t s, const PipeArgs &pa);
+void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st);
 constexpr int PIPE_FLAG_COPIES = 16, PIPE_FLAG_STRIDE = 1024;
-int pipe_run(hipStream_t s, const PipeRun &pr);   // 0, or the hipError_t of a refused cooperative launch
+constexpr int PIPE_ARRIVE_STRIDE = 32;                                    // words between the arrival counters of a step
+constexpr int PIPE_ARRIVE_STEP = PIPE_FLAG_COPIES * PIPE_ARRIVE_STRIDE;   // words per step
 void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *scales, int ncols);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);

@@ -22,15 +22,12 @@
 // normalised lazily (k_scale_columns) when something other than the combine needs them, which also
 // removes the in-place rescale that would race with a neighbour's halo reads.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernel_common.h"
 
 #ifndef PIPE_WAVES
 #define PIPE_WAVES 2
-#endif
-
-#ifndef PIPE_SPIN_LIMIT
-#define PIPE_SPIN_LIMIT 400000   // polls before a persistent launch gives up (status) instead of hanging
 #endif
 
 namespace expv_mi {
@@ -70,75 +67,6 @@ __device__ unsigned long long g_pipe_trace[33][1024][6];
 #else
 #define PIPE_STAMP(step, slot) do { } while (0)
 #endif
-// ---- grid reduction of the persistent launch: stamped partials, designated reducers, no atomics -------
-// A partial is published as two 8-byte words {bits(v), bits(v) ^ H}, H = hash(call sequence, step): a reader
-// accepts the pair only if w0 ^ w1 == H, so a slot needs no reset and no ticket, and a reader that races the
-// writer (or still sees the pair of an earlier step) simply polls again.  The first workgroup of each group of
-// 64 reduces its group, workgroup 0 reduces the groups -- the same fixed tree as hier_reduce, so the sums are
-// bit-identical to the step-wise kernel's; the waits are bounded like wait_step's.
-__device__ __forceinline__ unsigned long long stamp_hash(uint32_t seq, int step) {
-  return ((unsigned long long)seq * 256ull + (unsigned long long)step + 1ull) * 0x9E3779B97F4A7C15ull;
-}
-__device__ __forceinline__ void publish_stamped(double *slot, double v, unsigned long long h) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + 1, b ^ h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one stage: `count` <= 64 stamped partials per value (lane = partial), 16 values per wave and round
-template <bool TO_LDS>
-__device__ __forceinline__ bool stamped_stage(const double *src, size_t vstride, int count, int nvals, double *dst,
-                                              size_t dstride, unsigned long long h, int *budget) {
-  constexpr int RB = 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int v0 = wave * RB; v0 < nvals; v0 += RB * (BLOCK / 64)) {
-    double x[RB];
-    for (;;) {
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        x[k] = 0.0;
-        if (v0 + k < nvals && lane < count) {
-          const unsigned long long *q = reinterpret_cast<const unsigned long long *>(src + 2 * ((size_t)(v0 + k) * vstride + lane));
-          const unsigned long long w0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && ((w0 ^ w1) == h);
-          x[k] = __longlong_as_double((long long)w0);
-        }
-      }
-      if (__all(ok)) break;
-      if (--(*budget) < 0) return false;
-      __builtin_amdgcn_s_sleep(4);
-    }
-    wave_reduce_multi<RB>(x);
-    const int v = v0 + wave_multi_index<RB>(lane);
-    if ((lane & (64 / RB - 1)) == 0 && v < nvals) {
-      if constexpr (TO_LDS) dst[(size_t)v * dstride] = x[0];
-      else publish_stamped(dst + 2 * (size_t)v * dstride, x[0], h);
-    }
-  }
-  return true;
-}
-// precondition: this workgroup has published its stamped partials part[2*(v*MAX_GRID + blockIdx.x)].
-// Returns 1 in workgroup 0 with vals_s filled, 0 elsewhere, -1 if a wait expired.
-__device__ __forceinline__ int stamped_reduce(double *part, double *gpart, int nvals, double *vals_s, unsigned long long h,
-                                              int *flag_s, int step) {
-  const int nblk = gridDim.x, b = blockIdx.x;
-  if (b % GROUP_SIZE != 0) return 0;
-  const int g = b / GROUP_SIZE;
-  const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
-  const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
-  int budget = PIPE_SPIN_LIMIT;
-  bool ok = stamped_stage<false>(part + 2 * (size_t)g * GROUP_SIZE, MAX_GRID, gsize, nvals, gpart + 2 * g, MAX_GROUPS, h, &budget);
-  PIPE_STAMP(step, 4);
-  if (ok && b == 0) ok = stamped_stage<true>(gpart, MAX_GROUPS, ng, nvals, vals_s, 1, h, &budget);
-  if (threadIdx.x == 0) *flag_s = 1;
-  __syncthreads();
-  if (!ok) *flag_s = 0;          // any wave whose wait expired
-  __syncthreads();
-  if (*flag_s == 0) return -1;
-  return b == 0 ? 1 : 0;
-}
-
 struct PipeShared {
   double us[2 * BLOCK + 2 * PIPE_WMAX];
   double hs[32];                   // update coefficients (h_i s_i): LDS broadcast, no SGPRs
@@ -149,9 +77,40 @@ struct PipeShared {
   double gs_s[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2];
   double cs_s[64];                 // per-slot factors folded into the next pass's coefficients
 };
+// The grid-wide flag of the overlapped form: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels);
+// workgroup b polls copy b % COPIES.  A word holds (call sequence << 8) | stop << 7 | step, so it needs no reset
+// between calls; a stop (happy breakdown / zero vector) releases every later step's kernel as well.
+#ifndef PIPE_SPIN_LIMIT
+#define PIPE_SPIN_LIMIT 400000   // polls before a waiting kernel gives up (status 99) instead of hanging
+#endif
+constexpr uint32_t PIPE_STOP_BIT = 0x80u;
+__device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s) {
+  if (threadIdx.x == 0) {
+    const uint32_t *f = flags + (size_t)(blockIdx.x % PIPE_FLAG_COPIES) * PIPE_FLAG_STRIDE;
+    int res = 0, it = 0;
+    for (;;) {
+      const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 8) == seq) {
+        if (v & PIPE_STOP_BIT) { res = 1; break; }
+        if ((int)(v & 0x7fu) >= step) break;
+      }
+      if (++it > PIPE_SPIN_LIMIT) {
+        __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res = 99;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *flag_s = res;
+  }
+  __syncthreads();
+  const int bd = *flag_s;
+  __syncthreads();
+  return bd;
+}
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
-// last one found the breakdown / zero-vector condition
-template <int CH, int PS, bool PERSIST, bool DIA>
+// last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
+template <int CH, int PS, bool LIVE, bool DIA>
 __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block, PipeShared &sh) {
   constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
   constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
@@ -170,11 +129,18 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = pa.w, jcol = a.jcol, und = pa.und;
   const bool first = (pa.step == 1);
-  const double inv = first ? 1.0 : ld_shared_f64<PERSIST>(&a.st->inv);
   const bool slot_dots = (a.mode != DOTS_LANCZOS) && !first;
   double *Vw = const_cast<double *>(a.V);
-  if (tid < 32) hs[tid] = (tid < und) ? ld_shared_f64<PERSIST>(pa.hcoef_in + tid) : 0.0;
-  __syncthreads();
+  // LIVE: the previous step's kernel may still be running.  Its results (coefficients, 1/beta, its y~ and its
+  // column of V) are awaited INSIDE the first tile, after the loads that do not depend on them are in flight.
+  bool ready = !LIVE || first;
+  double inv = 1.0;
+  const int knew = (jcol - 1 - pa.uc0) * pa.udir;        // window slot of the column the previous step wrote
+  if (ready) {
+    if (!first) inv = a.st->inv;
+    if (tid < 32) hs[tid] = (tid < und && !first) ? pa.hcoef_in[tid] : 0.0;
+    __syncthreads();
+  }
   const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
   const int64_t nb = (a.n + 127) & ~(int64_t)127;        // library vectors are padded (zeros) up to here
   double acc = 0.0;                           // running total of one value of one set (see below)
@@ -185,19 +151,6 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   for (int64_t tile = t0; tile < t1; ++tile) {
     const int64_t r0 = tile * TR, i = r0 + 2 * (int64_t)tid;
     const bool act = i < nb;   // whole waves: nb is a multiple of the 128 rows a wave owns
-    // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
-    for (int e = tid; e < 2 * w * 32; e += BLOCK) {
-      const int hrow = e >> 5, k = e & 31;
-      const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
-      double val = 0.0;
-      if (hr >= 0 && hr < a.n) {
-        if (k == 31) val = first ? pa.u0[hr] : ld_shared_f64<PERSIST>(pa.yprev + hr) * inv;
-        else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
-      }
-#pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
-      if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
-    }
     // ---- operator slots of this lane's two rows: issued now, consumed after the barrier ------------
     Pack<double> av[PS > 0 ? PS : 1];
     int2 aci[PS > 0 ? PS : 1];
@@ -229,6 +182,45 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     Pack<double> vreg[CH - 1];
 #pragma unroll
     for (int k = 0; k < CH - 1; ++k) { vreg[k].v[0] = 0.0; vreg[k].v[1] = 0.0; }
+    const bool wload = !first && act;
+    const double *vp0 = a.V + (int64_t)pa.uc0 * a.ldv + i;    // window column k at vp0 + k * cstep
+    if (wload) {
+      const double *vp = vp0;                                  // one running pointer, stepped per column
+#pragma unroll
+      for (int k = 0; k < CH - 1; ++k) {
+        if (k < und && (ready || k != knew)) vreg[k] = *reinterpret_cast<const Pack<double> *>(vp);
+        vp += cstep;
+      }
+    }
+    if constexpr (LIVE) {
+      if (!ready) {   // first tile: everything above is in flight; now the previous step must be complete
+        const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s);
+        if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
+        PIPE_STAMP(pa.step, 4);
+        inv = consume_f64(&a.st->inv);
+        if (tid < 32) hs[tid] = (tid < und) ? consume_f64(pa.hcoef_in + tid) : 0.0;
+        __syncthreads();
+        if (wload) {
+#pragma unroll
+          for (int k = 0; k < CH - 1; ++k)
+            if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<double> *>(vp0 + (int64_t)k * cstep);
+        }
+        ready = true;
+      }
+    }
+    // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
+    for (int e = tid; e < 2 * w * 32; e += BLOCK) {
+      const int hrow = e >> 5, k = e & 31;
+      const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
+      double val = 0.0;
+      if (hr >= 0 && hr < a.n) {
+        if (k == 31) val = first ? pa.u0[hr] : pa.yprev[hr] * inv;
+        else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+      }
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+      if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
+    }
     Pack<double> u;
     u.v[0] = 0.0;
     u.v[1] = 0.0;
@@ -238,13 +230,6 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       u = *reinterpret_cast<const Pack<double> *>(pa.yprev + i);
       u.v[0] *= inv;
       u.v[1] *= inv;
-      const double *vp = a.V + (int64_t)pa.uc0 * a.ldv + i;    // one running pointer, stepped per column
-#pragma unroll
-      for (int k = 0; k < CH - 1; ++k)
-        if (k < und) {
-          vreg[k] = *reinterpret_cast<const Pack<double> *>(vp);
-          vp += cstep;
-        }
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
         if (k < und) {                          // MGS axpy order
@@ -255,7 +240,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     }
     us[w + 2 * tid] = u.v[0];
     us[w + 2 * tid + 1] = u.v[1];
-    if (act) st_tile<PERSIST>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
+    if (act) st_tile<LIVE>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
     __syncthreads();
     // ---- phase 2: y~ = A u_j for this lane's two rows (SELL-128: one slice per wave), u from LDS ----
     Pack<double> y;
@@ -296,7 +281,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       }
       if (i + 1 >= a.n) y.v[1] = 0.0;
     }
-    if (act) st_tile<PERSIST>(pa.ybuf + i, y);
+    if (act) st_tile<LIVE>(pa.ybuf + i, y);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -334,32 +319,22 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       else if (q < und) red_s[wave][t * und + q] = acc;
     }
   }
-  // persistent launch: this wave's write-through y~ / u_j stores are complete before the partials that
-  // announce the workgroup (the step-wise kernel drains them in take_ticket)
-  if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int nvals = 2 * und + 2;
-  const double mine = (tid < nvals) ? red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid] : 0.0;
-  if constexpr (PERSIST) {
-    if (tid < nvals) publish_stamped(a.part + 2 * ((size_t)tid * MAX_GRID + blockIdx.x), mine, pa.stamp);
-    const int r = stamped_reduce(a.part, a.gpart, nvals, vals_s, pa.stamp, &flag_s, pa.step);
-    if (r < 0) {
-      if (threadIdx.x == 0) __hip_atomic_store(&a.st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return 3;
-    }
-    if (r == 0) return 0;
-    __syncthreads();
-  } else {
-    if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, mine);
-    if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s)) return 0;
-  }
+  if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
+  // (LIVE: the write-through y~ / u_j stores of this workgroup are drained by take_ticket's vmcnt(0))
+  const bool gram_pf = (a.mode == DOTS_LOWSYNC);
+  auto pf = [&]() {   // Gram rows for the epilogue, in flight while this workgroup queues for the final ticket
+    if (gram_pf) gram_prefetch<double, LIVE>(a, gs_s);
+  };
+  if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
   PIPE_STAMP(pa.step, 2);
 
   // ---- last workgroup: finish step j-1, produce the Hessenberg column of step j ------------------
-  // (persistent launch: what earlier last workgroups wrote -- scales, Gram rows, H -- is read through to
-  // memory, and everything written here is stored through: no kernel boundary separates the steps)
+  // (LIVE: what the last workgroups of earlier steps wrote -- scales, Gram rows, H -- is read through to
+  // memory, and everything written here is stored through: the next step's kernel is already running)
   auto put = [](double *p, double v) {
-    if constexpr (PERSIST) publish_f64(p, v);
+    if constexpr (LIVE) publish_f64(p, v);
     else *p = v;
   };
   const double beta = sqrt(vals_s[2 * und + 1]);
@@ -373,6 +348,17 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     if (first) a.st->beta0sq = vals_s[2 * und + 1];
     else put(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);   // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = first ? 2 : 1;
+    if constexpr (LIVE) {
+      if (pa.mb_done) {   // the host's copy
+        publish_host_f64(&pa.mb_scales[jcol], invj);
+        if (first) publish_host_f64(&pa.mb_state[0], vals_s[2 * und + 1]);
+        else publish_host_f64(&a.Hhost[jcol + (int64_t)(jcol - 1) * a.ldh], beta);
+        if (stop) {
+          publish_host_f64(&pa.mb_state[1], first ? 2.0 : 1.0);
+          publish_host_f64(&pa.mb_state[2], (double)(pa.step - 1));
+        }
+      }
+    }
   }
   if (stop) return 2;
   // sums against the stored (raw) columns -> sums against the orthonormal basis, standard layout;
@@ -387,7 +373,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       sc = invj;
     } else {
       const int slot = (col - pa.uc0) * pa.udir;
-      sc = ld_shared_f64<PERSIST>(pa.scales + col);
+      sc = ld_shared_f64<LIVE>(pa.scales + col);
       f = sc * invj;
       dv = vals_s[slot];
       gv = vals_s[und + slot] * f;
@@ -398,11 +384,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   }
   if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) {
     sh.cs_s[0] = invj;
-    sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<PERSIST>(pa.scales + jcol - 1) : 1.0;
+    sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(pa.scales + jcol - 1) : 1.0;
   }
   __syncthreads();
   a.hcoef = pa.hcoef_out;
-  projection_epilogue<double, PERSIST>(a, std_s, gs_s, 1.0, sh.cs_s);
+  projection_epilogue<double, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
   return 1;
 }
 
@@ -413,79 +399,58 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
   (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
 }
 
-// ---- persistent form: steps j0..j1 in ONE cooperative launch -------------------------------------------
-// Every workgroup keeps its tiles for all the steps of the launch; between steps the grid synchronises on
-// StepState::step_done, which the last workgroup of a step publishes after its epilogue.  That removes the
-// launch boundary per step and lets the wait overlap with whatever does not depend on the reduction.
-// Waiting is bounded (PIPE_SPIN_LIMIT polls): a launch that cannot make progress reports breakdown = 99
-// instead of hanging the device.
-// The grid-wide flag: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels); workgroup b polls copy
-// b % COPIES.  A word holds (call sequence << 8) | stop << 7 | step, so it never needs a reset between calls.
-constexpr uint32_t PIPE_STOP_BIT = 0x80u;
-__device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s) {
-  if (threadIdx.x == 0) {
-    const uint32_t *f = flags + (size_t)(blockIdx.x % PIPE_FLAG_COPIES) * PIPE_FLAG_STRIDE;
-    int res = 0, it = 0;
-    for (;;) {
-      const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v >> 8) == seq && (int)(v & 0x7fu) >= step) { res = (v & PIPE_STOP_BIT) ? 1 : 0; break; }
-      if (++it > PIPE_SPIN_LIMIT) {
-        __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res = 99;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    *flag_s = res;
+// ---- overlapped form: the kernel of step j+1 runs while step j finishes ------------------------------
+// Consecutive steps go to two streams.  The workgroups of step j+1 become resident as those of step j leave,
+// put the loads that do not depend on step j in flight (operator diagonals, the older basis columns of their
+// first tile) and only then wait for step j's flag, so the ~10 us reduction epilogue of a step overlaps with the
+// start-up latency of the next one.  Everything a step hands to the next goes through memory (write-through
+// stores, sc1 loads): there is no kernel boundary between writer and reader.  The wait is bounded.
+// Residency gate: a waiting kernel must never keep a workgroup of the kernel it waits for from becoming
+// resident.  Every workgroup of a step announces itself in arrive[] when it starts; the one-workgroup gate
+// kernel queued in front of step j+1 returns only when all workgroups of step j have started, so step j+1 is not
+// even dispatched before step j is completely resident (and step j never waits for step j+1).
+__global__ __launch_bounds__(64) void k_pipe_gate(const uint32_t *arrive, int expected, StepState *st) {
+  const int lane = threadIdx.x;
+  for (int it = 0; it < PIPE_SPIN_LIMIT; ++it) {
+    int v = (lane < PIPE_FLAG_COPIES) ? (int)__hip_atomic_load(arrive + lane * PIPE_ARRIVE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (v >= expected) return;
+    if (__hip_atomic_load(&st->breakdown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 99) return;
+    __builtin_amdgcn_s_sleep(8);
   }
-  __syncthreads();
-  const int bd = *flag_s;
-  __syncthreads();
-  return bd;
+  if (lane == 0) __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int CH, int WAVES, int PS>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_run(PipeRun pr, int tiles_per_block) {
+void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st) {
+  hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st);
+}
+
+template <int CH, int WAVES, int PS, bool DIA>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
-  StepState *st = pr.base.d.st;
-  if (step_skipped(st, pr.j0)) return;
-  for (int j = pr.j0; j <= pr.j1; ++j) {
-    if (j > pr.j0 && wait_step(st, pr.flags, pr.seq, j - 1, &sh.flag_s) != 0) return;   // breakdown (or a stuck grid): all leave
-    PipeArgs pa = pr.base;
-    const int iop = pr.iop, lanczos = pr.lanczos;
-    const int i0 = lanczos ? j : (j - iop + 1 > 1 ? j - iop + 1 : 1);
-    const int nd = j - i0 + 1;
-    pa.yprev = (j & 1) ? pr.yb : pr.ya;
-    pa.ybuf = (j & 1) ? pr.ya : pr.yb;
-    if (j != 1) pa.u0 = nullptr;
-    pa.d.c0 = i0 - 1;
-    pa.d.nd = nd;
-    pa.d.mode = lanczos ? DOTS_LANCZOS : (nd >= 2 ? DOTS_LOWSYNC : DOTS_STRICT);
-    pa.d.jcol = j - 1;
-    pa.d.jrow = j - 1;
-    if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
-    else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
-    else { const int i0p = (j - 1) - iop + 1 > 1 ? (j - 1) - iop + 1 : 1; pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
-    pa.hcoef_in = (j & 1) ? pr.hcb : pr.hca;
-    pa.hcoef_out = (j & 1) ? pr.hca : pr.hcb;
-    pa.step = j;
-    pa.stamp = stamp_hash(pr.seq, j);
-    const int r = pipe_pass<CH, PS, true, false>(pa, tiles_per_block, sh);
-    if (r == 3) return;
-    if (r != 0) {   // last workgroup: publish the step (its results, stored through, first)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x < PIPE_FLAG_COPIES)
-        __hip_atomic_store(pr.flags + (size_t)threadIdx.x * PIPE_FLAG_STRIDE,
-                           (pr.seq << 8) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      PIPE_STAMP(j, 3);
-      if (r == 2) return;
-    }
+  if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
+    (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+  const int r = pipe_pass<CH, PS, true, DIA>(pa, tiles_per_block, sh);
+  if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < PIPE_FLAG_COPIES)
+      __hip_atomic_store(pa.flags + (size_t)threadIdx.x * PIPE_FLAG_STRIDE,
+                         (pa.seq << 8) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)pa.step, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    PIPE_STAMP(pa.step, 3);
+    if (pa.mb_done && (r == 2 || pa.step == pa.last_step) && threadIdx.x == 0)   // all mirrors above are complete
+      __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
 template <int CH, int WAVES, int PS, bool DIA>
 static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
+  int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
+  static const char *cap_env = std::getenv("EXPV_MI_PIPE_GRIDCAP");   // experiment: fraction of the resident capacity (percent)
+  if (cap_env) maxb = std::max(1, maxb * std::atoi(cap_env) / 100);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
@@ -512,48 +477,32 @@ void pipe_step(hipStream_t s, const PipeArgs &pa) {
   }
 }
 
-template <int CH, int WAVES, int PS>
-static hipError_t pipe_run_launch(hipStream_t s, PipeRun pr) {
-  const int64_t ntiles = (pr.base.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_run<CH, WAVES, PS>);
+template <int CH, int WAVES, int PS, bool DIA>
+static int pipe_live_launch(hipStream_t s, const PipeArgs &pa) {
+  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
+  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, DIA>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  int tpb_i = (int)tpb;
-  void *args[] = {&pr, &tpb_i};
-  // cooperative: the runtime guarantees that all nb workgroups are resident together (the grid waits on itself)
-  // every workgroup must be resident (the grid waits on itself): nb <= the occupancy bound, and the wait is
-  // bounded, so a launch that shares the device with something else fails (status) instead of hanging
-  (void)args;
-  hipLaunchKernelGGL((k_pipe_run<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pr, tpb_i);
-  return hipGetLastError();
+  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  return nb;
 }
-static int update_window(int j, int iop, int lanczos) {   // columns the update of step j-1 subtracts (pipe_step's und)
-  if (j == 1) return 0;
-  if (lanczos) return (j - 1 > 1) ? 2 : 1;
-  const int i0p = std::max(1, (j - 1) - iop + 1);
-  return (j - 1) - i0p + 1;
-}
-int pipe_run(hipStream_t s, const PipeRun &pr_in) {
-  int j = pr_in.j0;
-  while (j <= pr_in.j1) {
-    const int v = pipe_variant(update_window(j, pr_in.iop, pr_in.lanczos));
-    int e = j;
-    while (e + 1 <= pr_in.j1 && pipe_variant(update_window(e + 1, pr_in.iop, pr_in.lanczos)) == v) ++e;
-    PipeRun pr = pr_in;
-    pr.j0 = j;
-    pr.j1 = e;
-    hipError_t err;
+int pipe_step_live(hipStream_t s, const PipeArgs &pa) {   // returns the number of workgroups launched
+  const int v = pipe_variant(pa.und);
+  if (pa.ndiag > 0) {
     switch (v) {
-      case 0: err = pipe_run_launch<8, 4, 6>(s, pr); break;
-      case 1: err = pipe_run_launch<16, 3, 6>(s, pr); break;
-      case 2: err = pipe_run_launch<24, 3, 0>(s, pr); break;
-      default: err = pipe_run_launch<32, 2, 5>(s, pr); break;
+      case 0: return pipe_live_launch<8, 4, 6, true>(s, pa);
+      case 1: return pipe_live_launch<16, 3, 6, true>(s, pa);
+      case 2: return pipe_live_launch<24, 3, 0, true>(s, pa);
+      default: return pipe_live_launch<32, 2, 5, true>(s, pa);
     }
-    if (err != hipSuccess) return (int)err;
-    j = e + 1;
   }
-  return 0;
+  switch (v) {
+    case 0: return pipe_live_launch<8, 4, 6, false>(s, pa);
+    case 1: return pipe_live_launch<16, 3, 6, false>(s, pa);
+    case 2: return pipe_live_launch<24, 3, 0, false>(s, pa);
+    default: return pipe_live_launch<32, 2, 5, false>(s, pa);
+  }
 }
 
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation

@@ -61,6 +61,11 @@ typedef enum { EXPV_MI_ORTHO_AUTO = 0, EXPV_MI_ORTHO_MGS = 1, EXPV_MI_ORTHO_LOWS
 int expv_mi_ctx_create(int device_id, void *stream, expv_mi_ctx_t *ctx);
 int expv_mi_ctx_destroy(expv_mi_ctx_t ctx);
 int expv_mi_ctx_sync(expv_mi_ctx_t ctx);
+/* Device-resident outputs (w of expv!/phiv!, ...) are complete when a call returns (default), or -- on != 0 --
+ * stream-ordered like any HIP library: valid for later work on the context's stream, or after
+ * expv_mi_ctx_sync.  Host outputs are always complete on return.  Lets consecutive calls overlap the host part
+ * of one with the last kernel of the previous one. */
+int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on);
 const char *expv_mi_last_error(expv_mi_ctx_t ctx);
 const char *expv_mi_version(void);
 

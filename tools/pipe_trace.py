@@ -20,16 +20,15 @@ lib.expv_mi_pipe_trace_dump(sys.argv[1].encode())
 d = np.loadtxt(sys.argv[1], dtype=np.int64)
 step, blk, t0, t1, t2, t3, t4, t5 = d.T
 prev_pub = None
-print("step nblk | pass begin: first/median/last (us after previous publish) | main end median/last (us after first begin) | reduced | published")
+print("per step, us relative to the previous step's publish (step 1: to its own first start):")
+print("step nblk | kernel start first/median/last | released (after wait) median/last | main end median/last | reduced | published  [= step time]")
 for q in sorted(set(step)):
     mk = step == q
-    b0 = t0[mk].min()
-    last = t2[mk] > 0
-    red = (t2[mk][last].max() - b0) * 0.01 if last.any() else -1
-    pub = (t3[mk].max() - b0) * 0.01 if (t3[mk] > 0).any() else -1
-    rel = (lambda x: (x - prev_pub) * 0.01) if prev_pub is not None else (lambda x: (x - b0) * 0.01)
-    gs = t4[mk][t4[mk] > 0]
-    grp = f"group stage done: first {((gs.min() - b0) * 0.01):.1f} last {((gs.max() - b0) * 0.01):.1f}; blk0 main end {((t1[mk][blk[mk] == 0][0] - b0) * 0.01):.1f} blk0 group done {((t4[mk][blk[mk] == 0][0] - b0) * 0.01):.1f}" if len(gs) else ""
-    print(q, mk.sum(), "|", round(rel(t0[mk].min()), 1), round(rel(np.median(t0[mk])), 1), round(rel(t0[mk].max()), 1), "|",
-          round((np.median(t1[mk]) - b0) * 0.01, 1), round((t1[mk].max() - b0) * 0.01, 1), "|", round(red, 1), "|", round(pub, 1), "|", grp)
-    prev_pub = t3[mk].max() if (t3[mk] > 0).any() else None
+    ref = prev_pub if prev_pub is not None else t0[mk].min()
+    r = lambda x: round((x - ref) * 0.01, 1)
+    rel = t4[mk][t4[mk] > 0]
+    pub = t3[mk].max()
+    red = t2[mk].max()
+    print(q, mk.sum(), "|", r(t0[mk].min()), r(np.median(t0[mk])), r(t0[mk].max()), "|",
+          (r(np.median(rel)), r(rel.max())) if len(rel) else "-", "|", r(np.median(t1[mk])), r(t1[mk].max()), "|", r(red), "|", r(pub))
+    prev_pub = pub
