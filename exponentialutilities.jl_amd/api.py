@@ -83,6 +83,10 @@ class Context:
     def sync(self):
         _check(L.load().expv_mi_ctx_sync(self._h), self._h)
 
+    def set_pipeline_overlap(self, on=True):
+        """Banded pipeline: consecutive Krylov steps on two streams (default) or one launch after the other."""
+        _check(L.load().expv_mi_ctx_set_pipeline_overlap(self._h, int(bool(on))), self._h)
+
     # per-kernel timing for bench.py's roofline leg
     def prof_enable(self, on=True):
         L.load().expv_mi_prof_enable(self._h, int(bool(on)))

@@ -263,6 +263,11 @@ int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on) {
   ctx->async_out = (on != 0);
   return EXPV_MI_OK;
 }
+int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on) {
+  if (!ctx) return EXPV_MI_ARGUMENT_ERROR;
+  ctx->pipe_overlap = (on != 0);
+  return EXPV_MI_OK;
+}
 int expv_mi_ctx_sync(expv_mi_ctx_t ctx) {
   return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipStreamSynchronize(ctx->stream)); });
 }

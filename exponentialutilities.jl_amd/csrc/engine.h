@@ -51,6 +51,7 @@ struct Ctx {
   std::string last_error;
   bool prof_on = false;
   bool async_out = false;   // device outputs are stream-ordered instead of complete on return
+  bool pipe_overlap = true; // banded pipeline: consecutive steps on two streams
   ProfSlot prof[EXPV_MI_K_COUNT];
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
   hipStream_t stream2 = nullptr;          // second stream + fork/join events of the overlapped pipeline
@@ -100,7 +101,7 @@ struct ProfScope {  // brackets one launch with events when profiling is on
   hipEvent_t a = nullptr, b = nullptr;
   int nl;
   ProfScope(Ctx *c_, int id_, int nlaunch = 1) : c(c_), id(id_), nl(nlaunch) {
-    if (c->prof_on) {
+    if (c->prof_on && nl > 0) {   // nlaunch == 0: inert (the launches inside carry their own scopes)
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
       (void)hipEventRecord(a, c->stream);
@@ -169,7 +170,7 @@ struct Ks {
     if (mbox) (void)hipHostFree(mbox);
   }
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
-  DevBuf flags, arrive;              // ... the step flags and arrival counters of its overlapped form
+  DevBuf flags;                      // ... the step flags of its overlapped form (arrival counters: behind `state`)
   uint32_t pipe_seq = 0;
   bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait
   void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv

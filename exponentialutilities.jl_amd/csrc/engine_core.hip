@@ -71,7 +71,7 @@ static void ks_alloc_aux(Ks &ks) {
   if (!ks.part.p) ks.part.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GRID * sizeof(double));
   if (!ks.gpart.p) ks.gpart.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GROUPS * sizeof(double));
   if (!ks.state.p) {
-    ks.state.alloc(sizeof(StepState));
+    ks.state.alloc(sizeof(StepState) + sizeof(uint32_t) * (size_t)dev::PIPE_ARRIVE_STEP * (dev::PIPE_CH + 2));   // + arrival counters
     HIPCHECK(hipMemsetAsync(ks.state.p, 0, sizeof(StepState), ks.ctx->stream));
   }
 }
@@ -231,9 +231,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
       std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
-    StepState z;
-    std::memset(&z, 0, sizeof(z));
-    HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(st, 0, ks.state.bytes, s));   // step state and (behind it) the pipeline's arrival counters
     double extra = 0.0;
     const T *src = b;
     if (isaug) {
@@ -334,7 +332,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       ht_mark(1);
       static const bool serial_env = std::getenv("EXPV_MI_PIPE_SERIAL") != nullptr;
       static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
-      const bool live = !serial_env && !ks.pipe_serial && m >= 2;
+      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
       hipStream_t s2 = nullptr;
       if (live) {
         c->ensure_aux();
@@ -345,9 +343,6 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         }
         ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
         if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-        const size_t abytes = sizeof(uint32_t) * (size_t)dev::PIPE_ARRIVE_STEP * (dev::PIPE_CH + 2);
-        if (!ks.arrive.p) ks.arrive.alloc(abytes);
-        HIPCHECK(hipMemsetAsync(ks.arrive.p, 0, abytes, s));
         // whole-call expv: the kernels mirror H, the scales and the final state into host-mapped memory and raise a
         // flag there, so the host continues the moment the last step is done (no copy engine, no stream sync)
         static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
@@ -372,7 +367,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
       }
       {
-        ProfScope ps(c, EXPV_MI_K_FUSED_A, m);   // the whole sequence: overlapped kernels have no separate durations
+        // overlapped kernels have no separate durations: one scope over the sequence, counted as m launches
+        ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? m : 0);
         int prev_grid = 0;
         for (int j = 1; j <= m; ++j) {
           const int i0 = lanczos ? j : std::max(1, j - iop + 1);
@@ -405,7 +401,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           pa.tol = tol;
           if (live) {
             hipStream_t sj = (j & 1) ? s : s2;
-            uint32_t *arr = ks.arrive.as<uint32_t>();
+            uint32_t *arr = reinterpret_cast<uint32_t *>(ks.state.as<char>() + sizeof(StepState));   // zeroed with the state
             pa.flags = ks.flags.as<uint32_t>();
             pa.seq = ks.pipe_seq;
             pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
@@ -421,6 +417,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st);
             prev_grid = dev::pipe_step_live(sj, pa);
           } else {
+            ProfScope ps1(c, EXPV_MI_K_FUSED_A);
             dev::pipe_step(s, pa);
           }
         }

@@ -66,6 +66,10 @@ int expv_mi_ctx_sync(expv_mi_ctx_t ctx);
  * expv_mi_ctx_sync.  Host outputs are always complete on return.  Lets consecutive calls overlap the host part
  * of one with the last kernel of the previous one. */
 int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on);
+/* Banded pipeline: run consecutive Krylov steps on two streams so that a step's kernel starts while the previous
+ * one finishes (default on).  Off: one launch after the other on the context's stream -- same results; per-kernel
+ * durations are then meaningful to a profiler. */
+int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
 const char *expv_mi_last_error(expv_mi_ctx_t ctx);
 const char *expv_mi_version(void);
 
