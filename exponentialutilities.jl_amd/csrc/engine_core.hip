@@ -332,6 +332,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       ht_mark(1);
       static const bool serial_env = std::getenv("EXPV_MI_PIPE_SERIAL") != nullptr;
       static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
+      // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
+      static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
       const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
       hipStream_t s2 = nullptr;
       if (live) {
@@ -404,6 +406,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
             uint32_t *arr = reinterpret_cast<uint32_t *>(ks.state.as<char>() + sizeof(StepState));   // zeroed with the state
             pa.flags = ks.flags.as<uint32_t>();
             pa.seq = ks.pipe_seq;
+            pa.spin_limit = spin_limit;
             pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
             if (ks.mbox_armed) {
               double *md = reinterpret_cast<double *>(ks.mbox_dev);
@@ -414,7 +417,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
               pa.mb_done = reinterpret_cast<unsigned long long *>(md + hwords + swords + 4);
               pa.last_step = m;
             }
-            if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st);
+            if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
             prev_grid = dev::pipe_step_live(sj, pa);
           } else {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);

@@ -159,11 +159,12 @@ struct PipeArgs {
   double *mb_state;            // {beta_0^2, breakdown, m_done}
   unsigned long long *mb_done; // = seq when everything above is complete
   int last_step;
+  int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgs &pa);
-void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st);
+void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);
 constexpr int PIPE_FLAG_COPIES = 16, PIPE_FLAG_STRIDE = 1024;
 constexpr int PIPE_ARRIVE_STRIDE = 32;                                    // words between the arrival counters of a step
 constexpr int PIPE_ARRIVE_STEP = PIPE_FLAG_COPIES * PIPE_ARRIVE_STRIDE;   // words per step

@@ -80,11 +80,9 @@ struct PipeShared {
 // The grid-wide flag of the overlapped form: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels);
 // workgroup b polls copy b % COPIES.  A word holds (call sequence << 8) | stop << 7 | step, so it needs no reset
 // between calls; a stop (happy breakdown / zero vector) releases every later step's kernel as well.
-#ifndef PIPE_SPIN_LIMIT
-#define PIPE_SPIN_LIMIT 400000   // polls before a waiting kernel gives up (status 99) instead of hanging
-#endif
 constexpr uint32_t PIPE_STOP_BIT = 0x80u;
-__device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s) {
+__device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s,
+                                         int spin_limit) {
   if (threadIdx.x == 0) {
     const uint32_t *f = flags + (size_t)(blockIdx.x % PIPE_FLAG_COPIES) * PIPE_FLAG_STRIDE;
     int res = 0, it = 0;
@@ -94,7 +92,7 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
         if (v & PIPE_STOP_BIT) { res = 1; break; }
         if ((int)(v & 0x7fu) >= step) break;
       }
-      if (++it > PIPE_SPIN_LIMIT) {
+      if (++it > spin_limit) {
         __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         res = 99;
         break;
@@ -194,7 +192,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     }
     if constexpr (LIVE) {
       if (!ready) {   // first tile: everything above is in flight; now the previous step must be complete
-        const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s);
+        const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
         if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
         PIPE_STAMP(pa.step, 4);
         inv = consume_f64(&a.st->inv);
@@ -409,9 +407,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_pe
 // resident.  Every workgroup of a step announces itself in arrive[] when it starts; the one-workgroup gate
 // kernel queued in front of step j+1 returns only when all workgroups of step j have started, so step j+1 is not
 // even dispatched before step j is completely resident (and step j never waits for step j+1).
-__global__ __launch_bounds__(64) void k_pipe_gate(const uint32_t *arrive, int expected, StepState *st) {
+__global__ __launch_bounds__(64) void k_pipe_gate(const uint32_t *arrive, int expected, StepState *st, int spin_limit) {
   const int lane = threadIdx.x;
-  for (int it = 0; it < PIPE_SPIN_LIMIT; ++it) {
+  for (int it = 0; it < spin_limit; ++it) {
     int v = (lane < PIPE_FLAG_COPIES) ? (int)__hip_atomic_load(arrive + lane * PIPE_ARRIVE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -421,8 +419,8 @@ __global__ __launch_bounds__(64) void k_pipe_gate(const uint32_t *arrive, int ex
   }
   if (lane == 0) __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st) {
-  hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st);
+void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit) {
+  hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
 template <int CH, int WAVES, int PS, bool DIA>

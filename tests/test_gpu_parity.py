@@ -546,3 +546,38 @@ def test_banded_operator_forms(eu, case):
     assert relerr(w, wo) < max(1e-11, 10 * loss)
     assert np.max(np.abs(Ks.getV() - Ko.getV())) <= max(1e-10, 100 * loss)
     assert relerr(eu.expv(0.5, A, b, m=m, ishermitian=herm), wo) < max(1e-11, 10 * loss)     # whole-call form
+
+
+def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
+    """The overlapped pipeline, the one-launch-after-the-other form and the redo after an expired wait (forced
+    here by a spin limit of one poll, in a subprocess because the limit is read once) give the same result."""
+    import subprocess, sys, os, textwrap
+    n, m = 20000, 20
+    A = c2_operator(n)
+    b = np.random.default_rng(8).standard_normal(n)
+    wo = ko.expv(0.9, A, b, m=m, ishermitian=False)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    w1 = eu.expv(0.9, op, b, m=m, ishermitian=False)
+    ctx.set_pipeline_overlap(False)
+    w2 = eu.expv(0.9, op, b, m=m, ishermitian=False)
+    ctx.set_pipeline_overlap(True)
+    assert relerr(w1, wo) < 1e-12 and relerr(w2, wo) < 1e-12
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import expv_mi_loader
+        from tests._util import c2_operator
+        eu = expv_mi_loader.load()
+        A = c2_operator(%d)
+        b = np.random.default_rng(8).standard_normal(%d)
+        for _ in range(3):
+            w = eu.expv(0.9, A, b, m=%d, ishermitian=False)
+        np.save(sys.argv[1], w)
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n, m)
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "expv_mi_fallback_%d.npy" % os.getpid())
+    env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1")
+    r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert relerr(np.load(out), wo) < 1e-12
+    os.remove(out)
