@@ -346,7 +346,7 @@ __device__ __forceinline__ void gram_prefetch(const DotsArgs<T> &a, T *gs_s) {
 template <class T, bool SHARED = false>
 __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s,
                                                     double newest_scale = 1.0, const double *slot_scale_s = nullptr,
-                                                    bool gram_ready = false) {
+                                                    bool gram_ready = false, T *hcol_s = nullptr) {
   constexpr int NR = ST<T>::nreal;
   static_assert(!SHARED || NR == 1, "the write-through epilogue is fp64 only");
   auto ldg = [](const T *p) -> T {
@@ -357,18 +357,16 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     if constexpr (SHARED) publish_f64(reinterpret_cast<double *>(p), *reinterpret_cast<const double *>(&v));
     else *p = v;
   };
-  auto sth = [&](int64_t idx, T v) {   // an entry of H: device copy, and the host mirror if there is one
-    stg(&a.Hdev[idx], v);
-    if constexpr (SHARED) {
-      if (a.Hhost) publish_host_f64(reinterpret_cast<double *>(&a.Hhost[idx]), *reinterpret_cast<const double *>(&v));
-    }
+  auto sth = [&](int k, T v) {   // H[c0 + k, jcol]; hcol_s (LDS, optional) keeps the column for a later host mirror
+    stg(&a.Hdev[(a.c0 + k) + (int64_t)a.jcol * a.ldh], v);
+    if (hcol_s) hcol_s[k] = v;
   };
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (a.mode != DOTS_LOWSYNC) {
     if (threadIdx.x == 0) {
       T h = vals_to_T<T>(vals_s);
       if (a.real_coeff) h = ST<T>::real_only(h);     // coeff(U, alpha), arnoldi.jl:412-413
-      sth(a.c0 + (int64_t)a.jcol * a.ldh, h);
+      sth(0, h);
       stg(&a.hcoef[0], ST<T>::mul_real(h, slot_scale_s ? slot_scale_s[0] : newest_scale));
       if (a.mode == DOTS_LANCZOS && a.jcol >= 1)     // v[j-1] = H[j, j-1]  (arnoldi.jl:399)
         stg(&a.hcoef[1], ST<T>::mul_real(ST<T>::real_only(ldg(&a.Hdev[a.jcol + (int64_t)(a.jcol - 1) * a.ldh])),
@@ -403,7 +401,7 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     }
     if (a.real_coeff) sv = ST<T>::real_only(sv);
     if (lane < nd) {
-      sth((a.c0 + lane) + (int64_t)a.jcol * a.ldh, sv);
+      sth(lane, sv);
       const double f = slot_scale_s ? slot_scale_s[lane] : ((lane == nd - 1) ? newest_scale : 1.0);
       stg(&a.hcoef[lane], (slot_scale_s || lane == nd - 1) ? ST<T>::mul_real(sv, f) : sv);
     }

@@ -322,8 +322,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
   // (LIVE: the write-through y~ / u_j stores of this workgroup are drained by take_ticket's vmcnt(0))
   const bool gram_pf = (a.mode == DOTS_LOWSYNC);
-  auto pf = [&]() {   // Gram rows for the epilogue, in flight while this workgroup queues for the final ticket
+  auto pf = [&]() {   // Gram rows and column scales for the epilogue, in flight while this workgroup queues for the final ticket
     if (gram_pf) gram_prefetch<double, LIVE>(a, gs_s);
+    if (a.mode == DOTS_LANCZOS) {
+      if (threadIdx.x == 1) sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(pa.scales + jcol - 1) : 1.0;
+    } else {
+      for (int k = threadIdx.x; k < a.nd; k += BLOCK)
+        if (a.c0 + k != jcol) sh.cs_s[k] = ld_shared_f64<LIVE>(pa.scales + a.c0 + k);
+    }
   };
   if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
   PIPE_STAMP(pa.step, 2);
@@ -343,20 +349,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     put(&a.st->inv, invj);
     a.st->m_done = pa.step - 1;
     put(&pa.scales[jcol], invj);                                  // s_j: column j-1 holds u_j = beta * v_j
-    if (first) a.st->beta0sq = vals_s[2 * und + 1];
+    if (first) put(&a.st->beta0sq, vals_s[2 * und + 1]);
     else put(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);   // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = first ? 2 : 1;
-    if constexpr (LIVE) {
-      if (pa.mb_done) {   // the host's copy
-        publish_host_f64(&pa.mb_scales[jcol], invj);
-        if (first) publish_host_f64(&pa.mb_state[0], vals_s[2 * und + 1]);
-        else publish_host_f64(&a.Hhost[jcol + (int64_t)(jcol - 1) * a.ldh], beta);
-        if (stop) {
-          publish_host_f64(&pa.mb_state[1], first ? 2.0 : 1.0);
-          publish_host_f64(&pa.mb_state[2], (double)(pa.step - 1));
-        }
-      }
-    }
   }
   if (stop) return 2;
   // sums against the stored (raw) columns -> sums against the orthonormal basis, standard layout;
@@ -371,7 +366,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       sc = invj;
     } else {
       const int slot = (col - pa.uc0) * pa.udir;
-      sc = ld_shared_f64<LIVE>(pa.scales + col);
+      sc = sh.cs_s[k];                    // loaded by pf() before the final ticket (same thread)
       f = sc * invj;
       dv = vals_s[slot];
       gv = vals_s[und + slot] * f;
@@ -380,10 +375,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     std_s[nd + k] = gv;
     sh.cs_s[k] = sc;
   }
-  if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) {
-    sh.cs_s[0] = invj;
-    sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(pa.scales + jcol - 1) : 1.0;
-  }
+  if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) sh.cs_s[0] = invj;    // cs_s[1]: pf()
   __syncthreads();
   a.hcoef = pa.hcoef_out;
   projection_epilogue<double, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
@@ -438,8 +430,24 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(PipeArgs pa, int til
                          (pa.seq << 8) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)pa.step, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     PIPE_STAMP(pa.step, 3);
-    if (pa.mb_done && (r == 2 || pa.step == pa.last_step) && threadIdx.x == 0)   // all mirrors above are complete
-      __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (pa.mb_done && (r == 2 || pa.step == pa.last_step)) {
+      // The factorisation ends here: copy what the host reads -- the Hessenberg columns, the column scales, the
+      // final state -- from device memory (every step stored them through before raising its flag) into the
+      // host-mapped mailbox, then raise its flag.  One short copy per factorisation, formally ordered.
+      const DotsArgs<double> &a = pa.d;
+      const int tid = threadIdx.x;
+      const int ncols = pa.step;                       // columns 0 .. step-1 of H have entries
+      for (int e = tid; e < a.ldh * ncols; e += BLOCK) publish_host_f64(&a.Hhost[e], consume_f64(&a.Hdev[e]));
+      for (int k = tid; k < pa.step; k += BLOCK) publish_host_f64(&pa.mb_scales[k], consume_f64(&pa.scales[k]));
+      if (tid == 0) {
+        publish_host_f64(&pa.mb_state[0], consume_f64(&a.st->beta0sq));
+        publish_host_f64(&pa.mb_state[1], r == 2 ? (pa.step == 1 ? 2.0 : 1.0) : 0.0);
+        publish_host_f64(&pa.mb_state[2], (double)(pa.step - 1));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
