@@ -176,6 +176,7 @@ struct Ks {
   void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv
   size_t mbox_bytes = 0;
   bool mbox_armed = false;
+  bool pipe_closed = false;   // the overlapped pipeline produced v_{m+1} / H[m+1, m] itself (closing pass)
   std::vector<double> colscale_host; // ... and their host copy
   bool scale_pending = false;        // stored columns are v_c / s_c until materialised
   bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed

@@ -349,7 +349,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         // flag there, so the host continues the moment the last step is done (no copy engine, no stream sync)
         static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
         ks.mbox_armed = false;
-        if (ks.skip_tail && !no_mbox) {
+        if ((ks.skip_tail || m + 1 <= dev::PIPE_CH - 1) && !no_mbox) {
           const size_t need = sizeof(double) * ((size_t)ks.ldhd * (ks.maxiter + 1) + (size_t)(ks.maxiter + 2) + 8);
           if (ks.mbox_bytes < need) {
             if (ks.mbox) (void)hipHostFree(ks.mbox);
@@ -372,10 +372,15 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         // overlapped kernels have no separate durations: one scope over the sequence, counted as m launches
         ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? m : 0);
         int prev_grid = 0;
-        for (int j = 1; j <= m; ++j) {
+        // overlapped form with the tail requested: one more (closing) pass produces v_{m+1}, H[m+1, m] and the
+        // breakdown test of step m instead of the update2 + norm_final launches below
+        const bool closing = live && !ks.skip_tail && m + 1 <= dev::PIPE_CH - 1;
+        ks.pipe_closed = closing;
+        for (int j = 1; j <= m + (closing ? 1 : 0); ++j) {
           const int i0 = lanczos ? j : std::max(1, j - iop + 1);
           const int nd = j - i0 + 1;
           dev::PipeArgs pa{};
+          pa.final = (j == m + 1) ? 1 : 0;
           pa.A = A;
           if (op.ndiag > 0 && !no_dia) {
             pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
@@ -415,7 +420,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
               pa.mb_scales = md + hwords;
               pa.mb_state = md + hwords + swords;
               pa.mb_done = reinterpret_cast<unsigned long long *>(md + hwords + swords + 4);
-              pa.last_step = m;
+              pa.last_step = m + (closing ? 1 : 0);
             }
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
             prev_grid = dev::pipe_step_live(sj, pa);
@@ -431,7 +436,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       }
       ks.pipe_live_used = live;
       ht_mark(2);
-      if (!ks.skip_tail) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
+      if (!ks.skip_tail && !ks.pipe_closed) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
         dev::UpdateArgs<double> u{};
         u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
         if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }

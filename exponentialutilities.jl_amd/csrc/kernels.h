@@ -159,6 +159,7 @@ struct PipeArgs {
   double *mb_state;            // {beta_0^2, breakdown, m_done}
   unsigned long long *mb_done; // = seq when everything above is complete
   int last_step;
+  int final;                   // 1: closing pass of a factorisation: u_{m+1} and its norm only (no operator apply, no sums)
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa);

@@ -155,7 +155,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     int L = 0;
     const double *avp = nullptr;
     const int32_t *acp = nullptr;
-    if constexpr (DIA) {   // diagonal d of these two rows: one aligned 16-byte load, no column indices
+    if (pa.final) {
+      // closing pass: only u_{m+1} and its norm are needed
+    } else if constexpr (DIA) {   // diagonal d of these two rows: one aligned 16-byte load, no column indices
       if (act) {
         L = pa.ndiag;
         avp = pa.dia_val + i;
@@ -244,7 +246,8 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     Pack<double> y;
     y.v[0] = 0.0;
     y.v[1] = 0.0;
-    if constexpr (DIA) {
+    if (pa.final) {
+    } else if constexpr (DIA) {
       if (act) {
         const int base = w + 2 * tid;             // LDS index of this lane's first row
 #pragma unroll
@@ -279,7 +282,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       }
       if (i + 1 >= a.n) y.v[1] = 0.0;
     }
-    if (act) st_tile<LIVE>(pa.ybuf + i, y);
+    if (act && !pa.final) st_tile<LIVE>(pa.ybuf + i, y);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -354,6 +357,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     if (stop) a.st->breakdown = first ? 2 : 1;
   }
   if (stop) return 2;
+  if (pa.final) return 1;      // closing pass: H[m+1, m], the scale of column m and the breakdown test are all there is
   // sums against the stored (raw) columns -> sums against the orthonormal basis, standard layout;
   // the next pass subtracts h_i * v_i = (h_i s_i) * raw_i: s_i goes into cs_s
   const int nd = a.nd;
