@@ -581,3 +581,37 @@ def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
     assert r.returncode == 0, r.stderr[-2000:]
     assert relerr(np.load(out), wo) < 1e-12
     os.remove(out)
+
+
+def test_overlapped_and_serial_pipeline_are_bitwise_identical(eu):
+    """Same kernels, same arithmetic, same reduction tree: only the hand-over between steps differs (flags and
+    write-through memory traffic instead of kernel boundaries), so H, V and w must agree to the last bit --
+    over ragged sizes, short and long windows, IOP, Lanczos and a mid-run happy breakdown."""
+    rng = np.random.default_rng(21)
+    ctx = eu.Context()
+    cases = [(513, 5, 0, False), (1024, 31, 0, False), (4097, 30, 0, False), (10001, 32, 0, False), (3000, 25, 3, False),
+             (2500, 30, 0, True), (777, 12, 2, False), (70000, 30, 0, False), (256, 30, 0, False)]
+    for n, m, iop, herm in cases:
+        A = c2_operator(n)
+        if herm:
+            A = ((A + A.T) * 0.5).tocsr()
+        op = eu.MIOperator(A, ctx)
+        b = rng.standard_normal(n)
+        if n == 777:                      # an invariant subspace of dimension 6: breakdown inside the run
+            b = np.zeros(n)
+            b[:6] = rng.standard_normal(6)
+            A = sp.block_diag([sp.csr_matrix(np.diag(np.arange(1.0, 7.0)) + np.diag(np.ones(5), 1)), c2_operator(n - 6)]).tocsr()
+            op = eu.MIOperator(A, ctx)
+        out = []
+        for overlap in (True, False):
+            ctx.set_pipeline_overlap(overlap)
+            Ks = eu.KrylovSubspace(np.float64, np.float64, n, m, 0, ctx)
+            eu.arnoldi_(Ks, op, b, m=m, iop=iop, ishermitian=herm)
+            w = eu.expv(0.7, op, b, m=m, iop=iop, ishermitian=herm)
+            out.append((Ks.m, Ks.wasbreakdown, Ks.H.copy(), Ks.getV().copy(), np.asarray(w).copy()))
+        ctx.set_pipeline_overlap(True)
+        (m1, bd1, H1, V1, w1), (m2, bd2, H2, V2, w2) = out
+        assert (m1, bd1) == (m2, bd2), (n, m, iop, herm)
+        assert np.array_equal(H1, H2), (n, m, iop, herm)
+        assert np.array_equal(V1[:, : m1 + 1], V2[:, : m2 + 1]), (n, m, iop, herm)
+        assert np.array_equal(w1, w2), (n, m, iop, herm)
