@@ -9,7 +9,9 @@
 // breakdown flag and reduction buffers; nothing is shared between problems but the pattern of A.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <thread>
+#include <type_traits>
 
 #include "engine.h"
 
@@ -17,6 +19,174 @@ namespace expv_mi {
 
 using dense::cd;
 using dense::Mat;
+
+// DIA layout of a shared banded pattern (same rules as capi.hip:build_dia): offsets ascending, perm[d*ld + r] = index
+// of entry (r, r + off[d]) in the CSR arrays or -1.  ndiag == 0: the pattern does not qualify.
+struct DiaPattern {
+  int ndiag = 0;
+  int off[dev::PIPE_DIA_MAX];
+  int64_t ld = 0;
+  int bandwidth = 0;
+  std::vector<int32_t> perm;
+};
+static DiaPattern dia_pattern(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz) {
+  DiaPattern P;
+  const int W = dev::PIPE_WMAX;
+  std::vector<int64_t> cnt(2 * W + 1, 0);
+  int bw = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    int32_t prev = -1;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const int64_t o = (int64_t)ci[k] - r;
+      if (ci[k] <= prev || o < -W || o > W) return P;
+      prev = ci[k];
+      ++cnt[(size_t)(o + W)];
+      bw = std::max(bw, (int)std::llabs((long long)o));
+    }
+  }
+  int nd = 0, offs[2 * dev::PIPE_WMAX + 1];
+  for (int o = 0; o <= 2 * W; ++o)
+    if (cnt[o] > 0) offs[nd++] = o - W;
+  if (nd == 0 || nd > dev::PIPE_DIA_MAX || (double)nd * (double)n > 1.3 * (double)nnz + 1024.0) return P;
+  P.ld = (n + 511) / 512 * 512;
+  P.perm.assign((size_t)nd * (size_t)P.ld, -1);
+  int slot_of[2 * dev::PIPE_WMAX + 1];
+  for (int d = 0; d < nd; ++d) { slot_of[offs[d] + W] = d; P.off[d] = offs[d]; }
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) P.perm[(size_t)slot_of[ci[k] - r + W] * (size_t)P.ld + (size_t)r] = k;
+  P.ndiag = nd;
+  P.bandwidth = bw;
+  return P;
+}
+
+// Banded pattern, fp64: every problem of a chunk advances by ONE k_pipe launch per Krylov step (problem index in
+// blockIdx.y) -- the single-pass step of pipe.hip, V of each problem read once per step, diagonals without column
+// indices.  Only H[1:m, 1:m] is needed (krylov_phiv.jl:223), so v_{m+1} is never formed.
+static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P, const double *vals_dev, int64_t nnz,
+                            const double *t, const double *b_dev, int64_t ldb, double *w_dev, int64_t ldw,
+                            const expv_mi_arnoldi_opts &o, int32_t *m_used, int m, int herm, int iop) {
+  hipStream_t s = ctx->stream;
+  const double tol = o.tol;
+  const int64_t ldv = (n + 127) / 128 * 128;
+  const int64_t strideV = ldv * (m + 1);
+  const int ldhd = m + 2;
+  const int64_t strideH = (int64_t)ldhd * (m + 1);
+  const int ldg = m + 1;
+  const int64_t dia_words = (int64_t)P.ndiag * P.ld;
+  const size_t per_prob = sizeof(double) * (size_t)(strideV + 2 * ldv + dia_words);
+  size_t free_b = 0, total_b = 0;
+  HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+  int PC = (int)std::min<size_t>((size_t)nprob, std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / std::max<size_t>(per_prob, 1)));
+  PC = std::min(PC, 512);
+  const int64_t ntiles = (n + 2 * dev::BLOCK - 1) / (2 * dev::BLOCK);
+  const int64_t ngpart = (int64_t)64 * dev::MAX_GROUPS;
+  if (ntiles > dev::MAX_GRID) fail(EXPV_MI_UNSUPPORTED, "expv_batch: problem too large for the batched pipeline");
+  DevBuf d_perm(sizeof(int32_t) * P.perm.size());
+  HIPCHECK(hipMemcpyAsync(d_perm.p, P.perm.data(), sizeof(int32_t) * P.perm.size(), hipMemcpyHostToDevice, s));
+  DevBuf dV(sizeof(double) * (size_t)strideV * PC), dYa(sizeof(double) * (size_t)ldv * PC), dYb(sizeof(double) * (size_t)ldv * PC);
+  DevBuf dDia(sizeof(double) * (size_t)dia_words * PC + 16);
+  DevBuf dH(sizeof(double) * (size_t)strideH * PC), dG(sizeof(double) * (size_t)ldg * ldg * PC);
+  DevBuf dhca(sizeof(double) * (size_t)(m + 2) * PC), dhcb(sizeof(double) * (size_t)(m + 2) * PC), dsc(sizeof(double) * (size_t)(m + 2) * PC);
+  // partial buffers: the kernels index part[value * MAX_GRID + workgroup] (<= 64 values); one such block per problem
+  DevBuf dpart(sizeof(double) * (size_t)dev::MAX_GRID * 64 * (size_t)PC), dgpart(sizeof(double) * (size_t)ngpart * PC);
+  DevBuf dst(sizeof(StepState) * (size_t)PC), dcoef(sizeof(double) * (size_t)(m + 1) * PC), dbeta(sizeof(double) * PC), dmcols(sizeof(int32_t) * PC);
+  HIPCHECK(hipMemsetAsync(dV.p, 0, dV.bytes, s));
+  HIPCHECK(hipMemsetAsync(dYa.p, 0, dYa.bytes, s));
+  HIPCHECK(hipMemsetAsync(dYb.p, 0, dYb.bytes, s));
+  std::vector<double> Hh((size_t)strideH * PC), coefh((size_t)(m + 1) * PC), betah(PC), sch((size_t)(m + 2) * PC);
+  std::vector<StepState> sth(PC);
+  std::vector<int32_t> mch(PC);
+  for (int p0 = 0; p0 < nprob; p0 += PC) {
+    const int pc = std::min(PC, nprob - p0);
+    dev::permute_values<double>(s, dDia.as<double>(), dia_words, vals_dev + (int64_t)p0 * nnz, nnz, d_perm.as<int32_t>(), dia_words, pc);
+    HIPCHECK(hipMemsetAsync(dst.p, 0, sizeof(StepState) * (size_t)pc, s));
+    HIPCHECK(hipMemsetAsync(dH.p, 0, sizeof(double) * (size_t)strideH * pc, s));
+    for (int j = 1; j <= m; ++j) {
+      const int i0 = herm ? j : std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      dev::PipeArgs pa{};
+      pa.dia_val = dDia.as<double>(); pa.dia_ld = P.ld; pa.ndiag = P.ndiag;
+      for (int d = 0; d < P.ndiag; ++d) pa.dia_off[d] = P.off[d];
+      pa.w = P.bandwidth;
+      pa.yprev = (j & 1) ? dYb.as<double>() : dYa.as<double>();
+      pa.ybuf = (j & 1) ? dYa.as<double>() : dYb.as<double>();
+      pa.u0 = (j == 1) ? b_dev + (int64_t)p0 * ldb : nullptr;
+      dev::DotsArgs<double> &d = pa.d;
+      d.V = dV.as<double>(); d.ldv = ldv; d.n = n;
+      d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+      d.part = dpart.as<double>(); d.gpart = dgpart.as<double>(); d.st = dst.as<StepState>();
+      d.mode = herm ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+      d.Hdev = dH.as<double>(); d.ldh = ldhd; d.jcol = j - 1; d.gram = dG.as<double>(); d.ldg = ldg; d.jrow = j - 1;
+      if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
+      else if (herm) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+      else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
+      pa.hcoef_in = (j & 1) ? dhcb.as<double>() : dhca.as<double>();
+      pa.hcoef_out = (j & 1) ? dhca.as<double>() : dhcb.as<double>();
+      pa.scales = dsc.as<double>();
+      pa.step = j;
+      pa.tol = tol;
+      dev::PipeBatch &pb = pa.pb;
+      pb.V = strideV; pb.y = ldv; pb.part = (int64_t)dev::MAX_GRID * 64; pb.gpart = ngpart; pb.Hdev = strideH;
+      pb.gram = (int64_t)ldg * ldg; pb.hcoef = m + 2; pb.scales = m + 2; pb.dia = dia_words; pb.st = 1; pb.u0 = ldb;
+      ProfScope ps(ctx, EXPV_MI_K_BATCH);
+      dev::pipe_step(s, pa, pc);
+    }
+    HIPCHECK(hipMemcpyAsync(Hh.data(), dH.p, sizeof(double) * (size_t)strideH * pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(sth.data(), dst.p, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(sch.data(), dsc.p, sizeof(double) * (size_t)(m + 2) * pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    auto solve_one = [&](int q) {
+      const StepState &h = sth[q];
+      const double beta = std::sqrt(h.beta0sq);
+      const int mm = (h.breakdown == 1) ? h.m_done : m;
+      betah[q] = beta;
+      mch[q] = (beta == 0.0) ? 0 : mm;
+      if (m_used) m_used[p0 + q] = mm;
+      if (beta == 0.0) return;
+      const double *Hq = Hh.data() + (size_t)q * strideH;
+      double *cq = coefh.data() + (size_t)q * (m + 1);
+      const double tq = t[p0 + q];
+      if (herm) {   // lanczos!: v[j] = H[j+1, j] mirrors onto the superdiagonal (arnoldi.jl:488); eigen path of expv!
+        std::vector<double> dd(mm), ee(mm > 1 ? mm - 1 : 0);
+        for (int i = 0; i < mm; ++i) dd[i] = Hq[(size_t)i * ldhd + i];
+        for (int i = 0; i + 1 < mm; ++i) ee[i] = Hq[(size_t)i * ldhd + i + 1];
+        std::vector<double> cf = dense::symtridiag_expcol<double>(dd, ee, tq);
+        for (int i = 0; i < mm; ++i) cq[i] = cf[i];
+      } else {
+        Mat<double> Hm(mm, mm);
+        for (int jj = 0; jj < mm; ++jj)
+          for (int i = 0; i < mm; ++i) Hm(i, jj) = Hq[(size_t)jj * ldhd + i] * tq;
+        dense::expm_higham2005base(Hm);
+        for (int i = 0; i < mm; ++i) cq[i] = Hm(i, 0);
+      }
+      const double *sq = sch.data() + (size_t)q * (m + 2);      // stored columns are v_c / s_c
+      for (int i = 0; i < mm; ++i) cq[i] *= sq[i];
+    };
+    {
+      const int nth = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+      std::vector<std::thread> th;
+      std::vector<std::string> errs(nth);
+      for (int w = 0; w < nth; ++w)
+        th.emplace_back([&, w] {
+          try {
+            for (int q = w; q < pc; q += nth) solve_one(q);
+          } catch (const std::exception &e) { errs[w] = e.what(); }
+        });
+      for (auto &x : th) x.join();
+      for (auto &e : errs)
+        if (!e.empty()) fail(EXPV_MI_SINGULAR, e);
+    }
+    HIPCHECK(hipMemcpyAsync(dcoef.p, coefh.data(), sizeof(double) * (size_t)(m + 1) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dbeta.p, betah.data(), sizeof(double) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dmcols.p, mch.data(), sizeof(int32_t) * pc, hipMemcpyHostToDevice, s));
+    {
+      ProfScope ps(ctx, EXPV_MI_K_COMBINE);
+      dev::combine_batch<double>(s, n, dV.as<double>(), ldv, strideV, dcoef.as<double>(), m + 1, dbeta.as<double>(),
+                                 dmcols.as<int32_t>(), w_dev + (int64_t)p0 * ldw, ldw, pc);
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+}
 
 template <class T>
 static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h, const int32_t *colind_h,
@@ -29,6 +199,16 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
   const int iop = (o.iop == 0) ? m : o.iop;
   if (!herm && std::min(iop, m) > dev::LOWSYNC_MAX) fail(EXPV_MI_UNSUPPORTED, "expv_batch: window longer than 64 columns");
   if (m > dev::LOWSYNC_MAX * 2) fail(EXPV_MI_UNSUPPORTED, "expv_batch: m > 128");
+  if constexpr (std::is_same<T, double>::value) {
+    static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
+    if (!no_pipe && m <= dev::PIPE_CH && m >= 1) {
+      const DiaPattern P = dia_pattern(n, rowptr_h, colind_h, nnz);
+      if (P.ndiag > 0) {
+        expv_batch_pipe(ctx, n, nprob, P, vals_dev, nnz, t, b_dev, ldb, w_dev, ldw, o, m_used, m, herm, iop);
+        return;
+      }
+    }
+  }
   // ---- pattern -> SELL (once, shared by every problem) + the CSR->SELL value permutation ----------
   constexpr int N = 16 / (int)sizeof(T);
   const int SH = 64 * N;

@@ -131,6 +131,10 @@ constexpr int PIPE_CH = 32;       // longest window (m <= 32)
 constexpr int PIPE_TILE = BLOCK;  // rows per workgroup pass, one row per lane
 constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 256-row tile)
 constexpr int PIPE_DIA_MAX = 8;       // diagonals of the DIA form of a narrow-banded operator
+// batched launches (problem index in blockIdx.y): element strides between the per-problem arrays; all zero otherwise
+struct PipeBatch {
+  int64_t V, y, part, gpart, Hdev, gram, hcoef, scales, dia, st, u0;
+};
 struct PipeArgs {
   SellView<double> A;
   // DIA form (built when the pattern is a few full diagonals): value d of row r at dia_val[d*dia_ld + r],
@@ -150,6 +154,7 @@ struct PipeArgs {
   double *scales;              // s_c: stored column c = v_{c+1} / s_c
   int step;
   double tol;
+  PipeBatch pb;                // step-wise kernel only (the overlapped form is for a single problem)
   uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
   uint32_t seq;                // ... and the sequence number of this factorisation that stamps them
   uint32_t *arrive;            // ... and this step's arrival counters (residency gate)
@@ -162,7 +167,7 @@ struct PipeArgs {
   int final;                   // 1: closing pass of a factorisation: u_{m+1} and its norm only (no operator apply, no sums)
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
 };
-void pipe_step(hipStream_t s, const PipeArgs &pa);
+void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch = 1);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgs &pa);
 void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);

@@ -389,6 +389,23 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
 template <int CH, int WAVES, int PS, bool DIA>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
+  if (gridDim.y > 1) {   // batch of independent problems: everything per-problem moves by blockIdx.y strides
+    const int64_t q = blockIdx.y;
+    const PipeBatch &b = pa.pb;
+    pa.d.V += q * b.V;
+    pa.yprev += q * b.y;
+    pa.ybuf += q * b.y;
+    if (pa.u0) pa.u0 += q * b.u0;
+    pa.d.part += q * b.part;
+    pa.d.gpart += q * b.gpart;
+    pa.d.Hdev += q * b.Hdev;
+    pa.d.gram += q * b.gram;
+    pa.hcoef_in += q * b.hcoef;
+    pa.hcoef_out += q * b.hcoef;
+    pa.scales += q * b.scales;
+    pa.dia_val += q * b.dia;
+    pa.d.st += q * b.st;
+  }
   if (step_skipped(pa.d.st, pa.step)) return;
   (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
 }
@@ -456,34 +473,38 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(PipeArgs pa, int til
 }
 
 template <int CH, int WAVES, int PS, bool DIA>
-static void pipe_launch(hipStream_t s, const PipeArgs &pa) {
+static void pipe_launch(hipStream_t s, const PipeArgs &pa, int nbatch) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
   int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
   static const char *cap_env = std::getenv("EXPV_MI_PIPE_GRIDCAP");   // experiment: fraction of the resident capacity (percent)
   if (cap_env) maxb = std::max(1, maxb * std::atoi(cap_env) / 100);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
+  // batch: workgroups of all problems share the chip; a few resident rounds of fat workgroups instead of one tile each
+  // (start-up round trips and the ticket are per workgroup)
+  static const int batch_rounds = std::getenv("EXPV_MI_BATCH_ROUNDS") ? std::atoi(std::getenv("EXPV_MI_BATCH_ROUNDS")) : 2;
+  if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS, DIA>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
 static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
-void pipe_step(hipStream_t s, const PipeArgs &pa) {
+void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch) {
   // the register budget follows the window: short windows run with more workgroups per CU
   const int v = pipe_variant(pa.und);
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: pipe_launch<8, 4, 6, true>(s, pa); break;
-      case 1: pipe_launch<16, 3, 6, true>(s, pa); break;
-      case 2: pipe_launch<24, 3, 0, true>(s, pa); break;
-      default: pipe_launch<32, 2, 5, true>(s, pa); break;
+      case 0: pipe_launch<8, 4, 6, true>(s, pa, nbatch); break;
+      case 1: pipe_launch<16, 3, 6, true>(s, pa, nbatch); break;
+      case 2: pipe_launch<24, 3, 0, true>(s, pa, nbatch); break;
+      default: pipe_launch<32, 2, 5, true>(s, pa, nbatch); break;
     }
     return;
   }
   switch (v) {
-    case 0: pipe_launch<8, 4, 6, false>(s, pa); break;
-    case 1: pipe_launch<16, 3, 6, false>(s, pa); break;
-    case 2: pipe_launch<24, 3, 0, false>(s, pa); break;
-    default: pipe_launch<32, 2, 5, false>(s, pa); break;
+    case 0: pipe_launch<8, 4, 6, false>(s, pa, nbatch); break;
+    case 1: pipe_launch<16, 3, 6, false>(s, pa, nbatch); break;
+    case 2: pipe_launch<24, 3, 0, false>(s, pa, nbatch); break;
+    default: pipe_launch<32, 2, 5, false>(s, pa, nbatch); break;
   }
 }
 
