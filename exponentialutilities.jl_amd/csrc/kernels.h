@@ -128,8 +128,7 @@ void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, cons
 
 // ---- single-pass step for narrow-banded operators (pipe.hip, fp64) -------------------------
 constexpr int PIPE_CH = 32;       // longest window (m <= 32)
-constexpr int PIPE_TILE = BLOCK;  // rows per workgroup pass, one row per lane
-constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 256-row tile)
+constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 512-row tile)
 constexpr int PIPE_DIA_MAX = 8;       // diagonals of the DIA form of a narrow-banded operator
 // batched launches (problem index in blockIdx.y): element strides between the per-problem arrays; all zero otherwise
 struct PipeBatch {

@@ -16,33 +16,34 @@
 //     last workgroup: beta_{j-1} = ||u_j||, H[j, j-1], breakdown test of step j-1, s_j = 1/beta_{j-1},
 //        the rescaled sums -> Hessenberg column of step j (same epilogue as fused_a2)
 //
-// Each stored basis column is read ONCE per step (plus 2w/256 for the halo): per step
-// A_B + 8n(w_j - 1) + 8n [y~ read] + 16n [u_j, y~_j written] -- the contract traffic of SURVEY §8d.
+// Each stored basis column is read ONCE per step (plus 2w/512 for the halo): per step
+// A + 8n(w_j - 1) + 8n [y~ read] + 16n [u_j, y~_j written]; A is the DIA form (values only) when the pattern is a
+// few full diagonals, the SELL-128 form otherwise.
 // Columns are kept un-normalised in HBM during the factorisation (scales in Ks); they are
 // normalised lazily (k_scale_columns) when something other than the combine needs them, which also
 // removes the in-place rescale that would race with a neighbour's halo reads.
+//
+// Three ways to run the step:
+//   k_pipe        one launch after the other on one stream (also: batches of problems in blockIdx.y)
+//   k_pipe_live   consecutive steps on two streams, the next step's kernel starts while this one finishes
+//                 (flags + write-through memory traffic instead of kernel boundaries; k_pipe_gate keeps it deadlock-free)
+//   closing pass  (final = 1) u_{m+1}, H[m+1, m] and the breakdown test of step m for arnoldi!
 #include <algorithm>
 #include <cstdlib>
 
 #include "kernel_common.h"
 
-#ifndef PIPE_WAVES
-#define PIPE_WAVES 2
-#endif
-
 namespace expv_mi {
 namespace dev {
 
-// Value layout of the 64 sums a pass produces (per lane after the wave reduction: lane v holds value v):
-//   [0, 31)  d~ slots  <raw_i, y~_j>        [32, 63)  g~ slots  <raw_i, u_j>      (i = update-window slot)
-//   31       <u_j, y~_j>                     63        ||u_j||^2
-// Every 512-row tile's 64 per-lane products are summed across the wave at once by recursive halving
-// (63 exchanges), so a lane carries ONE running sum instead of 62 -- that is what lets the pass use
-// 16-byte loads with the whole window (<= 31 columns) of a tile in flight.
-// CH = window capacity (update window <= CH-1 columns), K = CH sums per set; WAVES = workgroups per CU the
-// register budget allows; PS = SELL slots prefetched into registers before the barrier.
+// Sums of a pass, compact layout (und = update-window length): [0, und) d~_i = <raw_i, y~_j>, [und, 2 und)
+// g~_i = <raw_i, u_j>, [2 und] <u_j, y~_j>, [2 und + 1] ||u_j||^2.  A tile's per-lane products are summed across the
+// wave at once by recursive halving in sets of K values, so a lane carries ONE running sum -- that is what lets the
+// pass hold the whole window (<= 31 columns) of a tile in registers with 16-byte loads.
+// Template parameters: CH = window capacity (update window <= CH-1 columns); WAVES = workgroups per CU the register
+// budget allows; PS = operator slots prefetched into registers before the barrier; DIA = operator form.
 // 16-byte store that goes through to memory (sc0 sc1): no dirty line stays in this XCD's L2, so a later reader on
-// another XCD needs no L2 write-back from us (persistent launch: no kernel boundary between writer and reader)
+// another XCD needs no L2 write-back from us (overlapped form: no kernel boundary between writer and reader)
 __device__ __forceinline__ void st_pack_wt(double *p, const Pack<double> &v) {
   typedef double vec2d __attribute__((ext_vector_type(2)));
   vec2d d;
@@ -475,9 +476,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(PipeArgs pa, int til
 template <int CH, int WAVES, int PS, bool DIA>
 static void pipe_launch(hipStream_t s, const PipeArgs &pa, int nbatch) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
-  static const char *cap_env = std::getenv("EXPV_MI_PIPE_GRIDCAP");   // experiment: fraction of the resident capacity (percent)
-  if (cap_env) maxb = std::max(1, maxb * std::atoi(cap_env) / 100);
+  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   // batch: workgroups of all problems share the chip; a few resident rounds of fat workgroups instead of one tile each
   // (start-up round trips and the ticket are per workgroup)
