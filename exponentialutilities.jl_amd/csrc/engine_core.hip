@@ -198,7 +198,7 @@ void ht_mark(int id) {
 void ht_report() {
   if (!g_ht_on) return;
   static const char *names[16] = {"", "front (reset, fork)", "step launches + join", "H/state read-back + sync", "scales read-back + sync",
-                                  "host exp(tH)", "combine launch", "", "", "", "", "", "", "", "", ""};
+                                  "host exp(tH)", "combine launch", "H copy + structure checks", "", "", "", "", "", "", "", ""};
   for (int i = 1; i < 16; ++i)
     if (g_ht_cnt[i]) std::fprintf(stderr, "[host timing] %-28s %8.2f us avg over %ld\n", names[i], g_ht_sum[i] / g_ht_cnt[i], g_ht_cnt[i]);
 }
@@ -817,6 +817,7 @@ void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype
   } else {
     Mat<double> Hr(m, m);
     for (size_t i = 0; i < Hr.a.size(); ++i) Hr.a[i] = Hc.a[i].real() * t_re;
+    ht_mark(7);
     dense::expm_higham2005base(Hr);
     ht_mark(5);
     combine_host_coef(ks, m, 1, Hr.data(), m, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);

@@ -278,21 +278,35 @@ inline void lu_solve(Mat<S> &M, Mat<S> &X) {
       for (int i = k + 1; i < n; ++i) mj[i] -= mk[i] * mkj;
     }
   }
-  for (int j = 0; j < nrhs; ++j) {
-    S *__restrict__ xj = &X.a[(size_t)j * n];
-    for (int k = 0; k < n; ++k) {  // forward (unit lower)
-      const S xk = xj[k];
-      if (!nonzero(xk)) continue;
-      const S *__restrict__ mk = &M.a[(size_t)k * n];
-      for (int i = k + 1; i < n; ++i) xj[i] -= mk[i] * xk;
-    }
-    for (int k = n - 1; k >= 0; --k) {  // backward
-      const S *__restrict__ mk = &M.a[(size_t)k * n];
-      xj[k] /= mk[k];
-      const S xk = xj[k];
-      for (int i = 0; i < k; ++i) xj[i] -= mk[i] * xk;
+  // triangular solves on the TRANSPOSED right-hand sides: row i of X is contiguous, so the inner loops run over all
+  // nrhs columns at once (full-length vector FMAs) instead of over the shrinking remainder of one column
+  std::vector<S> Xt((size_t)n * nrhs);
+  for (int j = 0; j < nrhs; ++j)
+    for (int i = 0; i < n; ++i) Xt[(size_t)i * nrhs + j] = X.a[(size_t)j * n + i];
+  for (int k = 0; k < n; ++k) {  // forward (unit lower): row_i -= L(i,k) * row_k
+    const S *__restrict__ rk = &Xt[(size_t)k * nrhs];
+    const S *__restrict__ mk = &M.a[(size_t)k * n];
+    for (int i = k + 1; i < n; ++i) {
+      const S l = mk[i];
+      if (!nonzero(l)) continue;
+      S *__restrict__ ri = &Xt[(size_t)i * nrhs];
+      for (int j = 0; j < nrhs; ++j) ri[j] -= l * rk[j];
     }
   }
+  for (int k = n - 1; k >= 0; --k) {  // backward: row_k /= U(k,k); row_i -= U(i,k) * row_k
+    S *__restrict__ rk = &Xt[(size_t)k * nrhs];
+    const S *__restrict__ mk = &M.a[(size_t)k * n];
+    const S d = mk[k];
+    for (int j = 0; j < nrhs; ++j) rk[j] /= d;
+    for (int i = 0; i < k; ++i) {
+      const S u = mk[i];
+      if (!nonzero(u)) continue;
+      S *__restrict__ ri = &Xt[(size_t)i * nrhs];
+      for (int j = 0; j < nrhs; ++j) ri[j] -= u * rk[j];
+    }
+  }
+  for (int j = 0; j < nrhs; ++j)
+    for (int i = 0; i < n; ++i) X.a[(size_t)j * n + i] = Xt[(size_t)i * nrhs + j];
 }
 
 // ---- Pade evaluation, generic Horner in A^2 for every order (exp_baseexp.jl:84-105) ----------
