@@ -198,7 +198,7 @@ void ht_mark(int id) {
 void ht_report() {
   if (!g_ht_on) return;
   static const char *names[16] = {"", "front (reset, fork)", "step launches + join", "H/state read-back + sync", "scales read-back + sync",
-                                  "host exp(tH)", "combine launch", "H copy + structure checks", "", "", "", "", "", "", "", ""};
+                                  "host exp(tH)", "combine launch", "H copy + structure checks", "combine: coefficient prep", "", "", "", "", "", "", ""};
   for (int i = 1; i < 16; ++i)
     if (g_ht_cnt[i]) std::fprintf(stderr, "[host timing] %-28s %8.2f us avg over %ld\n", names[i], g_ht_sum[i] / g_ht_cnt[i], g_ht_cnt[i]);
 }
@@ -736,6 +736,7 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
     Wd = wtmp.p;
     ldwd = rows;
   }
+  ht_mark(8);
   {
     ProfScope ps(c, EXPV_MI_K_COMBINE);
     const int mc = std::max(mcols, 0);
