@@ -185,6 +185,38 @@ static void read_state(Ks &ks, StepState *out) {
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
 }
 
+// Result mailbox of a factorisation whose H the host reads right away (see kernels.h:mailbox_fill, pipe.hip):
+// layout in 8-byte words: [0, hwords) H as on the device, [hwords, hwords + maxiter + 2) column scales,
+// then 4 words of state and the `done` word.
+struct MailboxView { double *H, *scales, *state; unsigned long long *done; };
+static size_t mailbox_hwords(const Ks &ks) { return (dtype_size(ks.dtypeT) / 8) * (size_t)ks.ldhd * (ks.maxiter + 1); }
+static MailboxView mailbox_view(const Ks &ks, void *base) {
+  double *m = reinterpret_cast<double *>(base);
+  const size_t hw = mailbox_hwords(ks), sw = (size_t)ks.maxiter + 2;
+  return MailboxView{m, m + hw, m + hw + sw, reinterpret_cast<unsigned long long *>(m + hw + sw + 4)};
+}
+static bool mailbox_arm(Ks &ks, int m) {
+  static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
+  ks.mbox_armed = false;
+  if (no_mbox) return false;
+  const size_t need = sizeof(double) * (mailbox_hwords(ks) + (size_t)(ks.maxiter + 2) + 8);
+  if (ks.mbox_bytes < need) {
+    if (ks.mbox) (void)hipHostFree(ks.mbox);
+    ks.mbox = nullptr;
+    HIPCHECK(hipHostMalloc(&ks.mbox, need, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHECK(hipHostGetDevicePointer(&ks.mbox_dev, ks.mbox, 0));
+    ks.mbox_bytes = need;
+    std::memset(ks.mbox, 0, need);
+  }
+  const MailboxView v = mailbox_view(ks, ks.mbox);
+  std::memset(v.H, 0, dtype_size(ks.dtypeT) * (size_t)ks.ldhd * (m + 1));   // columns this call fills
+  std::memset(v.state, 0, sizeof(double) * 4);
+  ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+  if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+  ks.mbox_armed = true;
+  return true;
+}
+
 static const bool g_ht_on = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
 static double g_ht_sum[16];
 static long g_ht_cnt[16];
@@ -226,7 +258,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   StepState *st = ks.state.as<StepState>();
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
-  bool use_fused = false, single_red = false, use_pipe = false;
+  bool use_fused = false, single_red = false, use_pipe = false, mbox_generic = false;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -343,27 +375,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           ks.flags.alloc(sizeof(uint32_t) * (size_t)dev::PIPE_FLAG_COPIES * dev::PIPE_FLAG_STRIDE);
           HIPCHECK(hipMemsetAsync(ks.flags.p, 0, ks.flags.bytes, s));
         }
-        ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
-        if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-        // whole-call expv: the kernels mirror H, the scales and the final state into host-mapped memory and raise a
-        // flag there, so the host continues the moment the last step is done (no copy engine, no stream sync)
-        static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
+        // the last kernel mirrors H, the scales and the final state into host-mapped memory and raises a flag there,
+        // so the host continues the moment the last step is done (no copy engine, no stream sync)
         ks.mbox_armed = false;
-        if ((ks.skip_tail || m + 1 <= dev::PIPE_CH - 1) && !no_mbox) {
-          const size_t need = sizeof(double) * ((size_t)ks.ldhd * (ks.maxiter + 1) + (size_t)(ks.maxiter + 2) + 8);
-          if (ks.mbox_bytes < need) {
-            if (ks.mbox) (void)hipHostFree(ks.mbox);
-            ks.mbox = nullptr;
-            HIPCHECK(hipHostMalloc(&ks.mbox, need, hipHostMallocMapped | hipHostMallocCoherent));
-            HIPCHECK(hipHostGetDevicePointer(&ks.mbox_dev, ks.mbox, 0));
-            ks.mbox_bytes = need;
-            std::memset(ks.mbox, 0, need);
-          }
-          double *mh = reinterpret_cast<double *>(ks.mbox);
-          const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
-          std::memset(mh, 0, sizeof(double) * (size_t)ks.ldhd * (m + 1));       // columns this call fills
-          std::memset(mh + hwords + swords, 0, sizeof(double) * 4);            // state
-          ks.mbox_armed = true;
+        if (ks.skip_tail || m + 1 <= dev::PIPE_CH - 1) (void)mailbox_arm(ks, m);
+        if (!ks.mbox_armed) {   // the flags still need a fresh sequence number
+          ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+          if (ks.pipe_seq == 0) ks.pipe_seq = 1;
         }
         HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
         HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
@@ -414,12 +432,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
             pa.spin_limit = spin_limit;
             pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
             if (ks.mbox_armed) {
-              double *md = reinterpret_cast<double *>(ks.mbox_dev);
-              const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
-              d.Hhost = md;
-              pa.mb_scales = md + hwords;
-              pa.mb_state = md + hwords + swords;
-              pa.mb_done = reinterpret_cast<unsigned long long *>(md + hwords + swords + 4);
+              const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+              d.Hhost = mv.H;
+              pa.mb_scales = mv.scales;
+              pa.mb_state = mv.state;
+              pa.mb_done = mv.done;
               pa.last_step = m + (closing ? 1 : 0);
             }
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
@@ -485,6 +502,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       ProfScope ps(c, EXPV_MI_K_SCALE);
       dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol);
       dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
+    } else if (mailbox_arm(ks, m)) {   // whole-call expv: H and the final state go to the host through the mailbox
+      const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+      dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)(dtype_size(ks.dtypeT) / 8) * ks.ldhd * m, st, mv.H,
+                        mv.state, mv.done, ks.pipe_seq);
+      mbox_generic = true;
     }
     ks.gram_rows = lanczos ? 1 : m;
   } else if (use_fused) {
@@ -590,12 +612,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   const T *Hh = reinterpret_cast<const T *>(ks.pin);   // Hessenberg columns as the device left them
   StepState &h = *reinterpret_cast<StepState *>(reinterpret_cast<char *>(ks.pin) + ks.pin_bytes - sizeof(StepState));
   bool from_mbox = false;
-  if (use_pipe && ks.pipe_live_used && ks.mbox_armed) {
+  if (((use_pipe && ks.pipe_live_used) || mbox_generic) && ks.mbox_armed) {
     // wait on the mailbox flag; the stream is queried now and then so a factorisation that ended without raising
     // it (expired wait) falls through to the copy path below
-    const double *mh = reinterpret_cast<const double *>(ks.mbox);
-    const size_t hwords = (size_t)ks.ldhd * (ks.maxiter + 1), swords = (size_t)ks.maxiter + 2;
-    const volatile unsigned long long *done = reinterpret_cast<const volatile unsigned long long *>(mh + hwords + swords + 4);
+    const MailboxView mvh = mailbox_view(ks, ks.mbox);
+    const double *mh = mvh.H;
+    const size_t hwords = mailbox_hwords(ks), swords = (size_t)ks.maxiter + 2;
+    const volatile unsigned long long *done = mvh.done;
     for (long it = 1;; ++it) {
       if (*done == (unsigned long long)ks.pipe_seq) { from_mbox = true; break; }
       __builtin_ia32_pause();
@@ -634,7 +657,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     const int ncol = ((h.breakdown == 1) ? h.m_done + 1 : (ks.skip_tail ? m : m + 1));
     ks.colscale_host.assign(ks.maxiter + 2, 1.0);
     if (from_mbox) {
-      const double *ms = reinterpret_cast<const double *>(ks.mbox) + (size_t)ks.ldhd * (ks.maxiter + 1);
+      const double *ms = mailbox_view(ks, ks.mbox).scales;
       for (int q = 0; q < ncol; ++q) ks.colscale_host[q] = ms[q];
     } else {
       HIPCHECK(hipMemcpyAsync(ks.colscale_host.data(), ks.colscale.p, sizeof(double) * (size_t)ncol, hipMemcpyDeviceToHost, s));

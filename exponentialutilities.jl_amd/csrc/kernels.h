@@ -55,6 +55,12 @@ struct UpdateArgs {
 
 int grid_for(int64_t n, int rows_per_block);
 
+// Result mailbox (host-mapped memory): one workgroup copies `nwords` 8-byte words of the device Hessenberg copy and the
+// final {beta_0^2, breakdown, m_done} there and then raises *done = seq.  Queued behind the last kernel of a
+// factorisation, it lets the host continue without a copy-engine transfer and a stream synchronisation.
+void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepState *st, double *mb_H, double *mb_state,
+                  unsigned long long *mb_done, uint32_t seq);
+
 // Balanced contiguous partition of n rows over at most max_blocks workgroups, in units of `unit`
 // rows: every workgroup streams the same number of bytes (no second, partially filled round).
 struct RowPlan { int nblocks; int64_t rows_per_block; };
