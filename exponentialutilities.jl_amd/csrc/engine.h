@@ -54,6 +54,8 @@ struct Ctx {
   bool pipe_overlap = true; // banded pipeline: consecutive steps on two streams
   ProfSlot prof[EXPV_MI_K_COUNT];
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
+  void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
+  void (*ws_kiops_free)(void *) = nullptr;
   hipStream_t stream2 = nullptr;          // second stream + fork/join events of the overlapped pipeline
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void ensure_aux() {

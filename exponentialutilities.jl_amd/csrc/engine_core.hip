@@ -282,18 +282,26 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
     static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
     single_red = !fused_v1;
-    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && !isaug && o.ortho != EXPV_MI_ORTHO_MGS &&
-                (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+    // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
+    //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
+    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
+                o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
     // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
     static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
     if constexpr (!ST<T>::is_complex)
-      use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+      use_pipe = use_fused && single_red && !isaug && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  m <= dev::PIPE_CH && !real_coeff;
     if (use_pipe) {
       // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
     } else if (use_fused && single_red) {
       // u_1 = b goes to V[:, 0] unnormalised; ||b|| comes out of the first fused half-step's reduction
       HIPCHECK(hipMemcpyAsync(V, src, sizeof(T) * (size_t)ks.n, hipMemcpyDeviceToDevice, s));
+      if (isaug) {   // u_1 = [bl; w_aug]  (arnoldi.jl:257-279), unnormalised like the rest of it
+        std::vector<T> tail(p);
+        for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
+        HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));   // `tail` is pageable and local
+      }
     } else {
       ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
       dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
@@ -481,6 +489,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       fa.u = V + (size_t)(j - 1) * ks.ldv;
       fa.ybuf = yb;
       fa.step = j;
+      if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       dev::DotsArgs<T> &d = fa.d;
       d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = yb; d.x = fa.u;
       d.c0 = i0 - 1; d.dir = 1; d.nd = nd;

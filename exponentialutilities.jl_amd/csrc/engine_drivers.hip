@@ -340,8 +340,21 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   const int mmin = o.mmin, mmax = o.mmax;
   const double tol = o.tol;
   int herm = o.ishermitian < 0 ? op.ishermitian : o.ishermitian;
-  expv_mi_ks_s ks;
-  ks_alloc(ks, ctx, dt, (herm ? EXPV_MI_F64 : dt), n, m, p);       // KrylovSubspace{T, U}(n, m, p)  (:74)
+  // KrylovSubspace{T, U}(n, m, p)  (:74).  The subspace and the flipped-input scratch are private to the call, and
+  // allocating ~n*(m+p)*sizeof(T) bytes costs more than a whole kiops step: keep them in the context between calls.
+  struct KiopsWs { expv_mi_ks_s ks; DevBuf uflip; };
+  KiopsWs *wsp = reinterpret_cast<KiopsWs *>(ctx->ws_kiops);
+  const int dtU = herm ? EXPV_MI_F64 : dt;
+  if (!wsp || wsp->ks.dtypeT != dt || wsp->ks.dtypeU != dtU || wsp->ks.n != n || wsp->ks.augmented != p || wsp->ks.maxiter < m) {
+    if (wsp) { delete wsp; ctx->ws_kiops = nullptr; }
+    wsp = new KiopsWs();
+    ctx->ws_kiops = wsp;
+    ctx->ws_kiops_free = [](void *q) { delete reinterpret_cast<KiopsWs *>(q); };
+    ks_alloc(wsp->ks, ctx, dt, dtU, n, std::max(m, std::min(o.mmax, 64)), p);
+  }
+  expv_mi_ks_s &ks = wsp->ks;
+  ks.m = m;
+  ks.wasbreakdown = false;
   int64_t step = 0, krystep = 0, ireject = 0, reject = 0, exps = 0;
   const double tau_last = tau_out[ntau - 1];
   const double sgn = (tau_last > 0) - (tau_last < 0);
@@ -361,7 +374,8 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
     mu = std::exp2(ex);
   }
   // u_flip = reverse(u[:, 2:end], dims = 2) * nu   (:105-106)
-  DevBuf uflip(sizeof(T) * n * p + 16);
+  DevBuf &uflip = wsp->uflip;
+  if (uflip.bytes < sizeof(T) * (size_t)n * p + 16) uflip.alloc(sizeof(T) * (size_t)n * p + 16);
   T *uf = uflip.as<T>();
   if (padded) {
     HIPCHECK(hipMemsetAsync(uf, 0, sizeof(T) * n * p, s));

@@ -236,14 +236,34 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
 #pragma unroll
       for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
     }
+    // augmented operator: the slices run over n_op + p rows; the last ones may lie beyond the operator's own
+    const int p_aug = fa.aug_p;
+    const int64_t nsl = p_aug ? (a.n + SH - 1) / SH : fa.A.nslices;
     const int64_t s0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * spw;
-    const int64_t s1 = (s0 + spw < fa.A.nslices) ? s0 + spw : fa.A.nslices;
+    const int64_t s1 = (s0 + spw < nsl) ? s0 + spw : nsl;
     for (int64_t slice = s0; slice < s1; ++slice) {
       const int64_t i = slice * SH + (int64_t)lane * N;
       Pack<T> yv;
       const Pack<T> xv = ld_pack(u, i, a.n, al);
       if (cb == 0) {
-        sell_rows<T>(fa.A, slice, lane, u, yv.v);             // y~ = A u_j
+        if (slice < fa.A.nslices) sell_rows<T>(fa.A, slice, lane, u, yv.v);             // y~ = A u_j
+        else {
+#pragma unroll
+          for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::zero();
+        }
+        if (p_aug) {   // [A B; 0 K]: + B u[n_op:] on the operator rows, the shift block below them
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const int64_t r = i + k;
+            if (r < fa.n_op) {
+              for (int q = 0; q < p_aug; ++q) ST<T>::fma_(yv.v[k], fa.B[r + (int64_t)q * fa.ldb], u[fa.n_op + q]);
+            } else if (r < fa.n_op + p_aug - 1) {
+              yv.v[k] = u[r + 1];
+            } else {
+              yv.v[k] = ST<T>::zero();
+            }
+          }
+        }
         st_pack(fa.ybuf, i, a.n, al, yv);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -293,6 +313,8 @@ static void plan_slices2(int64_t nslices, int max_blocks, int *nblocks, int *spw
 template <class T>
 void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
   constexpr int CH = DotChunk<T>::CH;
+  constexpr int SHL = 64 * Pack<T>::N;
+  const int64_t nslices = a.aug_p ? (a.d.n + SHL - 1) / SHL : a.A.nslices;   // augmented: slices over n_op + p rows
   // measured on C2 (profiles/r01_ab_variants.txt): the 2x-accumulator variant is slower (56 vs 48 us per launch),
   // so it is opt-in for experiments only
   static const bool wide_ok = std::getenv("EXPV_MI_WIDE") != nullptr;
@@ -302,16 +324,16 @@ void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
       // windows of 17..32 columns (fp64): one pass with twice the accumulators (2 workgroups/CU)
       // instead of a second sweep over y, v_j and a second workgroup reduction
       auto k = k_fused_a2<T, true, 2 * CH, 2>;
-      plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
       hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
     } else {
       auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
-      plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
       hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
     }
   } else {
     auto k = k_fused_a2<T, false, CH, DOTS_WAVES>;
-    plan_slices2(a.A.nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+    plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
     hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
   }
 }

@@ -105,7 +105,14 @@ struct FusedAArgs {
   T *ybuf;           // out: A * v_j
   DotsArgs<T> d;     // d.V/ldv/n, window, reduction buffers, epilogue targets; d.y = ybuf, d.x = V[:, jcol]
   int step;
+  // augmented operator [A B; 0 K] of kiops (arnoldi.jl:195-202), single-reduction step only: rows n_op .. n_op+aug_p-1
+  // are the shift block, rows < n_op get + B x[n_op:].  aug_p == 0: plain operator (d.n == n_op).
+  int aug_p;
+  int64_t n_op;
+  const T *B;
+  int64_t ldb;
 };
+constexpr int FUSED_AUG_MAX = 8;   // widest augmentation the fused step handles (kiops: p = number of extra columns)
 template <class T> void fused_a(hipStream_t s, const FusedAArgs<T> &a);
 
 // ---- single-reduction step (one grid reduction per Krylov step) ------------------------------

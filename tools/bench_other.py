@@ -55,7 +55,7 @@ if "c4" in which:
     ctx.sync()
     dt = time.perf_counter() - t0
     prof = ctx.prof_get(); ctx.prof_enable(False)
-    steps = prof.get("matvec", {"launches": 0})["launches"]
+    steps = prof.get("matvec", {"launches": 0})["launches"] + prof.get("fused_a", {"launches": 0})["launches"]   # modular + fused steps
     print(json.dumps({"config": "c4 kiops n=1e6 sparse complex-fp64 iop=2", "seconds": dt, "stats": st,
                       "krylov_steps": steps, "steps_per_s": steps / dt,
                       "alg_MB_per_step": 184, "frac_of_8TBps": 184e6 * steps / dt / 8e12,
