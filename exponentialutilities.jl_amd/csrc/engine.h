@@ -56,6 +56,8 @@ struct Ctx {
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
   void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
   void (*ws_kiops_free)(void *) = nullptr;
+  void *ws_batch = nullptr;   // cached device buffers of expv_batch (owned; see engine_batch.hip)
+  void (*ws_batch_free)(void *) = nullptr;
   hipStream_t stream2 = nullptr;          // second stream + fork/join events of the overlapped pipeline
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void ensure_aux() {

@@ -9,6 +9,8 @@
 // breakdown flag and reduction buffers; nothing is shared between problems but the pattern of A.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <type_traits>
@@ -67,6 +69,9 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
                             const expv_mi_arnoldi_opts &o, int32_t *m_used, int m, int herm, int iop) {
   hipStream_t s = ctx->stream;
   const double tol = o.tol;
+  const bool tm = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_begin = now();
   const int64_t ldv = (n + 127) / 128 * 128;
   const int64_t strideV = ldv * (m + 1);
   const int ldhd = m + 2;
@@ -81,22 +86,58 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   const int64_t ntiles = (n + 2 * dev::BLOCK - 1) / (2 * dev::BLOCK);
   const int64_t ngpart = (int64_t)64 * dev::MAX_GROUPS;
   if (ntiles > dev::MAX_GRID) fail(EXPV_MI_UNSUPPORTED, "expv_batch: problem too large for the batched pipeline");
-  DevBuf d_perm(sizeof(int32_t) * P.perm.size());
+  // the buffers of a chunk are tens of GB: allocating and freeing them per call costs far more than the kernels
+  // (hipMalloc + first touch: 0.3-0.7 s), so they stay in the context and only grow
+  struct BatchWs {
+    DevBuf perm, V, Ya, Yb, Dia, H, G, hca, hcb, sc, part, gpart, st, coef, beta, mcols;
+    int64_t n = -1;
+    int m = -1;
+  };
+  BatchWs *ws = reinterpret_cast<BatchWs *>(ctx->ws_batch);
+  if (!ws) {
+    ws = new BatchWs();
+    ctx->ws_batch = ws;
+    ctx->ws_batch_free = [](void *q) { delete reinterpret_cast<BatchWs *>(q); };
+  }
+  auto need = [&](DevBuf &b, size_t bytes, bool zero) {
+    if (b.bytes < bytes) {
+      b.alloc(bytes);
+      if (zero) HIPCHECK(hipMemsetAsync(b.p, 0, bytes, s));   // padding rows must be zero; they are never written
+    }
+  };
+  if (ws->n != n || ws->m != m) {   // another layout: what used to be data may now be padding -> zero the vectors again
+    ws->V.release();
+    ws->Ya.release();
+    ws->Yb.release();
+    ws->n = n;
+    ws->m = m;
+  }
+  need(ws->perm, sizeof(int32_t) * P.perm.size(), false);
+  need(ws->V, sizeof(double) * (size_t)strideV * PC, true);
+  need(ws->Ya, sizeof(double) * (size_t)ldv * PC, true);
+  need(ws->Yb, sizeof(double) * (size_t)ldv * PC, true);
+  need(ws->Dia, sizeof(double) * (size_t)dia_words * PC + 16, false);
+  need(ws->H, sizeof(double) * (size_t)strideH * PC, false);
+  need(ws->G, sizeof(double) * (size_t)ldg * ldg * PC, false);
+  need(ws->hca, sizeof(double) * (size_t)(m + 2) * PC, false);
+  need(ws->hcb, sizeof(double) * (size_t)(m + 2) * PC, false);
+  need(ws->sc, sizeof(double) * (size_t)(m + 2) * PC, false);
+  need(ws->part, sizeof(double) * (size_t)dev::MAX_GRID * 64 * (size_t)PC, false);
+  need(ws->gpart, sizeof(double) * (size_t)ngpart * PC, false);
+  need(ws->st, sizeof(StepState) * (size_t)PC, false);
+  need(ws->coef, sizeof(double) * (size_t)(m + 1) * PC, false);
+  need(ws->beta, sizeof(double) * PC, false);
+  need(ws->mcols, sizeof(int32_t) * PC, false);
+  DevBuf &d_perm = ws->perm, &dV = ws->V, &dYa = ws->Ya, &dYb = ws->Yb, &dDia = ws->Dia, &dH = ws->H, &dG = ws->G;
+  DevBuf &dhca = ws->hca, &dhcb = ws->hcb, &dsc = ws->sc, &dpart = ws->part, &dgpart = ws->gpart, &dst = ws->st;
+  DevBuf &dcoef = ws->coef, &dbeta = ws->beta, &dmcols = ws->mcols;
   HIPCHECK(hipMemcpyAsync(d_perm.p, P.perm.data(), sizeof(int32_t) * P.perm.size(), hipMemcpyHostToDevice, s));
-  DevBuf dV(sizeof(double) * (size_t)strideV * PC), dYa(sizeof(double) * (size_t)ldv * PC), dYb(sizeof(double) * (size_t)ldv * PC);
-  DevBuf dDia(sizeof(double) * (size_t)dia_words * PC + 16);
-  DevBuf dH(sizeof(double) * (size_t)strideH * PC), dG(sizeof(double) * (size_t)ldg * ldg * PC);
-  DevBuf dhca(sizeof(double) * (size_t)(m + 2) * PC), dhcb(sizeof(double) * (size_t)(m + 2) * PC), dsc(sizeof(double) * (size_t)(m + 2) * PC);
-  // partial buffers: the kernels index part[value * MAX_GRID + workgroup] (<= 64 values); one such block per problem
-  DevBuf dpart(sizeof(double) * (size_t)dev::MAX_GRID * 64 * (size_t)PC), dgpart(sizeof(double) * (size_t)ngpart * PC);
-  DevBuf dst(sizeof(StepState) * (size_t)PC), dcoef(sizeof(double) * (size_t)(m + 1) * PC), dbeta(sizeof(double) * PC), dmcols(sizeof(int32_t) * PC);
-  HIPCHECK(hipMemsetAsync(dV.p, 0, dV.bytes, s));
-  HIPCHECK(hipMemsetAsync(dYa.p, 0, dYa.bytes, s));
-  HIPCHECK(hipMemsetAsync(dYb.p, 0, dYb.bytes, s));
   std::vector<double> Hh((size_t)strideH * PC), coefh((size_t)(m + 1) * PC), betah(PC), sch((size_t)(m + 2) * PC);
   std::vector<StepState> sth(PC);
   std::vector<int32_t> mch(PC);
+  if (tm) { HIPCHECK(hipStreamSynchronize(s)); std::fprintf(stderr, "[batch timing] alloc+memset %.1f ms (PC=%d)\n", std::chrono::duration<double, std::milli>(now() - t_begin).count(), PC); }
   for (int p0 = 0; p0 < nprob; p0 += PC) {
+    auto t_chunk = now();
     const int pc = std::min(PC, nprob - p0);
     dev::permute_values<double>(s, dDia.as<double>(), dia_words, vals_dev + (int64_t)p0 * nnz, nnz, d_perm.as<int32_t>(), dia_words, pc);
     HIPCHECK(hipMemsetAsync(dst.p, 0, sizeof(StepState) * (size_t)pc, s));
@@ -135,6 +176,8 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     HIPCHECK(hipMemcpyAsync(sth.data(), dst.p, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(sch.data(), dsc.p, sizeof(double) * (size_t)(m + 2) * pc, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (tm) std::fprintf(stderr, "[batch timing] chunk factorisation %.1f ms\n", std::chrono::duration<double, std::milli>(now() - t_chunk).count());
+    t_chunk = now();
     auto solve_one = [&](int q) {
       const StepState &h = sth[q];
       const double beta = std::sqrt(h.beta0sq);
@@ -185,6 +228,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
                                  dmcols.as<int32_t>(), w_dev + (int64_t)p0 * ldw, ldw, pc);
     }
     HIPCHECK(hipStreamSynchronize(s));
+    if (tm) std::fprintf(stderr, "[batch timing] chunk host exp + combine %.1f ms\n", std::chrono::duration<double, std::milli>(now() - t_chunk).count());
   }
 }
 

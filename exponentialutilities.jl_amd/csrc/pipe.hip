@@ -124,6 +124,28 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   int &flag_s = sh.flag_s;
   double(&gs_s)[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2] = sh.gs_s;
   DotsArgs<double> a = pa.d;
+  // per-problem arrays: the kernel arguments stay untouched (a modified copy of the whole argument block, with its
+  // dynamically indexed dia_off[], would live in scratch); a batched launch moves these locals by blockIdx.y strides
+  const double *yprev = pa.yprev, *u0 = pa.u0, *hcoef_in = pa.hcoef_in, *dia_val = pa.dia_val;
+  double *ybuf = pa.ybuf, *hcoef_out = pa.hcoef_out, *scales = pa.scales;
+  if (!LIVE && gridDim.y > 1) {
+    const int64_t q = blockIdx.y;
+    const PipeBatch &b = pa.pb;
+    a.V += q * b.V;
+    yprev += q * b.y;
+    ybuf += q * b.y;
+    if (u0) u0 += q * b.u0;
+    a.part += q * b.part;
+    a.gpart += q * b.gpart;
+    a.Hdev += q * b.Hdev;
+    a.gram += q * b.gram;
+    hcoef_in += q * b.hcoef;
+    hcoef_out += q * b.hcoef;
+    scales += q * b.scales;
+    dia_val += q * b.dia;
+    a.st += q * b.st;
+  }
+  if (!LIVE && step_skipped(a.st, pa.step)) return 0;
   PIPE_STAMP(pa.step, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = pa.w, jcol = a.jcol, und = pa.und;
@@ -137,7 +159,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   const int knew = (jcol - 1 - pa.uc0) * pa.udir;        // window slot of the column the previous step wrote
   if (ready) {
     if (!first) inv = a.st->inv;
-    if (tid < 32) hs[tid] = (tid < und && !first) ? pa.hcoef_in[tid] : 0.0;
+    if (tid < 32) hs[tid] = (tid < und && !first) ? hcoef_in[tid] : 0.0;
     __syncthreads();
   }
   const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
@@ -161,7 +183,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     } else if constexpr (DIA) {   // diagonal d of these two rows: one aligned 16-byte load, no column indices
       if (act) {
         L = pa.ndiag;
-        avp = pa.dia_val + i;
+        avp = dia_val + i;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) av[sl] = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld);
@@ -199,7 +221,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
         if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
         PIPE_STAMP(pa.step, 4);
         inv = consume_f64(&a.st->inv);
-        if (tid < 32) hs[tid] = (tid < und) ? consume_f64(pa.hcoef_in + tid) : 0.0;
+        if (tid < 32) hs[tid] = (tid < und) ? consume_f64(hcoef_in + tid) : 0.0;
         __syncthreads();
         if (wload) {
 #pragma unroll
@@ -215,7 +237,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
       double val = 0.0;
       if (hr >= 0 && hr < a.n) {
-        if (k == 31) val = first ? pa.u0[hr] : pa.yprev[hr] * inv;
+        if (k == 31) val = first ? u0[hr] : yprev[hr] * inv;
         else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
 #pragma unroll
@@ -226,9 +248,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     u.v[0] = 0.0;
     u.v[1] = 0.0;
     if (first) {
-      u = ld_pack_user(pa.u0, i, a.n, is_al16(pa.u0));
+      u = ld_pack_user(u0, i, a.n, is_al16(u0));
     } else if (act) {
-      u = *reinterpret_cast<const Pack<double> *>(pa.yprev + i);
+      u = *reinterpret_cast<const Pack<double> *>(yprev + i);
       u.v[0] *= inv;
       u.v[1] *= inv;
 #pragma unroll
@@ -283,7 +305,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
       }
       if (i + 1 >= a.n) y.v[1] = 0.0;
     }
-    if (act && !pa.final) st_tile<LIVE>(pa.ybuf + i, y);
+    if (act && !pa.final) st_tile<LIVE>(ybuf + i, y);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -329,10 +351,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   auto pf = [&]() {   // Gram rows and column scales for the epilogue, in flight while this workgroup queues for the final ticket
     if (gram_pf) gram_prefetch<double, LIVE>(a, gs_s);
     if (a.mode == DOTS_LANCZOS) {
-      if (threadIdx.x == 1) sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(pa.scales + jcol - 1) : 1.0;
+      if (threadIdx.x == 1) sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(scales + jcol - 1) : 1.0;
     } else {
       for (int k = threadIdx.x; k < a.nd; k += BLOCK)
-        if (a.c0 + k != jcol) sh.cs_s[k] = ld_shared_f64<LIVE>(pa.scales + a.c0 + k);
+        if (a.c0 + k != jcol) sh.cs_s[k] = ld_shared_f64<LIVE>(scales + a.c0 + k);
     }
   };
   if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
@@ -352,7 +374,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     put(&a.st->hnorm, beta);
     put(&a.st->inv, invj);
     a.st->m_done = pa.step - 1;
-    put(&pa.scales[jcol], invj);                                  // s_j: column j-1 holds u_j = beta * v_j
+    put(&scales[jcol], invj);                                  // s_j: column j-1 holds u_j = beta * v_j
     if (first) put(&a.st->beta0sq, vals_s[2 * und + 1]);
     else put(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);   // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = first ? 2 : 1;
@@ -382,32 +404,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   }
   if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) sh.cs_s[0] = invj;    // cs_s[1]: pf()
   __syncthreads();
-  a.hcoef = pa.hcoef_out;
+  a.hcoef = hcoef_out;
   projection_epilogue<double, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
   return 1;
 }
 
 template <int CH, int WAVES, int PS, bool DIA>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(PipeArgs pa, int tiles_per_block) {
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
-  if (gridDim.y > 1) {   // batch of independent problems: everything per-problem moves by blockIdx.y strides
-    const int64_t q = blockIdx.y;
-    const PipeBatch &b = pa.pb;
-    pa.d.V += q * b.V;
-    pa.yprev += q * b.y;
-    pa.ybuf += q * b.y;
-    if (pa.u0) pa.u0 += q * b.u0;
-    pa.d.part += q * b.part;
-    pa.d.gpart += q * b.gpart;
-    pa.d.Hdev += q * b.Hdev;
-    pa.d.gram += q * b.gram;
-    pa.hcoef_in += q * b.hcoef;
-    pa.hcoef_out += q * b.hcoef;
-    pa.scales += q * b.scales;
-    pa.dia_val += q * b.dia;
-    pa.d.st += q * b.st;
-  }
-  if (step_skipped(pa.d.st, pa.step)) return;
   (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
 }
 
@@ -438,7 +442,7 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
 }
 
 template <int CH, int WAVES, int PS, bool DIA>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(PipeArgs pa, int tiles_per_block) {
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
