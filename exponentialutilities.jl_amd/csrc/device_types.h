@@ -71,6 +71,7 @@ template <> struct ST<cplx> {
 };
 
 // device-resident per-subspace step state (one per KrylovSubspace handle)
+constexpr int MAX_TICKET_GROUPS = 32, TICKET_STRIDE = 32;   // groups per grid reduction (kernels.h: MAX_GROUPS), words between counters
 struct StepState {
   double hnorm;          // beta_j of the last finished step (H[j+1,j])
   double sumsq;          // scratch: last reduced sum of squares
@@ -80,11 +81,11 @@ struct StepState {
   int32_t m_done;        // last step whose column of H is complete
   uint32_t ticket;       // arrival counter of the group reducers (stage 2 of the grid reduction)
   uint32_t pad;
-  uint32_t gticket[64];  // arrival counters of the workgroup groups (stage 1)
-  uint32_t pad2[20];     // -> 384: the polled flag below sits alone in its 128-byte line
-  uint32_t step_done;    // persistent pipeline: last step whose epilogue results are published (grid-wide flag)
-  uint32_t pad3[31];
+  uint32_t pad1[20];     // -> 128
+  // arrival counters of the workgroup groups (stage 1), one per 128-byte line: up to 64 workgroups of a group hit
+  // their counter within a few microseconds, and same-line atomics of different groups would queue behind each other
+  uint32_t gticket[MAX_TICKET_GROUPS * TICKET_STRIDE];
 };
-static_assert(sizeof(StepState) == 512, "StepState layout");
+static_assert(sizeof(StepState) == 128 + 4 * MAX_TICKET_GROUPS * TICKET_STRIDE, "StepState layout");
 
 }  // namespace expv_mi

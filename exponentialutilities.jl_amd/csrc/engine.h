@@ -176,7 +176,8 @@ struct Ks {
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
   DevBuf flags;                      // ... the step flags of its overlapped form (arrival counters: behind `state`)
   uint32_t pipe_seq = 0;
-  bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait
+  bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait ...
+  int pipe_serial_calls = 0;                           // ... and tried again after this many serial factorisations
   void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv
   size_t mbox_bytes = 0;
   bool mbox_armed = false;

@@ -374,6 +374,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
       // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
       static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
+      if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
       const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
       hipStream_t s2 = nullptr;
       if (live) {

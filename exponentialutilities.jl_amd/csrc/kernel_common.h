@@ -202,7 +202,7 @@ __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double 
   const int g = blockIdx.x / GROUP_SIZE;
   const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
   const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
-  if (!take_ticket(&st->gticket[g], (uint32_t)gsize, flag_s)) return false;
+  if (!take_ticket(&st->gticket[g * TICKET_STRIDE], (uint32_t)gsize, flag_s)) return false;
   reduce_stage(part + (size_t)g * GROUP_SIZE, MAX_GRID, gsize, nvals, gpart + g, MAX_GROUPS, false);
   pf();
   if (!take_ticket(&st->ticket, (uint32_t)ng, flag_s)) return false;
