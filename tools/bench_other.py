@@ -15,7 +15,7 @@ from tests._util import c2_operator
 
 eu = expv_mi_loader.load()
 ctx = eu.default_context()
-which = sys.argv[1:] or ["c3", "c4"]
+which = sys.argv[1:] or ["c3", "c4", "c2sym", "c2stencil"]
 
 if "c3" in which:
     for n in (16384, 65536):
@@ -60,3 +60,39 @@ if "c4" in which:
                       "krylov_steps": steps, "steps_per_s": steps / dt,
                       "alg_MB_per_step": 184, "frac_of_8TBps": 184e6 * steps / dt / 8e12,
                       "kernels": {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in prof.items()}}))
+
+
+def _c2_variant(name, A, herm, contract_bytes_per_step):
+    """SURVEY.md §8d secondary inputs on the C2 size: whole-call expv, m = 30."""
+    import scipy.sparse as sp
+    n, m = A.shape[0], 30
+    actx = eu.Context(async_outputs=True)
+    op = eu.MIOperator(A, actx)
+    b = torch.as_tensor(np.random.default_rng(3).standard_normal(n), device="cuda")
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        eu.expv(1.0, op, b, m=m, ishermitian=herm, out=w)
+    actx.sync()
+    reps = 30
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eu.expv(1.0, op, b, m=m, ishermitian=herm, out=w)
+    actx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    mm = eu.expv.last_stats["m"]
+    print(json.dumps({"config": name, "n": n, "m": mm, "ms_per_expv": 1e3 * dt, "matvecs_per_s": mm / dt,
+                      "contract_MB_per_step": contract_bytes_per_step / 1e6,
+                      "frac_of_8TBps": contract_bytes_per_step * mm / dt / 8e12}))
+
+
+if "c2sym" in which:      # symmetric diagonals (0.5, 1, -3, 1, 0.5): Lanczos path, window of 2
+    import scipy.sparse as sp
+    n = 1_000_000
+    A = sp.diags([0.5, 1.0, -3.0, 1.0, 0.5], [-2, -1, 0, 1, 2], shape=(n, n), format="csc")
+    _c2_variant("c2 symmetric (Lanczos), n=1e6 5-diagonal", A, True, A.nnz * 12 + 4 * (n + 1) + 8 * n * 4)
+
+if "c2stencil" in which:  # 2-D 5-point stencil offsets (-1000, -1, 0, 1, 1000): non-local x access, two-kernel path
+    import scipy.sparse as sp
+    n = 1_000_000
+    A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-1000, -1, 0, 1, 1000], shape=(n, n), format="csc")
+    _c2_variant("c2 stencil offsets (-1000,-1,0,1,1000), full Arnoldi", A, False, A.nnz * 12 + 4 * (n + 1) + 8 * n * (15.5 + 3))
