@@ -340,7 +340,7 @@ __device__ __forceinline__ void gram_prefetch(const DotsArgs<T> &a, T *gs_s) {
     else gs_s[e] = *p;
   }
 }
-// SHARED (fp64 only): the step results are read by OTHER workgroups of the same launch (persistent pipeline), and
+// SHARED (fp64 only): the step results are read by the NEXT step's kernel, which is already running (overlapped pipeline), and
 // the Gram rows / H were written by other workgroups earlier in it: every global access goes through to memory
 // (sc1) instead of relying on a kernel boundary.  slot_scale_s (LDS, optional): factor folded into hcoef[k].
 template <class T, bool SHARED = false>
