@@ -1,5 +1,6 @@
 // capi.hip -- the extern "C" surface declared in include/expv_mi.h.  Nothing here throws.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <mutex>
 #include <type_traits>
@@ -194,6 +195,53 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
   op.dia_ld = ld;
   for (int d = 0; d < nd; ++d) op.dia_off[d] = offs[d];
 }
+// General DIA form (any offsets): structured-grid stencils whose bandwidth is too wide for the banded pipeline.  Same
+// rules otherwise: rows sorted and free of duplicates, at most GDIA_MAX distinct offsets, zero fill below 30 %.
+template <class V>
+inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
+                       const std::vector<V> &va) {
+  op.gndiag = 0;
+  if (n == 0 || op.ndiag > 0) return;
+  std::vector<int64_t> offs;   // distinct offsets, found by scanning (few)
+  for (int64_t r = 0; r < n; ++r) {
+    int32_t prev = -1;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      if (ci[k] <= prev) return;
+      prev = ci[k];
+      const int64_t o = (int64_t)ci[k] - r;
+      bool seen = false;
+      for (int64_t x : offs)
+        if (x == o) { seen = true; break; }
+      if (!seen) {
+        if ((int)offs.size() >= dev::GDIA_MAX) return;
+        offs.push_back(o);
+      }
+    }
+  }
+  const int nd = (int)offs.size();
+  if (nd == 0 || (double)nd * (double)n > 1.3 * (double)ci.size() + 1024.0) return;
+  std::sort(offs.begin(), offs.end());
+  const int64_t ld = (n + 511) / 512 * 512;
+  std::vector<V> dv((size_t)nd * (size_t)ld, V(0));
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const int64_t o = (int64_t)ci[k] - r;
+      const int d = (int)(std::lower_bound(offs.begin(), offs.end(), o) - offs.begin());
+      dv[(size_t)d * (size_t)ld + (size_t)r] = va[k];
+    }
+  std::vector<int32_t> o32(nd);
+  for (int d = 0; d < nd; ++d) {
+    if (offs[d] > INT32_MAX || offs[d] < INT32_MIN) return;
+    o32[d] = (int32_t)offs[d];
+  }
+  op.gdia_val.alloc(sizeof(V) * dv.size());
+  op.gdia_off.alloc(sizeof(int32_t) * nd);
+  HIPCHECK(hipMemcpyAsync(op.gdia_val.p, dv.data(), sizeof(V) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.gdia_off.p, o32.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipStreamSynchronize(op.ctx->stream));
+  op.gndiag = nd;
+  op.gdia_ld = ld;
+}
 template <class V>
 inline void maybe_build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
                             const std::vector<V> &va) {
@@ -213,6 +261,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   upload_csr<V>(op, rp, ci, va);
   build_sell<V>(op, n, rp, ci, va);
   if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va);
+  if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va);
 }
 
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",

@@ -137,6 +137,11 @@ struct Op {
   int ndiag = 0;
   int64_t dia_ld = 0;
   int dia_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // general DIA form (fp64, any offsets, <= GDIA_MAX diagonals, <= 30 % zero fill): structured-grid stencils; read by
+  // the two-kernel step instead of the SELL slots (fused.hip) when the operator is too wide for the pipeline
+  DevBuf gdia_val, gdia_off;
+  int gndiag = 0;
+  int64_t gdia_ld = 0;
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;

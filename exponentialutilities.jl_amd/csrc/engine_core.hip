@@ -491,6 +491,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       fa.ybuf = yb;
       fa.step = j;
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
+      static const bool no_gdia = std::getenv("EXPV_MI_NO_DIA") != nullptr;
+      if (op.gndiag > 0 && !no_gdia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
+        fa.dia_val = op.gdia_val.as<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();
+        fa.n_dia = ks.n;
+      }
       dev::DotsArgs<T> &d = fa.d;
       d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = yb; d.x = fa.u;
       d.c0 = i0 - 1; d.dir = 1; d.nd = nd;

@@ -28,6 +28,41 @@ __device__ __forceinline__ void load_cols<double>(const int32_t *p, int32_t *c) 
 template <>
 __device__ __forceinline__ void load_cols<cplx>(const int32_t *p, int32_t *c) { c[0] = *p; }
 
+// y-rows of one slice for this lane from the DIA form: acc[k] = sum_d val[d][r] * x[r + off[d]]  (ascending offsets =
+// ascending columns: the order of the CSR/SELL row; absent entries are explicit zeros)
+template <class T>
+__device__ __forceinline__ void dia_rows(const T *__restrict__ dval, int64_t ld, int ndiag, const int32_t *__restrict__ doff,
+                                         int64_t i, int64_t n, const T *__restrict__ x, T *acc) {
+  constexpr int N = Pack<T>::N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = ST<T>::zero();
+  int d = 0;
+  for (; d + 4 <= ndiag; d += 4) {   // 4 diagonals in flight
+    Pack<T> v[4];
+    T xv[4][N];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = *reinterpret_cast<const Pack<T> *>(dval + (int64_t)(d + q) * ld + i);
+      const int64_t c0 = i + doff[d + q];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xv[q][k] = (c0 + k >= 0 && c0 + k < n) ? x[c0 + k] : ST<T>::zero();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::fma_(acc[k], v[q].v[k], xv[q][k]);
+  }
+  for (; d < ndiag; ++d) {
+    const Pack<T> v = *reinterpret_cast<const Pack<T> *>(dval + (int64_t)d * ld + i);
+    const int64_t c0 = i + doff[d];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const T xk = (c0 + k >= 0 && c0 + k < n) ? x[c0 + k] : ST<T>::zero();
+      ST<T>::fma_(acc[k], v.v[k], xk);
+    }
+  }
+}
+
 // y-rows of one slice for this lane: acc[k] = sum_slots val * x[col]
 template <class T>
 __device__ __forceinline__ void sell_rows(const SellView<T> &A, int64_t slice, int lane, const T *__restrict__ x,
@@ -246,7 +281,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
       Pack<T> yv;
       const Pack<T> xv = ld_pack(u, i, a.n, al);
       if (cb == 0) {
-        if (slice < fa.A.nslices) sell_rows<T>(fa.A, slice, lane, u, yv.v);             // y~ = A u_j
+        if (fa.ndiag > 0 && i < fa.n_dia) dia_rows<T>(fa.dia_val, fa.dia_ld, fa.ndiag, fa.dia_off, i, fa.n_dia, u, yv.v);   // y~ = A u_j
+        else if (fa.ndiag == 0 && slice < fa.A.nslices) sell_rows<T>(fa.A, slice, lane, u, yv.v);
         else {
 #pragma unroll
           for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::zero();

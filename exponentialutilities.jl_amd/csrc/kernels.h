@@ -111,8 +111,15 @@ struct FusedAArgs {
   int64_t n_op;
   const T *B;
   int64_t ldb;
+  // general DIA form of A (ndiag > 0): value d of row r at dia_val[d*dia_ld + r], column r + dia_off[d]
+  const T *dia_val;
+  int64_t dia_ld;
+  int ndiag;
+  const int32_t *dia_off;   // device, ascending
+  int64_t n_dia;            // operator rows (the DIA arrays cover rows < n_dia, padded to 512)
 };
-constexpr int FUSED_AUG_MAX = 8;   // widest augmentation the fused step handles (kiops: p = number of extra columns)
+constexpr int FUSED_AUG_MAX = 8;
+constexpr int GDIA_MAX = 32;       // most diagonals of the general DIA form   // widest augmentation the fused step handles (kiops: p = number of extra columns)
 template <class T> void fused_a(hipStream_t s, const FusedAArgs<T> &a);
 
 // ---- single-reduction step (one grid reduction per Krylov step) ------------------------------
