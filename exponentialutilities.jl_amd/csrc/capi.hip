@@ -241,6 +241,7 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
   op.gndiag = nd;
   op.gdia_ld = ld;
+  op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)offs.front()), std::llabs((long long)offs.back()));
 }
 template <class V>
 inline void maybe_build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,

@@ -141,7 +141,7 @@ struct Op {
   // the two-kernel step instead of the SELL slots (fused.hip) when the operator is too wide for the pipeline
   DevBuf gdia_val, gdia_off;
   int gndiag = 0;
-  int64_t gdia_ld = 0;
+  int64_t gdia_ld = 0, gdia_maxoff = 0;
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;
@@ -180,6 +180,7 @@ struct Ks {
   }
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
   DevBuf flags;                      // ... the step flags of its overlapped form (arrival counters: behind `state`)
+  DevBuf tflags;                     // ... the per-tile flags of its wave form
   uint32_t pipe_seq = 0;
   bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait ...
   int pipe_serial_calls = 0;                           // ... and tried again after this many serial factorisations

@@ -258,7 +258,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   StepState *st = ks.state.as<StepState>();
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
-  bool use_fused = false, single_red = false, use_pipe = false, mbox_generic = false;
+  bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -288,9 +288,20 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
                 o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
     // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
     static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
-    if constexpr (!ST<T>::is_complex)
+    if constexpr (!ST<T>::is_complex) {
       use_pipe = use_fused && single_red && !isaug && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  m <= dev::PIPE_CH && !real_coeff;
+      // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
+      // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
+      static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
+      static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
+      const int64_t ntiles_w = (ks.n + 511) / 512;
+      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !no_gdia_w && op.gndiag > 0 &&
+          m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (op.gdia_maxoff / 512 + 2) * 4 <= 400)) {
+        use_pipe = true;
+        use_wave = true;
+      }
+    }
     if (use_pipe) {
       // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
     } else if (use_fused && single_red) {
@@ -375,7 +386,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
       static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
       if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
-      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
+      const bool live = !use_wave && !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
       hipStream_t s2 = nullptr;
       if (live) {
         c->ensure_aux();
@@ -395,6 +406,19 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
         HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
       }
+      if (use_wave) {
+        const size_t tb = sizeof(uint32_t) * (size_t)((ks.n + 511) / 512 + 1);
+        if (ks.tflags.bytes < tb) {
+          ks.tflags.alloc(tb);
+          HIPCHECK(hipMemsetAsync(ks.tflags.p, 0, tb, s));
+        }
+        ks.mbox_armed = false;
+        if (ks.skip_tail) (void)mailbox_arm(ks, m);
+        if (!ks.mbox_armed) {
+          ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+          if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+        }
+      }
       {
         // overlapped kernels have no separate durations: one scope over the sequence, counted as m launches
         ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? m : 0);
@@ -409,7 +433,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           dev::PipeArgs pa{};
           pa.final = (j == m + 1) ? 1 : 0;
           pa.A = A;
-          if (op.ndiag > 0 && !no_dia) {
+          if (use_wave) {
+            pa.dia_val = op.gdia_val.as<double>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
+            pa.gdia_off = op.gdia_off.as<int32_t>();
+            pa.tile_flags = ks.tflags.as<uint32_t>();
+            pa.tile_stamp = (ks.pipe_seq << 8) | (uint32_t)j;
+            pa.spin_limit = spin_limit;
+          } else if (op.ndiag > 0 && !no_dia) {
             pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
             for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
           }
@@ -450,6 +480,9 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
             }
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
             prev_grid = dev::pipe_step_live(sj, pa);
+          } else if (use_wave) {
+            ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+            if (!dev::pipe_step_wave(s, pa, op.gdia_maxoff)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
           } else {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);
             dev::pipe_step(s, pa);
@@ -461,6 +494,12 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         }
       }
       ks.pipe_live_used = live;
+      if (use_wave && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
+        const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+        dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)ks.ldhd * m, st, mv.H, mv.state, mv.done, ks.pipe_seq,
+                          ks.colscale.as<double>(), m, mv.scales);
+        mbox_generic = true;
+      }
       ht_mark(2);
       if (!ks.skip_tail && !ks.pipe_closed) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
         dev::UpdateArgs<double> u{};

@@ -59,7 +59,8 @@ int grid_for(int64_t n, int rows_per_block);
 // final {beta_0^2, breakdown, m_done} there and then raises *done = seq.  Queued behind the last kernel of a
 // factorisation, it lets the host continue without a copy-engine transfer and a stream synchronisation.
 void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepState *st, double *mb_H, double *mb_state,
-                  unsigned long long *mb_done, uint32_t seq);
+                  unsigned long long *mb_done, uint32_t seq, const double *scales = nullptr, int nscales = 0,
+                  double *mb_scales = nullptr);
 
 // Balanced contiguous partition of n rows over at most max_blocks workgroups, in units of `unit`
 // rows: every workgroup streams the same number of bytes (no second, partially filled round).
@@ -174,6 +175,11 @@ struct PipeArgs {
   int step;
   double tol;
   PipeBatch pb;                // step-wise kernel only (the overlapped form is for a single problem)
+  // wave form (general DIA operator, any offsets): no halo recompute; a tile publishes "u_j stored" in tile_flags and
+  // waits for the tiles its diagonals reach into before it applies the operator (pipe.hip)
+  const int32_t *gdia_off;     // device: ndiag ascending offsets
+  uint32_t *tile_flags;        // device: one word per 512-row tile, = tile_stamp when u_j of the tile is in memory
+  uint32_t tile_stamp;
   uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
   uint32_t seq;                // ... and the sequence number of this factorisation that stamps them
   uint32_t *arrive;            // ... and this step's arrival counters (residency gate)
@@ -187,6 +193,8 @@ struct PipeArgs {
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch = 1);
+// wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
+bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgs &pa);
 void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);

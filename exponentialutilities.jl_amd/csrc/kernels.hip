@@ -59,8 +59,10 @@ RowPlan plan_rows(int64_t n, int unit, int max_blocks) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_mailbox_fill(const double *Hdev, int64_t nwords, const StepState *st, double *mb_H,
-                                                        double *mb_state, unsigned long long *mb_done, uint32_t seq) {
+                                                        double *mb_state, unsigned long long *mb_done, uint32_t seq,
+                                                        const double *scales, int nscales, double *mb_scales) {
   for (int64_t e = threadIdx.x; e < nwords; e += BLOCK) publish_host_f64(&mb_H[e], Hdev[e]);
+  for (int k = threadIdx.x; k < nscales; k += BLOCK) publish_host_f64(&mb_scales[k], scales[k]);
   if (threadIdx.x == 0) {
     publish_host_f64(&mb_state[0], st->beta0sq);
     publish_host_f64(&mb_state[1], (double)st->breakdown);
@@ -71,8 +73,9 @@ __global__ __launch_bounds__(BLOCK) void k_mailbox_fill(const double *Hdev, int6
   if (threadIdx.x == 0) __hip_atomic_store(mb_done, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepState *st, double *mb_H, double *mb_state,
-                  unsigned long long *mb_done, uint32_t seq) {
-  hipLaunchKernelGGL(k_mailbox_fill, dim3(1), dim3(BLOCK), 0, s, Hdev, nwords, st, mb_H, mb_state, mb_done, seq);
+                  unsigned long long *mb_done, uint32_t seq, const double *scales, int nscales, double *mb_scales) {
+  hipLaunchKernelGGL(k_mailbox_fill, dim3(1), dim3(BLOCK), 0, s, Hdev, nwords, st, mb_H, mb_state, mb_done, seq, scales, nscales,
+                     mb_scales);
 }
 
 int grid_for(int64_t n, int rows_per_block) {

@@ -109,7 +109,7 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
 }
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
-template <int CH, int PS, bool LIVE, bool DIA>
+template <int CH, int PS, bool LIVE, bool DIA, bool WAVE = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block, PipeShared &sh) {
   constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
   constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
@@ -169,7 +169,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   const int64_t ntiles = (a.n + TR - 1) / TR;
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
-  for (int64_t tile = t0; tile < t1; ++tile) {
+  for (int tl = 0; tl < tiles_per_block; ++tl) {
+    // WAVE: tiles are dealt round-robin, so the tiles a tile waits for are in flight in neighbouring workgroups
+    const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : t0 + tl;
+    if (tile >= (WAVE ? ntiles : t1)) break;
     const int64_t r0 = tile * TR, i = r0 + 2 * (int64_t)tid;
     const bool act = i < nb;   // whole waves: nb is a multiple of the 128 rows a wave owns
     // ---- operator slots of this lane's two rows: issued now, consumed after the barrier ------------
@@ -231,6 +234,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
         ready = true;
       }
     }
+    if constexpr (!WAVE) {
     // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
     for (int e = tid; e < 2 * w * 32; e += BLOCK) {
       const int hrow = e >> 5, k = e & 31;
@@ -243,6 +247,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
 #pragma unroll
       for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
       if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
+    }
     }
     Pack<double> u;
     u.v[0] = 0.0;
@@ -261,15 +266,66 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
           u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
         }
     }
-    us[w + 2 * tid] = u.v[0];
-    us[w + 2 * tid + 1] = u.v[1];
-    if (act) st_tile<LIVE>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
-    __syncthreads();
+    if constexpr (WAVE) {
+      // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
+      // u_j of the tiles their diagonals reach into, so wait for those flags (bounded)
+      if (act) st_tile<true>(Vw + (int64_t)jcol * a.ldv + i, u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(pa.tile_flags + tile, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!pa.final) {
+        if (tid < 64) {
+          bool ok = true;
+          int64_t tlo = 0, thi = -1;
+          if (tid < pa.ndiag) {
+            const int64_t c0 = r0 + pa.gdia_off[tid], c1 = c0 + TR - 1;
+            tlo = (c0 < 0 ? 0 : c0) / TR;
+            thi = (c1 >= a.n ? a.n - 1 : c1) / TR;
+            if (c1 < 0 || c0 >= a.n) thi = tlo - 1;     // the whole diagonal piece lies outside the matrix
+          }
+          int res = 0;
+          for (int it = 0;; ++it) {
+            ok = true;
+            for (int64_t t = tlo; t <= thi; ++t)
+              ok = ok && (__hip_atomic_load(pa.tile_flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pa.tile_stamp);
+            if (__all(ok)) break;
+            if (it > pa.spin_limit) { res = 99; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (tid == 0) {
+            flag_s = res;
+            if (res) __hip_atomic_store(&a.st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __syncthreads();
+        if (flag_s != 0) return 3;
+      }
+    } else {
+      us[w + 2 * tid] = u.v[0];
+      us[w + 2 * tid + 1] = u.v[1];
+      if (act) st_tile<LIVE>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
+      __syncthreads();
+    }
     // ---- phase 2: y~ = A u_j for this lane's two rows (SELL-128: one slice per wave), u from LDS ----
     Pack<double> y;
     y.v[0] = 0.0;
     y.v[1] = 0.0;
     if (pa.final) {
+    } else if constexpr (WAVE) {
+      if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
+        const double *ucol = a.V + (int64_t)jcol * a.ldv;
+        auto term = [&](const Pack<double> &v2, int sl) {
+          const int64_t c0 = i + pa.gdia_off[sl];
+          const double x0 = (c0 >= 0 && c0 < a.n) ? ucol[c0] : 0.0;
+          const double x1 = (c0 + 1 >= 0 && c0 + 1 < a.n) ? ucol[c0 + 1] : 0.0;
+          y.v[0] = fma(v2.v[0], x0, y.v[0]);
+          y.v[1] = fma(v2.v[1], x1, y.v[1]);
+        };
+#pragma unroll
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) term(av[sl], sl);
+        for (int sl = PS; sl < L; ++sl) term(*reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld), sl);
+      }
     } else if constexpr (DIA) {
       if (act) {
         const int base = w + 2 * tid;             // LDS index of this lane's first row
@@ -415,6 +471,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgs pa, int ti
   (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
 }
 
+// ---- wave form: single-pass step for operators made of a few diagonals with ARBITRARY offsets (structured grids) ----
+// Recomputing a halo is only cheap for narrow bands.  Here every tile stores its piece of u_j, raises a per-tile flag and
+// waits for the tiles its diagonals reach into; tiles are dealt round-robin to the resident workgroups so those
+// neighbours are being worked on at the same time (pipe_step_wave checks that the reach is small against the grid, which
+// makes the wait graph acyclic: the first half of a tile never waits).  V is read once per step, as in the banded form.
+template <int CH, int WAVES, int PS>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_wave(const PipeArgs pa, int tiles_per_block) {
+  __shared__ PipeShared sh;
+  (void)pipe_pass<CH, PS, false, true, true>(pa, tiles_per_block, sh);
+}
+
 // ---- overlapped form: the kernel of step j+1 runs while step j finishes ------------------------------
 // Consecutive steps go to two streams.  The workgroups of step j+1 become resident as those of step j leave,
 // put the loads that do not depend on step j in flight (operator diagonals, the older basis columns of their
@@ -508,6 +575,27 @@ void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch) {
     case 1: pipe_launch<16, 3, 6, false>(s, pa, nbatch); break;
     case 2: pipe_launch<24, 3, 0, false>(s, pa, nbatch); break;
     default: pipe_launch<32, 2, 5, false>(s, pa, nbatch); break;
+  }
+}
+
+template <int CH, int WAVES, int PS>
+static bool pipe_wave_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
+  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
+  const int maxb = resident_blocks((const void *)k_pipe_wave<CH, WAVES, PS>);
+  int64_t tpb = (ntiles + maxb - 1) / maxb;
+  if (tpb < 1) tpb = 1;
+  const int nb = (int)((ntiles + tpb - 1) / tpb);
+  const int64_t reach = max_abs_off / (2 * BLOCK) + 2;       // tiles a tile may wait for, on each side
+  if (tpb > 1 && reach * 4 > nb) return false;               // too far for the round-robin deal: not acyclic for sure
+  hipLaunchKernelGGL((k_pipe_wave<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  return true;
+}
+bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_wave_launch<8, 4, 6>(s, pa, max_abs_off);
+    case 1: return pipe_wave_launch<16, 3, 6>(s, pa, max_abs_off);
+    case 2: return pipe_wave_launch<24, 3, 0>(s, pa, max_abs_off);
+    default: return pipe_wave_launch<32, 2, 5>(s, pa, max_abs_off);
   }
 }
 

@@ -615,3 +615,42 @@ def test_overlapped_and_serial_pipeline_are_bitwise_identical(eu):
         assert np.array_equal(H1, H2), (n, m, iop, herm)
         assert np.array_equal(V1[:, : m1 + 1], V2[:, : m2 + 1]), (n, m, iop, herm)
         assert np.array_equal(w1, w2), (n, m, iop, herm)
+
+
+@pytest.mark.parametrize("case", ["grid2d_small", "grid2d_multi_round", "odd_offsets", "symmetric_grid", "many_diagonals"])
+def test_wide_diagonal_operators_wave_form(eu, case):
+    """Operators made of a few diagonals with arbitrary offsets (structured grids) take the wave form of the single-pass
+    step: tiles publish their piece of u_j and wait for the tiles their diagonals reach into.  Parity with the oracle
+    (small sizes) and with the strict-MGS modular path (every size)."""
+    rng = np.random.default_rng(31)
+    herm = False
+    if case == "grid2d_small":
+        n, m, offs = 40_000, 20, [-200, -1, 0, 1, 200]
+    elif case == "grid2d_multi_round":          # more tiles than resident workgroups: several rounds of tiles per workgroup
+        n, m, offs = 700_000, 30, [-700, -1, 0, 1, 700]
+    elif case == "odd_offsets":
+        n, m, offs = 123_457, 17, [-3001, -7, 0, 5, 1999]
+    elif case == "symmetric_grid":
+        n, m, offs, herm = 90_000, 25, [-300, -1, 0, 1, 300], True
+    else:
+        n, m, offs = 64_000, 12, [-1600, -41, -40, -39, -1, 0, 1, 39, 40, 41, 1600]
+    diags = [rng.standard_normal(n - abs(o)) * 0.4 - (2.0 if o == 0 else 0.0) for o in offs]   # variable coefficients
+    A = sp.diags(diags, offs, shape=(n, n), format="csr")
+    if herm:
+        A = ((A + A.T) * 0.5).tocsr()
+    b = rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=herm)                      # wave form
+    Km = eu.arnoldi(A, b, m=m, ishermitian=herm, ortho="mgs")         # literal MGS, modular path
+    assert Ks.m == Km.m and Ks.wasbreakdown == Km.wasbreakdown
+    Vm = Km.getV()[:, : m + 1]
+    loss = float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1))))           # rounding differences scale with this
+    tol = max(1e-11, 10 * loss)
+    assert herr(Ks.H[: m + 1, :m], Km.H[: m + 1, :m]) <= tol
+    w = eu.expv(0.4, A, b, m=m, ishermitian=herm)
+    wm = eu.expv_(np.empty(n), 0.4, Km)
+    assert relerr(w, wm) < tol
+    assert np.max(np.abs(Ks.getV()[:, : m + 1] - Vm)) <= 100 * tol
+    if n <= 100_000:
+        Ko = ko.arnoldi(A, b, m=m, ishermitian=herm)
+        assert herr(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m]) <= tol
+        assert relerr(w, ko.expv_(np.empty(n), 0.4, Ko)) < tol

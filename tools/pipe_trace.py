@@ -8,7 +8,8 @@ import expv_mi_loader
 eu = expv_mi_loader.load()
 from exponentialutilities_jl_amd import _lib as L
 n, m = 1_000_000, 30
-A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-2, -1, 0, 1, 2], shape=(n, n), format="csc")
+offs = [-1000, -1, 0, 1, 1000] if (len(sys.argv) > 2 and sys.argv[2] == "stencil") else [-2, -1, 0, 1, 2]
+A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], offs, shape=(n, n), format="csc")
 op = eu.MIOperator(A)
 b = torch.randn(n, dtype=torch.float64, device="cuda")
 for _ in range(12):
