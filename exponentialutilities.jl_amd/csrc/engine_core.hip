@@ -386,7 +386,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
       static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
       if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
-      const bool live = !use_wave && !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
+      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
       hipStream_t s2 = nullptr;
       if (live) {
         c->ensure_aux();
@@ -412,11 +412,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           ks.tflags.alloc(tb);
           HIPCHECK(hipMemsetAsync(ks.tflags.p, 0, tb, s));
         }
-        ks.mbox_armed = false;
-        if (ks.skip_tail) (void)mailbox_arm(ks, m);
-        if (!ks.mbox_armed) {
-          ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
-          if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+        if (!live) {   // (the overlapped form arms the mailbox and takes its sequence number above)
+          ks.mbox_armed = false;
+          if (ks.skip_tail) (void)mailbox_arm(ks, m);
+          if (!ks.mbox_armed) {
+            ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+            if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+          }
         }
       }
       {
@@ -479,7 +481,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
               pa.last_step = m + (closing ? 1 : 0);
             }
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-            prev_grid = dev::pipe_step_live(sj, pa);
+            prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, op.gdia_maxoff) : dev::pipe_step_live(sj, pa);
+            if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
           } else if (use_wave) {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);
             if (!dev::pipe_step_wave(s, pa, op.gdia_maxoff)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
@@ -494,7 +497,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         }
       }
       ks.pipe_live_used = live;
-      if (use_wave && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
+      if (use_wave && !live && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
         const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
         dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)ks.ldhd * m, st, mv.H, mv.state, mv.done, ks.pipe_seq,
                           ks.colscale.as<double>(), m, mv.scales);

@@ -195,6 +195,7 @@ struct PipeArgs {
 void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch = 1);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);
+int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgs &pa);
 void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);

@@ -508,13 +508,13 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
   hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
-template <int CH, int WAVES, int PS, bool DIA>
+template <int CH, int WAVES, int PS, bool DIA, bool WAVE = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-  const int r = pipe_pass<CH, PS, true, DIA>(pa, tiles_per_block, sh);
+  const int r = pipe_pass<CH, PS, true, DIA, WAVE>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -608,6 +608,26 @@ static int pipe_live_launch(hipStream_t s, const PipeArgs &pa) {
   const int nb = (int)((ntiles + tpb - 1) / tpb);
   hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
+}
+template <int CH, int WAVES, int PS>
+static int pipe_wave_live_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
+  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
+  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, true, true>);
+  int64_t tpb = (ntiles + maxb - 1) / maxb;
+  if (tpb < 1) tpb = 1;
+  const int nb = (int)((ntiles + tpb - 1) / tpb);
+  const int64_t reach = max_abs_off / (2 * BLOCK) + 2;
+  if (tpb > 1 && reach * 4 > nb) return 0;
+  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, true, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  return nb;
+}
+int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {   // workgroups launched, 0: refused
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_wave_live_launch<8, 4, 6>(s, pa, max_abs_off);
+    case 1: return pipe_wave_live_launch<16, 3, 6>(s, pa, max_abs_off);
+    case 2: return pipe_wave_live_launch<24, 3, 0>(s, pa, max_abs_off);
+    default: return pipe_wave_live_launch<32, 2, 5>(s, pa, max_abs_off);
+  }
 }
 int pipe_step_live(hipStream_t s, const PipeArgs &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);
