@@ -184,6 +184,8 @@ struct Ks {
   uint32_t pipe_seq = 0;
   bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait ...
   int pipe_serial_calls = 0;                           // ... and tried again after this many serial factorisations
+  bool wave_off = false;                               // wave form switched off after an expired wait (two-kernel step instead)
+  int wave_off_calls = 0;
   void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv
   size_t mbox_bytes = 0;
   bool mbox_armed = false;

@@ -296,7 +296,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
       static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
       const int64_t ntiles_w = (ks.n + 511) / 512;
-      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !no_gdia_w && op.gndiag > 0 &&
+      if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
+      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !no_gdia_w && !ks.wave_off && op.gndiag > 0 &&
           m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (op.gdia_maxoff / 512 + 2) * 4 <= 400)) {
         use_pipe = true;
         use_wave = true;
@@ -702,6 +703,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   if (h.breakdown == 99) {
     // a kernel of the overlapped form waited in vain (its predecessor could not become resident: the device is
     // shared with other work).  Nothing is lost: redo the factorisation with one launch after the other.
+    // (the wave form's tiles also wait for each other inside one kernel: if that is what expired -- its workgroups
+    //  were not all resident -- the redo takes the two-kernel step, which never waits on the device)
+    if (use_wave && !ks.wave_off) {
+      ks.wave_off = true;
+      ks.wave_off_calls = 0;
+      return arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+    }
     if (!ks.pipe_live_used || ks.pipe_serial) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: bounded wait expired");
     ks.pipe_serial = true;
     return arnoldi_T<T>(ks, op, b, o, aug, lanczos);

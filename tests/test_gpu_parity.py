@@ -564,22 +564,27 @@ def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
     ctx.set_pipeline_overlap(True)
     assert relerr(w1, wo) < 1e-12 and relerr(w2, wo) < 1e-12
     code = textwrap.dedent("""
-        import sys, numpy as np
+        import sys, numpy as np, scipy.sparse as sp
         sys.path.insert(0, %r)
         import expv_mi_loader
         from tests._util import c2_operator
         eu = expv_mi_loader.load()
         A = c2_operator(%d)
+        G = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-150, -1, 0, 1, 150], shape=A.shape, format="csr")   # wave form
         b = np.random.default_rng(8).standard_normal(%d)
         for _ in range(3):
             w = eu.expv(0.9, A, b, m=%d, ishermitian=False)
-        np.save(sys.argv[1], w)
-    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n, m)
+            g = eu.expv(0.9, G, b, m=%d, ishermitian=False)
+        np.save(sys.argv[1], np.stack([w, g]))
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n, m, m)
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "expv_mi_fallback_%d.npy" % os.getpid())
     env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1")
     r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert relerr(np.load(out), wo) < 1e-12
+    got = np.load(out)
+    assert relerr(got[0], wo) < 1e-12
+    G = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-150, -1, 0, 1, 150], shape=A.shape, format="csr")
+    assert relerr(got[1], ko.expv(0.9, G, b, m=m, ishermitian=False)) < 1e-11      # wave -> two-kernel step after the expired wait
     os.remove(out)
 
 

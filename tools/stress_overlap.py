@@ -18,14 +18,20 @@ while time.time() - t0 < budget:
     n = int(rng.choice([300, 513, 2048, 5000, 20011, 65536, 150000, 400000]))
     m = int(rng.integers(1, 33))
     iop = int(rng.choice([0, 0, 0, 2, 5]))
-    if n not in ops:
-        ops[n] = eu.MIOperator(c2_operator(n), ctx)
+    kind = int(rng.integers(0, 2))          # 0: narrow band (halo form), 1: structured-grid offsets (wave form)
+    if (n, kind) not in ops:
+        if kind == 0:
+            ops[(n, kind)] = eu.MIOperator(c2_operator(n), ctx)
+        else:
+            import scipy.sparse as sp
+            k = max(3, int(np.sqrt(n)) // 2)
+            ops[(n, kind)] = eu.MIOperator(sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr"), ctx)
     b = rng.standard_normal(n)
     res = []
     for overlap in (True, False):
         ctx.set_pipeline_overlap(overlap)
         for rep in range(3 if overlap else 1):        # back-to-back overlapped calls reuse flags, mailbox, workspace
-            w = eu.expv(float(rng.choice([0.3, 1.0])) if False else 0.7, ops[n], b, m=m, iop=iop, ishermitian=False)
+            w = eu.expv(float(rng.choice([0.3, 1.0])) if False else 0.7, ops[(n, kind)], b, m=m, iop=iop, ishermitian=False)
             if overlap:
                 res.append(np.asarray(w).copy())
         if not overlap:
@@ -35,6 +41,6 @@ while time.time() - t0 < budget:
     for r in res:
         if not np.array_equal(r, ref):
             bad += 1
-            print("MISMATCH n=%d m=%d iop=%d maxdiff=%g" % (n, m, iop, float(np.max(np.abs(r - ref)))), flush=True)
+            print("MISMATCH n=%d kind=%d m=%d iop=%d maxdiff=%g" % (n, kind, m, iop, float(np.max(np.abs(r - ref)))), flush=True)
 print("calls %d, mismatches %d, %.0f s" % (calls, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
