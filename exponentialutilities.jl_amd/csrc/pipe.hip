@@ -266,10 +266,27 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
           u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
         }
     }
+    // products of one set (t = 0: against y~, t = 1: against u_j) of this tile, summed across the wave at once
+    auto tile_set = [&](int sidx, const Pack<double> &o) {
+      const int part = sidx % P;
+      double arr[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int q = part * K + k;                 // position in the CH-long vector of the set
+        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? fma(vreg[q < CH - 1 ? q : 0].v[0], o.v[0], vreg[q < CH - 1 ? q : 0].v[1] * o.v[1]) : 0.0;
+        else if (q == CH - 1) arr[k] = fma(u.v[0], o.v[0], u.v[1] * o.v[1]);
+        else arr[k] = 0.0;
+      }
+      wave_reduce_multi<K>(arr);
+      if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
+    };
     if constexpr (WAVE) {
       // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
       // u_j of the tiles their diagonals reach into, so wait for those flags (bounded)
       if (act) st_tile<true>(Vw + (int64_t)jcol * a.ldv + i, u);
+      // the sums against u_j do not need the operator: they fill the time the store takes to reach memory
+#pragma unroll
+      for (int sidx = P; sidx < NSETS; ++sidx) tile_set(sidx, u);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(pa.tile_flags + tile, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,20 +386,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     // set s = part + P*t (t = 0: d~ against y~, t = 1: g~ against u): ONE accumulator per lane.
 #pragma unroll
     for (int sidx = 0; sidx < NSETS; ++sidx) {
-      const int part = sidx % P, t = sidx / P;
-      const double o0 = t ? u.v[0] : y.v[0], o1 = t ? u.v[1] : y.v[1];
-      double arr[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int q = part * K + k;                 // position in the CH-long vector of the set
-        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? fma(vreg[q < CH - 1 ? q : 0].v[0], o0, vreg[q < CH - 1 ? q : 0].v[1] * o1) : 0.0;
-        else if (q == CH - 1) arr[k] = fma(u.v[0], o0, u.v[1] * o1);
-        else arr[k] = 0.0;
-      }
-      wave_reduce_multi<K>(arr);
-      if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
+      if (WAVE && sidx >= P) break;                  // (wave form: the sets against u_j were taken before the wait)
+      tile_set(sidx, sidx < P ? y : u);
     }
-    __syncthreads();   // us is rewritten by the next tile
+    if constexpr (!WAVE) __syncthreads();   // us is rewritten by the next tile
   }
 
   PIPE_STAMP(pa.step, 1);
