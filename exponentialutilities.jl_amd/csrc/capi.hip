@@ -141,11 +141,15 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
   for (int64_t s = 0; s < nsl; ++s)
     for (int64_t r = s * SH; r < std::min<int64_t>(n, (s + 1) * SH); ++r) {
       const int q = (int)(r - s * SH);
+      const int L = (int)((off[s + 1] - off[s]) / SH);
       int slot = 0;
       for (int32_t k = rp[r]; k < rp[r + 1]; ++k, ++slot) {
         sv[(size_t)(off[s] + (int64_t)slot * SH + q)] = va[k];
         sc[(size_t)(off[s] + (int64_t)slot * SH + q)] = ci[k];
       }
+      // padding slots (value 0) point at the row itself: whatever reads x[col] for them reads an entry that is as
+      // available as the row's own data (the wave form of the pipeline relies on that), never a far-away one
+      for (; slot < L; ++slot) sc[(size_t)(off[s] + (int64_t)slot * SH + q)] = (int32_t)r;
     }
   Ctx *c = op.ctx;
   op.sell_off.alloc(sizeof(int64_t) * off.size());
@@ -263,6 +267,27 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   build_sell<V>(op, n, rp, ci, va);
   if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va);
   if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va);
+  if (op.sell_ok && std::is_same<V, double>::value && op.ndiag == 0 && op.gndiag == 0 && n > 0) {
+    // wave form on SELL slots: which tiles does a tile's piece of A read u from?
+    const int64_t TR = 512, nt = (n + TR - 1) / TR;
+    std::vector<int32_t> lo(nt), hi(nt);
+    int64_t reach = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+      int64_t cmin = INT64_MAX, cmax = -1;
+      for (int64_t r = t * TR; r < std::min<int64_t>(n, (t + 1) * TR); ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) { cmin = std::min<int64_t>(cmin, ci[k]); cmax = std::max<int64_t>(cmax, ci[k]); }
+      if (cmax < 0) { cmin = t * TR; cmax = t * TR; }     // only empty rows: nothing but itself (padding slots read the own row)
+      lo[t] = (int32_t)(cmin / TR);
+      hi[t] = (int32_t)(cmax / TR);
+      reach = std::max(reach, std::max(t * TR + TR - 1 - cmin, cmax - t * TR));
+    }
+    op.tile_lo.alloc(sizeof(int32_t) * nt);
+    op.tile_hi.alloc(sizeof(int32_t) * nt);
+    HIPCHECK(hipMemcpyAsync(op.tile_lo.p, lo.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, op.ctx->stream));
+    HIPCHECK(hipMemcpyAsync(op.tile_hi.p, hi.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, op.ctx->stream));
+    HIPCHECK(hipStreamSynchronize(op.ctx->stream));
+    op.tile_reach = reach;
+  }
 }
 
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",

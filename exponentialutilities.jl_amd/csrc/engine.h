@@ -139,6 +139,8 @@ struct Op {
   int dia_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // general DIA form (fp64, any offsets, <= GDIA_MAX diagonals, <= 30 % zero fill): structured-grid stencils; read by
   // the two-kernel step instead of the SELL slots (fused.hip) when the operator is too wide for the pipeline
+  DevBuf tile_lo, tile_hi;   // per 512-row tile: first / last tile its columns lie in (wave form on SELL slots)
+  int64_t tile_reach = -1;   // largest distance (rows) between a tile and a tile it reads from; -1: not computed
   DevBuf gdia_val, gdia_off;
   int gndiag = 0;
   int64_t gdia_ld = 0, gdia_maxoff = 0;

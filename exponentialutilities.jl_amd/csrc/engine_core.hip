@@ -259,6 +259,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
   const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
+  int64_t wave_reach = 0;
 
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -297,10 +298,14 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
       const int64_t ntiles_w = (ks.n + 511) / 512;
       if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
-      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !no_gdia_w && !ks.wave_off && op.gndiag > 0 &&
-          m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (op.gdia_maxoff / 512 + 2) * 4 <= 400)) {
+      const bool wave_dia = op.gndiag > 0 && !no_gdia_w;
+      const bool wave_sell = !wave_dia && op.tile_reach >= 0;
+      const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
+      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
+          m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
         use_pipe = true;
         use_wave = true;
+        wave_reach = reach_rows;
       }
     }
     if (use_pipe) {
@@ -437,8 +442,12 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
           pa.final = (j == m + 1) ? 1 : 0;
           pa.A = A;
           if (use_wave) {
-            pa.dia_val = op.gdia_val.as<double>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
-            pa.gdia_off = op.gdia_off.as<int32_t>();
+            if (op.gndiag > 0 && !no_dia) {
+              pa.dia_val = op.gdia_val.as<double>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
+              pa.gdia_off = op.gdia_off.as<int32_t>();
+            } else {   // SELL slots + the per-tile column ranges
+              pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
+            }
             pa.tile_flags = ks.tflags.as<uint32_t>();
             pa.tile_stamp = (ks.pipe_seq << 8) | (uint32_t)j;
             pa.spin_limit = spin_limit;
@@ -482,11 +491,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
               pa.last_step = m + (closing ? 1 : 0);
             }
             if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-            prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, op.gdia_maxoff) : dev::pipe_step_live(sj, pa);
+            prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
             if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
           } else if (use_wave) {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);
-            if (!dev::pipe_step_wave(s, pa, op.gdia_maxoff)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+            if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
           } else {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);
             dev::pipe_step(s, pa);

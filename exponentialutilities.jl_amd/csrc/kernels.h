@@ -177,7 +177,8 @@ struct PipeArgs {
   PipeBatch pb;                // step-wise kernel only (the overlapped form is for a single problem)
   // wave form (general DIA operator, any offsets): no halo recompute; a tile publishes "u_j stored" in tile_flags and
   // waits for the tiles its diagonals reach into before it applies the operator (pipe.hip)
-  const int32_t *gdia_off;     // device: ndiag ascending offsets
+  const int32_t *gdia_off;     // device: ndiag ascending offsets (DIA operators)
+  const int32_t *tile_lo, *tile_hi;   // device: first / last tile the columns of a tile's rows lie in (SELL operators)
   uint32_t *tile_flags;        // device: one word per 512-row tile, = tile_stamp when u_j of the tile is in memory
   uint32_t tile_stamp;
   uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
@@ -194,7 +195,7 @@ struct PipeArgs {
 };
 void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch = 1);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
-bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);
+bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // operator form: pa.ndiag > 0 ? DIA : SELL
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgs &pa);

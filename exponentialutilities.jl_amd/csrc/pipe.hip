@@ -294,11 +294,18 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
         if (tid < 64) {
           bool ok = true;
           int64_t tlo = 0, thi = -1;
-          if (tid < pa.ndiag) {
-            const int64_t c0 = r0 + pa.gdia_off[tid], c1 = c0 + TR - 1;
-            tlo = (c0 < 0 ? 0 : c0) / TR;
-            thi = (c1 >= a.n ? a.n - 1 : c1) / TR;
-            if (c1 < 0 || c0 >= a.n) thi = tlo - 1;     // the whole diagonal piece lies outside the matrix
+          if constexpr (DIA) {
+            if (tid < pa.ndiag) {     // lane d: the tiles diagonal d of this tile reaches into
+              const int64_t c0 = r0 + pa.gdia_off[tid], c1 = c0 + TR - 1;
+              tlo = (c0 < 0 ? 0 : c0) / TR;
+              thi = (c1 >= a.n ? a.n - 1 : c1) / TR;
+              if (c1 < 0 || c0 >= a.n) thi = tlo - 1;     // the whole diagonal piece lies outside the matrix
+            }
+          } else {                    // SELL: the precomputed range of column tiles, split over the lanes
+            const int64_t lo = pa.tile_lo[tile], hi = pa.tile_hi[tile];
+            const int64_t per = (hi - lo + 64) / 64;
+            tlo = lo + (int64_t)tid * per;
+            thi = tlo + per - 1 < hi ? tlo + per - 1 : hi;
           }
           int res = 0;
           for (int it = 0;; ++it) {
@@ -328,6 +335,23 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     y.v[0] = 0.0;
     y.v[1] = 0.0;
     if (pa.final) {
+    } else if constexpr (WAVE && !DIA) {
+      if (i < a.n) {   // SELL slots, u_j gathered straight from its column in memory
+        const double *ucol = a.V + (int64_t)jcol * a.ldv;
+#pragma unroll
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) {
+            y.v[0] = fma(av[sl].v[0], ucol[aci[sl].x], y.v[0]);   // padding entries: value 0, column 0
+            y.v[1] = fma(av[sl].v[1], ucol[aci[sl].y], y.v[1]);
+          }
+        for (int sl = PS; sl < L; ++sl) {
+          const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
+          const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
+          y.v[0] = fma(v2.v[0], ucol[ci.x], y.v[0]);
+          y.v[1] = fma(v2.v[1], ucol[ci.y], y.v[1]);
+        }
+        if (i + 1 >= a.n) y.v[1] = 0.0;
+      }
     } else if constexpr (WAVE) {
       if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
         const double *ucol = a.V + (int64_t)jcol * a.ldv;
@@ -483,10 +507,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgs pa, int ti
 // waits for the tiles its diagonals reach into; tiles are dealt round-robin to the resident workgroups so those
 // neighbours are being worked on at the same time (pipe_step_wave checks that the reach is small against the grid, which
 // makes the wait graph acyclic: the first half of a tile never waits).  V is read once per step, as in the banded form.
-template <int CH, int WAVES, int PS>
+template <int CH, int WAVES, int PS, bool DIA>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_wave(const PipeArgs pa, int tiles_per_block) {
   __shared__ PipeShared sh;
-  (void)pipe_pass<CH, PS, false, true, true>(pa, tiles_per_block, sh);
+  (void)pipe_pass<CH, PS, false, DIA, true>(pa, tiles_per_block, sh);
 }
 
 // ---- overlapped form: the kernel of step j+1 runs while step j finishes ------------------------------
@@ -585,25 +609,26 @@ void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch) {
   }
 }
 
-template <int CH, int WAVES, int PS>
+template <int CH, int WAVES, int PS, bool DIA>
 static bool pipe_wave_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_wave<CH, WAVES, PS>);
+  const int maxb = resident_blocks((const void *)k_pipe_wave<CH, WAVES, PS, DIA>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
   const int64_t reach = max_abs_off / (2 * BLOCK) + 2;       // tiles a tile may wait for, on each side
   if (tpb > 1 && reach * 4 > nb) return false;               // too far for the round-robin deal: not acyclic for sure
-  hipLaunchKernelGGL((k_pipe_wave<CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_wave<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return true;
 }
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
-  switch (pipe_variant(pa.und)) {
-    case 0: return pipe_wave_launch<8, 4, 6>(s, pa, max_abs_off);
-    case 1: return pipe_wave_launch<16, 3, 6>(s, pa, max_abs_off);
-    case 2: return pipe_wave_launch<24, 3, 0>(s, pa, max_abs_off);
-    default: return pipe_wave_launch<32, 2, 5>(s, pa, max_abs_off);
-  }
+  const int v = pipe_variant(pa.und);
+#define PIPE_WCASE(i, ch, waves, ps)                                                     \
+  if (v == i) return pa.ndiag > 0 ? pipe_wave_launch<ch, waves, ps, true>(s, pa, max_abs_off) \
+                                  : pipe_wave_launch<ch, waves, ps, false>(s, pa, max_abs_off);
+  PIPE_WCASE(0, 8, 4, 6) PIPE_WCASE(1, 16, 3, 6) PIPE_WCASE(2, 24, 3, 0) PIPE_WCASE(3, 32, 2, 5)
+#undef PIPE_WCASE
+  return false;
 }
 
 template <int CH, int WAVES, int PS, bool DIA>
@@ -616,25 +641,26 @@ static int pipe_live_launch(hipStream_t s, const PipeArgs &pa) {
   hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
-template <int CH, int WAVES, int PS>
+template <int CH, int WAVES, int PS, bool DIA>
 static int pipe_wave_live_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, true, true>);
+  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, DIA, true>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
   const int64_t reach = max_abs_off / (2 * BLOCK) + 2;
   if (tpb > 1 && reach * 4 > nb) return 0;
-  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, true, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {   // workgroups launched, 0: refused
-  switch (pipe_variant(pa.und)) {
-    case 0: return pipe_wave_live_launch<8, 4, 6>(s, pa, max_abs_off);
-    case 1: return pipe_wave_live_launch<16, 3, 6>(s, pa, max_abs_off);
-    case 2: return pipe_wave_live_launch<24, 3, 0>(s, pa, max_abs_off);
-    default: return pipe_wave_live_launch<32, 2, 5>(s, pa, max_abs_off);
-  }
+  const int v = pipe_variant(pa.und);
+#define PIPE_WCASE(i, ch, waves, ps)                                                          \
+  if (v == i) return pa.ndiag > 0 ? pipe_wave_live_launch<ch, waves, ps, true>(s, pa, max_abs_off) \
+                                  : pipe_wave_live_launch<ch, waves, ps, false>(s, pa, max_abs_off);
+  PIPE_WCASE(0, 8, 4, 6) PIPE_WCASE(1, 16, 3, 6) PIPE_WCASE(2, 24, 3, 0) PIPE_WCASE(3, 32, 2, 5)
+#undef PIPE_WCASE
+  return 0;
 }
 int pipe_step_live(hipStream_t s, const PipeArgs &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);

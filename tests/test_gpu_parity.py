@@ -659,3 +659,29 @@ def test_wide_diagonal_operators_wave_form(eu, case):
         Ko = ko.arnoldi(A, b, m=m, ishermitian=herm)
         assert herr(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m]) <= tol
         assert relerr(w, ko.expv_(np.empty(n), 0.4, Ko)) < tol
+
+
+@pytest.mark.parametrize("n,m,band", [(60_000, 20, 1500), (650_000, 30, 2500)])
+def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
+    """No diagonal structure, but every row's columns lie within `band` of the diagonal (a reordered mesh operator): the
+    wave form runs on the SELL slots, a tile waiting for the precomputed range of tiles its columns lie in."""
+    rng = np.random.default_rng(41)
+    k = 6
+    rows = np.repeat(np.arange(n), k)
+    cols = rows + rng.integers(-band, band + 1, size=n * k)
+    cols = np.clip(cols, 0, n - 1)
+    vals = rng.standard_normal(n * k) * 0.15
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    A.sum_duplicates()
+    A = (A - 2.0 * sp.eye(n)).tocsr()
+    b = rng.standard_normal(n)
+    Ks = eu.arnoldi(A, b, m=m, ishermitian=False)
+    Km = eu.arnoldi(A, b, m=m, ishermitian=False, ortho="mgs")
+    Vm = Km.getV()[:, : m + 1]
+    tol = max(1e-11, 10 * float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1)))))
+    assert Ks.m == Km.m and Ks.wasbreakdown == Km.wasbreakdown
+    assert herr(Ks.H[: m + 1, :m], Km.H[: m + 1, :m]) <= tol
+    w = eu.expv(0.4, A, b, m=m, ishermitian=False)
+    assert relerr(w, eu.expv_(np.empty(n), 0.4, Km)) < tol
+    if n <= 100_000:
+        assert relerr(w, ko.expv(0.4, A, b, m=m, ishermitian=False)) < tol
