@@ -595,9 +595,15 @@ def test_overlapped_and_serial_pipeline_are_bitwise_identical(eu):
     rng = np.random.default_rng(21)
     ctx = eu.Context()
     cases = [(513, 5, 0, False), (1024, 31, 0, False), (4097, 30, 0, False), (10001, 32, 0, False), (3000, 25, 3, False),
-             (2500, 30, 0, True), (777, 12, 2, False), (70000, 30, 0, False), (256, 30, 0, False)]
+             (2500, 30, 0, True), (777, 12, 2, False), (70000, 30, 0, False), (256, 30, 0, False),
+             (-40001, 30, 0, False), (-300000, 24, 0, False), (-9000, 31, 4, False), (-25000, 20, 0, True)]
     for n, m, iop, herm in cases:
+        grid = n < 0                       # negative size: structured-grid offsets -> wave form of the step
+        n = abs(n)
         A = c2_operator(n)
+        if grid:
+            k = max(9, int(np.sqrt(n)))
+            A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
         if herm:
             A = ((A + A.T) * 0.5).tocsr()
         op = eu.MIOperator(A, ctx)
