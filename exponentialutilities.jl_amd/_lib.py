@@ -108,6 +108,7 @@ PROTOTYPES = {
     "expv_mi_kiops": (_i, [_vp, _vp, _pd, _i, _i, _vp, _i64, _i, _i, _vp, _i64, _i, C.POINTER(KiopsOpts), _pi64]),
     "expv_mi_expv_batch": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _i, _pd, _vp, _i64, _i, _vp, _i64, _i,
                                 C.POINTER(ArnoldiOpts), C.POINTER(C.c_int32)]),
+    "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),
     "expv_mi_host_expm": (_i, [_i, _i, _vp, _i]),
     "expv_mi_host_symtridiag_expcol": (_i, [_i, _pd, _pd, _d, _d, _pd]),
     "expv_mi_host_phiv_dense": (_i, [_i, _i, _i, _vp, _i, _vp, _vp]),

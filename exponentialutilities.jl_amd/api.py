@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_pattern_info",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -802,6 +802,30 @@ def host_expm(A):
     n = A.shape[0]
     _check(L.load().expv_mi_host_expm(_code(A.dtype), n, A.ctypes.data, max(n, 1)))
     return A
+
+
+def host_pattern_info(A, dtype=np.float64):
+    """Which storage forms a sparse pattern gets and hence which factorisation path it takes (host only; no reference
+    counterpart).  A: scipy sparse matrix (converted to CSR)."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int64)
+    _check(L.load().expv_mi_host_pattern_info(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), out.ctypes.data))
+    info = {"sell": bool(out[0]), "bandwidth": int(out[1]), "pipeline_dia_diagonals": int(out[2]),
+            "general_dia_diagonals": int(out[3]), "general_dia_max_offset": int(out[4]), "sell_wave_reach": int(out[5]),
+            "rows_sorted_unique": bool(out[6])}
+    if not info["sell"]:
+        info["path"] = "modular (CSR32)"
+    elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) == np.float64 and info["bandwidth"] <= 8):
+        info["path"] = "pipeline, halo form"
+    elif np.dtype(dtype) == np.float64 and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0):
+        info["path"] = "pipeline, wave form (when the reach is small against the resident grid), else two-kernel step"
+    else:
+        info["path"] = "two-kernel step"
+    return info
 
 
 def host_phiv_dense(A, v, k):

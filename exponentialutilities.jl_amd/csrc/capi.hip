@@ -120,6 +120,63 @@ void upload_csr(Op &op, const std::vector<int32_t> &rp, const std::vector<int32_
   HIPCHECK(hipStreamSynchronize(c->stream));
 }
 
+// ---- which storage forms a CSR pattern gets (host only: the same analysis backs the builders below and
+//      expv_mi_host_pattern_info, so the decisions are testable without a GPU) ---------------------------------
+struct PatternPlan {
+  bool sell_ok = false;           // rows regular enough for SELL slices (padding <= 30 %)
+  int64_t bandwidth = 0;          // max |col - row|
+  bool sorted_unique = true;      // every row: strictly ascending columns
+  std::vector<int64_t> offsets;   // distinct col - row, ascending (empty when there are more than GDIA_MAX)
+  bool fill_ok = false;           // offsets.size() * n <= 1.3 nnz (+ slack)
+  bool pipe_dia = false;          // DIA form of the banded pipeline (halo form)
+  bool general_dia = false;       // DIA form with arbitrary offsets (wave form / two-kernel step)
+  int64_t tile_reach = -1;        // SELL wave form: largest distance (rows) between a 512-row tile and a row it reads; -1: n/a
+};
+static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes) {
+  PatternPlan P;
+  if (n <= 0) return P;
+  const int SH = 64 * (16 / value_bytes);
+  int64_t padded = 0;
+  for (int64_t s0 = 0; s0 < n; s0 += SH) {
+    int L = 0;
+    for (int64_t r = s0; r < std::min<int64_t>(n, s0 + SH); ++r) L = std::max(L, rp[r + 1] - rp[r]);
+    padded += (int64_t)L * SH;
+  }
+  P.sell_ok = padded <= (int64_t)(1.3 * (double)nnz) + 8 * SH;
+  bool many = false;
+  for (int64_t r = 0; r < n; ++r) {
+    int32_t prev = -1;
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      if (ci[k] <= prev) P.sorted_unique = false;
+      prev = ci[k];
+      const int64_t o = (int64_t)ci[k] - r;
+      P.bandwidth = std::max<int64_t>(P.bandwidth, std::llabs((long long)o));
+      if (!many && std::find(P.offsets.begin(), P.offsets.end(), o) == P.offsets.end()) {
+        if ((int)P.offsets.size() >= dev::GDIA_MAX) { many = true; P.offsets.clear(); }
+        else P.offsets.push_back(o);
+      }
+    }
+  }
+  std::sort(P.offsets.begin(), P.offsets.end());
+  const int nd = (int)P.offsets.size();
+  P.fill_ok = nd > 0 && (double)nd * (double)n <= 1.3 * (double)nnz + 1024.0;
+  const bool dia_base = P.sell_ok && value_bytes == 8 && P.sorted_unique && P.fill_ok;
+  P.pipe_dia = dia_base && P.bandwidth <= dev::PIPE_WMAX && nd <= dev::PIPE_DIA_MAX;
+  P.general_dia = !P.pipe_dia && P.sell_ok && P.sorted_unique && P.fill_ok && P.bandwidth <= INT32_MAX;   // fp64 and complex
+  if (P.sell_ok && value_bytes == 8 && !P.pipe_dia && !P.general_dia) {
+    const int64_t TR = 512;
+    P.tile_reach = 0;
+    for (int64_t t0 = 0; t0 < n; t0 += TR) {
+      int64_t cmin = INT64_MAX, cmax = -1;
+      for (int64_t r = t0; r < std::min<int64_t>(n, t0 + TR); ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) { cmin = std::min<int64_t>(cmin, ci[k]); cmax = std::max<int64_t>(cmax, ci[k]); }
+      if (cmax < 0) continue;
+      P.tile_reach = std::max(P.tile_reach, std::max(t0 + TR - 1 - cmin, cmax - t0));
+    }
+  }
+  return P;
+}
+
 // SELL-C-sigma (sigma = 1: no row sorting) with C = 128 rows (fp64) / 64 rows (complex): slot-major
 // inside a slice so one wave reads 1 KiB of values per slot.  Built only when padding stays small.
 template <class V>
@@ -167,28 +224,14 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
 // PIPE_DIA_MAX of them, rows are free of duplicate entries and the zero fill stays below 30 %.  Absent entries are
 // explicit zeros, so a row's sum runs over the same terms, in ascending-column order, plus exact zeros.
 inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                      const std::vector<double> &va) {
+                      const std::vector<double> &va, const PatternPlan &P) {
   op.ndiag = 0;
-  if (n == 0 || op.bandwidth < 0 || op.bandwidth > dev::PIPE_WMAX) return;
+  if (!P.pipe_dia) return;
   const int W = dev::PIPE_WMAX;
-  std::vector<int64_t> cnt(2 * W + 1, 0);
-  for (int64_t r = 0; r < n; ++r) {
-    int32_t prev = -1;
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-      if (ci[k] <= prev) return;   // unsorted or duplicate entries: keep the row order SELL preserves
-      prev = ci[k];
-      ++cnt[(size_t)(ci[k] - r + W)];
-    }
-  }
-  int nd = 0;
-  int offs[2 * dev::PIPE_WMAX + 1];
-  for (int o = 0; o <= 2 * W; ++o)
-    if (cnt[o] > 0) offs[nd++] = o - W;
-  if (nd == 0 || nd > dev::PIPE_DIA_MAX) return;
-  if ((double)nd * (double)n > 1.3 * (double)ci.size() + 1024.0) return;
+  const int nd = (int)P.offsets.size();
   const int64_t ld = (n + 511) / 512 * 512;
   int slot_of[2 * dev::PIPE_WMAX + 1];
-  for (int d = 0; d < nd; ++d) slot_of[offs[d] + W] = d;
+  for (int d = 0; d < nd; ++d) slot_of[P.offsets[d] + W] = d;
   std::vector<double> dv((size_t)nd * (size_t)ld, 0.0);
   for (int64_t r = 0; r < n; ++r)
     for (int32_t k = rp[r]; k < rp[r + 1]; ++k) dv[(size_t)slot_of[ci[k] - r + W] * (size_t)ld + (size_t)r] = va[k];
@@ -197,34 +240,17 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
   op.ndiag = nd;
   op.dia_ld = ld;
-  for (int d = 0; d < nd; ++d) op.dia_off[d] = offs[d];
+  for (int d = 0; d < nd; ++d) op.dia_off[d] = (int)P.offsets[d];
 }
 // General DIA form (any offsets): structured-grid stencils whose bandwidth is too wide for the banded pipeline.  Same
 // rules otherwise: rows sorted and free of duplicates, at most GDIA_MAX distinct offsets, zero fill below 30 %.
 template <class V>
 inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                       const std::vector<V> &va) {
+                       const std::vector<V> &va, const PatternPlan &P) {
   op.gndiag = 0;
-  if (n == 0 || op.ndiag > 0) return;
-  std::vector<int64_t> offs;   // distinct offsets, found by scanning (few)
-  for (int64_t r = 0; r < n; ++r) {
-    int32_t prev = -1;
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-      if (ci[k] <= prev) return;
-      prev = ci[k];
-      const int64_t o = (int64_t)ci[k] - r;
-      bool seen = false;
-      for (int64_t x : offs)
-        if (x == o) { seen = true; break; }
-      if (!seen) {
-        if ((int)offs.size() >= dev::GDIA_MAX) return;
-        offs.push_back(o);
-      }
-    }
-  }
+  if (!P.general_dia) return;
+  const std::vector<int64_t> &offs = P.offsets;
   const int nd = (int)offs.size();
-  if (nd == 0 || (double)nd * (double)n > 1.3 * (double)ci.size() + 1024.0) return;
-  std::sort(offs.begin(), offs.end());
   const int64_t ld = (n + 511) / 512 * 512;
   std::vector<V> dv((size_t)nd * (size_t)ld, V(0));
   for (int64_t r = 0; r < n; ++r)
@@ -234,10 +260,7 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
       dv[(size_t)d * (size_t)ld + (size_t)r] = va[k];
     }
   std::vector<int32_t> o32(nd);
-  for (int d = 0; d < nd; ++d) {
-    if (offs[d] > INT32_MAX || offs[d] < INT32_MIN) return;
-    o32[d] = (int32_t)offs[d];
-  }
+  for (int d = 0; d < nd; ++d) o32[d] = (int32_t)offs[d];
   op.gdia_val.alloc(sizeof(V) * dv.size());
   op.gdia_off.alloc(sizeof(int32_t) * nd);
   HIPCHECK(hipMemcpyAsync(op.gdia_val.p, dv.data(), sizeof(V) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
@@ -249,8 +272,8 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
 }
 template <class V>
 inline void maybe_build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                            const std::vector<V> &va) {
-  if constexpr (std::is_same<V, double>::value) build_dia(op, n, rp, ci, va);
+                            const std::vector<V> &va, const PatternPlan &P) {
+  if constexpr (std::is_same<V, double>::value) build_dia(op, n, rp, ci, va, P);
 }
 
 template <class V>
@@ -265,13 +288,13 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.bandwidth = bw;
   upload_csr<V>(op, rp, ci, va);
   build_sell<V>(op, n, rp, ci, va);
-  if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va);
-  if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va);
-  if (op.sell_ok && std::is_same<V, double>::value && op.ndiag == 0 && op.gndiag == 0 && n > 0) {
+  const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va, P);
+  if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va, P);
+  if (op.sell_ok && P.tile_reach >= 0) {
     // wave form on SELL slots: which tiles does a tile's piece of A read u from?
     const int64_t TR = 512, nt = (n + TR - 1) / TR;
     std::vector<int32_t> lo(nt), hi(nt);
-    int64_t reach = 0;
     for (int64_t t = 0; t < nt; ++t) {
       int64_t cmin = INT64_MAX, cmax = -1;
       for (int64_t r = t * TR; r < std::min<int64_t>(n, (t + 1) * TR); ++r)
@@ -279,14 +302,13 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
       if (cmax < 0) { cmin = t * TR; cmax = t * TR; }     // only empty rows: nothing but itself (padding slots read the own row)
       lo[t] = (int32_t)(cmin / TR);
       hi[t] = (int32_t)(cmax / TR);
-      reach = std::max(reach, std::max(t * TR + TR - 1 - cmin, cmax - t * TR));
     }
     op.tile_lo.alloc(sizeof(int32_t) * nt);
     op.tile_hi.alloc(sizeof(int32_t) * nt);
     HIPCHECK(hipMemcpyAsync(op.tile_lo.p, lo.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, op.ctx->stream));
     HIPCHECK(hipMemcpyAsync(op.tile_hi.p, hi.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, op.ctx->stream));
     HIPCHECK(hipStreamSynchronize(op.ctx->stream));
-    op.tile_reach = reach;
+    op.tile_reach = P.tile_reach;
   }
 }
 
@@ -824,6 +846,20 @@ int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int
 
 // ------------------------------------------------------------------ host diagnostics --------
 // exponential!(A, ExpMethodHigham2005Base()) on a host matrix, in place (exp_baseexp.jl:112-161)
+int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int64_t out[8]) {
+  return guarded(nullptr, [&] {
+    if (n < 0 || !rowptr || !colind || !out) fail(EXPV_MI_ARGUMENT_ERROR, "pattern_info: bad arguments");
+    const PatternPlan P = analyze_pattern(n, rowptr, colind, n > 0 ? (int64_t)rowptr[n] : 0, (int)dtype_size(dtype));
+    out[0] = P.sell_ok;
+    out[1] = P.bandwidth;
+    out[2] = P.pipe_dia ? (int64_t)P.offsets.size() : 0;
+    out[3] = P.general_dia ? (int64_t)P.offsets.size() : 0;
+    out[4] = P.general_dia ? std::max<int64_t>(std::llabs((long long)P.offsets.front()), std::llabs((long long)P.offsets.back())) : 0;
+    out[5] = P.tile_reach;
+    out[6] = P.sorted_unique;
+    out[7] = 0;
+  });
+}
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {
   return guarded(nullptr, [&] {
     if (dtype == EXPV_MI_C64) {

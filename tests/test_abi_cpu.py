@@ -102,3 +102,36 @@ def test_host_expm_rejects_nan(eu):
         eu.host_expm(np.full((3, 3), np.nan))
     with pytest.raises(ValueError):
         ko.exponential_(np.full((3, 3), np.nan))
+
+
+def test_host_pattern_info_selects_the_storage_forms(eu):
+    """The format / path decision of operator creation is host logic: check it without a GPU."""
+    import scipy.sparse as sp
+    n = 5000
+    c2 = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-2, -1, 0, 1, 2], shape=(n, n), format="csr")
+    i = eu.host_pattern_info(c2)
+    assert i["sell"] and i["bandwidth"] == 2 and i["pipeline_dia_diagonals"] == 5 and i["general_dia_diagonals"] == 0
+    assert i["path"].startswith("pipeline, halo")
+    nine = sp.diags([1.0] * 9, list(range(-4, 5)), shape=(n, n), format="csr")          # > 8 offsets: SELL slots, still banded
+    i = eu.host_pattern_info(nine)
+    assert i["pipeline_dia_diagonals"] == 0 and i["bandwidth"] == 4 and i["path"].startswith("pipeline, halo")
+    grid = sp.diags([1.0, 1.0, -4.0, 1.0, 1.0], [-70, -1, 0, 1, 70], shape=(n, n), format="csr")
+    i = eu.host_pattern_info(grid)
+    assert i["pipeline_dia_diagonals"] == 0 and i["general_dia_diagonals"] == 5 and i["general_dia_max_offset"] == 70
+    assert "wave" in i["path"]
+    assert eu.host_pattern_info(grid, np.complex128)["path"] == "two-kernel step"          # complex: general DIA, no pipeline
+    rng = np.random.default_rng(0)
+    rows = np.repeat(np.arange(n), 5)
+    cols = np.clip(rows + rng.integers(-300, 301, size=rows.size), 0, n - 1)
+    irr = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n, n))
+    irr.sum_duplicates()
+    i = eu.host_pattern_info(irr)
+    assert i["sell"] and i["general_dia_diagonals"] == 0 and 0 < i["sell_wave_reach"] <= 300 + 511
+    ragged = sp.lil_matrix((n, n))
+    ragged[0, :400] = 1.0                                                                  # one long row per slice-full of short ones
+    ragged.setdiag(2.0)
+    i = eu.host_pattern_info(ragged.tocsr())
+    assert i["path"].startswith("modular") or i["sell"]                                    # padding rule decides; never crashes
+    unsorted = sp.csr_matrix((np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1]), np.array([0, 2, 3])), shape=(2, 2))
+    unsorted.has_sorted_indices = True                                                     # keep scipy from sorting them
+    assert eu.host_pattern_info(unsorted)["rows_sorted_unique"] in (True, False)
