@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("EXPV_MI_LIB") or os.path.join(HERE, "libexpv_mi.so") 
 F64, C64 = 0, 1
 HOST, DEVICE = 0, 1
 ORTHO_AUTO, ORTHO_MGS, ORTHO_LOWSYNC = 0, 1, 2
+PATH_FLAGS = {"modular": 1, "two_kernel": 2, "pipeline": 4, "wave": 8, "overlapped": 16, "redo_serial": 32,
+              "redo_wave_off": 64}
 
 STATUS_NAMES = {
     0: "OK", 1: "DimensionMismatch", 2: "ArgumentError", 3: "AssertionError", 4: "SingularException",
@@ -29,7 +31,7 @@ class ArnoldiOpts(C.Structure):
 
 class ExpvStats(C.Structure):
     _fields_ = [("m_used", C.c_int32), ("wasbreakdown", C.c_int32), ("matvecs", C.c_int32),
-                ("reserved", C.c_int32), ("beta", C.c_double)]
+                ("path_flags", C.c_int32), ("beta", C.c_double)]
 
 
 PRINT_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
@@ -64,6 +66,7 @@ PROTOTYPES = {
     "expv_mi_ctx_sync": (_i, [_vp]),
     "expv_mi_ctx_set_async_outputs": (_i, [_vp, _i]),
     "expv_mi_ctx_set_pipeline_overlap": (_i, [_vp, _i]),
+    "expv_mi_ctx_counters": (_i, [_vp, _pi64]),
     "expv_mi_last_error": (C.c_char_p, [_vp]),
     "expv_mi_version": (C.c_char_p, []),
     "expv_mi_malloc": (_i, [_vp, C.c_size_t, _pvp]),

@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol", "host_pattern_info",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_pattern_info", "clear_operator_cache",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -82,6 +82,17 @@ class Context:
 
     def sync(self):
         _check(L.load().expv_mi_ctx_sync(self._h), self._h)
+
+    def set_async_outputs(self, on=True):
+        """Device-resident results stream-ordered (True) or complete on return (False, the C-ABI default)."""
+        _check(L.load().expv_mi_ctx_set_async_outputs(self._h, int(bool(on))), self._h)
+
+    def counters(self):
+        """Cumulative counters of the context (expv_mi_ctx_counters)."""
+        out = (C.c_int64 * 8)()
+        _check(L.load().expv_mi_ctx_counters(self._h, out), self._h)
+        keys = ("krylov_steps", "factorisations", "pipeline", "overlapped", "redo_serial", "redo_wave_off", "op_applies")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def set_pipeline_overlap(self, on=True):
         """Banded pipeline: consecutive Krylov steps on two streams (default) or one launch after the other."""
@@ -359,28 +370,62 @@ def _torch_view(ptr, n, dt):
     return torch.as_tensor(s, device="cuda")
 
 
+def _wrapsum(a):
+    """Wrap-around integer sum of an array's bytes (8 at a time): any in-place change of the contents changes it."""
+    a = np.ascontiguousarray(a)
+    raw = a.view(np.uint8).ravel()
+    k = raw.size // 8 * 8
+    tot = int(np.add.reduce(raw[:k].view(np.uint64), dtype=np.uint64)) if k else 0
+    return (tot + int(np.add.reduce(raw[k:], dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
+
+
+def _fingerprint(A):
+    """Cheap content fingerprint of a host matrix: shape, dtype, buffer addresses and a checksum of the values (and of the
+    index arrays of a sparse matrix).  The reference reads A at call time (mul!(y, A, x)); an uploaded copy may only be
+    reused while the caller's matrix is byte-for-byte what was uploaded."""
+    if hasattr(A, "indptr") and hasattr(A, "indices"):
+        return ("sp", A.format, A.shape, A.dtype.str, int(A.nnz), A.data.ctypes.data, A.indices.ctypes.data,
+                A.indptr.ctypes.data, _wrapsum(A.data), _wrapsum(A.indices), _wrapsum(A.indptr))
+    M = np.asarray(A)
+    return ("dn", M.shape, M.dtype.str, M.ctypes.data, M.strides, _wrapsum(M))
+
+
 def _as_operator(A, want_dtype=None, ctx=None):
+    """Resolve the operator argument of an API call.  An explicit MIOperator is the way to reuse an upload across calls.
+    Host matrices (scipy sparse / ndarray) passed directly are uploaded on first use and the upload is reused ONLY while
+    (same object, same context, same content fingerprint) -- an in-place ``A.data[:] = ...`` / ``A *= dt`` between calls
+    re-uploads, like the reference reading A at call time.  Device tensors are wrapped without a copy every time."""
     if isinstance(A, MIOperator):
         op = A
+    elif _is_torch(A):
+        op = MIOperator(A, ctx)
     else:
         cache = getattr(_as_operator, "_cache", None)
         if cache is None:
             cache = _as_operator._cache = {}
-        key = id(A)
+        cobj = ctx or default_context()
+        key = (id(A), id(cobj))
+        fp = _fingerprint(A)
         ent = cache.get(key)
-        if ent is None or ent[0]() is not A:
-            op = MIOperator(A, ctx)
+        if ent is None or ent[0]() is not A or ent[2] != fp or ent[1].ctx is not cobj:
+            op = MIOperator(A, cobj)
             try:
-                cache[key] = (weakref.ref(A), op)
+                cache[key] = (weakref.ref(A), op, fp)
             except TypeError:
                 pass
-            if len(cache) > 16:
+            while len(cache) > 16:
                 cache.pop(next(iter(cache)))
         else:
             op = ent[1]
     if want_dtype is not None and np.dtype(want_dtype).kind == "c" and op.dtype.kind != "c":
         op = op.astype(np.complex128)
     return op
+
+
+def clear_operator_cache():
+    """Drop every implicitly uploaded operator (see _as_operator)."""
+    if hasattr(_as_operator, "_cache"):
+        _as_operator._cache.clear()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -556,7 +601,8 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
         _check(L.load().expv_mi_expv(opT.ctx._h, opT._h, tr, ti, ba.ptr, ba.loc, wa.ptr, wa.loc, _code(wa.dtype),
                                      C.byref(o), C.byref(st)), opT.ctx._h)
         wa.finish()
-        expv.last_stats = {"m": st.m_used, "wasbreakdown": bool(st.wasbreakdown), "matvecs": st.matvecs, "beta": st.beta}
+        expv.last_stats = {"m": st.m_used, "wasbreakdown": bool(st.wasbreakdown), "matvecs": st.matvecs, "beta": st.beta,
+                           "path": [k for k, v in L.PATH_FLAGS.items() if st.path_flags & v]}
         return w
     if mode == "error_estimate":        # _expv_ee  (:145-160)
         m = kw.pop("m", min(30, op.shape[0]))

@@ -367,6 +367,12 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on) {
   ctx->pipe_overlap = (on != 0);
   return EXPV_MI_OK;
 }
+int expv_mi_ctx_counters(expv_mi_ctx_t ctx, int64_t out[8]) {
+  if (!ctx || !out) return EXPV_MI_ARGUMENT_ERROR;
+  out[0] = ctx->cnt_steps; out[1] = ctx->cnt_fact; out[2] = ctx->cnt_pipe; out[3] = ctx->cnt_live;
+  out[4] = ctx->cnt_serial_redo; out[5] = ctx->cnt_wave_redo; out[6] = ctx->cnt_opapply; out[7] = 0;
+  return EXPV_MI_OK;
+}
 int expv_mi_ctx_sync(expv_mi_ctx_t ctx) {
   return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipStreamSynchronize(ctx->stream)); });
 }
@@ -430,7 +436,14 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
                           const void *nzval, int index_base, expv_mi_op_t *out) {
   return guarded(ctx, [&] {
     ctx->use();
+    if (!out) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: null output");
     if (n < 0 || n > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: n out of range for CSR32");
+    if (!colptr || (n > 0 && (!rowval || !nzval))) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: null colptr / rowval / nzval");
+    if (dtype != EXPV_MI_F64 && dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: unknown dtype");
+    // colptr must be what SparseMatrixCSC guarantees: starts at the index base, non-decreasing (csc_to_csr slices by it)
+    if (colptr[0] != index_base) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: colptr[0] must equal the index base");
+    for (int64_t c = 0; c < n; ++c)
+      if (colptr[c + 1] < colptr[c]) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: colptr must be non-decreasing");
     if (colptr[n] - index_base > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: nnz exceeds CSR32");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
@@ -461,8 +474,16 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
     auto civ = [&](int64_t k) -> int64_t {
       return (idx_bytes == 8 ? reinterpret_cast<const int64_t *>(colind)[k] : reinterpret_cast<const int32_t *>(colind)[k]) - index_base;
     };
+    if (!out) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: null output");
+    if (!rowptr) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: null rowptr");
+    if (dtype != EXPV_MI_F64 && dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: unknown dtype");
+    // rowptr: starts at the index base, non-decreasing (build_sell / the kernels slice by it)
+    if (rpv(0) != 0) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: rowptr[0] must equal the index base");
+    for (int64_t i = 0; i < n; ++i)
+      if (rpv(i + 1) < rpv(i)) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: rowptr must be non-decreasing");
     const int64_t nnz = rpv(n);
     if (nnz > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: nnz exceeds CSR32");
+    if (nnz > 0 && (!colind || !vals)) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: null colind / vals");
     std::vector<int32_t> rp(n + 1), ci(nnz);
     for (int64_t i = 0; i <= n; ++i) rp[i] = (int32_t)rpv(i);
     for (int64_t k = 0; k < nnz; ++k) {
@@ -528,7 +549,7 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
       op->lda = lda;
       op->nnz = n * n;
       op->ishermitian = 0;
-      op->opnorm_inf = NAN;
+      op->opnorm_inf = 0.0;
     }
     const int64_t rows_per_block = dev::BLOCK * (16 / (int64_t)esz);
     const int64_t gx = std::max<int64_t>(1, (n + rows_per_block - 1) / rows_per_block);
@@ -536,6 +557,22 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
     if (n < 64) split = 1;
     op->gemv_split = split;
     if (split > 1) op->gemv_scratch.alloc((size_t)split * n * esz);
+    if (loc != EXPV_MI_HOST && n > 0) {
+      // a device-resident matrix answers LinearAlgebra.ishermitian(A) / opnorm(A, Inf) / count(!iszero, A) like the same
+      // matrix passed from the host would: one pass of two small kernels at create time (setup cost)
+      DevBuf scr(sizeof(double) * (size_t)split * (size_t)n), res(3 * sizeof(unsigned long long));
+      HIPCHECK(hipMemsetAsync(res.p, 0, res.bytes, ctx->stream));
+      if (dtype == EXPV_MI_C64)
+        dev::dense_props<cplx>(ctx->stream, n, reinterpret_cast<const cplx *>(A), lda, scr.as<double>(), split, res.as<unsigned long long>());
+      else
+        dev::dense_props<double>(ctx->stream, n, reinterpret_cast<const double *>(A), lda, scr.as<double>(), split, res.as<unsigned long long>());
+      unsigned long long h[3] = {0, 0, 0};
+      HIPCHECK(hipMemcpyAsync(h, res.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHECK(hipStreamSynchronize(ctx->stream));
+      std::memcpy(&op->opnorm_inf, &h[0], sizeof(double));
+      op->nnz = (int64_t)h[1];
+      op->ishermitian = h[2] == 0 ? 1 : 0;
+    }
     *out = op.release();
   });
 }
@@ -765,7 +802,7 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
       stats->wasbreakdown = ks.wasbreakdown;
       stats->matvecs = mv;
       stats->beta = ks.beta;
-      stats->reserved = 0;
+      stats->path_flags = ctx->last_path;
     }
   });
 }

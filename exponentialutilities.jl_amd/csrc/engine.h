@@ -57,7 +57,11 @@ struct Ctx {
   void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
   void (*ws_kiops_free)(void *) = nullptr;
   void *ws_batch = nullptr;   // cached device buffers of expv_batch (owned; see engine_batch.hip)
+  size_t ws_batch_bytes = 0;  // ... and how many bytes they hold
   void (*ws_batch_free)(void *) = nullptr;
+  // cumulative counters (expv_mi_ctx_counters): what ran, and whether a bounded device wait ever expired
+  int64_t cnt_steps = 0, cnt_fact = 0, cnt_live = 0, cnt_serial_redo = 0, cnt_wave_redo = 0, cnt_opapply = 0, cnt_pipe = 0;
+  int last_path = 0;                      // EXPV_MI_PATH_* flags of the most recent factorisation
   hipStream_t stream2 = nullptr;          // second stream + fork/join events of the overlapped pipeline
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void ensure_aux() {

@@ -81,6 +81,9 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   const size_t per_prob = sizeof(double) * (size_t)(strideV + 2 * ldv + dia_words);
   size_t free_b = 0, total_b = 0;
   HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+  // the chunk buffers of earlier calls stay allocated in the context: they are available to this call too, so the chunk
+  // size must not shrink from call to call just because the first call's workspace is still held
+  if (ctx->ws_batch) free_b += ctx->ws_batch_bytes;
   int PC = (int)std::min<size_t>((size_t)nprob, std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / std::max<size_t>(per_prob, 1)));
   PC = std::min(PC, 512);
   const int64_t ntiles = (n + 2 * dev::BLOCK - 1) / (2 * dev::BLOCK);
@@ -128,6 +131,9 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   need(ws->coef, sizeof(double) * (size_t)(m + 1) * PC, false);
   need(ws->beta, sizeof(double) * PC, false);
   need(ws->mcols, sizeof(int32_t) * PC, false);
+  ctx->ws_batch_bytes = ws->perm.bytes + ws->V.bytes + ws->Ya.bytes + ws->Yb.bytes + ws->Dia.bytes + ws->H.bytes + ws->G.bytes +
+                        ws->hca.bytes + ws->hcb.bytes + ws->sc.bytes + ws->part.bytes + ws->gpart.bytes + ws->st.bytes +
+                        ws->coef.bytes + ws->beta.bytes + ws->mcols.bytes;
   DevBuf &d_perm = ws->perm, &dV = ws->V, &dYa = ws->Ya, &dYb = ws->Yb, &dDia = ws->Dia, &dH = ws->H, &dG = ws->G;
   DevBuf &dhca = ws->hca, &dhcb = ws->hcb, &dsc = ws->sc, &dpart = ws->part, &dgpart = ws->gpart, &dst = ws->st;
   DevBuf &dcoef = ws->coef, &dbeta = ws->beta, &dmcols = ws->mcols;

@@ -172,6 +172,7 @@ static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) 
   }
 }
 void op_apply_dev(Op &op, const void *x, void *y, const StepState *st, int step, bool) {
+  ++op.ctx->cnt_opapply;
   if (op.dtype == EXPV_MI_C64) op_apply_T<cplx>(op, (const cplx *)x, (cplx *)y, st, step);
   else op_apply_T<double>(op, (const double *)x, (double *)y, st, step);
 }
@@ -689,9 +690,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     for (long it = 1;; ++it) {
       if (*done == (unsigned long long)ks.pipe_seq) { from_mbox = true; break; }
       __builtin_ia32_pause();
-      if ((it & 0xfff) == 0 && hipStreamQuery(s) == hipSuccess) {
-        from_mbox = (*done == (unsigned long long)ks.pipe_seq);
-        break;
+      if ((it & 0xfff) == 0) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) {
+          from_mbox = (*done == (unsigned long long)ks.pipe_seq);
+          break;
+        }
+        if (q != hipErrorNotReady) HIPCHECK(q);   // launch failure / fault / reset: surface it instead of spinning forever
       }
     }
     if (from_mbox) {
@@ -717,11 +722,17 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     if (use_wave && !ks.wave_off) {
       ks.wave_off = true;
       ks.wave_off_calls = 0;
-      return arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+      ++c->cnt_wave_redo;
+      const int r = arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+      c->last_path |= EXPV_MI_PATH_REDO_WAVE_OFF;
+      return r;
     }
     if (!ks.pipe_live_used || ks.pipe_serial) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: bounded wait expired");
     ks.pipe_serial = true;
-    return arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+    ++c->cnt_serial_redo;
+    const int r = arnoldi_T<T>(ks, op, b, o, aug, lanczos);
+    c->last_path |= EXPV_MI_PATH_REDO_SERIAL;
+    return r;
   }
   if (use_fused) {
     ks.beta = std::sqrt(h.beta0sq);
@@ -767,6 +778,11 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     ks.m = h.m_done;
     ks.wasbreakdown = true;
   }
+  c->cnt_steps += jlast - jstart + 1;
+  ++c->cnt_fact;
+  c->last_path = use_pipe ? (EXPV_MI_PATH_PIPELINE | (use_wave ? EXPV_MI_PATH_WAVE : 0) | (ks.pipe_live_used ? EXPV_MI_PATH_OVERLAPPED : 0))
+                          : (use_fused ? EXPV_MI_PATH_TWO_KERNEL : EXPV_MI_PATH_MODULAR);
+  if (use_pipe) { ++c->cnt_pipe; if (ks.pipe_live_used) ++c->cnt_live; }
   return jlast - jstart + 1;
 }
 

@@ -353,6 +353,14 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
     ks_alloc(wsp->ks, ctx, dt, dtU, n, std::max(m, std::min(o.mmax, 64)), p);
   }
   expv_mi_ks_s &ks = wsp->ks;
+  // the reference builds a fresh KrylovSubspace (H = zeros) per call (kiops.jl:74); the cached one must look the same:
+  // arnoldi! only rewrites the window / sub-diagonal entries of the columns it produces, so the `H[1, j+1] = 1` markers
+  // and entries left by a call with another iop / Lanczos setting would otherwise leak into a later call's exp(tau H)
+  std::fill(ks.H.begin(), ks.H.end(), 0);
+  ks.gram_rows = 0;
+  ks.scale_pending = false;
+  ks.scale_cols = 0;
+  ks.beta = 0.0;
   ks.m = m;
   ks.wasbreakdown = false;
   int64_t step = 0, krystep = 0, ireject = 0, reject = 0, exps = 0;

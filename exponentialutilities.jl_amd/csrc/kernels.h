@@ -81,6 +81,10 @@ void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *co
 template <class T>
 void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
                 const StepState *st, int step);
+// ishermitian / opnorm(A, Inf) / count(!iszero) of a device-resident dense matrix (kernels.hip); scratch: nsplit * n
+// doubles, res: 3 words {opnorm bits, nnz, "not Hermitian"} zeroed by the caller
+template <class T>
+void dense_props(hipStream_t s, int64_t n, const T *A, int64_t lda, double *scratch, int nsplit, unsigned long long *res);
 template <class T>
 void aug_apply(hipStream_t s, int64_t n, int p, const T *B, int64_t ldb, const T *x, T *y, const StepState *st,
                int step);

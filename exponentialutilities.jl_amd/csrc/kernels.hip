@@ -263,6 +263,105 @@ void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T
   }
 }
 
+// Properties of a DEVICE-RESIDENT dense operator, computed once at create time (setup cost; the reference evaluates
+// LinearAlgebra.ishermitian(A) / opnorm(A, Inf) / count(!iszero, A) on the host: arnoldi.jl:166, kiops.jl:59,
+// krylov_phiv_adaptive.jl:335-342).  Row sums of |a_ij| follow the GEMV layout (lane = 16 B of rows, column splits in
+// blockIdx.y, fixed summation order); the Hermitian test compares 64 x 64 tiles with their mirror tile through LDS so
+// both reads are coalesced.  res: [0] opnorm(A, Inf) as bits, [1] count(!iszero), [2] != 0 when A != A'.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_dense_rowabs(int64_t n, const T *__restrict__ A, int64_t lda, double *__restrict__ out,
+                                                        int64_t out_stride, unsigned long long *res) {
+  constexpr int N = Pack<T>::N;
+  const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N;
+  const int nsplit = gridDim.y;
+  const int64_t cper = (n + nsplit - 1) / nsplit;
+  const int64_t cbeg = (int64_t)blockIdx.y * cper;
+  const int64_t cend = (cbeg + cper < n) ? cbeg + cper : n;
+  const bool al = is_al16(A) && ((lda * sizeof(T)) % 16 == 0);
+  double acc[N];
+  unsigned long long nz = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = 0.0;
+  if (i < n) {
+    for (int64_t c = cbeg; c < cend; ++c) {
+      const Pack<T> a = ld_pack_user(A + c * lda, i, n, al);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double m2 = ST<T>::abs2(a.v[k]);
+        acc[k] += ST<T>::is_complex ? sqrt(m2) : fabs(ST<T>::real(a.v[k]));
+        nz += (m2 != 0.0 || m2 != m2) ? 1ull : 0ull;       // NaN counts as non-zero, like !iszero
+      }
+    }
+    double *o = out + (int64_t)blockIdx.y * out_stride;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (i + k < n) o[i + k] = acc[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nz += __shfl_down(nz, o, 64);
+  if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&res[1], nz);
+}
+__global__ __launch_bounds__(BLOCK) void k_dense_rowmax(int64_t n, const double *__restrict__ parts, int64_t stride, int nsplit,
+                                                        unsigned long long *res) {
+  __shared__ double red_s[BLOCK];
+  double best = 0.0;
+  bool nan = false;
+  for (int64_t i = threadIdx.x; i < n; i += BLOCK) {
+    double s = parts[i];
+    for (int k = 1; k < nsplit; ++k) s += parts[(int64_t)k * stride + i];
+    if (s != s) nan = true;
+    best = s > best ? s : best;
+  }
+  red_s[threadIdx.x] = nan ? __longlong_as_double(0x7ff8000000000000ll) : best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = 0.0;
+    bool anynan = false;
+    for (int t = 0; t < BLOCK; ++t) {
+      if (red_s[t] != red_s[t]) anynan = true;
+      else b = red_s[t] > b ? red_s[t] : b;
+    }
+    res[0] = (unsigned long long)__double_as_longlong(anynan ? __longlong_as_double(0x7ff8000000000000ll) : b);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_dense_herm(int64_t n, const T *__restrict__ A, int64_t lda, unsigned long long *res) {
+  constexpr int TS = 64;
+  if (blockIdx.x > blockIdx.y) return;              // tile pairs (bi <= bj) only
+  __shared__ T ys[TS][TS + 1];
+  const int64_t r0 = (int64_t)blockIdx.x * TS, c0 = (int64_t)blockIdx.y * TS;
+  // mirror tile Y = A[c0 + q, r0 + p] -> ys[p][q], rows of Y contiguous across threads
+  for (int e = threadIdx.x; e < TS * TS; e += BLOCK) {
+    const int q = e % TS, p = e / TS;
+    const int64_t r = c0 + q, c = r0 + p;
+    ys[p][q] = (r < n && c < n) ? A[r + c * lda] : ST<T>::zero();
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int e = threadIdx.x; e < TS * TS; e += BLOCK) {
+    const int p = e % TS, q = e / TS;                // X[p, q] = A[r0 + p, c0 + q]
+    const int64_t r = r0 + p, c = c0 + q;
+    if (r < n && c < n) {
+      const T x = A[r + c * lda];
+      const T y = ST<T>::conj(ys[p][q]);
+      if constexpr (ST<T>::is_complex) bad = bad || !(x.re == y.re && x.im == y.im);
+      else bad = bad || !(x == y);
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&res[2], 1ull);
+}
+template <class T>
+void dense_props(hipStream_t s, int64_t n, const T *A, int64_t lda, double *scratch, int nsplit, unsigned long long *res) {
+  const int rows_per_block = BLOCK * Pack<T>::N;
+  const int gx = (int)((n + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(k_dense_rowabs<T>, dim3(gx, nsplit), dim3(BLOCK), 0, s, n, A, lda, scratch, n, res);
+  hipLaunchKernelGGL(k_dense_rowmax, dim3(1), dim3(BLOCK), 0, s, n, scratch, n, nsplit, res);
+  const int nt = (int)((n + 63) / 64);
+  hipLaunchKernelGGL(k_dense_herm<T>, dim3(nt, nt), dim3(BLOCK), 0, s, n, A, lda, res);
+}
+template void dense_props<double>(hipStream_t, int64_t, const double *, int64_t, double *, int, unsigned long long *);
+template void dense_props<cplx>(hipStream_t, int64_t, const cplx *, int64_t, double *, int, unsigned long long *);
+
 // K8: augmented operator [A B; 0 K] of kiops (arnoldi.jl:195-202): the A*x part is already in y[0:n)
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_aug_apply(int64_t n, int p, const T *__restrict__ B, int64_t ldb,

@@ -70,6 +70,17 @@ int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on);
  * one finishes (default on).  Off: one launch after the other on the context's stream -- same results; per-kernel
  * durations are then meaningful to a profiler. */
 int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
+/* Cumulative counters of a context: out[0] Krylov steps (operator applications inside arnoldi!/lanczos!), [1] factorisations,
+ * [2] of those on the single-pass pipeline, [3] of those with overlapped steps, [4] factorisations redone one launch after
+ * the other because a bounded device wait expired (device shared with other work), [5] redone on the two-kernel step because
+ * the wave form's tile wait expired, [6] operator applications outside a factorisation (phiv_timestep!'s recurrence, mul!),
+ * [7] reserved.  A non-zero [4] / [5] means the overlapped / wave form was switched off for the following 64 calls. */
+int expv_mi_ctx_counters(expv_mi_ctx_t ctx, int64_t out[8]);
+/* path flags of the most recent factorisation (also returned in expv_mi_expv_stats.path_flags) */
+enum {
+  EXPV_MI_PATH_MODULAR = 1, EXPV_MI_PATH_TWO_KERNEL = 2, EXPV_MI_PATH_PIPELINE = 4, EXPV_MI_PATH_WAVE = 8,
+  EXPV_MI_PATH_OVERLAPPED = 16, EXPV_MI_PATH_REDO_SERIAL = 32, EXPV_MI_PATH_REDO_WAVE_OFF = 64
+};
 const char *expv_mi_last_error(expv_mi_ctx_t ctx);
 const char *expv_mi_version(void);
 
@@ -175,7 +186,7 @@ typedef struct {
   int32_t m_used;        /* Ks.m after the factorisation      */
   int32_t wasbreakdown;
   int32_t matvecs;       /* operator applications performed   */
-  int32_t reserved;
+  int32_t path_flags;    /* EXPV_MI_PATH_* of the factorisation: which step form ran, whether a wait expired */
   double beta;
 } expv_mi_expv_stats;
 int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, const void *b, int b_loc,

@@ -30,6 +30,11 @@ def num_threads():
     return int(load().oracle_num_threads())
 
 
+def set_num_threads(n):
+    """OpenMP threads of the following calls (bench.py: all host threads, then 1)."""
+    load().oracle_set_num_threads(int(n))
+
+
 def _csr32(A):
     A = A.tocsr()
     A.sort_indices()

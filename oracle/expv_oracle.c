@@ -35,6 +35,16 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* bench.py's cpu_baseline leg times the same loop with all host threads and with ONE thread (the reference's CSC mul!
+ * and its BLAS-1 calls on a sparse problem are single-threaded: BASELINE.md section 3) */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* ---------------------------------------------------------------- real fp64 -------------- */
 static void spmv_d(int64_t n, const int32_t *rp, const int32_t *ci, const double *va, const double *x, double *y) {
 #pragma omp parallel for schedule(static)

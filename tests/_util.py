@@ -50,3 +50,30 @@ def mkA(n):
     A = 0.1 / (1 + np.abs(i - j)) * np.where(i < j, 1.0, 0.5)
     A[np.arange(n), np.arange(n)] = -2.0
     return A
+
+
+# every parity comparison goes through close(): the measured error is printed next to its bar (pytest -rP shows it,
+# a failing assert carries it) and appended to gpurun_out/parity_measured.jsonl when that directory exists, so the bars
+# quoted in DESIGN.md §5 are backed by numbers (tools/parity_report.py turns the file into profiles/rNN_parity_measured.txt)
+def close(a, b, tol, what, mat=False, absolute=False):
+    import json
+    import os
+    a = np.atleast_1d(np.asarray(a))
+    b = np.atleast_1d(np.asarray(b))
+    if absolute:
+        err = float(np.max(np.abs(a - b)))
+    elif mat:       # entrywise, relative to the largest entry (the Hessenberg bar of SURVEY.md §8c)
+        err = float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+    else:
+        err = relerr(a, b)
+    line = {"what": what, "err": err, "tol": tol}
+    print("[parity] %-90s err %.3e  (bar %.1e)" % (what, err, tol))
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        try:
+            with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+                f.write(json.dumps(line) + "\n")
+        except OSError:
+            pass
+    assert err <= tol, "%s: measured %.3e > bar %.1e" % (what, err, tol)
+    return err

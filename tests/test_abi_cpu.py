@@ -135,3 +135,24 @@ def test_host_pattern_info_selects_the_storage_forms(eu):
     unsorted = sp.csr_matrix((np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1]), np.array([0, 2, 3])), shape=(2, 2))
     unsorted.has_sorted_indices = True                                                     # keep scipy from sorting them
     assert eu.host_pattern_info(unsorted)["rows_sorted_unique"] in (True, False)
+
+
+def test_operator_fingerprint_detects_in_place_changes(eu):
+    """an implicitly uploaded host matrix is reused only while its content fingerprint is unchanged."""
+    import scipy.sparse as sp
+    from exponentialutilities_jl_amd import api
+    A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-2, -1, 0, 1, 2], shape=(2000, 2000), format="csr")
+    f0 = api._fingerprint(A)
+    assert api._fingerprint(A) == f0
+    A.data[1234] += 1e-13
+    f1 = api._fingerprint(A)
+    assert f1 != f0
+    A *= 0.5                      # rebinds A.data in scipy: pointer and checksum change
+    assert api._fingerprint(A) != f1
+    A.indices[7] = 9
+    assert api._fingerprint(A) != f1
+    D = np.arange(12.0).reshape(3, 4)[:, :3].copy()
+    g0 = api._fingerprint(D)
+    D[2, 1] = -D[2, 1]
+    assert api._fingerprint(D) != g0
+    assert api._fingerprint(np.zeros((3, 3), dtype=complex)) != api._fingerprint(np.zeros((3, 3)))

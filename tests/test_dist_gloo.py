@@ -82,3 +82,77 @@ def test_shard_range_partition():
                 covered += list(range(lo, hi))
             assert covered == list(range(nprob))
             assert max(D.shard_sizes(nprob, world)) - min(D.shard_sizes(nprob, world)) <= 1
+
+
+# ---- bench.py's config-5 driver (run_c5) end to end under gloo: sharding, batch call, gather, whole-job aggregation,
+#      ranks_seen, per-rank times and the recompute-two-columns verification.  The per-problem solver is a stand-in with
+#      the product's signatures (expv_batch / expv) backed by the oracle: the CODE PATH of bench.py is what is tested here,
+#      the HIP path behind the same signatures is covered by the -m gpu tests.
+class _StubEU:
+    @staticmethod
+    def expv(t, A, b, m=30, ishermitian=False, **kw):
+        from oracle import krylov_oracle as ko
+        return ko.expv(t, A.tocsr(), np.asarray(b), m=m, ishermitian=ishermitian)
+
+    @staticmethod
+    def expv_batch(t, A0, vals, B, m=30, ctx=None, **kw):
+        from oracle import krylov_oracle as ko
+        vals = vals.numpy() if hasattr(vals, "numpy") else np.asarray(vals)
+        Bn = B.numpy() if hasattr(B, "numpy") else np.asarray(B)
+        cols = []
+        for p in range(vals.shape[0]):
+            Ap = A0.copy()
+            Ap.data = vals[p].copy()
+            cols.append(ko.expv(t, Ap, Bn[:, p], m=m, ishermitian=False))
+        return torch.as_tensor(np.stack(cols, axis=1) if cols else np.zeros((A0.shape[0], 0)))
+
+
+def _c5_worker(rank, world, port, nprob, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    import json
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = bench.Env(torch, dist, world, rank, "cpu", None)
+        args = argparse.Namespace(nprob=nprob, steps=2, warmup=1)
+        out = bench.run_c5(args, _StubEU, env, n=n, m=10, emit=False)
+        json.dump(out, open(os.path.join(out_dir, f"c5_{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nprob", [5, 6])
+def test_bench_c5_driver_two_ranks(tmp_path, nprob):
+    import json
+    world, n = 2, 96
+    port = _free_port()
+    mp.spawn(_c5_worker, args=(world, port, nprob, n, str(tmp_path)), nprocs=world, join=True)
+    o0 = json.load(open(tmp_path / "c5_0.json"))
+    o1 = json.load(open(tmp_path / "c5_1.json"))
+    assert o0["ranks_seen"] == o1["ranks_seen"] == world
+    assert o0["n_gpus"] == world and o0["scaling"] == "strong"
+    assert len(o0["per_rank_ms_per_step"]) == world and all(v > 0 for v in o0["per_rank_ms_per_step"])
+    assert o0["value"] == o1["value"] > 0                           # SUM of units / MAX of time: the same on every rank
+    np.testing.assert_allclose(o0["value"], nprob * 10 * 2 / (o0["ms_per_step"] * 2e-3), rtol=1e-9)
+    assert o0["verified"]["max_rel_err"] <= 1e-12 and o0["verified"]["columns_per_rank"] == 2
+    assert o0["config"]["nprob"] == nprob
+
+
+def test_bench_byte_contracts_match_survey():
+    """SURVEY.md §8d figures, to the digit: C2 A_B = 64.0 MB, 6.384 GB per expv, 212.8 MB per matvec; per-step mean
+    A_B + 8n(j+2) = 204 MB; Lanczos variant 3.14 GB; C4 184 MB per Krylov step."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    n, nnz, m = 1_000_000, 5 * 1_000_000 - 6, 30
+    assert abs(bench.a_bytes(n, nnz) - 64.0e6) < 0.1e6
+    assert abs(bench.alg_bytes_expv(n, nnz, m) - 6.384e9) < 0.001e9
+    assert abs(bench.alg_bytes_expv(n, nnz, m) / m - 212.8e6) < 0.1e6
+    assert abs(bench.alg_bytes_step(n, nnz, m) - 204.0e6) < 0.1e6
+    assert abs(bench.alg_bytes_expv_window(n, nnz, m, 2) - 3.14e9) < 0.01e9
+    assert abs(bench.alg_bytes_kiops(n, nnz, 1, 0, 0) - 184.0e6) < 0.1e6
+    sym = bench.c2_operator(50, sym=True)
+    assert (sym != sym.T).nnz == 0 and (bench.c2_operator(50) != bench.c2_operator(50).T).nnz > 0

@@ -10,7 +10,7 @@ import scipy.sparse as sp
 
 from oracle import c_oracle as co
 from oracle import krylov_oracle as ko
-from tests._util import c2_operator, dense_phis, mkA, relerr, stencil2d
+from tests._util import c2_operator, close, dense_phis, mkA, relerr, stencil2d
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -40,8 +40,8 @@ def test_arnoldi_H_V_parity_sparse_real(eu, n, m, iop, ortho):
     ko.arnoldi_(Ko, A, b, m=m, iop=iop, ishermitian=False)
     assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
     assert abs(Ks.beta - Ko.beta) <= 1e-14 * Ko.beta
-    assert herr(Ks.getH(), Ko.getH()) <= TOL
-    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-11
+    close(Ks.getH(), Ko.getH(), TOL, "arnoldi H sparse real n=%d m=%d iop=%d %s" % (n, m, iop, ortho), mat=True)
+    close(Ks.getV(), Ko.getV(), TOL, "arnoldi V sparse real n=%d m=%d iop=%d %s (max abs)" % (n, m, iop, ortho), absolute=True)
 
 
 @pytest.mark.parametrize("ortho", ["mgs", "lowsync"])
@@ -61,8 +61,8 @@ def test_arnoldi_parity_other_operators(eu, kind, ortho):
     Ks = eu.arnoldi(A, b, m=m, ishermitian=False, ortho=ortho)
     Ko = ko.arnoldi(A, b, m=m, ishermitian=False)
     assert Ks.m == Ko.m
-    assert herr(Ks.getH(), Ko.getH()) <= TOL
-    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-11
+    close(Ks.getH(), Ko.getH(), TOL, "arnoldi H %s %s" % (kind, ortho), mat=True)
+    close(Ks.getV(), Ko.getV(), TOL, "arnoldi V %s %s (max abs)" % (kind, ortho), absolute=True)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -79,8 +79,8 @@ def test_lanczos_parity(eu, cplx):
     Ks = eu.arnoldi(A, b, m=m)          # ishermitian(A) -> lanczos!
     Ko = ko.arnoldi(A, b, m=m)
     assert Ks.U == np.float64 and Ks.m == Ko.m
-    assert herr(Ks.getH(), Ko.getH()) <= TOL
-    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= 1e-10
+    close(Ks.getH(), Ko.getH(), TOL, "lanczos H cplx=%s" % cplx, mat=True)
+    close(Ks.getV(), Ko.getV(), TOL, "lanczos V cplx=%s (max abs)" % cplx, absolute=True)
 
 
 def test_hermitian_H_real_arnoldi_vs_lanczos(eu):
@@ -175,7 +175,11 @@ def test_arnoldi_krylov_testset(eu):
     w3, st3 = eu.kiops(t, A, np.stack([b * (1 / t) ** i for i in range(K)], axis=1))
     assert relerr(w3[:, 0], W[:, :K].sum(axis=1)) < SQRT_EPS
     wo, so = ko.kiops(t, A, np.stack([b * (1 / t) ** i for i in range(K)], axis=1))
-    assert st3 == so and relerr(w3, wo) < 1e-10
+    assert st3 == so
+    # the one bar above 1e-12 in this file: the columns b * (1/t)^i span six orders of magnitude (t = 1e-2), kiops rescales the
+    # augmented block by mu = 2^20 (kiops.jl:94-103) and the result (norm ~ 4 |b|) is what is left after cancelling terms of
+    # size 1e6 |b|: two correct evaluations differ by ~1e6 eps.  Measured on MI355X: 7.5e-11 (profiles/r02_parity_measured.txt)
+    close(w3, wo, 1e-9, "kiops n=20 dense, 4 columns spanning 1e6 in scale vs oracle")
 
 
 def test_phiv_matrix_kat(eu):
@@ -233,7 +237,10 @@ def test_error_estimate_mode(eu):
     dw = np.linalg.norm(w - wp)
     assert dw < 1e-10 and dw / abs(1e-16 + np.linalg.norm(w)) < 1e-10
     wo = ko.expv(-1j, dt * A, b, m=m, tol=1e-10, rtol=1e-10, mode="error_estimate")
-    assert relerr(w, wo) < 1e-11
+    # rand(n, n) has one dominant eigenvalue (~n/2 against |lambda| < ~5): its Ritz value converges after ~5 steps and
+    # the Lanczos basis then loses orthogonality completely (max |V'V - I| = 0.79 at the stopping step m = 11, in the
+    # reference's recurrence too), so two correct recurrences differ by rounding x that amplification: measured 6.6e-12
+    close(w, wo, 1e-10, "error_estimate mode vs oracle (basis has lost orthogonality: 0.79)")
     wz = eu.expv(-1j, dt * A, np.zeros(n, dtype=complex), m=m, tol=1e-10, rtol=1e-10, mode="error_estimate")
     assert np.linalg.norm(wz) == 0
     with pytest.raises(RuntimeError):
@@ -264,7 +271,7 @@ def test_adaptive_krylov(eu):
     Uo = ko.phiv_timestep(np.array([t / 2, t]), A, B, adaptive=True, tol=tol, stats=so)
     assert relerr(U[:, 0], uhalf) < tol and relerr(U[:, 1], u_exact) < tol
     assert st["num_timesteps"] == so["num_timesteps"] and st["matvecs"] == so["matvecs"] and st["m"] == so["m"]
-    assert relerr(U, Uo) < 1e-10
+    close(U, Uo, TOL, "phiv_timestep adaptive sparse n=100 U vs oracle")
     u_exact0 = Ph[0] @ B[:, 0]
     opn = lambda M, p: abs(M).sum(axis=1).max()
     assert relerr(eu.expv_timestep(t, A, B[:, 0], adaptive=True, tol=tol, opnorm=opn), u_exact0) < tol
@@ -294,7 +301,8 @@ def test_expv_timestep_300_snapshots_complex_sparse(eu):
     ts = np.linspace(0, 1, 300)
     E1 = ko.expv_timestep(ts.copy(), A, b)
     E2 = eu.expv_timestep(ts.copy(), A, b)
-    assert relerr(E2, E1) < SQRT_EPS
+    # (the reference's own bar for this test is sqrt(eps): test/gpu/gputests.jl:58 uses isapprox)
+    close(E2, E1, TOL, "expv_timestep 300 snapshots complex sparse vs oracle")
 
 
 def test_kiops_parity(eu):
@@ -306,7 +314,7 @@ def test_kiops_parity(eu):
         w, st = eu.kiops(1.0, herm_A, u)
         wo, so = ko.kiops(1.0, herm_A, u)
         assert st == so
-        assert relerr(w, wo) < 1e-9
+        close(w, wo, TOL, "kiops real n=400, 3 columns vs oracle")
     with pytest.raises(eu.DimensionMismatch):
         eu.kiops(np.array([[0.5, 1.0]]), A, u[:, 0])
     with pytest.raises(TypeError):
@@ -324,7 +332,8 @@ def test_kiops_complex_extension(eu):
     truth = sl.expm(A.toarray()) @ u
     assert relerr(w[:, 0], truth) < 1e-6
     wo, so = ko.kiops(1.0, A, u, allow_complex=True, ishermitian=False)
-    assert st == so and relerr(w, wo) < 1e-9
+    assert st == so
+    close(w, wo, TOL, "kiops complex extension n=300 vs oracle")
 
 
 # ------------------------------------------------------------------ full-size properties -----
@@ -336,15 +345,15 @@ def test_c2_full_size_parity_with_c_oracle(eu):
     Ks = eu.arnoldi(A, b, m=m)
     r = co.arnoldi_csr(A, b, m=m)
     assert Ks.m == r["m"] == m
-    assert herr(Ks.getH(), r["H"]) <= TOL
+    close(Ks.getH(), r["H"], TOL, "C2 full size H vs C oracle", mat=True)
     w = eu.expv_(np.empty(n), 1.0, Ks)
     wo, _ = co.expv_csr(1.0, A, b, m=m)
-    assert relerr(w, wo) <= TOL
+    close(w, wo, TOL, "C2 full size w vs C oracle")
     # size-independent properties: group property and linearity of exp(tA)
     back = eu.expv(-1.0, A, w, m=m)
-    assert relerr(back, b) < 1e-9
+    close(back, b, 1e-9, "C2 full size group property exp(-A) exp(A) b = b (m = 30 truncation both ways)")
     w2 = eu.expv(1.0, A, 2.5 * b, m=m)
-    assert relerr(w2, 2.5 * w) < 1e-13
+    close(w2, 2.5 * w, 1e-13, "C2 full size linearity")
 
 
 def test_c2_symmetric_and_stencil_variants(eu):
@@ -353,12 +362,12 @@ def test_c2_symmetric_and_stencil_variants(eu):
     As = c2_operator(n, sym=True)
     w = eu.expv(1.0, As, b, m=m)
     wo, r = co.expv_csr(1.0, As, b, m=m, hermitian=True)
-    assert relerr(w, wo) <= 1e-11
+    close(w, wo, TOL, "C2 symmetric variant n=2e5 (Lanczos) w vs C oracle")
     St = stencil2d(448)
     bs = np.random.default_rng(4).standard_normal(St.shape[0])
     ws = eu.expv(0.2, St, bs, m=m)
     wso, _ = co.expv_csr(0.2, St, bs, m=m)
-    assert relerr(ws, wso) <= TOL
+    close(ws, wso, TOL, "2-D stencil n=448^2 w vs C oracle")
 
 
 def test_device_resident_vectors(eu):
@@ -422,9 +431,9 @@ def test_sizes_around_tile_boundaries(eu, n):
         Ko = ko.arnoldi(A, b, m=m, ishermitian=False)
         assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
         mm = Ks.m
-        assert herr(Ks.H[: mm + 1, :mm], Ko.H[: mm + 1, :mm]) <= 1e-10      # near-breakdown columns amplify rounding
+        close(Ks.H[: mm + 1, :mm], Ko.H[: mm + 1, :mm], TOL, "H at ragged size n=%d %s" % (n, ortho), mat=True)
         w = eu.expv_(np.empty(n), 0.7, Ks)
-        assert relerr(w, sl.expm(0.7 * A.toarray()) @ b) < 1e-9
+        close(w, sl.expm(0.7 * A.toarray()) @ b, 1e-9, "expv at ragged size n=%d vs dense truth (m = 30 truncation)" % n)
 
 
 def test_m_larger_than_n_breaks_down(eu):
@@ -478,7 +487,7 @@ def test_window_longer_than_one_chunk_and_iop(eu):
         Ko = ko.KrylovSubspace(float, float, n, m)
         ko.arnoldi_(Ko, A, b, m=m, iop=iop, ishermitian=False)
         assert Ks.m == Ko.m
-        assert herr(Ks.getH(), Ko.getH()) <= 1e-11
+        close(Ks.getH(), Ko.getH(), TOL, "H stencil n=3000 m=%d iop=%d" % (m, iop), mat=True)
 
 
 def test_timestep_sorts_ts_in_place_and_matrix_output(eu):
@@ -489,7 +498,7 @@ def test_timestep_sorts_ts_in_place_and_matrix_output(eu):
     ts = np.array([0.9, 0.1, 0.5])
     U = eu.expv_timestep(ts, A, b, tol=1e-9)
     Uo = ko.expv_timestep(np.array([0.9, 0.1, 0.5]), A, b, tol=1e-9)
-    assert relerr(U, Uo) < 1e-10
+    close(U, Uo, TOL, "expv_timestep unsorted ts vs oracle")
     for j, t in enumerate(sorted([0.9, 0.1, 0.5])):       # non-adaptive, m = 10: the method's own accuracy
         assert relerr(U[:, j], sl.expm(t * A.toarray()) @ b) < 1e-5
 
@@ -540,12 +549,13 @@ def test_banded_operator_forms(eu, case):
     # between two correct orthogonalisations are amplified by that loss, so the bar scales with it
     Vo = Ko.V[:, : m + 1]
     loss = float(np.max(np.abs(Vo.T @ Vo - np.eye(m + 1))))
-    assert herr(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m]) <= max(TOL, 10 * loss)
+    print("[parity] %-90s loss of orthogonality of the oracle's own basis: %.3e" % ("banded forms: " + case, loss))
+    close(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m], max(TOL, 10 * loss), "banded form %s: H" % case, mat=True)
     w = eu.expv_(np.empty(n), 0.5, Ks)
     wo = ko.expv_(np.empty(n), 0.5, Ko)
-    assert relerr(w, wo) < max(1e-11, 10 * loss)
-    assert np.max(np.abs(Ks.getV() - Ko.getV())) <= max(1e-10, 100 * loss)
-    assert relerr(eu.expv(0.5, A, b, m=m, ishermitian=herm), wo) < max(1e-11, 10 * loss)     # whole-call form
+    close(w, wo, max(TOL, 10 * loss), "banded form %s: w" % case)
+    close(Ks.getV(), Ko.getV(), max(TOL, 100 * loss), "banded form %s: V (max abs)" % case, absolute=True)
+    close(eu.expv(0.5, A, b, m=m, ishermitian=herm), wo, max(TOL, 10 * loss), "banded form %s: whole-call w" % case)
 
 
 def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
@@ -584,7 +594,7 @@ def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
     got = np.load(out)
     assert relerr(got[0], wo) < 1e-12
     G = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-150, -1, 0, 1, 150], shape=A.shape, format="csr")
-    assert relerr(got[1], ko.expv(0.9, G, b, m=m, ishermitian=False)) < 1e-11      # wave -> two-kernel step after the expired wait
+    close(got[1], ko.expv(0.9, G, b, m=m, ishermitian=False), TOL, "wave -> two-kernel step after the expired wait")
     os.remove(out)
 
 
@@ -655,16 +665,17 @@ def test_wide_diagonal_operators_wave_form(eu, case):
     assert Ks.m == Km.m and Ks.wasbreakdown == Km.wasbreakdown
     Vm = Km.getV()[:, : m + 1]
     loss = float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1))))           # rounding differences scale with this
-    tol = max(1e-11, 10 * loss)
-    assert herr(Ks.H[: m + 1, :m], Km.H[: m + 1, :m]) <= tol
+    tol = max(TOL, 10 * loss)
+    print("[parity] %-90s loss of orthogonality of the strict-MGS basis: %.3e" % ("wave form: " + case, loss))
+    close(Ks.H[: m + 1, :m], Km.H[: m + 1, :m], tol, "wave form %s: H vs strict MGS" % case, mat=True)
     w = eu.expv(0.4, A, b, m=m, ishermitian=herm)
     wm = eu.expv_(np.empty(n), 0.4, Km)
-    assert relerr(w, wm) < tol
-    assert np.max(np.abs(Ks.getV()[:, : m + 1] - Vm)) <= 100 * tol
+    close(w, wm, tol, "wave form %s: w vs strict MGS" % case)
+    close(Ks.getV()[:, : m + 1], Vm, 100 * tol, "wave form %s: V vs strict MGS (max abs)" % case, absolute=True)
     if n <= 100_000:
         Ko = ko.arnoldi(A, b, m=m, ishermitian=herm)
-        assert herr(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m]) <= tol
-        assert relerr(w, ko.expv_(np.empty(n), 0.4, Ko)) < tol
+        close(Ks.H[: m + 1, :m], Ko.H[: m + 1, :m], tol, "wave form %s: H vs oracle" % case, mat=True)
+        close(w, ko.expv_(np.empty(n), 0.4, Ko), tol, "wave form %s: w vs oracle" % case)
 
 
 @pytest.mark.parametrize("n,m,band", [(60_000, 20, 1500), (650_000, 30, 2500)])
@@ -684,10 +695,10 @@ def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
     Ks = eu.arnoldi(A, b, m=m, ishermitian=False)
     Km = eu.arnoldi(A, b, m=m, ishermitian=False, ortho="mgs")
     Vm = Km.getV()[:, : m + 1]
-    tol = max(1e-11, 10 * float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1)))))
+    tol = max(TOL, 10 * float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1)))))
     assert Ks.m == Km.m and Ks.wasbreakdown == Km.wasbreakdown
-    assert herr(Ks.H[: m + 1, :m], Km.H[: m + 1, :m]) <= tol
+    close(Ks.H[: m + 1, :m], Km.H[: m + 1, :m], tol, "SELL wave form n=%d: H vs strict MGS" % n, mat=True)
     w = eu.expv(0.4, A, b, m=m, ishermitian=False)
-    assert relerr(w, eu.expv_(np.empty(n), 0.4, Km)) < tol
+    close(w, eu.expv_(np.empty(n), 0.4, Km), tol, "SELL wave form n=%d: w vs strict MGS" % n)
     if n <= 100_000:
-        assert relerr(w, ko.expv(0.4, A, b, m=m, ishermitian=False)) < tol
+        close(w, ko.expv(0.4, A, b, m=m, ishermitian=False), tol, "SELL wave form n=%d: w vs oracle" % n)
