@@ -11,7 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libexpv_mi.so")
 SOURCES = ["kernels.hip", "fused.hip", "pipe.hip", "engine_core.hip", "engine_drivers.hip", "engine_batch.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma"]   # host small-dense exp: every MI355X host is x86-64-v3
+         "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma",
+         "-Xarch_host", "-fcx-limited-range"]   # complex products of the host small-dense code: plain (ac-bd, ad+bc), no __muldc3 NaN recovery   # host small-dense exp: every MI355X host is x86-64-v3
 
 
 def _hipcc():
@@ -61,5 +62,24 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_trace(verbose=True):
+    """libexpv_mi_trace.so: the same library with pipe.hip compiled under -DPIPE_TRACE (per-workgroup wall_clock64 stamps of the
+    single-pass step; tools/pipe_trace.py).  Profiling aid only -- never loaded by the product or the tests."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    tobj = os.path.join(objdir, "pipe_trace.o")
+    cmd = [hipcc] + FLAGS + ["-DPIPE_TRACE", "-c", os.path.join(CSRC, "pipe.hip"), "-o", tobj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES if s != "pipe.hip"] + [tobj]
+    out = os.path.join(HERE, "libexpv_mi_trace.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_trace() if "--trace" in sys.argv else build(force="--force" in sys.argv))

@@ -178,6 +178,7 @@ struct Ks {
   int ldg = 0;
   int gram_rows = 0;   // leading basis vectors whose Gram rows are valid
   DevBuf hcoef, part, gpart, state;
+  StepState state_host;   // staging of the step-state reset of a continuation (asynchronous copy source)
   void *pin = nullptr;   // pinned host staging for the Hessenberg / step-state read-back
   size_t pin_bytes = 0;
   ~Ks() {

@@ -262,6 +262,45 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
   int64_t wave_reach = 0;
 
+  const bool fresh = (init == 0);
+  // ---- which step form runs ----------------------------------------------------------------
+  static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
+  static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
+  single_red = !fused_v1;
+  // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
+  //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
+  use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
+              o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+  // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
+  static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
+  if constexpr (!ST<T>::is_complex) {
+    use_pipe = use_fused && single_red && !isaug && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+               m <= dev::PIPE_CH && !real_coeff;
+    // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
+    // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
+    static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
+    static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
+    const int64_t ntiles_w = (ks.n + 511) / 512;
+    if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
+    const bool wave_dia = op.gndiag > 0 && !no_gdia_w;
+    const bool wave_sell = !wave_dia && op.tile_reach >= 0;
+    const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
+    if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
+        m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
+      use_pipe = true;
+      use_wave = true;
+      wave_reach = reach_rows;
+    }
+  }
+  if (!fresh) {
+    // a continuation (init > 0: kiops after a rejected step, arnoldi!(...; init)) reads the stored, NORMALISED basis: the
+    // single-reduction two-kernel step takes it from any column (its first pass treats v_init as already normalised);
+    // the single-pass pipeline keeps un-normalised columns + scales during a factorisation and always starts at step 1
+    use_pipe = use_wave = false;
+    if (!single_red) use_fused = false;
+    const int wcont = lanczos ? 2 : std::min(o.iop == 0 ? m : o.iop, m);
+    if (!lanczos && wcont >= 3 && ks.gram_rows < (lanczos ? 0 : init) - 1) use_fused = false;   // Gram rows of the older window columns missing
+  }
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
       std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
@@ -280,34 +319,6 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         extra += aug->w_aug_host[k - 1] * aug->w_aug_host[k - 1];
       }
       src = reinterpret_cast<const T *>(aug->w);
-    }
-    static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
-    static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
-    single_red = !fused_v1;
-    // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
-    //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
-    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
-                o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
-    // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
-    static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
-    if constexpr (!ST<T>::is_complex) {
-      use_pipe = use_fused && single_red && !isaug && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
-                 m <= dev::PIPE_CH && !real_coeff;
-      // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
-      // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
-      static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
-      static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
-      const int64_t ntiles_w = (ks.n + 511) / 512;
-      if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
-      const bool wave_dia = op.gndiag > 0 && !no_gdia_w;
-      const bool wave_sell = !wave_dia && op.tile_reach >= 0;
-      const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
-      if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
-          m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
-        use_pipe = true;
-        use_wave = true;
-        wave_reach = reach_rows;
-      }
     }
     if (use_pipe) {
       // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
@@ -357,11 +368,12 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
 
   // reset the device step state; zero the columns of Hdev this call will fill
   {
-    if (!use_fused) {   // fused path: the sumsq epilogue left {hnorm = beta_0, m_done = 0} on the device
-      StepState z;
+    if (!use_fused || !fresh) {   // fresh fused path: the first pass leaves {hnorm = beta_0, m_done = 0} on the device itself
+      StepState &z = ks.state_host;   // (member: the copy below is asynchronous)
       std::memset(&z, 0, sizeof(z));
       z.m_done = jstart - 1;
       z.hnorm = ks.beta;
+      z.inv = 1.0;
       z.beta0sq = ks.beta * ks.beta;
       HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
     }
@@ -535,7 +547,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
     T *yb = ks.ybuf.as<T>();
     dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
-    for (int j = 1; j <= m; ++j) {
+    for (int j = jstart; j <= m; ++j) {
       const int i0 = lanczos ? j : std::max(1, j - iop + 1);
       const int nd = j - i0 + 1;
       dev::FusedAArgs<T> fa{};
@@ -543,6 +555,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       fa.u = V + (size_t)(j - 1) * ks.ldv;
       fa.ybuf = yb;
       fa.step = j;
+      fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       static const bool no_gdia = std::getenv("EXPV_MI_NO_DIA") != nullptr;
       if (op.gndiag > 0 && !no_gdia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
@@ -734,7 +747,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     c->last_path |= EXPV_MI_PATH_REDO_SERIAL;
     return r;
   }
-  if (use_fused) {
+  if (use_fused && fresh) {
     ks.beta = std::sqrt(h.beta0sq);
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
   }

@@ -319,17 +319,21 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
   if (!hier_reduce(a.st, a.part, a.gpart, NV + 1, vals_s, &flag_s)) return;
 
   // ---- last workgroup: finish step j-1 (norm, breakdown) and produce the column of step j -------
-  const double beta = sqrt(vals_s[NV]);
-  const double inv = 1.0 / beta;
+  // (continuation: u is the stored, normalised v_j -- its norm is 1 by construction, H[j, j-1] and the breakdown test of
+  //  step j-1 belong to the call that produced it)
+  const double beta = fa.cont ? 1.0 : sqrt(vals_s[NV]);
+  const double inv = fa.cont ? 1.0 : 1.0 / beta;
   const int jcol = a.jcol;
   bool stop = false;
-  if (fa.step == 1) stop = (beta == 0.0);                  // iszero(Ks.beta) && return  (arnoldi.jl:366)
+  if (fa.cont) stop = false;
+  else if (fa.step == 1) stop = (beta == 0.0);             // iszero(Ks.beta) && return  (arnoldi.jl:366)
   else stop = (beta < tol);                                // happy breakdown of step j-1  (arnoldi.jl:370)
   if (threadIdx.x == 0) {
-    a.st->hnorm = beta;
+    if (!fa.cont) a.st->hnorm = beta;
     a.st->inv = inv;
     a.st->m_done = fa.step - 1;
-    if (fa.step == 1) a.st->beta0sq = vals_s[NV];
+    if (fa.cont) {
+    } else if (fa.step == 1) a.st->beta0sq = vals_s[NV];
     else a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh] = ST<T>::from_real(beta);   // H[j, j-1] = ||u_j||
     if (stop) a.st->breakdown = (fa.step == 1) ? 2 : 1;
   }

@@ -110,6 +110,7 @@ struct FusedAArgs {
   T *ybuf;           // out: A * v_j
   DotsArgs<T> d;     // d.V/ldv/n, window, reduction buffers, epilogue targets; d.y = ybuf, d.x = V[:, jcol]
   int step;
+  int cont;          // single-reduction step only: first step of a continuation -- u IS v_j (normalised), no H[j, j-1] / breakdown test
   // augmented operator [A B; 0 K] of kiops (arnoldi.jl:195-202), single-reduction step only: rows n_op .. n_op+aug_p-1
   // are the shift block, rows < n_op get + B x[n_op:].  aug_p == 0: plain operator (d.n == n_op).
   int aug_p;
