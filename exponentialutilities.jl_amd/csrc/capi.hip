@@ -160,7 +160,7 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
   std::sort(P.offsets.begin(), P.offsets.end());
   const int nd = (int)P.offsets.size();
   P.fill_ok = nd > 0 && (double)nd * (double)n <= 1.3 * (double)nnz + 1024.0;
-  const bool dia_base = P.sell_ok && value_bytes == 8 && P.sorted_unique && P.fill_ok;
+  const bool dia_base = P.sell_ok && P.sorted_unique && P.fill_ok;   // fp64 and complex-fp64
   P.pipe_dia = dia_base && P.bandwidth <= dev::PIPE_WMAX && nd <= dev::PIPE_DIA_MAX;
   P.general_dia = !P.pipe_dia && P.sell_ok && P.sorted_unique && P.fill_ok && P.bandwidth <= INT32_MAX;   // fp64 and complex
   if (P.sell_ok && value_bytes == 8 && !P.pipe_dia && !P.general_dia) {
@@ -220,11 +220,12 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
   op.sell_ok = true;
 }
 
-// DIA form for the banded pipeline (fp64): the distinct offsets col-row, ascending; built when there are at most
+// DIA form for the banded pipeline (fp64 and complex-fp64): the distinct offsets col-row, ascending; built when there are at most
 // PIPE_DIA_MAX of them, rows are free of duplicate entries and the zero fill stays below 30 %.  Absent entries are
 // explicit zeros, so a row's sum runs over the same terms, in ascending-column order, plus exact zeros.
+template <class V>
 inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                      const std::vector<double> &va, const PatternPlan &P) {
+                      const std::vector<V> &va, const PatternPlan &P) {
   op.ndiag = 0;
   if (!P.pipe_dia) return;
   const int W = dev::PIPE_WMAX;
@@ -232,22 +233,30 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
   const int64_t ld = (n + 511) / 512 * 512;
   int slot_of[2 * dev::PIPE_WMAX + 1];
   for (int d = 0; d < nd; ++d) slot_of[P.offsets[d] + W] = d;
-  std::vector<double> dv((size_t)nd * (size_t)ld, 0.0);
+  std::vector<V> dv((size_t)nd * (size_t)ld, V(0));
   for (int64_t r = 0; r < n; ++r)
     for (int32_t k = rp[r]; k < rp[r + 1]; ++k) dv[(size_t)slot_of[ci[k] - r + W] * (size_t)ld + (size_t)r] = va[k];
-  op.dia_val.alloc(sizeof(double) * dv.size());
-  HIPCHECK(hipMemcpyAsync(op.dia_val.p, dv.data(), sizeof(double) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  std::vector<int32_t> o32(nd);
+  for (int d = 0; d < nd; ++d) o32[d] = (int32_t)P.offsets[d];
+  op.dia_val.alloc(sizeof(V) * dv.size());
+  op.gdia_off.alloc(sizeof(int32_t) * nd);
+  HIPCHECK(hipMemcpyAsync(op.dia_val.p, dv.data(), sizeof(V) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.gdia_off.p, o32.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
   op.ndiag = nd;
   op.dia_ld = ld;
   for (int d = 0; d < nd; ++d) op.dia_off[d] = (int)P.offsets[d];
+  // the two-kernel step reads the same [ndiag][ld] array through its "general DIA" arguments (device offsets)
+  op.gndiag = nd;
+  op.gdia_ld = ld;
+  op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)P.offsets.front()), std::llabs((long long)P.offsets.back()));
+  op.gdia_alias = true;
 }
 // General DIA form (any offsets): structured-grid stencils whose bandwidth is too wide for the banded pipeline.  Same
 // rules otherwise: rows sorted and free of duplicates, at most GDIA_MAX distinct offsets, zero fill below 30 %.
 template <class V>
 inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
                        const std::vector<V> &va, const PatternPlan &P) {
-  op.gndiag = 0;
   if (!P.general_dia) return;
   const std::vector<int64_t> &offs = P.offsets;
   const int nd = (int)offs.size();
@@ -270,11 +279,6 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
   op.gdia_ld = ld;
   op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)offs.front()), std::llabs((long long)offs.back()));
 }
-template <class V>
-inline void maybe_build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                            const std::vector<V> &va, const PatternPlan &P) {
-  if constexpr (std::is_same<V, double>::value) build_dia(op, n, rp, ci, va, P);
-}
 
 template <class V>
 void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
@@ -289,7 +293,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   upload_csr<V>(op, rp, ci, va);
   build_sell<V>(op, n, rp, ci, va);
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
-  if (op.sell_ok) maybe_build_dia<V>(op, n, rp, ci, va, P);
+  if (op.sell_ok) build_dia<V>(op, n, rp, ci, va, P);
   if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va, P);
   if (op.sell_ok && P.tile_reach >= 0) {
     // wave form on SELL slots: which tiles does a tile's piece of A read u from?

@@ -146,6 +146,8 @@ struct Op {
   DevBuf tile_lo, tile_hi;   // per 512-row tile: first / last tile its columns lie in (wave form on SELL slots)
   int64_t tile_reach = -1;   // largest distance (rows) between a tile and a tile it reads from; -1: not computed
   DevBuf gdia_val, gdia_off;
+  bool gdia_alias = false;   // the general-DIA arguments point at the banded form's array (dia_val): same [ndiag][ld] layout
+  template <class T> const T *gdia_ptr() const { return reinterpret_cast<const T *>(gdia_alias ? dia_val.p : gdia_val.p); }
   int gndiag = 0;
   int64_t gdia_ld = 0, gdia_maxoff = 0;
   DevBuf dense;              // owned copy when created from host

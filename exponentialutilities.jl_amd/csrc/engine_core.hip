@@ -70,9 +70,11 @@ static void ks_alloc_aux(Ks &ks) {
   ks.hcoef.alloc((size_t)(ks.maxiter + 2) * esz);
   if (!ks.part.p) ks.part.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GRID * sizeof(double));
   if (!ks.gpart.p) ks.gpart.alloc((size_t)(dev::MAX_RED_VALUES + 8) * dev::MAX_GROUPS * sizeof(double));
-  if (!ks.state.p) {
-    ks.state.alloc(sizeof(StepState) + sizeof(uint32_t) * (size_t)dev::PIPE_ARRIVE_STEP * (dev::PIPE_CH + 2));   // + arrival counters
-    HIPCHECK(hipMemsetAsync(ks.state.p, 0, sizeof(StepState), ks.ctx->stream));
+  // step state + behind it the arrival counters of the overlapped pipeline: one set per step (+ closing pass)
+  const size_t state_bytes = sizeof(StepState) + sizeof(uint32_t) * (size_t)dev::PIPE_ARRIVE_STEP * (size_t)(std::max(ks.maxiter, dev::PIPE_CH) + 3);
+  if (ks.state.bytes < state_bytes) {
+    ks.state.alloc(state_bytes);
+    HIPCHECK(hipMemsetAsync(ks.state.p, 0, state_bytes, ks.ctx->stream));
   }
 }
 
@@ -138,8 +140,10 @@ void ks_resize(Ks &ks, int maxiter) {  // arnoldi.jl:80-93
 void ks_materialize(Ks &ks) {
   if (!ks.scale_pending) return;
   ks.ctx->use();
-  if (ks.dtypeT == EXPV_MI_F64 && ks.scale_cols > 0)
-    dev::scale_columns(ks.ctx->stream, ks.V.as<double>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+  if (ks.scale_cols > 0) {
+    if (ks.dtypeT == EXPV_MI_F64) dev::scale_columns<double>(ks.ctx->stream, ks.V.as<double>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+    else dev::scale_columns<cplx>(ks.ctx->stream, ks.V.as<cplx>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+  }
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
   ks.scale_pending = false;
   ks.scale_cols = 0;
@@ -245,8 +249,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   const double tol = o.tol;
   int init = o.init;
   ks.wasbreakdown = false;
-  if (init != 0) ks_materialize(ks);        // a continuation reads the stored basis
-  else { ks.scale_pending = false; ks.scale_cols = 0; }   // a fresh factorisation overwrites it
+  if (init == 0) { ks.scale_pending = false; ks.scale_cols = 0; }   // a fresh factorisation overwrites the stored basis
   if (m > ks.maxiter) ks_resize(ks, m);
   else ks.m = m;
   // checkdims (arnoldi.jl:207-220)
@@ -273,33 +276,45 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
               o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
   // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
   static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
+  static const bool no_dia_env = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
+  {
+    // the update window of a pass is the projection window of the step before it: at most min(m - 1, iop) columns
+    // (2 for Lanczos), min(m, iop) for the closing pass that produces v_{m+1}
+    const int iopw = lanczos ? 2 : (o.iop == 0 ? m : std::min(o.iop, m));
+    const int wstep = std::min(m - 1, iopw);
+    const bool have_dia = op.ndiag > 0 && !no_dia_env;
+    use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+               wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
+               (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
+               (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
+  }
   if constexpr (!ST<T>::is_complex) {
-    use_pipe = use_fused && single_red && !isaug && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
-               m <= dev::PIPE_CH && !real_coeff;
     // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
     // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
     static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
-    static const bool no_gdia_w = std::getenv("EXPV_MI_NO_DIA") != nullptr;
     const int64_t ntiles_w = (ks.n + 511) / 512;
     if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
-    const bool wave_dia = op.gndiag > 0 && !no_gdia_w;
+    const bool wave_dia = op.gndiag > 0 && !no_dia_env;
     const bool wave_sell = !wave_dia && op.tile_reach >= 0;
     const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
     if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
-        m <= dev::PIPE_CH && !real_coeff && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
+        m <= dev::PIPE_CH && !real_coeff && fresh && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
       use_pipe = true;
       use_wave = true;
       wave_reach = reach_rows;
     }
   }
   if (!fresh) {
-    // a continuation (init > 0: kiops after a rejected step, arnoldi!(...; init)) reads the stored, NORMALISED basis: the
-    // single-reduction two-kernel step takes it from any column (its first pass treats v_init as already normalised);
-    // the single-pass pipeline keeps un-normalised columns + scales during a factorisation and always starts at step 1
-    use_pipe = use_wave = false;
-    if (!single_red) use_fused = false;
+    // a continuation (init > 0: kiops after a rejected step, arnoldi!(...; init)) reads the stored, NORMALISED basis: its
+    // first pass treats v_init as already normalised (pipe.hip / fused.hip `cont`).  Windows of 3+ columns need the Gram
+    // rows of the older window columns from the call that produced them.
+    if (!single_red) use_fused = use_pipe = false;
     const int wcont = lanczos ? 2 : std::min(o.iop == 0 ? m : o.iop, m);
-    if (!lanczos && wcont >= 3 && ks.gram_rows < (lanczos ? 0 : init) - 1) use_fused = false;   // Gram rows of the older window columns missing
+    if (!lanczos && wcont >= 3 && ks.gram_rows < init - 1) use_fused = use_pipe = false;
+    if (!use_fused) use_pipe = false;
+    // a continuation reads the stored basis: the pipeline takes un-normalised columns + their scales as they are,
+    // every other path needs them normalised
+    if (!use_pipe) ks_materialize(ks);
   }
   if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
     for (int j = 0; j < hview_cols; ++j)
@@ -387,26 +402,41 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   const int ortho = o.ortho;
 
   if (use_pipe) {
-    if constexpr (!ST<T>::is_complex) {
+    {
       // ---- single-pass banded pipeline: ONE launch, ONE reduction, ONE read of V per step (pipe.hip) --
       const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
       if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
       if (ks.hcoef2.bytes < ks.hcoef.bytes) ks.hcoef2.alloc(ks.hcoef.bytes);
       if (ks.colscale.bytes < sizeof(double) * (size_t)(ks.maxiter + 2)) ks.colscale.alloc(sizeof(double) * (size_t)(ks.maxiter + 2));
-      double *ya = ks.ybuf.as<double>(), *yb2 = ks.ubuf.as<double>();
-      double *hca = ks.hcoef.as<double>(), *hcb = ks.hcoef2.as<double>();
-      dev::SellView<double> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<double>(), op.nslices};
+      T *ya = ks.ybuf.as<T>(), *yb2 = ks.ubuf.as<T>();
+      T *hca = ks.hcoef.as<T>(), *hcb = ks.hcoef2.as<T>();
+      dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
       // Overlapped form (default): consecutive steps on two streams, the next step's kernel starts while this one
       // finishes (pipe.hip).  EXPV_MI_PIPE_SERIAL=1 / profiling / a previous expired wait: one stream, one launch
       // after the other.
       ht_mark(1);
       static const bool serial_env = std::getenv("EXPV_MI_PIPE_SERIAL") != nullptr;
-      static const bool no_dia = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
       // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
       static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
       if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
-      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && m >= 2;
+      const int nsteps = m - jstart + 1;
+      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && nsteps >= 2;
+      const int iopw = lanczos ? 2 : iop;
+      // overlapped form with the tail requested: one more (closing) pass produces v_{m+1}, H[m+1, m] and the
+      // breakdown test of step m instead of the update2 + norm_final launches below
+      const bool closing = live && !ks.skip_tail && std::min(m, iopw) <= dev::pipe_max_window<T>();
       hipStream_t s2 = nullptr;
+      auto next_seq = [&]() {
+        ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;
+        if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+      };
+      if (!fresh) {
+        // continuation: the stored columns keep their scales (all 1 when the basis has been materialised since); the
+        // arrival counters of the steps of this call start at 0
+        if (!ks.scale_pending || (int)ks.colscale_host.size() < ks.maxiter + 2) ks.colscale_host.assign(ks.maxiter + 2, 1.0);
+        HIPCHECK(hipMemcpyAsync(ks.colscale.p, ks.colscale_host.data(), sizeof(double) * (size_t)jstart, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(ks.state.as<char>() + sizeof(StepState), 0, ks.state.bytes - sizeof(StepState), s));
+      }
       if (live) {
         c->ensure_aux();
         s2 = c->stream2;
@@ -417,11 +447,8 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         // the last kernel mirrors H, the scales and the final state into host-mapped memory and raises a flag there,
         // so the host continues the moment the last step is done (no copy engine, no stream sync)
         ks.mbox_armed = false;
-        if (ks.skip_tail || m + 1 <= dev::PIPE_CH - 1) (void)mailbox_arm(ks, m);
-        if (!ks.mbox_armed) {   // the flags still need a fresh sequence number
-          ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
-          if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-        }
+        if (ks.skip_tail || closing) (void)mailbox_arm(ks, m);
+        if (!ks.mbox_armed) next_seq();   // the flags still need a fresh sequence number
         HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
         HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
       }
@@ -434,54 +461,60 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         if (!live) {   // (the overlapped form arms the mailbox and takes its sequence number above)
           ks.mbox_armed = false;
           if (ks.skip_tail) (void)mailbox_arm(ks, m);
-          if (!ks.mbox_armed) {
-            ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
-            if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-          }
+          if (!ks.mbox_armed) next_seq();
         }
       }
       {
-        // overlapped kernels have no separate durations: one scope over the sequence, counted as m launches
-        ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? m : 0);
+        // overlapped kernels have no separate durations: one scope over the sequence, counted as its launches
+        ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? nsteps : 0);
         int prev_grid = 0;
-        // overlapped form with the tail requested: one more (closing) pass produces v_{m+1}, H[m+1, m] and the
-        // breakdown test of step m instead of the update2 + norm_final launches below
-        const bool closing = live && !ks.skip_tail && m + 1 <= dev::PIPE_CH - 1;
         ks.pipe_closed = closing;
-        for (int j = 1; j <= m + (closing ? 1 : 0); ++j) {
+        for (int j = jstart; j <= m + (closing ? 1 : 0); ++j) {
           const int i0 = lanczos ? j : std::max(1, j - iop + 1);
           const int nd = j - i0 + 1;
-          dev::PipeArgs pa{};
+          const bool cont = (!fresh && j == jstart);
+          dev::PipeArgsT<T> pa{};
           pa.final = (j == m + 1) ? 1 : 0;
+          pa.cont = cont ? 1 : 0;
+          pa.cont_inv = cont ? ks.colscale_host[j - 1] : 1.0;
           pa.A = A;
-          if (use_wave) {
-            if (op.gndiag > 0 && !no_dia) {
-              pa.dia_val = op.gdia_val.as<double>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
-              pa.gdia_off = op.gdia_off.as<int32_t>();
-            } else {   // SELL slots + the per-tile column ranges
-              pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
+          if constexpr (!ST<T>::is_complex) {
+            if (use_wave) {
+              if (op.gndiag > 0 && !no_dia_env) {
+                pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
+                pa.gdia_off = op.gdia_off.as<int32_t>();
+              } else {   // SELL slots + the per-tile column ranges
+                pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
+              }
+              pa.tile_flags = ks.tflags.as<uint32_t>();
+              pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
+              pa.spin_limit = spin_limit;
             }
-            pa.tile_flags = ks.tflags.as<uint32_t>();
-            pa.tile_stamp = (ks.pipe_seq << 8) | (uint32_t)j;
-            pa.spin_limit = spin_limit;
-          } else if (op.ndiag > 0 && !no_dia) {
-            pa.dia_val = op.dia_val.as<double>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
+          }
+          if (!use_wave && op.ndiag > 0 && !no_dia_env) {
+            pa.dia_val = op.dia_val.as<T>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
             for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
           }
           pa.w = (int)op.bandwidth;
-          pa.yprev = (j & 1) ? yb2 : ya;
+          pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
           pa.ybuf = (j & 1) ? ya : yb2;
-          pa.u0 = (j == 1) ? reinterpret_cast<const double *>(b) : nullptr;
-          dev::DotsArgs<double> &d = pa.d;
+          pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
+          if (isaug) {
+            pa.aug_p = p; pa.n_op = ks.n; pa.B = reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;
+            if (j == 1 && fresh)
+              for (int k = 0; k < p; ++k) pa.u0_tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
+          }
+          dev::DotsArgs<T> &d = pa.d;
           d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
           d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
           d.part = part; d.gpart = gpart; d.st = st;
           d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
-          d.real_coeff = 0;
-          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<double>(); d.ldg = ks.ldg; d.jrow = j - 1;
+          d.real_coeff = real_coeff;
+          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
           d.hcoef = nullptr;
           if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
           else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+          else if (cont) { pa.uc0 = i0 - 1; pa.udir = 1; pa.und = nd - 1; }   // the older columns of this step's own window (zero coefficients)
           else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
           pa.hcoef_in = (j & 1) ? hcb : hca;
           pa.hcoef_out = (j & 1) ? hca : hcb;
@@ -497,18 +530,24 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
             pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
             if (ks.mbox_armed) {
               const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-              d.Hhost = mv.H;
+              d.Hhost = reinterpret_cast<T *>(mv.H);
               pa.mb_scales = mv.scales;
               pa.mb_state = mv.state;
               pa.mb_done = mv.done;
               pa.last_step = m + (closing ? 1 : 0);
             }
-            if (j > 1) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-            prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
+            if (j > jstart) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
+            if constexpr (!ST<T>::is_complex) {
+              prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
+            } else {
+              prev_grid = dev::pipe_step_live(sj, pa);
+            }
             if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
           } else if (use_wave) {
-            ProfScope ps1(c, EXPV_MI_K_FUSED_A);
-            if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+            if constexpr (!ST<T>::is_complex) {
+              ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+              if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+            }
           } else {
             ProfScope ps1(c, EXPV_MI_K_FUSED_A);
             dev::pipe_step(s, pa);
@@ -528,16 +567,16 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       }
       ht_mark(2);
       if (!ks.skip_tail && !ks.pipe_closed) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
-        dev::UpdateArgs<double> u{};
+        dev::UpdateArgs<T> u{};
         u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
         if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }
         else { const int i0 = std::max(1, m - iop + 1); u.c0 = i0 - 1; u.dir = 1; u.nd = m - i0 + 1; }
         u.hcoef = (m & 1) ? hca : hcb; u.do_norm = 0; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
         u.jcol = m - 1; u.tol = tol; u.step = m + 1;
-        { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<double>(s, u, -1); }
+        { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, -1); }
         ProfScope ps(c, EXPV_MI_K_SCALE);
-        dev::norm_final<double>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol, dev::BatchStrides{}, 1,
-                                ks.colscale.as<double>() + m);
+        dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol, dev::BatchStrides{}, 1,
+                           ks.colscale.as<double>() + m);
       }
       ks.gram_rows = lanczos ? 1 : m;
     }
@@ -559,7 +598,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       static const bool no_gdia = std::getenv("EXPV_MI_NO_DIA") != nullptr;
       if (op.gndiag > 0 && !no_gdia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
-        fa.dia_val = op.gdia_val.as<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();
+        fa.dia_val = op.gdia_ptr<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();
         fa.n_dia = ks.n;
       }
       dev::DotsArgs<T> &d = fa.d;

@@ -92,6 +92,19 @@ __device__ __forceinline__ double consume_f64(const double *p) {
   return __longlong_as_double((long long)u);
 }
 
+// typed forms (complex: the two halves separately -- readers are ordered behind the writer by a flag, never racing it)
+template <class T> __device__ __forceinline__ T consume_T(const T *p);
+template <> __device__ __forceinline__ double consume_T<double>(const double *p) { return consume_f64(p); }
+template <> __device__ __forceinline__ cplx consume_T<cplx>(const cplx *p) {
+  return make_cplx(consume_f64(&p->re), consume_f64(&p->im));
+}
+template <class T> __device__ __forceinline__ void publish_T(T *p, T v);
+template <> __device__ __forceinline__ void publish_T<double>(double *p, double v) { publish_f64(p, v); }
+template <> __device__ __forceinline__ void publish_T<cplx>(cplx *p, cplx v) {
+  publish_f64(&p->re, v.re);
+  publish_f64(&p->im, v.im);
+}
+
 __device__ __forceinline__ bool step_skipped(const StepState *st, int step) {
   // after a happy breakdown at step m_done the remaining launches of the call are no-ops
   return st != nullptr && st->breakdown != 0 && step > st->m_done;
@@ -336,11 +349,11 @@ __device__ __forceinline__ void gram_prefetch(const DotsArgs<T> &a, T *gs_s) {
     while ((i + 1) * i / 2 <= e) ++i;
     const int k = e - i * (i - 1) / 2;
     const T *p = &a.gram[(a.c0 + i) + (int64_t)(a.c0 + k) * a.ldg];
-    if constexpr (SHARED) gs_s[e] = consume_f64(reinterpret_cast<const double *>(p));
+    if constexpr (SHARED) gs_s[e] = consume_T<T>(p);
     else gs_s[e] = *p;
   }
 }
-// SHARED (fp64 only): the step results are read by the NEXT step's kernel, which is already running (overlapped pipeline), and
+// SHARED: the step results are read by the NEXT step's kernel, which is already running (overlapped pipeline), and
 // the Gram rows / H were written by other workgroups earlier in it: every global access goes through to memory
 // (sc1) instead of relying on a kernel boundary.  slot_scale_s (LDS, optional): factor folded into hcoef[k].
 template <class T, bool SHARED = false>
@@ -348,13 +361,12 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
                                                     double newest_scale = 1.0, const double *slot_scale_s = nullptr,
                                                     bool gram_ready = false, T *hcol_s = nullptr) {
   constexpr int NR = ST<T>::nreal;
-  static_assert(!SHARED || NR == 1, "the write-through epilogue is fp64 only");
   auto ldg = [](const T *p) -> T {
-    if constexpr (SHARED) return consume_f64(reinterpret_cast<const double *>(p));
+    if constexpr (SHARED) return consume_T<T>(p);
     else return *p;
   };
   auto stg = [](T *p, T v) {
-    if constexpr (SHARED) publish_f64(reinterpret_cast<double *>(p), *reinterpret_cast<const double *>(&v));
+    if constexpr (SHARED) publish_T<T>(p, v);
     else *p = v;
   };
   auto sth = [&](int k, T v) {   // H[c0 + k, jcol]; hcol_s (LDS, optional) keeps the column for a later host mirror

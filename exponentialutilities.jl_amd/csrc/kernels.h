@@ -152,30 +152,34 @@ template <class T>
 void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, const StepState *st, int64_t strideV = 0,
                    int nbatch = 1);
 
-// ---- single-pass step for narrow-banded operators (pipe.hip, fp64) -------------------------
-constexpr int PIPE_CH = 32;       // longest window (m <= 32)
-constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per 512-row tile)
+// ---- single-pass step for narrow-banded operators (pipe.hip; fp64 and complex-fp64) ---------
+constexpr int PIPE_CH = 32;       // longest window + 1 (fp64); complex-fp64: 16
+constexpr int PIPE_CH_CPLX = 16;
+constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per tile)
 constexpr int PIPE_DIA_MAX = 8;       // diagonals of the DIA form of a narrow-banded operator
+constexpr int PIPE_AUG_MAX = 8;       // widest augmentation (kiops: p extra rows / columns)
+constexpr int PIPE_MAX_STEPS = 2000;  // step numbers travel in 11 bits of the step flag
 // batched launches (problem index in blockIdx.y): element strides between the per-problem arrays; all zero otherwise
 struct PipeBatch {
   int64_t V, y, part, gpart, Hdev, gram, hcoef, scales, dia, st, u0;
 };
-struct PipeArgs {
-  SellView<double> A;
+template <class T>
+struct PipeArgsT {
+  SellView<T> A;
   // DIA form (built when the pattern is a few full diagonals): value d of row r at dia_val[d*dia_ld + r],
-  // column r + dia_off[d]; no column indices are read.  ndiag == 0: use the SELL view.
-  const double *dia_val;
+  // column r + dia_off[d]; no column indices are read.  ndiag == 0: use the SELL view (fp64 only).
+  const T *dia_val;
   int64_t dia_ld;
   int ndiag;
   int dia_off[PIPE_DIA_MAX];
   int w;                       // half-bandwidth of A
-  const double *yprev;         // y~_{j-1} = A u_{j-1}
-  double *ybuf;                // out: y~_j
-  const double *u0;            // step 1: the starting vector b (u_1 = b)
-  DotsArgs<double> d;          // basis, projection window of step j, reduction buffers, epilogue targets
+  const T *yprev;              // y~_{j-1} = A u_{j-1}
+  T *ybuf;                     // out: y~_j
+  const T *u0;                 // step 1: the starting vector b (u_1 = b)
+  DotsArgs<T> d;               // basis, projection window of step j, reduction buffers, epilogue targets
   int uc0, udir, und;          // update window of step j-1: columns uc0 + udir*i, i < und
-  const double *hcoef_in;      // its coefficients (h_i * s_i), produced by the previous pass
-  double *hcoef_out;           // coefficients for the next pass
+  const T *hcoef_in;           // its coefficients (h_i * s_i), produced by the previous pass
+  T *hcoef_out;                // coefficients for the next pass
   double *scales;              // s_c: stored column c = v_{c+1} / s_c
   int step;
   double tol;
@@ -184,7 +188,7 @@ struct PipeArgs {
   // waits for the tiles its diagonals reach into before it applies the operator (pipe.hip)
   const int32_t *gdia_off;     // device: ndiag ascending offsets (DIA operators)
   const int32_t *tile_lo, *tile_hi;   // device: first / last tile the columns of a tile's rows lie in (SELL operators)
-  uint32_t *tile_flags;        // device: one word per 512-row tile, = tile_stamp when u_j of the tile is in memory
+  uint32_t *tile_flags;        // device: one word per tile, = tile_stamp when u_j of the tile is in memory
   uint32_t tile_stamp;
   uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
   uint32_t seq;                // ... and the sequence number of this factorisation that stamps them
@@ -197,18 +201,35 @@ struct PipeArgs {
   int last_step;
   int final;                   // 1: closing pass of a factorisation: u_{m+1} and its norm only (no operator apply, no sums)
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
+  // continuation (arnoldi!(...; init = j), arnoldi.jl:350,368): the first pass of the call takes the stored, normalised
+  // v_j (yprev = its column, inv = 1, zero coefficients): its norm is 1 by construction, H[j, j-1] is already known
+  int cont;
+  double cont_inv;             // ... scale of that stored column (1 when the basis is materialised): v_j = raw * cont_inv
+  // augmented operator [A B; 0 K] of kiops (arnoldi.jl:191-205): rows n_op .. n_op+aug_p-1 of every vector are the
+  // shift block, rows < n_op get + B u[n_op:].  aug_p == 0: plain operator (d.n == n_op).
+  int aug_p;
+  int64_t n_op;
+  const T *B;
+  int64_t ldb;
+  T u0_tail[PIPE_AUG_MAX];     // step 1 of an augmented factorisation: rows n_op.. of u_1 (by value: no staging copy)
 };
-void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch = 1);
+using PipeArgs = PipeArgsT<double>;
+void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1);
+void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch = 1);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // operator form: pa.ndiag > 0 ? DIA : SELL
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
-int pipe_step_live(hipStream_t s, const PipeArgs &pa);
+int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa);
+int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa);
+// longest update window the single-pass step takes for this element type
+template <class T> constexpr int pipe_max_window() { return ST<T>::is_complex ? PIPE_CH_CPLX - 1 : PIPE_CH - 1; }
 void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);
 constexpr int PIPE_FLAG_COPIES = 16, PIPE_FLAG_STRIDE = 1024;
 constexpr int PIPE_ARRIVE_STRIDE = 32;                                    // words between the arrival counters of a step
 constexpr int PIPE_ARRIVE_STEP = PIPE_FLAG_COPIES * PIPE_ARRIVE_STRIDE;   // words per step
-void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *scales, int ncols);
+constexpr uint32_t PIPE_SEQ_MASK = 0xfffffu;                              // sequence numbers: 20 bits (flag = seq << 12 | stop << 11 | step)
+template <class T> void scale_columns(hipStream_t s, T *V, int64_t ldv, int64_t n, const double *scales, int ncols);
 
 template <class T> void dots(hipStream_t s, const DotsArgs<T> &a);
 template <class T> void update(hipStream_t s, const UpdateArgs<T> &a);

@@ -1,4 +1,4 @@
-// pipe.hip -- single-pass Krylov step for narrow-banded operators (fp64, gfx950).
+// pipe.hip -- single-pass Krylov step for narrow-banded operators (fp64 and complex-fp64, gfx950).
 //
 // The two-kernel step (fused.hip) streams the window of V twice per Krylov step: once for the
 // projection sums, once for the update.  For an operator whose entries all lie within `w` of the
@@ -6,28 +6,31 @@
 // can be done in ONE pass over the rows, because a row tile only needs u_j on the tile plus a halo
 // of w rows on each side, and the halo can be recomputed locally:
 //
-//   k_pipe(j), per 512-row tile (two rows per lane, 16-byte loads):
+//   k_pipe(j), per tile of 256 lanes x 16 B (512 fp64 rows / 256 complex rows):
 //     1. u_j = y~_{j-1}/beta_{j-1} - sum_i (h_i s_i) raw_i      on the tile AND its 2w halo rows
 //        (raw_i = basis columns as stored: un-normalised, with per-column scales s_i; the window
 //        values of the tile rows stay in REGISTERS for phase 3)                  arnoldi.jl:303,306
 //     2. y~_j = A u_j on the tile, gathering u_j from LDS (tile + halo)                 arnoldi.jl:185
+//        augmented operator [A B; 0 K] of kiops: + B u_j[n:] on the operator rows, the shift block on
+//        the p rows below them (u_j[n:] is recomputed by every workgroup: p <= 8 values)  arnoldi.jl:191-205
 //     3. d~_i = <raw_i, y~_j>, g~_i = <raw_i, u_j>, <u_j, y~_j>, ||u_j||^2 from the registers of (1)
 //                                                                                       arnoldi.jl:302,305
 //     last workgroup: beta_{j-1} = ||u_j||, H[j, j-1], breakdown test of step j-1, s_j = 1/beta_{j-1},
 //        the rescaled sums -> Hessenberg column of step j (same epilogue as fused_a2)
 //
-// Each stored basis column is read ONCE per step (plus 2w/512 for the halo): per step
-// A + 8n(w_j - 1) + 8n [y~ read] + 16n [u_j, y~_j written]; A is the DIA form (values only) when the pattern is a
-// few full diagonals, the SELL-128 form otherwise.
+// Each stored basis column is read ONCE per step (plus 2w/tile for the halo): per step
+// A + s n (w_j - 1) + s n [y~ read] + 2 s n [u_j, y~_j written]; A is the DIA form (values only) when the pattern
+// is a few full diagonals, the SELL-128 form otherwise (fp64).
 // Columns are kept un-normalised in HBM during the factorisation (scales in Ks); they are
 // normalised lazily (k_scale_columns) when something other than the combine needs them, which also
 // removes the in-place rescale that would race with a neighbour's halo reads.
 //
-// Three ways to run the step:
+// Ways to run the step:
 //   k_pipe        one launch after the other on one stream (also: batches of problems in blockIdx.y)
 //   k_pipe_live   consecutive steps on two streams, the next step's kernel starts while this one finishes
 //                 (flags + write-through memory traffic instead of kernel boundaries; k_pipe_gate keeps it deadlock-free)
 //   closing pass  (final = 1) u_{m+1}, H[m+1, m] and the breakdown test of step m for arnoldi!
+//   continuation  (cont = 1) first pass of arnoldi!(...; init = j): starts from the stored, normalised v_j
 #include <algorithm>
 #include <cstdlib>
 
@@ -36,25 +39,27 @@
 namespace expv_mi {
 namespace dev {
 
-// Sums of a pass, compact layout (und = update-window length): [0, und) d~_i = <raw_i, y~_j>, [und, 2 und)
-// g~_i = <raw_i, u_j>, [2 und] <u_j, y~_j>, [2 und + 1] ||u_j||^2.  A tile's per-lane products are summed across the
-// wave at once by recursive halving in sets of K values, so a lane carries ONE running sum -- that is what lets the
-// pass hold the whole window (<= 31 columns) of a tile in registers with 16-byte loads.
+// Sums of a pass, compact layout (und = update-window length, NR = reals per element):
+//   [0, NR und) d~_i = <raw_i, y~_j>, [NR und, 2 NR und) g~_i = <raw_i, u_j>, then NR words <u_j, y~_j>, then ||u_j||^2.
+// A tile's per-lane products are summed across the wave at once by recursive halving in sets of K values, so a lane
+// carries ONE running sum -- that is what lets the pass hold the whole window of a tile in registers with 16-byte loads.
 // Template parameters: CH = window capacity (update window <= CH-1 columns); WAVES = workgroups per CU the register
 // budget allows; PS = operator slots prefetched into registers before the barrier; DIA = operator form.
 // 16-byte store that goes through to memory (sc0 sc1): no dirty line stays in this XCD's L2, so a later reader on
 // another XCD needs no L2 write-back from us (overlapped form: no kernel boundary between writer and reader)
-__device__ __forceinline__ void st_pack_wt(double *p, const Pack<double> &v) {
+template <class T>
+__device__ __forceinline__ void st_pack_wt(T *p, const Pack<T> &v) {
   typedef double vec2d __attribute__((ext_vector_type(2)));
   vec2d d;
-  d.x = v.v[0];
-  d.y = v.v[1];
+  const double *src = reinterpret_cast<const double *>(&v);
+  d.x = src[0];
+  d.y = src[1];
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
 }
-template <bool WT>
-__device__ __forceinline__ void st_tile(double *p, const Pack<double> &v) {
-  if constexpr (WT) st_pack_wt(p, v);
-  else *reinterpret_cast<Pack<double> *>(p) = v;
+template <bool WT, class T>
+__device__ __forceinline__ void st_tile(T *p, const Pack<T> &v) {
+  if constexpr (WT) st_pack_wt<T>(p, v);
+  else *reinterpret_cast<Pack<T> *>(p) = v;
 }
 template <bool FRESH>
 __device__ __forceinline__ double ld_shared_f64(const double *p) {   // value another workgroup wrote during this launch
@@ -68,20 +73,24 @@ __device__ unsigned long long g_pipe_trace[33][1024][6];
 #else
 #define PIPE_STAMP(step, slot) do { } while (0)
 #endif
-struct PipeShared {
-  double us[2 * BLOCK + 2 * PIPE_WMAX];
-  double hs[32];                   // update coefficients (h_i s_i): LDS broadcast, no SGPRs
+template <class T>
+struct PipeSharedT {
+  T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX];
+  T hs[32];                        // update coefficients (h_i s_i): LDS broadcast, no SGPRs
+  T ut[PIPE_AUG_MAX];              // augmented operator: rows n_op.. of u_j
+  int doff[PIPE_DIA_MAX];          // DIA offsets (a dynamically indexed kernel argument would be copied to scratch)
   double red_s[BLOCK / 64][64];
   double vals_s[64];
   double std_s[MAX_RED_VALUES];
   int flag_s;
-  double gs_s[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2];
+  T gs_s[PIPE_CH * (PIPE_CH - 1) / 2];   // Gram entries of a window of <= PIPE_CH columns
   double cs_s[64];                 // per-slot factors folded into the next pass's coefficients
 };
 // The grid-wide flag of the overlapped form: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels);
-// workgroup b polls copy b % COPIES.  A word holds (call sequence << 8) | stop << 7 | step, so it needs no reset
+// workgroup b polls copy b % COPIES.  A word holds (call sequence << 12) | stop << 11 | step, so it needs no reset
 // between calls; a stop (happy breakdown / zero vector) releases every later step's kernel as well.
-constexpr uint32_t PIPE_STOP_BIT = 0x80u;
+constexpr uint32_t PIPE_STOP_BIT = 0x800u, PIPE_STEP_MASK = 0x7ffu;
+constexpr int PIPE_SEQ_SHIFT = 12;
 __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s,
                                          int spin_limit) {
   if (threadIdx.x == 0) {
@@ -89,9 +98,9 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
     int res = 0, it = 0;
     for (;;) {
       const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v >> 8) == seq) {
+      if ((v >> PIPE_SEQ_SHIFT) == seq) {
         if (v & PIPE_STOP_BIT) { res = 1; break; }
-        if ((int)(v & 0x7fu) >= step) break;
+        if ((int)(v & PIPE_STEP_MASK) >= step) break;
       }
       if (++it > spin_limit) {
         __hip_atomic_store(&st->breakdown, 99, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,27 +116,42 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
   __syncthreads();
   return bd;
 }
+// component r of conj(v) * o summed over the elements of a 16-byte pack (the two rows of a lane for fp64)
+__device__ __forceinline__ double pack_prod(const Pack<double> &v, const Pack<double> &o, int) {
+  return fma(v.v[0], o.v[0], v.v[1] * o.v[1]);
+}
+__device__ __forceinline__ double pack_prod(const Pack<cplx> &v, const Pack<cplx> &o, int r) {
+  return r == 0 ? fma(v.v[0].re, o.v[0].re, v.v[0].im * o.v[0].im) : fma(v.v[0].re, o.v[0].im, -(v.v[0].im * o.v[0].re));
+}
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
-template <int CH, int PS, bool LIVE, bool DIA, bool WAVE = false>
-__device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block, PipeShared &sh) {
-  constexpr int TR = 2 * BLOCK;               // rows per tile: two per lane
-  constexpr int K = (CH <= 16) ? CH : 16;     // values per halving reduction
-  constexpr int P = (CH + K - 1) / K;         // parts per set
+template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false>
+__device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
+  static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
+  constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64) or 1 (complex)
+  constexpr int NR = ST<T>::nreal;
+  constexpr int TR = N * BLOCK;               // rows per tile
+  constexpr int LSET = NR * CH;               // real values of one set: (CH-1 window slots + the self term) x NR
+  constexpr int K = (LSET <= 16) ? LSET : 16; // values per halving reduction
+  constexpr int P = (LSET + K - 1) / K;       // parts per set
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
-  double(&us)[2 * BLOCK + 2 * PIPE_WMAX] = sh.us;
-  double(&hs)[32] = sh.hs;
+  static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
+  static_assert(!(WAVE && ST<T>::is_complex), "the wave form is fp64 only");
+  static_assert(DIA || !ST<T>::is_complex, "complex operators use the DIA form");
+  T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
+  T(&hs)[32] = sh.hs;
   double(&red_s)[BLOCK / 64][64] = sh.red_s;
   double(&vals_s)[64] = sh.vals_s;
   double(&std_s)[MAX_RED_VALUES] = sh.std_s;
   int &flag_s = sh.flag_s;
-  double(&gs_s)[LOWSYNC_MAX * (LOWSYNC_MAX - 1) / 2] = sh.gs_s;
-  DotsArgs<double> a = pa.d;
+  T(&gs_s)[PIPE_CH * (PIPE_CH - 1) / 2] = sh.gs_s;
+  DotsArgs<T> a = pa.d;
   // per-problem arrays: the kernel arguments stay untouched (a modified copy of the whole argument block, with its
   // dynamically indexed dia_off[], would live in scratch); a batched launch moves these locals by blockIdx.y strides
-  const double *yprev = pa.yprev, *u0 = pa.u0, *hcoef_in = pa.hcoef_in, *dia_val = pa.dia_val;
-  double *ybuf = pa.ybuf, *hcoef_out = pa.hcoef_out, *scales = pa.scales;
+  const T *yprev = pa.yprev, *u0 = pa.u0, *hcoef_in = pa.hcoef_in, *dia_val = pa.dia_val;
+  T *ybuf = pa.ybuf, *hcoef_out = pa.hcoef_out;
+  double *scales = pa.scales;
   if (!LIVE && gridDim.y > 1) {
     const int64_t q = blockIdx.y;
     const PipeBatch &b = pa.pb;
@@ -149,18 +173,46 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   PIPE_STAMP(pa.step, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = pa.w, jcol = a.jcol, und = pa.und;
-  const bool first = (pa.step == 1);
+  if constexpr (DIA && !WAVE) {
+    if (tid < PIPE_DIA_MAX) {
+      int v = 0;
+#pragma unroll
+      for (int q = 0; q < PIPE_DIA_MAX; ++q)
+        if (tid == q) v = pa.dia_off[q];
+      sh.doff[tid] = v;      // (read after the barrier that follows the LDS copy of u_j)
+    }
+  }
+  const bool first = (pa.step == 1) && !pa.cont;
   const bool slot_dots = (a.mode != DOTS_LANCZOS) && !first;
-  double *Vw = const_cast<double *>(a.V);
+  const int p_aug = AUG ? pa.aug_p : 0;
+  const int64_t n_op = AUG ? pa.n_op : a.n;             // operator rows (the vectors have a.n = n_op + p_aug rows)
+  T *Vw = const_cast<T *>(a.V);
   // LIVE: the previous step's kernel may still be running.  Its results (coefficients, 1/beta, its y~ and its
   // column of V) are awaited INSIDE the first tile, after the loads that do not depend on them are in flight.
-  bool ready = !LIVE || first;
+  bool ready = !LIVE || first || pa.cont;
   double inv = 1.0;
   const int knew = (jcol - 1 - pa.uc0) * pa.udir;        // window slot of the column the previous step wrote
+  auto tail_of_u = [&]() {   // augmented operator: u_j[n_op + q], q < p_aug -> sh.ut (every workgroup needs them for B u_j[n:])
+    if (AUG && tid < p_aug) {
+      T v;
+      if (first) {
+        v = ST<T>::zero();
+#pragma unroll
+        for (int q = 0; q < PIPE_AUG_MAX; ++q)     // (static indices: a dynamically indexed kernel argument would live in scratch)
+          if (tid == q) v = pa.u0_tail[q];
+      } else {
+        v = ST<T>::mul_real(yprev[n_op + tid], inv);
+        for (int k = 0; k < und; ++k) ST<T>::nfma(v, hs[k], a.V[n_op + tid + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv]);
+      }
+      sh.ut[tid] = v;
+    }
+  };
   if (ready) {
-    if (!first) inv = a.st->inv;
-    if (tid < 32) hs[tid] = (tid < und && !first) ? hcoef_in[tid] : 0.0;
+    if (pa.cont) inv = pa.cont_inv;
+    else if (!first) inv = a.st->inv;
+    if (tid < 32) hs[tid] = (tid < und && !first && !pa.cont) ? hcoef_in[tid] : ST<T>::zero();
     __syncthreads();
+    tail_of_u();
   }
   const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
   const int64_t nb = (a.n + 127) & ~(int64_t)127;        // library vectors are padded (zeros) up to here
@@ -173,48 +225,52 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     // WAVE: tiles are dealt round-robin, so the tiles a tile waits for are in flight in neighbouring workgroups
     const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : t0 + tl;
     if (tile >= (WAVE ? ntiles : t1)) break;
-    const int64_t r0 = tile * TR, i = r0 + 2 * (int64_t)tid;
-    const bool act = i < nb;   // whole waves: nb is a multiple of the 128 rows a wave owns
-    // ---- operator slots of this lane's two rows: issued now, consumed after the barrier ------------
-    Pack<double> av[PS > 0 ? PS : 1];
+    const int64_t r0 = tile * TR, i = r0 + N * (int64_t)tid;
+    const bool act = i < nb;   // whole waves: nb is a multiple of the rows a wave owns
+    // ---- operator slots of this lane's rows: issued now, consumed after the barrier ------------
+    Pack<T> av[PS > 0 ? PS : 1];
     int2 aci[PS > 0 ? PS : 1];
     int L = 0;
-    const double *avp = nullptr;
+    const T *avp = nullptr;
     const int32_t *acp = nullptr;
     if (pa.final) {
       // closing pass: only u_{m+1} and its norm are needed
-    } else if constexpr (DIA) {   // diagonal d of these two rows: one aligned 16-byte load, no column indices
-      if (act) {
+    } else if constexpr (DIA) {   // diagonal d of these rows: one aligned 16-byte load, no column indices
+      if (act && (!AUG || i < n_op)) {      // (rows of the augmentation carry no operator entries)
         L = pa.ndiag;
         avp = dia_val + i;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
-          if (sl < L) av[sl] = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld);
+          if (sl < L) av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld);
       }
     } else if (i < a.n) {
-      const int64_t slice = i >> 7;
-      const int64_t off = pa.A.slice_off[slice];
-      L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
-      avp = pa.A.val + off + 2 * lane;
-      acp = pa.A.col + off + 2 * lane;
+      if constexpr (!ST<T>::is_complex) {
+        const int64_t slice = i >> 7;
+        const int64_t off = pa.A.slice_off[slice];
+        L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
+        avp = pa.A.val + off + 2 * lane;
+        acp = pa.A.col + off + 2 * lane;
 #pragma unroll
-      for (int sl = 0; sl < PS; ++sl)
-        if (sl < L) {
-          av[sl] = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
-          aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
-        }
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) {
+            av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
+            aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
+          }
+      }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
-    Pack<double> vreg[CH - 1];
+    Pack<T> vreg[CH - 1];
 #pragma unroll
-    for (int k = 0; k < CH - 1; ++k) { vreg[k].v[0] = 0.0; vreg[k].v[1] = 0.0; }
+    for (int k = 0; k < CH - 1; ++k)
+#pragma unroll
+      for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
     const bool wload = !first && act;
-    const double *vp0 = a.V + (int64_t)pa.uc0 * a.ldv + i;    // window column k at vp0 + k * cstep
+    const T *vp0 = a.V + (int64_t)pa.uc0 * a.ldv + i;    // window column k at vp0 + k * cstep
     if (wload) {
-      const double *vp = vp0;                                  // one running pointer, stepped per column
+      const T *vp = vp0;                                  // one running pointer, stepped per column
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k) {
-        if (k < und && (ready || k != knew)) vreg[k] = *reinterpret_cast<const Pack<double> *>(vp);
+        if (k < und && (ready || k != knew)) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp);
         vp += cstep;
       }
     }
@@ -224,12 +280,13 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
         if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
         PIPE_STAMP(pa.step, 4);
         inv = consume_f64(&a.st->inv);
-        if (tid < 32) hs[tid] = (tid < und) ? consume_f64(hcoef_in + tid) : 0.0;
+        if (tid < 32) hs[tid] = (tid < und) ? consume_T<T>(hcoef_in + tid) : ST<T>::zero();
         __syncthreads();
+        tail_of_u();
         if (wload) {
 #pragma unroll
           for (int k = 0; k < CH - 1; ++k)
-            if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<double> *>(vp0 + (int64_t)k * cstep);
+            if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * cstep);
         }
         ready = true;
       }
@@ -239,42 +296,65 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     for (int e = tid; e < 2 * w * 32; e += BLOCK) {
       const int hrow = e >> 5, k = e & 31;
       const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
-      double val = 0.0;
-      if (hr >= 0 && hr < a.n) {
-        if (k == 31) val = first ? u0[hr] : yprev[hr] * inv;
-        else if (!first && k < und) val = -hs[k] * a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+      T val = ST<T>::zero();
+      if (hr >= 0 && hr < n_op) {        // (operator rows only read operator columns: rows of the augmentation never matter here)
+        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real(yprev[hr], inv);
+        else if (!first && k < und) {
+          const T hv = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+          if constexpr (ST<T>::is_complex) ST<T>::nfma(val, hs[k], hv);
+          else val = -hs[k] * hv;
+        }
       }
+      if constexpr (ST<T>::is_complex) {
 #pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+        for (int o = 16; o >= 1; o >>= 1) { val.re += __shfl_xor(val.re, o, 64); val.im += __shfl_xor(val.im, o, 64); }
+      } else {
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+      }
       if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
     }
     }
-    Pack<double> u;
-    u.v[0] = 0.0;
-    u.v[1] = 0.0;
+    Pack<T> u;
+#pragma unroll
+    for (int e = 0; e < N; ++e) u.v[e] = ST<T>::zero();
     if (first) {
-      u = ld_pack_user(u0, i, a.n, is_al16(u0));
+      if (AUG) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int64_t r = i + e;
+          if (r < n_op) u.v[e] = u0[r];
+          else if (r < a.n) {
+#pragma unroll
+            for (int q = 0; q < PIPE_AUG_MAX; ++q)
+              if (r - n_op == q) u.v[e] = pa.u0_tail[q];
+          }
+        }
+      } else {
+        u = ld_pack_user(u0, i, a.n, is_al16(u0));
+      }
     } else if (act) {
-      u = *reinterpret_cast<const Pack<double> *>(yprev + i);
-      u.v[0] *= inv;
-      u.v[1] *= inv;
+      u = *reinterpret_cast<const Pack<T> *>(yprev + i);
+#pragma unroll
+      for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
         if (k < und) {                          // MGS axpy order
-          const double h = hs[k];
-          u.v[0] = fma(-h, vreg[k].v[0], u.v[0]);
-          u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
+          const T h = hs[k];
+#pragma unroll
+          for (int e = 0; e < N; ++e) ST<T>::nfma(u.v[e], h, vreg[k].v[e]);
         }
     }
     // products of one set (t = 0: against y~, t = 1: against u_j) of this tile, summed across the wave at once
-    auto tile_set = [&](int sidx, const Pack<double> &o) {
+    auto tile_set = [&](int sidx, const Pack<T> &o) {
       const int part = sidx % P;
       double arr[K];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int q = part * K + k;                 // position in the CH-long vector of the set
-        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? fma(vreg[q < CH - 1 ? q : 0].v[0], o.v[0], vreg[q < CH - 1 ? q : 0].v[1] * o.v[1]) : 0.0;
-        else if (q == CH - 1) arr[k] = fma(u.v[0], o.v[0], u.v[1] * o.v[1]);
+        const int qq = part * K + k;                // position in the LSET-long vector of the set
+        const int q = qq / NR, r = qq % NR;         // window slot (or the self term), component
+        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? pack_prod(vreg[q < CH - 1 ? q : 0], o, r) : 0.0;
+        else if (q == CH - 1) arr[k] = pack_prod(u, o, r);
         else arr[k] = 0.0;
       }
       wave_reduce_multi<K>(arr);
@@ -283,7 +363,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     if constexpr (WAVE) {
       // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
       // u_j of the tiles their diagonals reach into, so wait for those flags (bounded)
-      if (act) st_tile<true>(Vw + (int64_t)jcol * a.ldv + i, u);
+      if (act) st_tile<true, T>(Vw + (int64_t)jcol * a.ldv + i, u);
       // the sums against u_j do not need the operator: they fill the time the store takes to reach memory
 #pragma unroll
       for (int sidx = P; sidx < NSETS; ++sidx) tile_set(sidx, u);
@@ -325,19 +405,20 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
         if (flag_s != 0) return 3;
       }
     } else {
-      us[w + 2 * tid] = u.v[0];
-      us[w + 2 * tid + 1] = u.v[1];
-      if (act) st_tile<LIVE>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1
+#pragma unroll
+      for (int e = 0; e < N; ++e) us[w + N * tid + e] = u.v[e];
+      if (act && !pa.cont) st_tile<LIVE, T>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1 (a continuation's is there already)
       __syncthreads();
     }
-    // ---- phase 2: y~ = A u_j for this lane's two rows (SELL-128: one slice per wave), u from LDS ----
-    Pack<double> y;
-    y.v[0] = 0.0;
-    y.v[1] = 0.0;
+    // ---- phase 2: y~ = A u_j for this lane's rows, u from LDS ---------------------------------------
+    Pack<T> y;
+#pragma unroll
+    for (int e = 0; e < N; ++e) y.v[e] = ST<T>::zero();
     if (pa.final) {
     } else if constexpr (WAVE && !DIA) {
+      if constexpr (!ST<T>::is_complex) {
       if (i < a.n) {   // SELL slots, u_j gathered straight from its column in memory
-        const double *ucol = a.V + (int64_t)jcol * a.ldv;
+        const T *ucol = a.V + (int64_t)jcol * a.ldv;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
@@ -345,17 +426,19 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
             y.v[1] = fma(av[sl].v[1], ucol[aci[sl].y], y.v[1]);
           }
         for (int sl = PS; sl < L; ++sl) {
-          const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
+          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
           const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
           y.v[0] = fma(v2.v[0], ucol[ci.x], y.v[0]);
           y.v[1] = fma(v2.v[1], ucol[ci.y], y.v[1]);
         }
         if (i + 1 >= a.n) y.v[1] = 0.0;
       }
+      }
     } else if constexpr (WAVE) {
+      if constexpr (!ST<T>::is_complex) {
       if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
-        const double *ucol = a.V + (int64_t)jcol * a.ldv;
-        auto term = [&](const Pack<double> &v2, int sl) {
+        const T *ucol = a.V + (int64_t)jcol * a.ldv;
+        auto term = [&](const Pack<T> &v2, int sl) {
           const int64_t c0 = i + pa.gdia_off[sl];
           const double x0 = (c0 >= 0 && c0 < a.n) ? ucol[c0] : 0.0;
           const double x1 = (c0 + 1 >= 0 && c0 + 1 < a.n) ? ucol[c0 + 1] : 0.0;
@@ -365,26 +448,28 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) term(av[sl], sl);
-        for (int sl = PS; sl < L; ++sl) term(*reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld), sl);
+        for (int sl = PS; sl < L; ++sl) term(*reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld), sl);
+      }
       }
     } else if constexpr (DIA) {
       if (act) {
-        const int base = w + 2 * tid;             // LDS index of this lane's first row
+        const int base = w + N * tid;             // LDS index of this lane's first row
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
             const int o = base + pa.dia_off[sl];
-            y.v[0] = fma(av[sl].v[0], us[o], y.v[0]);     // rows beyond n and absent entries carry value 0
-            y.v[1] = fma(av[sl].v[1], us[o + 1], y.v[1]);
+#pragma unroll
+            for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], av[sl].v[e], us[o + e]);     // rows beyond n and absent entries carry value 0
           }
         for (int sl = PS; sl < L; ++sl) {
-          const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * pa.dia_ld);
-          const int o = base + pa.dia_off[sl];
-          y.v[0] = fma(v2.v[0], us[o], y.v[0]);
-          y.v[1] = fma(v2.v[1], us[o + 1], y.v[1]);
+          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld);
+          const int o = base + sh.doff[sl];
+#pragma unroll
+          for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], v2.v[e], us[o + e]);
         }
       }
     } else if (i < a.n) {
+      if constexpr (!ST<T>::is_complex) {
       const int lim = TR + 2 * w, shift = (int)(w - r0);
 #pragma unroll
       for (int sl = 0; sl < PS; ++sl)
@@ -394,17 +479,32 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
           y.v[1] = fma(av[sl].v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
         }
       for (int sl = PS; sl < L; ++sl) {
-        const Pack<double> v2 = *reinterpret_cast<const Pack<double> *>(avp + (int64_t)sl * 128);
+        const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
         const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
         const int i0 = ci.x + shift, i1 = ci.y + shift;
         y.v[0] = fma(v2.v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);
         y.v[1] = fma(v2.v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
       }
       if (i + 1 >= a.n) y.v[1] = 0.0;
+      }
     }
-    if (act && !pa.final) st_tile<LIVE>(ybuf + i, y);
+    if (AUG && !pa.final && act) {
+      // [A B; 0 K]: operator rows get + B u_j[n_op:], the p rows below them the shift block (arnoldi.jl:195-202)
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const int64_t r = i + e;
+        if (r < n_op) {
+          for (int q = 0; q < p_aug; ++q) ST<T>::fma_(y.v[e], pa.B[r + (int64_t)q * pa.ldb], sh.ut[q]);
+        } else if (r < n_op + p_aug - 1) {
+          y.v[e] = sh.ut[r - n_op + 1];
+        } else {
+          y.v[e] = ST<T>::zero();
+        }
+      }
+    }
+    if (act && !pa.final) st_tile<LIVE, T>(ybuf + i, y);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
-    // The CH values of a set (CH-1 window slots + the self term) are reduced in P parts of K values by
+    // The LSET values of a set (CH-1 window slots + the self term, NR reals each) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
     // COPIES = 64/K lanes hold the same one, so lane (l & (NSETS-1)) == s keeps the running sum of
     // set s = part + P*t (t = 0: d~ against y~, t = 1: g~ against u): ONE accumulator per lane.
@@ -418,25 +518,29 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
 
   PIPE_STAMP(pa.step, 1);
   // ---- workgroup: 4 waves -> one partial per value ------------------------------------------------------
-  // compact value layout: [0,und) d~ slots, [und,2und) g~ slots, 2und: <u,y~>, 2und+1: ||u||^2
+  // compact value layout: [0, NR und) d~ slots, [NR und, 2 NR und) g~ slots, NR words <u,y~>, then ||u||^2
+  const int o_self = 2 * NR * und, o_nrm = 2 * NR * und + NR;
   {
     constexpr int COPIES = 64 / K;             // lanes holding the same value index after the reduction
     const int idx = wave_multi_index<K>(lane);
     const int sidx = lane & (NSETS - 1);
     if ((lane & (COPIES - 1)) == sidx) {
       const int part = sidx % P, t = sidx / P;
-      const int q = part * K + idx;
-      if (q == CH - 1) red_s[wave][2 * und + t] = acc;
-      else if (q < und) red_s[wave][t * und + q] = acc;
+      const int qq = part * K + idx;
+      const int q = qq / NR, r = qq % NR;
+      if (q == CH - 1) {
+        if (t == 0) red_s[wave][o_self + r] = acc;
+        else if (r == 0) red_s[wave][o_nrm] = acc;
+      } else if (q < und) red_s[wave][t * NR * und + NR * q + r] = acc;
     }
   }
   __syncthreads();
-  const int nvals = 2 * und + 2;
+  const int nvals = o_nrm + 1;
   if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
   // (LIVE: the write-through y~ / u_j stores of this workgroup are drained by take_ticket's vmcnt(0))
   const bool gram_pf = (a.mode == DOTS_LOWSYNC);
   auto pf = [&]() {   // Gram rows and column scales for the epilogue, in flight while this workgroup queues for the final ticket
-    if (gram_pf) gram_prefetch<double, LIVE>(a, gs_s);
+    if (gram_pf) gram_prefetch<T, LIVE>(a, gs_s);
     if (a.mode == DOTS_LANCZOS) {
       if (threadIdx.x == 1) sh.cs_s[1] = (jcol >= 1) ? ld_shared_f64<LIVE>(scales + jcol - 1) : 1.0;
     } else {
@@ -454,16 +558,23 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
     if constexpr (LIVE) publish_f64(p, v);
     else *p = v;
   };
-  const double beta = sqrt(vals_s[2 * und + 1]);
-  const double invj = 1.0 / beta;
-  const bool stop = first ? (beta == 0.0) : (beta < pa.tol);
+  // (continuation: u is the stored, normalised v_j -- norm 1 by construction; H[j, j-1] and the breakdown test of
+  //  step j-1 belong to the call that produced it)
+  const double beta = pa.cont ? 1.0 : sqrt(vals_s[o_nrm]);
+  const double invj = pa.cont ? 1.0 : 1.0 / beta;
+  const bool stop = pa.cont ? false : (first ? (beta == 0.0) : (beta < pa.tol));
   if (threadIdx.x == 0) {
-    put(&a.st->hnorm, beta);
+    if (!pa.cont) put(&a.st->hnorm, beta);
     put(&a.st->inv, invj);
     a.st->m_done = pa.step - 1;
-    put(&scales[jcol], invj);                                  // s_j: column j-1 holds u_j = beta * v_j
-    if (first) put(&a.st->beta0sq, vals_s[2 * und + 1]);
-    else put(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);   // H[j, j-1] = ||u_j||
+    if (!pa.cont) put(&scales[jcol], invj);                    // s_j: column j-1 holds u_j = beta * v_j (a continuation's keeps its scale)
+    if (pa.cont) {
+    } else if (first) put(&a.st->beta0sq, vals_s[o_nrm]);
+    else {
+      T *hp = &a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh];      // H[j, j-1] = ||u_j||
+      if constexpr (LIVE) publish_T<T>(hp, ST<T>::from_real(beta));
+      else *hp = ST<T>::from_real(beta);
+    }
     if (stop) a.st->breakdown = first ? 2 : 1;
   }
   if (stop) return 2;
@@ -473,33 +584,37 @@ __device__ __forceinline__ int pipe_pass(const PipeArgs &pa, int tiles_per_block
   const int nd = a.nd;
   for (int k = threadIdx.x; k < nd; k += BLOCK) {
     const int col = a.c0 + k;
-    double dv, gv = 0.0, f, sc;
+    double f, sc;
+    int src_d, src_g = -1;
     if (col == jcol) {
       f = invj * invj;
-      dv = vals_s[2 * und];
-      sc = invj;
+      src_d = o_self;
+      sc = pa.cont ? pa.cont_inv : invj;
     } else {
       const int slot = (col - pa.uc0) * pa.udir;
       sc = sh.cs_s[k];                    // loaded by pf() before the final ticket (same thread)
       f = sc * invj;
-      dv = vals_s[slot];
-      gv = vals_s[und + slot] * f;
+      src_d = NR * slot;
+      src_g = NR * und + NR * slot;
     }
-    std_s[k] = dv * f;
-    std_s[nd + k] = gv;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      std_s[NR * k + r] = vals_s[src_d + r] * f;
+      std_s[NR * nd + NR * k + r] = (src_g >= 0) ? vals_s[src_g + r] * f : 0.0;
+    }
     sh.cs_s[k] = sc;
   }
-  if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) sh.cs_s[0] = invj;    // cs_s[1]: pf()
+  if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) sh.cs_s[0] = pa.cont ? pa.cont_inv : invj;    // cs_s[1]: pf()
   __syncthreads();
   a.hcoef = hcoef_out;
-  projection_epilogue<double, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
+  projection_epilogue<T, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
   return 1;
 }
 
-template <int CH, int WAVES, int PS, bool DIA>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgs pa, int tiles_per_block) {
-  __shared__ PipeShared sh;
-  (void)pipe_pass<CH, PS, false, DIA>(pa, tiles_per_block, sh);
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgsT<T> pa, int tiles_per_block) {
+  __shared__ PipeSharedT<T> sh;
+  (void)pipe_pass<T, CH, PS, false, DIA, false, AUG>(pa, tiles_per_block, sh);
 }
 
 // ---- wave form: single-pass step for operators made of a few diagonals with ARBITRARY offsets (structured grids) ----
@@ -509,8 +624,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgs pa, int ti
 // makes the wait graph acyclic: the first half of a tile never waits).  V is read once per step, as in the banded form.
 template <int CH, int WAVES, int PS, bool DIA>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_wave(const PipeArgs pa, int tiles_per_block) {
-  __shared__ PipeShared sh;
-  (void)pipe_pass<CH, PS, false, DIA, true>(pa, tiles_per_block, sh);
+  __shared__ PipeSharedT<double> sh;
+  (void)pipe_pass<double, CH, PS, false, DIA, true>(pa, tiles_per_block, sh);
 }
 
 // ---- overlapped form: the kernel of step j+1 runs while step j finishes ------------------------------
@@ -539,29 +654,32 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
   hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
-template <int CH, int WAVES, int PS, bool DIA, bool WAVE = false>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgs pa, int tiles_per_block) {
-  __shared__ PipeShared sh;
+template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
+  __shared__ PipeSharedT<T> sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-  const int r = pipe_pass<CH, PS, true, DIA, WAVE>(pa, tiles_per_block, sh);
+  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < PIPE_FLAG_COPIES)
       __hip_atomic_store(pa.flags + (size_t)threadIdx.x * PIPE_FLAG_STRIDE,
-                         (pa.seq << 8) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)pa.step, __ATOMIC_RELAXED,
+                         (pa.seq << PIPE_SEQ_SHIFT) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)pa.step, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     PIPE_STAMP(pa.step, 3);
     if (pa.mb_done && (r == 2 || pa.step == pa.last_step)) {
       // The factorisation ends here: copy what the host reads -- the Hessenberg columns, the column scales, the
       // final state -- from device memory (every step stored them through before raising its flag) into the
       // host-mapped mailbox, then raise its flag.  One short copy per factorisation, formally ordered.
-      const DotsArgs<double> &a = pa.d;
+      const DotsArgs<T> &a = pa.d;
       const int tid = threadIdx.x;
       const int ncols = pa.step;                       // columns 0 .. step-1 of H have entries
-      for (int e = tid; e < a.ldh * ncols; e += BLOCK) publish_host_f64(&a.Hhost[e], consume_f64(&a.Hdev[e]));
+      constexpr int NRW = ST<T>::nreal;
+      double *hh = reinterpret_cast<double *>(a.Hhost);
+      const double *hd = reinterpret_cast<const double *>(a.Hdev);
+      for (int e = tid; e < NRW * a.ldh * ncols; e += BLOCK) publish_host_f64(&hh[e], consume_f64(&hd[e]));
       for (int k = tid; k < pa.step; k += BLOCK) publish_host_f64(&pa.mb_scales[k], consume_f64(&pa.scales[k]));
       if (tid == 0) {
         publish_host_f64(&pa.mb_state[0], consume_f64(&a.st->beta0sq));
@@ -575,10 +693,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgs pa, i
   }
 }
 
-template <int CH, int WAVES, int PS, bool DIA>
-static void pipe_launch(hipStream_t s, const PipeArgs &pa, int nbatch) {
-  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe<CH, WAVES, PS, DIA>);
+template <class T> constexpr int pipe_tile_rows() { return Pack<T>::N * BLOCK; }
+
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch) {
+  const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
+  const int maxb = resident_blocks((const void *)k_pipe<T, CH, WAVES, PS, DIA, AUG>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   // batch: workgroups of all problems share the chip; a few resident rounds of fat workgroups instead of one tile each
   // (start-up round trips and the ticket are per workgroup)
@@ -586,27 +706,46 @@ static void pipe_launch(hipStream_t s, const PipeArgs &pa, int nbatch) {
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  hipLaunchKernelGGL((k_pipe<CH, WAVES, PS, DIA>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
 static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
-void pipe_step(hipStream_t s, const PipeArgs &pa, int nbatch) {
+// complex windows of <= 3 columns (Hermitian Lanczos, iop <= 3): a leaner variant that stays spill-free at 4 workgroups per
+// CU.  (The fp64 analogue at 5 workgroups per CU measured 1.5 % SLOWER than the 8-column variant on the Lanczos input:
+// profiles/r02_ab_variants.txt.)
+static bool pipe_small(int und, int nbatch) { return und <= 3 && nbatch == 1; }
+void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch) {
   // the register budget follows the window: short windows run with more workgroups per CU
   const int v = pipe_variant(pa.und);
+  if (pa.aug_p > 0) {   // augmented operator (kiops): DIA form, windows <= 7
+    if (pa.und <= 3) pipe_launch<double, 4, 4, 6, true, true>(s, pa, nbatch);
+    else pipe_launch<double, 8, 4, 6, true, true>(s, pa, nbatch);
+    return;
+  }
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: pipe_launch<8, 4, 6, true>(s, pa, nbatch); break;
-      case 1: pipe_launch<16, 3, 6, true>(s, pa, nbatch); break;
-      case 2: pipe_launch<24, 3, 0, true>(s, pa, nbatch); break;
-      default: pipe_launch<32, 2, 5, true>(s, pa, nbatch); break;
+      case 0: pipe_launch<double, 8, 4, 6, true>(s, pa, nbatch); break;
+      case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch); break;
+      case 2: pipe_launch<double, 24, 3, 0, true>(s, pa, nbatch); break;
+      default: pipe_launch<double, 32, 2, 5, true>(s, pa, nbatch); break;
     }
     return;
   }
   switch (v) {
-    case 0: pipe_launch<8, 4, 6, false>(s, pa, nbatch); break;
-    case 1: pipe_launch<16, 3, 6, false>(s, pa, nbatch); break;
-    case 2: pipe_launch<24, 3, 0, false>(s, pa, nbatch); break;
-    default: pipe_launch<32, 2, 5, false>(s, pa, nbatch); break;
+    case 0: pipe_launch<double, 8, 4, 6, false>(s, pa, nbatch); break;
+    case 1: pipe_launch<double, 16, 3, 6, false>(s, pa, nbatch); break;
+    case 2: pipe_launch<double, 24, 3, 0, false>(s, pa, nbatch); break;
+    default: pipe_launch<double, 32, 2, 5, false>(s, pa, nbatch); break;
   }
+}
+void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch) {   // complex: DIA form, windows <= 15
+  if (pa.aug_p > 0) {
+    if (pa.und <= 3) pipe_launch<cplx, 4, 4, 6, true, true>(s, pa, nbatch);
+    else pipe_launch<cplx, 8, 3, 6, true, true>(s, pa, nbatch);
+    return;
+  }
+  if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch);
+  else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch);
+  else pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch);
 }
 
 template <int CH, int WAVES, int PS, bool DIA>
@@ -631,26 +770,26 @@ bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   return false;
 }
 
-template <int CH, int WAVES, int PS, bool DIA>
-static int pipe_live_launch(hipStream_t s, const PipeArgs &pa) {
-  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, DIA>);
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
+  const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
+  const int maxb = resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 template <int CH, int WAVES, int PS, bool DIA>
 static int pipe_wave_live_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_live<CH, WAVES, PS, DIA, true>);
+  const int maxb = resident_blocks((const void *)k_pipe_live<double, CH, WAVES, PS, DIA, true>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
   const int64_t reach = max_abs_off / (2 * BLOCK) + 2;
   if (tpb > 1 && reach * 4 > nb) return 0;
-  hipLaunchKernelGGL((k_pipe_live<CH, WAVES, PS, DIA, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_live<double, CH, WAVES, PS, DIA, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {   // workgroups launched, 0: refused
@@ -662,45 +801,63 @@ int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) 
 #undef PIPE_WCASE
   return 0;
 }
-int pipe_step_live(hipStream_t s, const PipeArgs &pa) {   // returns the number of workgroups launched
+int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);
+  if (pa.aug_p > 0) {
+    if (pa.und <= 3) return pipe_live_launch<double, 4, 4, 6, true, true>(s, pa);
+    return pipe_live_launch<double, 8, 4, 6, true, true>(s, pa);
+  }
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: return pipe_live_launch<8, 4, 6, true>(s, pa);
-      case 1: return pipe_live_launch<16, 3, 6, true>(s, pa);
-      case 2: return pipe_live_launch<24, 3, 0, true>(s, pa);
-      default: return pipe_live_launch<32, 2, 5, true>(s, pa);
+      case 0: return pipe_live_launch<double, 8, 4, 6, true>(s, pa);
+      case 1: return pipe_live_launch<double, 16, 3, 6, true>(s, pa);
+      case 2: return pipe_live_launch<double, 24, 3, 0, true>(s, pa);
+      default: return pipe_live_launch<double, 32, 2, 5, true>(s, pa);
     }
   }
   switch (v) {
-    case 0: return pipe_live_launch<8, 4, 6, false>(s, pa);
-    case 1: return pipe_live_launch<16, 3, 6, false>(s, pa);
-    case 2: return pipe_live_launch<24, 3, 0, false>(s, pa);
-    default: return pipe_live_launch<32, 2, 5, false>(s, pa);
+    case 0: return pipe_live_launch<double, 8, 4, 6, false>(s, pa);
+    case 1: return pipe_live_launch<double, 16, 3, 6, false>(s, pa);
+    case 2: return pipe_live_launch<double, 24, 3, 0, false>(s, pa);
+    default: return pipe_live_launch<double, 32, 2, 5, false>(s, pa);
   }
+}
+int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
+  if (pa.aug_p > 0) {
+    if (pa.und <= 3) return pipe_live_launch<cplx, 4, 4, 6, true, true>(s, pa);
+    return pipe_live_launch<cplx, 8, 3, 6, true, true>(s, pa);
+  }
+  if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx, 4, 4, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx, 8, 3, 6, true>(s, pa);
+  return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);
 }
 
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation
-__global__ __launch_bounds__(BLOCK) void k_scale_columns(double *V, int64_t ldv, int64_t n, const double *scales,
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_scale_columns(T *V, int64_t ldv, int64_t n, const double *scales,
                                                          int ncols, int64_t rpb) {
+  constexpr int N = Pack<T>::N;
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
   for (int c = blockIdx.y; c < ncols; c += gridDim.y) {
     const double sc = scales[c];
-    double *col = V + (int64_t)c * ldv;
-    for (int64_t i = r0 + (int64_t)threadIdx.x * 2; i < r1; i += (int64_t)BLOCK * 2) {
-      Pack<double> p = ld_pack(col, i, n, true);
-      p.v[0] *= sc;
-      p.v[1] *= sc;
+    T *col = V + (int64_t)c * ldv;
+    for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+      Pack<T> p = ld_pack(col, i, n, true);
+#pragma unroll
+      for (int e = 0; e < N; ++e) p.v[e] = ST<T>::mul_real(p.v[e], sc);
       st_pack(col, i, n, true, p);
     }
   }
 }
-void scale_columns(hipStream_t s, double *V, int64_t ldv, int64_t n, const double *scales, int ncols) {
+template <class T>
+void scale_columns(hipStream_t s, T *V, int64_t ldv, int64_t n, const double *scales, int ncols) {
   if (ncols <= 0) return;
   const RowPlan p = plan_rows(n, 128, 256);
-  hipLaunchKernelGGL(k_scale_columns, dim3(p.nblocks, std::min(ncols, 8)), dim3(BLOCK), 0, s, V, ldv, n, scales, ncols,
+  hipLaunchKernelGGL(k_scale_columns<T>, dim3(p.nblocks, std::min(ncols, 8)), dim3(BLOCK), 0, s, V, ldv, n, scales, ncols,
                      p.rows_per_block);
 }
+template void scale_columns<double>(hipStream_t, double *, int64_t, int64_t, const double *, int);
+template void scale_columns<cplx>(hipStream_t, cplx *, int64_t, int64_t, const double *, int);
 
 }  // namespace dev
 }  // namespace expv_mi

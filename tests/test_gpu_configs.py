@@ -266,3 +266,101 @@ def test_malformed_sparse_input_is_an_argument_error(eu):
     assert b"rowptr" in lib.expv_mi_last_error(ctx._h)
     assert csr([0, 2, 3, 4, 6], [0, 1, 2, 3, 0, 1]) == 0          # and the well-formed one still works
     lib.expv_mi_op_destroy(h)
+
+
+# ------------------------------------------------------------------ single-pass step: complex / augmented / long IOP runs ----
+def _path_of(eu, ctx, fn):
+    """run fn() and return how the context's factorisations ran (context counters before / after)."""
+    c0 = ctx.counters()
+    out = fn()
+    c1 = ctx.counters()
+    return out, {k: c1[k] - c0[k] for k in c1}
+
+
+@pytest.mark.parametrize("case", ["complex_full_m12", "complex_iop3_m48", "complex_hermitian_lanczos", "real_iop3_m60",
+                                  "real_iop5_m100", "complex_iop7_m20"])
+def test_single_pass_step_variants_match_oracle(eu, case):
+    """The banded single-pass step (pipe.hip) for complex operators (windows <= 15 columns), for incomplete orthogonalisation
+    over more than 32 steps (kiops grows m to 128: the window, not m, bounds the register budget) and for the complex
+    Hermitian Lanczos recurrence (real coefficients, arnoldi.jl:412-413).  Checked against the oracle AND that the
+    factorisation really ran on the single-pass step."""
+    rng = np.random.default_rng(77)
+    ctx = eu.Context()
+    n = 3001
+    herm, iop, cplx = False, 0, True
+    if case == "complex_full_m12":
+        m = 12
+    elif case == "complex_iop3_m48":
+        m, iop = 48, 3
+    elif case == "complex_iop7_m20":
+        m, iop = 20, 7
+    elif case == "complex_hermitian_lanczos":
+        m, herm = 30, True
+    elif case == "real_iop3_m60":
+        m, iop, cplx = 60, 3, False
+    else:
+        m, iop, cplx = 100, 5, False
+    offs = [-2, -1, 0, 1, 2]
+    diags = [rng.standard_normal(n - abs(o)) * 0.3 + (1j * rng.standard_normal(n - abs(o)) * 0.2 if cplx else 0) - (2.0 if o == 0 else 0)
+             for o in offs]
+    A = sp.diags(diags, offs, shape=(n, n), format="csr")
+    if herm:
+        A = ((A + A.conj().T) * 0.5).tocsr()
+    b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    op = eu.MIOperator(A, ctx)
+    T = np.complex128 if cplx else np.float64
+    Ks = eu.KrylovSubspace(T, np.float64 if herm else T, n, m, 0, ctx)
+    _, path = _path_of(eu, ctx, lambda: eu.arnoldi_(Ks, op, b, m=m, iop=iop, ishermitian=herm))
+    assert path["pipeline"] == 1 and path["krylov_steps"] == m, path
+    Ko = ko.KrylovSubspace(T, float if herm else T, n, m)
+    ko.arnoldi_(Ko, A, b, m=m, iop=iop, ishermitian=herm)
+    assert Ks.m == Ko.m and Ks.wasbreakdown == Ko.wasbreakdown
+    tol = 1e-12        # (measured <= 4e-13 on every case, IOP windows included: profiles/r02_parity_measured.txt)
+    close(Ks.getH(), Ko.getH(), tol, "single-pass step %s: H vs oracle" % case, mat=True)
+    close(Ks.getV(), Ko.getV(), tol, "single-pass step %s: V vs oracle (max abs)" % case, absolute=True)
+    t = 0.3 - 0.1j if cplx else 0.3
+    w = eu.expv_(np.empty(n, dtype=complex if cplx else float), t, Ks)
+    close(w, ko.expv_(np.empty(n, dtype=complex if cplx else float), t, Ko), tol, "single-pass step %s: expv! vs oracle" % case)
+    if not iop:
+        wc, pc = _path_of(eu, ctx, lambda: eu.expv(t, op, b, m=m, ishermitian=herm))           # whole-call form (mailbox, no tail)
+        assert pc["pipeline"] == 1
+        close(wc, w, 1e-13, "single-pass step %s: whole-call expv vs arnoldi! + expv!" % case)
+
+
+def test_single_pass_step_continuation_and_augmented_bitwise_forms(eu):
+    """(i) arnoldi!(...; init = j) continues on the single-pass step from un-normalised columns + scales and gives what a
+    from-scratch factorisation gives; (ii) kiops on a banded operator (augmented operator [A B; 0 K], real and complex)
+    runs on it, overlapped and one-launch-after-the-other bit for bit alike."""
+    rng = np.random.default_rng(5)
+    ctx = eu.Context()
+    n = 4000
+    A = c2_operator(n)
+    op = eu.MIOperator(A, ctx)
+    b = rng.standard_normal(n)
+    for m0, m1, iop in ((8, 24, 0), (10, 40, 4), (5, 31, 0)):
+        Ks = eu.KrylovSubspace(np.float64, np.float64, n, m1, 0, ctx)
+        eu.arnoldi_(Ks, op, b, m=m0, iop=iop, ishermitian=False)
+        _, path = _path_of(eu, ctx, lambda: eu.arnoldi_(Ks, op, b, m=m1, iop=iop, init=m0, ishermitian=False))
+        assert path["pipeline"] == 1 and path["krylov_steps"] == m1 - m0 + 1, path
+        Kf = eu.KrylovSubspace(np.float64, np.float64, n, m1, 0, ctx)
+        eu.arnoldi_(Kf, op, b, m=m1, iop=iop, ishermitian=False)
+        close(Ks.getH(), Kf.getH(), 1e-13, "continuation %d -> %d (iop %d): H vs from scratch" % (m0, m1, iop), mat=True)
+        close(Ks.getV(), Kf.getV(), 1e-13, "continuation %d -> %d (iop %d): V vs from scratch (max abs)" % (m0, m1, iop), absolute=True)
+        Ko = ko.KrylovSubspace(float, float, n, m1)
+        ko.arnoldi_(Ko, A, b, m=m1, iop=iop, ishermitian=False)
+        close(Ks.getH(), Ko.getH(), 1e-12, "continuation %d -> %d (iop %d): H vs oracle" % (m0, m1, iop), mat=True)
+    for cplx in (False, True):
+        Ac = (A * (1 + 0.25j)).tocsr() if cplx else A
+        opc = eu.MIOperator(Ac, ctx)
+        u = rng.standard_normal((n, 3)) * 30.0 + (1j * rng.standard_normal((n, 3)) if cplx else 0)
+        res = []
+        for overlap in (True, False):
+            ctx.set_pipeline_overlap(overlap)
+            (w, st), path = _path_of(eu, ctx, lambda: eu.kiops(1.5, opc, u, allow_complex=cplx, ishermitian=False, tol=1e-9))
+            assert path["pipeline"] == path["factorisations"] >= 2, path        # every factorisation (fresh and continued)
+            res.append((np.asarray(w).copy(), st))
+        ctx.set_pipeline_overlap(True)
+        assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+        wo, so = ko.kiops(1.5, Ac, u, allow_complex=cplx, ishermitian=False, tol=1e-9)
+        assert res[0][1] == so
+        close(res[0][0], wo, 1e-12, "kiops on the single-pass step (complex=%s) vs oracle" % cplx)
