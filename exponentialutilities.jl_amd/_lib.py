@@ -34,6 +34,7 @@ class ExpvStats(C.Structure):
                 ("path_flags", C.c_int32), ("beta", C.c_double)]
 
 
+ABI_KINDS = {"ArnoldiOpts": 0, "ExpvStats": 1, "TimestepOpts": 2, "TimestepStats": 3, "KiopsOpts": 4}
 PRINT_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
 MATVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
@@ -111,6 +112,10 @@ PROTOTYPES = {
     "expv_mi_kiops": (_i, [_vp, _vp, _pd, _i, _i, _vp, _i64, _i, _i, _vp, _i64, _i, C.POINTER(KiopsOpts), _pi64]),
     "expv_mi_expv_batch": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _i, _pd, _vp, _i64, _i, _vp, _i64, _i,
                                 C.POINTER(ArnoldiOpts), C.POINTER(C.c_int32)]),
+    "expv_mi_expv_batch_multi": (_i, [_pvp, _i, _i, _i64, _i, _vp, _vp, _vp, _i64, _pd, _vp, _i64, _vp, _i64, _i,
+                                      C.POINTER(ArnoldiOpts), C.POINTER(C.c_int32)]),
+    "expv_mi_abi_sizeof": (C.c_size_t, [_i]),
+    "expv_mi_abi_layout": (C.c_char_p, [_i]),
     "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),
     "expv_mi_host_expm": (_i, [_i, _i, _vp, _i]),
     "expv_mi_host_symtridiag_expcol": (_i, [_i, _pd, _pd, _d, _d, _pd]),

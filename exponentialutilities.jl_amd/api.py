@@ -29,7 +29,7 @@ from . import _lib as L
 __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
-    "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "ExpvMIError", "DimensionMismatch", "host_expm",
+    "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
     "host_phiv_dense", "host_symtridiag_expcol", "host_pattern_info", "clear_operator_cache",
 ]
 
@@ -835,6 +835,42 @@ def expv_batch(ts, pattern, vals, B, *, m=None, tol=1e-7, iop=0, ishermitian=Fal
                                        L.HOST if va.loc == L.HOST else L.DEVICE, tarr.ctypes.data_as(L._pd), Ba.ptr, Ba.ld,
                                        Ba.loc, Wa.ptr, Wa.ld, Wa.loc, C.byref(o), mu.ctypes.data_as(C.POINTER(C.c_int32))),
            ctx._h)
+    Wa.finish()
+    return (W, mu) if return_m else W
+
+
+def expv_batch_multi(ts, pattern, vals, B, ctxs, *, m=None, tol=1e-7, iop=0, ishermitian=False, return_m=False, out=None):
+    """The same batch sharded over several contexts (one per GPU) from ONE host process -- expv_mi_expv_batch_multi: what
+    a Julia host calls for BASELINE config 5.  ``vals`` / ``B`` are host arrays; the result is a host matrix, or -- when
+    ``out`` is a DeviceArray / torch tensor on ctxs[0]'s device -- gathered there by peer copies."""
+    P = pattern.tocsr()
+    P.sort_indices()
+    n, nnz = P.shape[0], int(P.nnz)
+    T = _work_dtype(_np_dtype_of(vals), _np_dtype_of(B))
+    vh = np.ascontiguousarray(np.asarray(vals, dtype=T))
+    nprob = int(vh.shape[0])
+    if vh.size != nprob * nnz:
+        raise DimensionMismatch("vals must hold nprob x nnz values")
+    Ba = _Arg(np.asarray(B), T)
+    if Ba.shape[0] != n or (len(Ba.shape) == 2 and Ba.shape[1] != nprob):
+        raise DimensionMismatch("B must be n x nprob")
+    W = out if out is not None else np.empty((n, nprob), dtype=T, order="F")
+    Wa = _Arg(W, T, writable=True)
+    rp = np.ascontiguousarray(P.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(P.indices, dtype=np.int32)
+    tarr = np.ascontiguousarray(np.broadcast_to(np.asarray(ts, dtype=np.float64), (nprob,)))
+    o = _opts(m, tol, iop, 0, ishermitian, "auto")
+    mu = np.zeros(nprob, dtype=np.int32)
+    hs = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    code = L.load().expv_mi_expv_batch_multi(hs, len(ctxs), _code(T), n, nprob, rp.ctypes.data, ci.ctypes.data, vh.ctypes.data, nnz,
+                                             tarr.ctypes.data_as(L._pd), Ba.ptr, Ba.ld, Wa.ptr, Wa.ld, Wa.loc, C.byref(o),
+                                             mu.ctypes.data_as(C.POINTER(C.c_int32)))
+    if code != 0:
+        for c in ctxs:            # the failing shard's context holds the message
+            msg = L.load().expv_mi_last_error(c._h)
+            if msg:
+                _check(code, c._h)
+        _check(code, ctxs[0]._h)
     Wa.finish()
     return (W, mu) if return_m else W
 

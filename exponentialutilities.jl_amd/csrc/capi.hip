@@ -3,6 +3,8 @@
 #include <climits>
 #include <cmath>
 #include <mutex>
+#include <thread>
+#include <cstddef>
 #include <type_traits>
 
 #include "engine.h"
@@ -960,6 +962,105 @@ int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const
     expv_batch_run(ctx, dtype, n, nprob, rowptr, colind, vals, nnz_per_prob, mat_loc, t, b, ldb, b_loc, w, ldw, w_loc, o,
                    m_used);
   });
+}
+
+// ------------------------------------------------------------------ ABI self-description --------
+#define EXPV_MI_F(st, f, ty) #f ":" ty "@" + std::to_string(offsetof(st, f))
+size_t expv_mi_abi_sizeof(int kind) {
+  switch (kind) {
+    case EXPV_MI_ABI_ARNOLDI_OPTS: return sizeof(expv_mi_arnoldi_opts);
+    case EXPV_MI_ABI_EXPV_STATS: return sizeof(expv_mi_expv_stats);
+    case EXPV_MI_ABI_TIMESTEP_OPTS: return sizeof(expv_mi_timestep_opts);
+    case EXPV_MI_ABI_TIMESTEP_STATS: return sizeof(expv_mi_timestep_stats);
+    case EXPV_MI_ABI_KIOPS_OPTS: return sizeof(expv_mi_kiops_opts);
+    default: return 0;
+  }
+}
+const char *expv_mi_abi_layout(int kind) {
+  static std::string out[EXPV_MI_ABI_COUNT];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto join = [](std::initializer_list<std::string> v) {
+      std::string r;
+      for (const auto &x : v) r += (r.empty() ? "" : ",") + x;
+      return r;
+    };
+    out[EXPV_MI_ABI_ARNOLDI_OPTS] = join({std::string(EXPV_MI_F(expv_mi_arnoldi_opts, m, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, iop, "i32")),
+                                          std::string(EXPV_MI_F(expv_mi_arnoldi_opts, init, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, ishermitian, "i32")),
+                                          std::string(EXPV_MI_F(expv_mi_arnoldi_opts, ortho, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, reserved, "i32")),
+                                          std::string(EXPV_MI_F(expv_mi_arnoldi_opts, tol, "f64"))});
+    out[EXPV_MI_ABI_EXPV_STATS] = join({std::string(EXPV_MI_F(expv_mi_expv_stats, m_used, "i32")), std::string(EXPV_MI_F(expv_mi_expv_stats, wasbreakdown, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_expv_stats, matvecs, "i32")), std::string(EXPV_MI_F(expv_mi_expv_stats, path_flags, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_expv_stats, beta, "f64"))});
+    out[EXPV_MI_ABI_TIMESTEP_OPTS] = join({std::string(EXPV_MI_F(expv_mi_timestep_opts, tau, "f64")), std::string(EXPV_MI_F(expv_mi_timestep_opts, tol, "f64")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, delta, "f64")), std::string(EXPV_MI_F(expv_mi_timestep_opts, gamma, "f64")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, opnorm, "f64")), std::string(EXPV_MI_F(expv_mi_timestep_opts, has_opnorm, "i32")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, m, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_opts, iop, "i32")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, correct, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_opts, adaptive, "i32")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, ishermitian, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_opts, verbose, "i32")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, ortho, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_opts, NA, "i64")),
+                                           std::string(EXPV_MI_F(expv_mi_timestep_opts, print, "ptr")), std::string(EXPV_MI_F(expv_mi_timestep_opts, print_user, "ptr"))});
+    out[EXPV_MI_ABI_TIMESTEP_STATS] = join({std::string(EXPV_MI_F(expv_mi_timestep_stats, num_timesteps, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, matvecs, "i32")),
+                                            std::string(EXPV_MI_F(expv_mi_timestep_stats, m_final, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, arnoldi_calls, "i32"))});
+    out[EXPV_MI_ABI_KIOPS_OPTS] = join({std::string(EXPV_MI_F(expv_mi_kiops_opts, mmin, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, mmax, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_kiops_opts, m, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, iop, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_kiops_opts, ishermitian, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, task1, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_kiops_opts, ortho, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, reserved, "i32")),
+                                        std::string(EXPV_MI_F(expv_mi_kiops_opts, tol, "f64"))});
+  });
+  return (kind >= 0 && kind < EXPV_MI_ABI_COUNT) ? out[kind].c_str() : "";
+}
+#undef EXPV_MI_F
+
+// ------------------------------------------------------------------ batch over several GPUs, one host process --------
+int expv_mi_expv_batch_multi(expv_mi_ctx_t *ctxs, int nctx, int dtype, int64_t n, int nprob, const int32_t *rowptr,
+                             const int32_t *colind, const void *vals, int64_t nnz_per_prob, const double *t, const void *b,
+                             int64_t ldb, void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used) {
+  if (!ctxs || nctx < 1) return EXPV_MI_ARGUMENT_ERROR;
+  for (int k = 0; k < nctx; ++k)
+    if (!ctxs[k]) return EXPV_MI_ARGUMENT_ERROR;
+  if (nprob <= 0 || n <= 0) return EXPV_MI_OK;
+  const size_t esz = dtype_size(dtype);
+  std::vector<int> rc(nctx, EXPV_MI_OK);
+  std::vector<std::thread> th;
+  const int base = nprob / nctx, extra = nprob % nctx;
+  for (int k = 0; k < nctx; ++k) {
+    const int lo = k * base + std::min(k, extra), cnt = base + (k < extra ? 1 : 0);
+    if (cnt == 0) continue;
+    th.emplace_back([&, k, lo, cnt] {
+      Ctx *c = ctxs[k];
+      rc[k] = guarded(c, [&] {
+        c->use();
+        const char *vk = reinterpret_cast<const char *>(vals) + (size_t)lo * (size_t)nnz_per_prob * esz;
+        const char *bk = reinterpret_cast<const char *>(b) + (size_t)lo * (size_t)ldb * esz;
+        expv_mi_arnoldi_opts o;
+        if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
+        int32_t *mu = m_used ? m_used + lo : nullptr;
+        if (w_loc == EXPV_MI_HOST) {          // every shard writes its own columns of the caller's host matrix
+          char *wk = reinterpret_cast<char *>(w) + (size_t)lo * (size_t)ldw * esz;
+          expv_batch_run(c, dtype, n, cnt, rowptr, colind, vk, nnz_per_prob, EXPV_MI_HOST, t + lo, bk, ldb, EXPV_MI_HOST, wk, ldw,
+                         EXPV_MI_HOST, o, mu);
+        } else {                              // result block on this shard's device, then ONE peer copy into ctxs[0]'s matrix
+          DevBuf wl((size_t)n * cnt * esz + 16);
+          expv_batch_run(c, dtype, n, cnt, rowptr, colind, vk, nnz_per_prob, EXPV_MI_HOST, t + lo, bk, ldb, EXPV_MI_HOST, wl.p, n,
+                         EXPV_MI_DEVICE, o, mu);
+          char *dst = reinterpret_cast<char *>(w) + (size_t)lo * (size_t)ldw * esz;
+          if (ldw == n) {
+            HIPCHECK(hipMemcpyPeerAsync(dst, ctxs[0]->device, wl.p, c->device, (size_t)n * cnt * esz, c->stream));
+          } else {
+            for (int q = 0; q < cnt; ++q)
+              HIPCHECK(hipMemcpyPeerAsync(dst + (size_t)q * ldw * esz, ctxs[0]->device, wl.as<char>() + (size_t)q * n * esz, c->device,
+                                          (size_t)n * esz, c->stream));
+          }
+          HIPCHECK(hipStreamSynchronize(c->stream));
+        }
+      });
+    });
+  }
+  for (auto &x : th) x.join();
+  for (int k = 0; k < nctx; ++k)
+    if (rc[k] != EXPV_MI_OK) return rc[k];
+  return EXPV_MI_OK;
 }
 
 }  // extern "C"

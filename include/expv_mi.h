@@ -261,6 +261,31 @@ int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const
                        const double *t, const void *b, int64_t ldb, int b_loc, void *w, int64_t ldw,
                        int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used);
 
+/* The same batch over SEVERAL GPUs of one node from ONE host process (the Julia shim's way to run BASELINE config 5: a Julia
+ * host has no torch.distributed).  ctxs[0..nctx) are contexts on the participating devices; problem p goes to context
+ * floor(p * nctx / nprob)-style contiguous blocks (first nprob % nctx contexts get one more), every shard runs in its own
+ * host thread, nothing is exchanged between the shards while they run, and the FINAL GATHER of the
+ * result columns happens here: w_loc = EXPV_MI_HOST -> each shard writes its columns of the caller's host matrix;
+ * w_loc = EXPV_MI_DEVICE -> w lives on ctxs[0]'s device and the other shards' blocks arrive by peer copies over xGMI
+ * (hipMemcpyPeerAsync; within one process peer copies ARE the xGMI collective -- RCCL is what the one-process-per-GPU
+ * form uses, exponentialutilities.jl_amd/dist.py).  vals, t, b are host arrays (mat_loc / b_loc must be EXPV_MI_HOST).
+ * Returns the first failing shard's status; expv_mi_last_error(ctxs[k]) has the message. */
+int expv_mi_expv_batch_multi(expv_mi_ctx_t *ctxs, int nctx, int dtype, int64_t n, int nprob, const int32_t *rowptr,
+                             const int32_t *colind, const void *vals, int64_t nnz_per_prob, const double *t,
+                             const void *b, int64_t ldb, void *w, int64_t ldw, int w_loc,
+                             const expv_mi_arnoldi_opts *opts, int32_t *m_used);
+
+/* ------------------------------------------------------------------ ABI self-description -- */
+/* sizeof and field layout of the option / result structs as THIS library was compiled, so a host language that restates
+ * them (Julia `struct`, ctypes.Structure) can verify its layout at load time instead of trusting the header by eye.
+ * layout string: "name:type@offset,..." with type in {i32, i64, f64, ptr}. */
+enum {
+  EXPV_MI_ABI_ARNOLDI_OPTS = 0, EXPV_MI_ABI_EXPV_STATS = 1, EXPV_MI_ABI_TIMESTEP_OPTS = 2,
+  EXPV_MI_ABI_TIMESTEP_STATS = 3, EXPV_MI_ABI_KIOPS_OPTS = 4, EXPV_MI_ABI_COUNT = 5
+};
+size_t expv_mi_abi_sizeof(int kind);
+const char *expv_mi_abi_layout(int kind);
+
 /* ------------------------------------------------------------------ host small-dense ---- */
 /* The m x m pieces that stay on the host (north_star); exported so a host language can reuse them
  * and so they can be tested without a GPU.

@@ -156,3 +156,82 @@ def test_operator_fingerprint_detects_in_place_changes(eu):
     D[2, 1] = -D[2, 1]
     assert api._fingerprint(D) != g0
     assert api._fingerprint(np.zeros((3, 3), dtype=complex)) != api._fingerprint(np.zeros((3, 3)))
+
+
+def test_struct_layouts_match_the_library(eu):
+    """Every options / result struct a host language restates (ctypes here, `struct` in julia/MIKrylov.jl) against what
+    the library was compiled with: size, field order, offsets and types (expv_mi_abi_sizeof / expv_mi_abi_layout)."""
+    import ctypes as C
+    from exponentialutilities_jl_amd import _lib as L
+    lib = L.load()
+    tyname = {C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_void_p: "ptr", L.PRINT_FN: "ptr"}
+    for name, kind in L.ABI_KINDS.items():
+        st = getattr(L, name)
+        assert lib.expv_mi_abi_sizeof(kind) == C.sizeof(st), name
+        mine = ",".join("%s:%s@%d" % (f, tyname[t], getattr(st, f).offset) for f, t in st._fields_)
+        assert lib.expv_mi_abi_layout(kind).decode() == mine, (name, lib.expv_mi_abi_layout(kind).decode(), mine)
+    assert lib.expv_mi_abi_sizeof(99) == 0 and lib.expv_mi_abi_layout(99) == b""
+    # the Julia shim restates the same structs: its field lists must be the library's, in order
+    src = open(os.path.join(ROOT, "julia", "MIKrylov.jl")).read()
+    for jl, kind in (("ArnoldiOpts", 0), ("ExpvStats", 1), ("TimestepOpts", 2), ("TimestepStats", 3), ("KiopsOpts", 4)):
+        body = re.search(r"struct %s\n(.*?)\nend" % jl, src, flags=re.S).group(1)
+        fields = [l.split("::")[0].strip() for l in body.splitlines() if "::" in l]
+        want = [f.split(":")[0] for f in lib.expv_mi_abi_layout(kind).decode().split(",")]
+        assert fields == want, (jl, fields, want)
+        jt = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Ptr{Cvoid}": "ptr"}
+        types = [jt[l.split("::")[1].split("#")[0].strip()] for l in body.splitlines() if "::" in l]
+        assert types == [f.split(":")[1].split("@")[0] for f in lib.expv_mi_abi_layout(kind).decode().split(",")], jl
+
+
+def _split_top(argstr):
+    out, depth, cur = [], 0, ""
+    for ch in argstr:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_julia_shim_calls_match_the_header():
+    """julia/MIKrylov.jl cannot run here (no Julia in the image): at least every ccall in it must name a symbol the header
+    declares, with the header's number of arguments, pointer arguments as pointers and scalars as scalars."""
+    hdr = open(os.path.join(ROOT, "include", "expv_mi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|void|size_t|const char \*)\s*\*?\s*(expv_mi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = [] if args in ("", "void") else _split_top(args)
+    src = open(os.path.join(ROOT, "julia", "MIKrylov.jl")).read()
+    calls = 0
+    for m in re.finditer(r"ccall\(\(:(expv_mi_[a-z0-9_]+), lib\),\s*([A-Za-z{}]+),\s*\(", src):
+        name = m.group(1)
+        assert name in protos, "MIKrylov.jl calls %s, which include/expv_mi.h does not declare" % name
+        i, depth = m.end(), 1                     # the Julia argument-type tuple: balanced parentheses from here
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        jl = [a for a in _split_top(src[m.end(): i - 1]) if a]
+        c = protos[name]
+        assert len(jl) == len(c), (name, jl, c)
+        for ja, ca in zip(jl, c):
+            c_is_ptr = "*" in ca or "[" in ca or "_fn" in ca or ca.split()[0].endswith("_t") and "expv_mi_" in ca and "int" not in ca.split()[0]
+            j_is_ptr = ja.startswith(("Ptr{", "Ref{", "Cstring"))
+            assert c_is_ptr == j_is_ptr, (name, ja, ca)
+            if not c_is_ptr:
+                width = {"int": "Cint", "int32_t": "Cint", "int64_t": "Int64", "double": "Cdouble", "size_t": "Csize_t"}
+                assert ja == width[ca.replace("const", "").split()[0]], (name, ja, ca)
+        calls += 1
+    assert calls >= 25
+    used = set(re.findall(r":(expv_mi_[a-z0-9_]+), lib", src))
+    for must in ("expv_mi_arnoldi", "expv_mi_lanczos", "expv_mi_expv_ks", "expv_mi_phiv_ks", "expv_mi_phiv_timestep", "expv_mi_kiops",
+                 "expv_mi_timestep_caches_create", "expv_mi_expv_error_estimate", "expv_mi_expv", "expv_mi_expv_batch_multi",
+                 "expv_mi_abi_sizeof", "expv_mi_ks_resize"):
+        assert must in used, must

@@ -364,3 +364,27 @@ def test_single_pass_step_continuation_and_augmented_bitwise_forms(eu):
         wo, so = ko.kiops(1.5, Ac, u, allow_complex=cplx, ishermitian=False, tol=1e-9)
         assert res[0][1] == so
         close(res[0][0], wo, 1e-12, "kiops on the single-pass step (complex=%s) vs oracle" % cplx)
+
+
+def test_batch_over_several_contexts_from_one_process(eu):
+    """expv_mi_expv_batch_multi (the Julia host's way to run config 5): shards over contexts, one host thread per shard,
+    final gather into a host matrix or into ctxs[0]'s device matrix.  One GPU here, so the contexts share device 0 -- the
+    sharding, threading and gather code is the same."""
+    rng = np.random.default_rng(17)
+    n, nprob, m = 20_000, 7, 30
+    A0 = c2_operator(n).tocsr()
+    A0.sort_indices()
+    vals = np.stack([A0.data * s for s in 1 + 0.1 * rng.random(nprob)])
+    B = np.asfortranarray(rng.standard_normal((n, nprob)))
+    ts = np.linspace(0.5, 1.0, nprob)
+    ref, mref = eu.expv_batch(ts, A0, vals, B, m=m, return_m=True)
+    for nctx in (1, 2, 3):
+        ctxs = [eu.Context() for _ in range(nctx)]
+        W, mu = eu.expv_batch_multi(ts, A0, vals, B, ctxs, m=m, return_m=True)
+        close(W, ref, 1e-15, "batch over %d context(s), host gather, vs single-context batch" % nctx)
+        assert np.array_equal(mu, mref)
+        Wd = eu.DeviceArray((n, nprob), np.float64, ctxs[0])
+        eu.expv_batch_multi(ts, A0, vals, B, ctxs, m=m, out=Wd)
+        close(Wd.to_host(), ref, 1e-15, "batch over %d context(s), device gather (peer copies)" % nctx)
+    with pytest.raises(eu.DimensionMismatch):
+        eu.expv_batch_multi(ts, A0, vals[:, :-1], B, [eu.Context()], m=m)
