@@ -43,13 +43,14 @@ class TimestepOpts(C.Structure):
     _fields_ = [("tau", C.c_double), ("tol", C.c_double), ("delta", C.c_double), ("gamma", C.c_double),
                 ("opnorm", C.c_double), ("has_opnorm", C.c_int32), ("m", C.c_int32), ("iop", C.c_int32),
                 ("correct", C.c_int32), ("adaptive", C.c_int32), ("ishermitian", C.c_int32),
-                ("verbose", C.c_int32), ("ortho", C.c_int32), ("NA", C.c_int64), ("print", PRINT_FN),
+                ("verbose", C.c_int32), ("ortho", C.c_int32), ("no_basis_reuse", C.c_int32), ("reserved", C.c_int32),
+                ("NA", C.c_int64), ("print", PRINT_FN),
                 ("print_user", C.c_void_p)]
 
 
 class TimestepStats(C.Structure):
     _fields_ = [("num_timesteps", C.c_int32), ("matvecs", C.c_int32), ("m_final", C.c_int32),
-                ("arnoldi_calls", C.c_int32)]
+                ("arnoldi_calls", C.c_int32), ("arnoldi_reused", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KiopsOpts(C.Structure):

@@ -675,7 +675,7 @@ def timestep_caches(u_prototype, maxiter, p, ctx=None):
 
 def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0, correct=False, caches=None,
                    adaptive=False, delta=1.2, ishermitian=None, gamma=0.8, NA=0, verbose=False, ortho="auto",
-                   out=None, stats=None):
+                   out=None, stats=None, reuse_basis=True):
     """phiv_timestep!(U, ts, A, B; ...)  (krylov_phiv_adaptive.jl:260-453).  ``ts`` is sorted in place."""
     Bdt = _np_dtype_of(B)
     T = _work_dtype(Bdt)
@@ -706,6 +706,7 @@ def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0
     o.verbose = int(bool(verbose))
     o.ortho = {"auto": 0, "mgs": 1, "lowsync": 2}[ortho] if isinstance(ortho, str) else int(ortho)
     o.NA = int(NA)
+    o.no_basis_reuse = int(not reuse_basis)
     sink = out if out is not None else print
     cb = L.PRINT_FN(lambda line, user: sink(line.decode()))
     o.print = cb
@@ -717,7 +718,8 @@ def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0
     if ts_arr is not ts and isinstance(ts, np.ndarray):
         ts[...] = ts_arr
     if stats is not None:
-        stats.update(num_timesteps=st.num_timesteps, matvecs=st.matvecs, m=st.m_final, arnoldi_calls=st.arnoldi_calls)
+        stats.update(num_timesteps=st.num_timesteps, matvecs=st.matvecs, m=st.m_final, arnoldi_calls=st.arnoldi_calls,
+                     arnoldi_reused=st.arnoldi_reused)
     return U
 
 

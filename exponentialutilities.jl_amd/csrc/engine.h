@@ -269,6 +269,8 @@ void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, in
 void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
                        void *W, int64_t ldw, int w_loc, int w_dtype);
 
+// max |x_i| (mode 0) / sum |x_i| (mode 1) of a DEVICE vector: partials on the device, finished on the host in index order
+double abs_reduce_dev(Ctx *ctx, int dtype, const void *x_dev, int64_t n, int mode);
 // stage a caller buffer (host or device) as a device pointer; `tmp` owns the copy when one is made
 const void *stage_in(Ctx *ctx, const void *p, int loc, size_t bytes, DevBuf &tmp);
 // 2-D (column-major, ld in elements) variant producing a packed device matrix with ld = rows

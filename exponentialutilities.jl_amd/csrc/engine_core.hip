@@ -33,6 +33,23 @@ const void *stage_in(Ctx *ctx, const void *p, int loc, size_t bytes, DevBuf &tmp
   return tmp.p;
 }
 
+double abs_reduce_dev(Ctx *ctx, int dtype, const void *x, int64_t n, int mode) {
+  if (n <= 0) return 0.0;
+  ctx->use();
+  DevBuf part(sizeof(double) * dev::MAX_GRID);
+  const int g = (dtype == EXPV_MI_C64) ? dev::abs_partial<cplx>(ctx->stream, (const cplx *)x, n, part.as<double>(), mode)
+                                       : dev::abs_partial<double>(ctx->stream, (const double *)x, n, part.as<double>(), mode);
+  std::vector<double> h(g);
+  HIPCHECK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  double r = 0.0;
+  for (double v : h) {
+    if (mode == 0) r = (v > r || v != v) ? v : r;
+    else r += v;
+  }
+  return r;
+}
+
 const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t cols, int64_t ld, size_t esz,
                         DevBuf &tmp, int64_t *ld_out) {
   if (loc == EXPV_MI_DEVICE) {

@@ -94,8 +94,7 @@ static double hnorm1(const Ks &ks) {
 
 template <class T>
 static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, int64_t ldb, int ncoef, T *Udev,
-                            int64_t ldu, const expv_mi_timestep_opts &o, TsCache *cache, const double *b0_host,
-                            expv_mi_timestep_stats *stats) {
+                            int64_t ldu, const expv_mi_timestep_opts &o, TsCache *cache, expv_mi_timestep_stats *stats) {
   const int64_t n = op.n;
   const int dt = op.dtype;
   int m = o.m > 0 ? o.m : (int)std::min<int64_t>(10, n);
@@ -105,16 +104,8 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
   const bool arnoldi_scale = !o.has_opnorm;
   bool have_abstol = false;
   double abstol = 0.0, opn = 0.0;
-  auto b0norm = [&]() {
-    double v = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      double a;
-      if constexpr (ST<T>::is_complex) a = std::hypot(b0_host[2 * i], b0_host[2 * i + 1]);
-      else a = std::fabs(b0_host[i]);
-      v = std::max(v, a);
-    }
-    return v;
-  };
+  // norm(b0, Inf) (:285, :375): B is device-resident here -- reduced on the device, no O(n) copy to the host
+  auto b0norm = [&]() { return abs_reduce_dev(ctx, dt, B, n, 0); };
   const double E = 2.718281828459045, PI = 3.141592653589793;
   if (!arnoldi_scale) {
     opn = o.opnorm;
@@ -169,7 +160,7 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
   ao.ishermitian = -1;          // arnoldi! evaluates LinearAlgebra.ishermitian(A) itself (:364)
   ao.ortho = o.ortho;
   double t = 0.0;
-  int snapshot = 1, num_timesteps = 0, matvecs = 0, arn_calls = 0;
+  int snapshot = 1, num_timesteps = 0, matvecs = 0, arn_calls = 0, arn_reused = 0, last_fact_matvecs = 0;
   while (t < tend) {
     if (t + tau > tend) tau = tend - t;
     // Part 1: w0..wp by recurrence (16)  (:353-362)
@@ -191,7 +182,8 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
     ao.m = m;
     ao.iop = iop;
     ao.init = 0;
-    matvecs += arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);
+    last_fact_matvecs = arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);
+    matvecs += last_fact_matvecs;
     ++arn_calls;
     if (!have_abstol) {
       opn = hnorm1(*ks);
@@ -233,7 +225,16 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
         tau_old = tau;
         tau = tau_new;
         ao.m = m;
-        matvecs += arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);   // from scratch, like :417
+        if (m == m_old && !o.no_basis_reuse) {
+          // only tau changed: arnoldi!(Ks, A, w_p; m) of :417 would rebuild exactly the basis Ks already holds (it depends
+          // on A, w_p and m, not on tau; the factorisation is deterministic), so keep it.  The statistics keep counting
+          // the operator applications the reference performs.
+          matvecs += last_fact_matvecs;
+          ++arn_reused;
+        } else {
+          last_fact_matvecs = arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);   // from scratch, like :417
+          matvecs += last_fact_matvecs;
+        }
         ++arn_calls;
         double epsilon_new = 0.0;
         phiv_eval(*ks, tau, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &epsilon_new);
@@ -272,6 +273,8 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
     stats->matvecs = matvecs;
     stats->m_final = m;
     stats->arnoldi_calls = arn_calls;
+    stats->arnoldi_reused = arn_reused;
+    stats->reserved = 0;
   }
 }
 
@@ -286,16 +289,6 @@ void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int
   DevBuf btmp, utmp;
   int64_t ldbd = ldb;
   const void *Bd = stage_in_2d(ctx, B, b_loc, n, ncoef, ldb, esz, btmp, &ldbd);
-  // ||b0||_inf is needed on the host only when tau is seeded (:285, :375)
-  std::vector<double> b0((size_t)n * (esz / 8));
-  const bool need_b0 = (o.tau == 0.0);
-  if (need_b0 && n > 0) {
-    if (b_loc == EXPV_MI_HOST) std::memcpy(b0.data(), B, (size_t)n * esz);
-    else {
-      HIPCHECK(hipMemcpyAsync(b0.data(), B, (size_t)n * esz, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHECK(hipStreamSynchronize(ctx->stream));
-    }
-  }
   void *Ud = U;
   int64_t ldud = ldu;
   if (u_loc == EXPV_MI_HOST) {
@@ -304,10 +297,9 @@ void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int
     ldud = n;
   }
   if (op.dtype == EXPV_MI_C64)
-    phiv_timestep_T<cplx>(ctx, op, nts, ts, (const cplx *)Bd, ldbd, ncoef, (cplx *)Ud, ldud, o, cache, b0.data(), stats);
+    phiv_timestep_T<cplx>(ctx, op, nts, ts, (const cplx *)Bd, ldbd, ncoef, (cplx *)Ud, ldud, o, cache, stats);
   else
-    phiv_timestep_T<double>(ctx, op, nts, ts, (const double *)Bd, ldbd, ncoef, (double *)Ud, ldud, o, cache, b0.data(),
-                            stats);
+    phiv_timestep_T<double>(ctx, op, nts, ts, (const double *)Bd, ldbd, ncoef, (double *)Ud, ldud, o, cache, stats);
   if (u_loc == EXPV_MI_HOST) copy_out_2d(ctx, U, EXPV_MI_HOST, ldu, Ud, ldud, n, nts, esz);
 }
 
@@ -531,21 +523,10 @@ void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols,
   DevBuf utmp, wtmp;
   int64_t ldud = ldu;
   const void *ud = stage_in_2d(ctx, u, u_loc, n, ncols_u, ldu, esz, utmp, &ldud);
-  // entrywise 1-norm of u[:, 2:end] on the host (setup cost, :94)
+  // norm(u[:, 2:end], 1), entrywise (:94): u is staged in HBM already -- per-column device reductions, finished on the host
   double normU = 0.0;
-  if (ncols_u > 1) {
-    std::vector<double> hb((size_t)n * (esz / 8));
-    for (int cidx = 1; cidx < ncols_u; ++cidx) {
-      const char *src = reinterpret_cast<const char *>(u) + (size_t)cidx * ldu * esz;
-      if (u_loc == EXPV_MI_HOST) std::memcpy(hb.data(), src, (size_t)n * esz);
-      else {
-        HIPCHECK(hipMemcpyAsync(hb.data(), src, (size_t)n * esz, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-      }
-      for (int64_t i = 0; i < n; ++i)
-        normU += (esz == 16) ? std::hypot(hb[2 * i], hb[2 * i + 1]) : std::fabs(hb[i]);
-    }
-  }
+  for (int cidx = 1; cidx < ncols_u; ++cidx)
+    normU += abs_reduce_dev(ctx, op.dtype, reinterpret_cast<const char *>(ud) + (size_t)cidx * ldud * esz, n, 1);
   void *wd = w;
   if (w_loc == EXPV_MI_HOST) {
     wtmp.alloc((size_t)n * esz + 16);

@@ -70,6 +70,8 @@ int device_cus();
 // workgroups of BLOCK threads of `kernel` that fit on the chip at once (occupancy query, cached)
 int resident_blocks(const void *kernel);
 
+// per-workgroup partials (returns how many) of max |x_i| (mode 0) / sum |x_i| (mode 1); the host finishes them in order
+template <class T> int abs_partial(hipStream_t s, const T *x, int64_t n, double *part, int mode);
 template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, StepState *st);
 template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t n, double scal, int divide);
 template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);

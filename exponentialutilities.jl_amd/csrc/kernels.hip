@@ -122,6 +122,48 @@ void sumsq(hipStream_t s, const T *x, int64_t n, double *part, double *gpart, St
   hipLaunchKernelGGL(k_sumsq<T>, dim3(g), dim3(BLOCK), 0, s, x, n, part, gpart, st);
 }
 
+// per-workgroup partials of max |x_i| (mode 0) or sum |x_i| (mode 1); the host finishes the <= MAX_GRID partials in index
+// order (deterministic).  ||b0||_inf of phiv_timestep! (krylov_phiv_adaptive.jl:285, :375), norm(u[:, 2:end], 1) of kiops
+// (kiops.jl:94) for device-resident inputs: no O(n) copy to the host.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_abs_partial(const T *__restrict__ x, int64_t n, double *part, int mode) {
+  __shared__ double red_s[BLOCK / 64];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const T v = x[i];
+    double a;
+    if constexpr (ST<T>::is_complex) a = hypot(v.re, v.im);
+    else a = fabs(v);
+    if (mode == 0) acc = (a > acc || a != a) ? a : acc;      // NaN propagates like maximum(abs, x)
+    else acc += a;
+  }
+  if (mode == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double other = __shfl_down(acc, o, 64);
+      acc = (other > acc || other != other) ? other : acc;
+    }
+    if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double m = red_s[0];
+      for (int w = 1; w < BLOCK / 64; ++w) m = (red_s[w] > m || red_s[w] != red_s[w]) ? red_s[w] : m;
+      part[blockIdx.x] = m;
+    }
+  } else {
+    const double ssum = block_sum(acc, red_s);
+    if (threadIdx.x == 0) part[blockIdx.x] = ssum;
+  }
+}
+template <class T>
+int abs_partial(hipStream_t s, const T *x, int64_t n, double *part, int mode) {
+  const int g = grid_for(n, BLOCK * 8);
+  hipLaunchKernelGGL(k_abs_partial<T>, dim3(g), dim3(BLOCK), 0, s, x, n, part, mode);
+  return g;
+}
+template int abs_partial<double>(hipStream_t, const double *, int64_t, double *, int);
+template int abs_partial<cplx>(hipStream_t, const cplx *, int64_t, double *, int);
+
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_scale_copy(T *__restrict__ dst, const T *__restrict__ src, int64_t n,
                                                       double scal, int divide) {

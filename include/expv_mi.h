@@ -214,6 +214,10 @@ typedef struct {
   int32_t ishermitian; /* -1 ask operator; only steers the flop model (see :332-334) */
   int32_t verbose;
   int32_t ortho;
+  int32_t no_basis_reuse; /* 1: rebuild the Krylov basis on every adaptation retry like krylov_phiv_adaptive.jl:417 does
+                             even when only tau changed (the basis does not depend on tau); 0 (default): reuse it --
+                             bit-identical results, the saved factorisations are counted in stats.arnoldi_reused */
+  int32_t reserved;
   int64_t NA;          /* 0: nnz of the operator                                    */
   expv_mi_print_fn print;
   void *print_user;
@@ -222,7 +226,10 @@ typedef struct {
   int32_t num_timesteps;
   int32_t matvecs;
   int32_t m_final;
-  int32_t arnoldi_calls;
+  int32_t arnoldi_calls;  /* factorisations the reference performs for this call (control-flow parity)             */
+  int32_t arnoldi_reused; /* ... of which this many were NOT recomputed (tau-only retries reuse the basis);
+                             `matvecs` keeps counting what the reference performs                                   */
+  int32_t reserved;
 } expv_mi_timestep_stats;
 void expv_mi_timestep_opts_default(expv_mi_timestep_opts *o);
 /* _phiv_timestep_caches(u_prototype, maxiter, p)  (krylov_phiv_adaptive.jl:502-511) */

@@ -66,6 +66,8 @@ struct TimestepOpts
     ishermitian::Cint
     verbose::Cint
     ortho::Cint
+    no_basis_reuse::Cint
+    reserved::Cint
     NA::Int64
     print::Ptr{Cvoid}
     print_user::Ptr{Cvoid}
@@ -75,6 +77,8 @@ struct TimestepStats
     matvecs::Cint
     m_final::Cint
     arnoldi_calls::Cint
+    arnoldi_reused::Cint
+    reserved::Cint
 end
 struct KiopsOpts
     mmin::Cint
@@ -373,9 +377,9 @@ function phiv_timestep!(U::MIVecOrMat{T}, ts::AbstractVector{tType}, A::MIOperat
     if opnorm !== nothing
         has_opn, opn = 1, Float64(opnorm isa Number ? opnorm : opnorm(A, Inf))  # a number or a function (:276-281)
     end
-    o = Ref(TimestepOpts(tau, tol, delta, gamma, opn, has_opn, m, iop, correct, adaptive, ishermitian, verbose, 0, NA,
+    o = Ref(TimestepOpts(tau, tol, delta, gamma, opn, has_opn, m, iop, correct, adaptive, ishermitian, verbose, 0, 0, 0, NA,
                          verbose ? println_ptr() : C_NULL, C_NULL))
-    st = Ref(TimestepStats(0, 0, 0, 0))
+    st = Ref(TimestepStats(0, 0, 0, 0, 0, 0))
     check(ccall((:expv_mi_phiv_timestep, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cvoid}, Int64, Cint, Cint, Ptr{Cvoid}, Int64, Cint,
                  Ref{TimestepOpts}, Ptr{Cvoid}, Ref{TimestepStats}),
