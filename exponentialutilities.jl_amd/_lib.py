@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EXPV_MI_LIB") or os.path.join(HERE, "libexpv_mi.so")   # EXPV_MI_LIB: A/B builds when profiling
 
-F64, C64 = 0, 1
+F64, C64, F32, C32 = 0, 1, 2, 3
 HOST, DEVICE = 0, 1
 ORTHO_AUTO, ORTHO_MGS, ORTHO_LOWSYNC = 0, 1, 2
 PATH_FLAGS = {"modular": 1, "two_kernel": 2, "pipeline": 4, "wave": 8, "overlapped": 16, "redo_serial": 32,

@@ -174,6 +174,29 @@ def _code(dt):
     return L.C64 if np.issubdtype(np.dtype(dt), np.complexfloating) else L.F64
 
 
+def _ref_dtype(*dts):
+    """promote_type of the reference for the given operand element types, restricted to the BlasFloats: Float32 operands give a
+    Float32 result there.  The device path computes in fp64 / complex-fp64 (the operands are promoted on upload) and the
+    front ends round the result to this type."""
+    dt = np.result_type(*[np.dtype(d) for d in dts])
+    if dt.kind == "c":
+        return np.dtype(np.complex64 if dt.itemsize <= 8 else np.complex128)
+    return np.dtype(np.float32 if (dt.kind == "f" and dt.itemsize <= 4) else np.float64)
+
+
+def _round_to(x, dtype):
+    """round a computed (fp64 / complex-fp64) result to the reference's result type when that is a 32-bit one"""
+    dtype = np.dtype(dtype)
+    if dtype.itemsize * (1 if dtype.kind == "f" else 1) >= (8 if dtype.kind == "f" else 16):
+        return x
+    if _is_torch(x):
+        import torch
+        return x.to(torch.complex64 if dtype.kind == "c" else torch.float32)
+    if isinstance(x, DeviceArray):
+        return x
+    return np.asarray(x).astype(dtype)
+
+
 def _work_dtype(*dts):
     return np.dtype(np.complex128) if any(np.issubdtype(np.dtype(d), np.complexfloating) for d in dts) \
         else np.dtype(np.float64)
@@ -327,6 +350,10 @@ class MIOperator:
                                                    C.byref(h)), self.ctx._h)
         self._h = h
         self._finalizer = weakref.finalize(self, lib.expv_mi_op_destroy, h)
+        try:            # element type the caller handed over (Float32 operands: see _ref_dtype)
+            self.src_dtype = _np_dtype_of(A) if A is not None else np.dtype(dtype or np.float64)
+        except Exception:
+            self.src_dtype = np.dtype(np.float64)
         n_, nnz, herm, opn, dtc = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
         _check(lib.expv_mi_op_info(h, C.byref(n_), C.byref(nnz), C.byref(herm), C.byref(opn), C.byref(dtc)))
         self.shape = (int(n_.value), int(n_.value))
@@ -601,6 +628,8 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
         _check(L.load().expv_mi_expv(opT.ctx._h, opT._h, tr, ti, ba.ptr, ba.loc, wa.ptr, wa.loc, _code(wa.dtype),
                                      C.byref(o), C.byref(st)), opT.ctx._h)
         wa.finish()
+        if kw.get("out") is None:
+            w = _round_to(w, _ref_dtype(tdt if tc else np.float32, getattr(op, "src_dtype", op.dtype), bdt))
         expv.last_stats = {"m": st.m_used, "wasbreakdown": bool(st.wasbreakdown), "matvecs": st.matvecs, "beta": st.beta,
                            "path": [k for k, v in L.PATH_FLAGS.items() if st.path_flags & v]}
         return w
@@ -880,11 +909,28 @@ def expv_batch_multi(ts, pattern, vals, B, ctxs, *, m=None, tol=1e-7, iop=0, ish
 # ---------------------------------------------------------------------------------------------
 # host small-dense functions (no GPU needed)
 # ---------------------------------------------------------------------------------------------
+_HOST_CODES = {np.dtype(np.float64): L.F64, np.dtype(np.complex128): L.C64, np.dtype(np.float32): L.F32,
+               np.dtype(np.complex64): L.C32}
+
+
+def _host_dtype(*dts):
+    """Element type of the host small-dense functions: every BlasFloat is kept (Float32 stays Float32)."""
+    dt = np.result_type(*[np.dtype(d) for d in dts])
+    if dt.kind not in "fc" or dt.itemsize < 4:
+        dt = np.result_type(dt, np.float64)
+    if dt.itemsize > 16 or (dt.kind == "f" and dt.itemsize > 8):
+        dt = np.dtype(np.complex128 if dt.kind == "c" else np.float64)
+    if dt == np.dtype(np.float16):
+        dt = np.dtype(np.float32)
+    return dt
+
+
 def host_expm(A):
-    """exponential!(copy(A), ExpMethodHigham2005Base()) on the host (exp_baseexp.jl:112-161)."""
-    A = np.array(A, dtype=_work_dtype(np.asarray(A).dtype), order="F", copy=True)
+    """exponential!(copy(A), ExpMethodHigham2005Base()) on the host (exp_baseexp.jl:112-161), for every BlasFloat element
+    type (Float32 / ComplexF32 stay what they are: test/basictests.jl:952-974)."""
+    A = np.array(A, dtype=_host_dtype(np.asarray(A).dtype), order="F", copy=True)
     n = A.shape[0]
-    _check(L.load().expv_mi_host_expm(_code(A.dtype), n, A.ctypes.data, max(n, 1)))
+    _check(L.load().expv_mi_host_expm(_HOST_CODES[A.dtype], n, A.ctypes.data, max(n, 1)))
     return A
 
 
@@ -913,13 +959,13 @@ def host_pattern_info(A, dtype=np.float64):
 
 
 def host_phiv_dense(A, v, k):
-    """phiv_dense(A, v, k)  (phi.jl:75-115)."""
-    dt = _work_dtype(np.asarray(A).dtype, np.asarray(v).dtype)
+    """phiv_dense(A, v, k)  (phi.jl:75-115), element type kept (see host_expm)."""
+    dt = _host_dtype(np.asarray(A).dtype, np.asarray(v).dtype)
     A = np.asfortranarray(A, dtype=dt)
     v = np.ascontiguousarray(v, dtype=dt)
     m = A.shape[0]
     w = np.empty((m, k + 1), dtype=dt, order="F")
-    _check(L.load().expv_mi_host_phiv_dense(_code(dt), m, int(k), A.ctypes.data, max(m, 1), v.ctypes.data,
+    _check(L.load().expv_mi_host_phiv_dense(_HOST_CODES[dt], m, int(k), A.ctypes.data, max(m, 1), v.ctypes.data,
                                             w.ctypes.data))
     return w
 

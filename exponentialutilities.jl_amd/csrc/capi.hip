@@ -318,8 +318,37 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   }
 }
 
+// the device path computes in fp64 / complex-fp64 (include/expv_mi.h: expv_mi_dtype)
+void check_device_dtype(int dt, const char *who) {
+  if (dt == EXPV_MI_F32 || dt == EXPV_MI_C32)
+    fail(EXPV_MI_UNSUPPORTED, std::string(who) + ": the device path computes in fp64 / complex-fp64; promote 32-bit operands (the host mirrors do)");
+  if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": unknown dtype");
+}
+
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",
                                              "fused_a",   "fused_b", "lincomb", "aug",    "batch"};
+}  // namespace
+
+namespace {
+template <class S>
+void host_expm_T(int n, void *A, int lda) {
+  Mat<S> M(n, n);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) M(i, j) = reinterpret_cast<S *>(A)[(size_t)j * lda + i];
+  dense::expm_higham2005base(M);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) reinterpret_cast<S *>(A)[(size_t)j * lda + i] = M(i, j);
+}
+template <class S>
+void host_phiv_dense_T(int m, int k, const void *A, int lda, const void *v, void *w) {
+  Mat<S> M(m, m);
+  std::vector<S> vv(m);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) M(i, j) = reinterpret_cast<const S *>(A)[(size_t)j * lda + i];
+  for (int i = 0; i < m; ++i) vv[i] = reinterpret_cast<const S *>(v)[i];
+  Mat<S> R = dense::phiv_dense(M, vv, k);
+  std::copy(R.a.begin(), R.a.end(), reinterpret_cast<S *>(w));
+}
 }  // namespace
 
 extern "C" {
@@ -445,7 +474,7 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
     if (!out) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: null output");
     if (n < 0 || n > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: n out of range for CSR32");
     if (!colptr || (n > 0 && (!rowval || !nzval))) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: null colptr / rowval / nzval");
-    if (dtype != EXPV_MI_F64 && dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: unknown dtype");
+    check_device_dtype(dtype, "op_create_csc");
     // colptr must be what SparseMatrixCSC guarantees: starts at the index base, non-decreasing (csc_to_csr slices by it)
     if (colptr[0] != index_base) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: colptr[0] must equal the index base");
     for (int64_t c = 0; c < n; ++c)
@@ -482,7 +511,7 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
     };
     if (!out) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: null output");
     if (!rowptr) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: null rowptr");
-    if (dtype != EXPV_MI_F64 && dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: unknown dtype");
+    check_device_dtype(dtype, "op_create_csr");
     // rowptr: starts at the index base, non-decreasing (build_sell / the kernels slice by it)
     if (rpv(0) != 0) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csr: rowptr[0] must equal the index base");
     for (int64_t i = 0; i < n; ++i)
@@ -516,6 +545,7 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
   return guarded(ctx, [&] {
     ctx->use();
     if (n < 0 || lda < n) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_dense: bad n / lda");
+    check_device_dtype(dtype, "op_create_dense");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
     op->dtype = dtype;
@@ -587,6 +617,7 @@ int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_
                                int ishermitian, int64_t nnz_hint, expv_mi_op_t *out) {
   return guarded(ctx, [&] {
     if (!fn) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_callback: null callback");
+    check_device_dtype(dtype, "op_create_callback");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
     op->dtype = dtype;
@@ -905,20 +936,13 @@ int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *c
 }
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {
   return guarded(nullptr, [&] {
-    if (dtype == EXPV_MI_C64) {
-      Mat<cd> M(n, n);
-      for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) M(i, j) = reinterpret_cast<cd *>(A)[(size_t)j * lda + i];
-      dense::expm_higham2005base(M);
-      for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) reinterpret_cast<cd *>(A)[(size_t)j * lda + i] = M(i, j);
-    } else {
-      Mat<double> M(n, n);
-      for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) M(i, j) = reinterpret_cast<double *>(A)[(size_t)j * lda + i];
-      dense::expm_higham2005base(M);
-      for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) reinterpret_cast<double *>(A)[(size_t)j * lda + i] = M(i, j);
+    if (n < 0 || lda < n || (n > 0 && !A)) fail(EXPV_MI_ARGUMENT_ERROR, "host_expm: bad n / lda / A");
+    switch (dtype) {
+      case EXPV_MI_F64: host_expm_T<double>(n, A, lda); break;
+      case EXPV_MI_C64: host_expm_T<cd>(n, A, lda); break;
+      case EXPV_MI_F32: host_expm_T<float>(n, A, lda); break;
+      case EXPV_MI_C32: host_expm_T<dense::cf>(n, A, lda); break;
+      default: fail(EXPV_MI_ARGUMENT_ERROR, "host_expm: unknown dtype");
     }
   });
 }
@@ -933,22 +957,12 @@ int expv_mi_host_symtridiag_expcol(int n, const double *d, const double *e, doub
 // phiv_dense!(w, A, v, k)  (phi.jl:84-115); w is m x (k+1), ldw = m
 int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, const void *v, void *w) {
   return guarded(nullptr, [&] {
-    if (dtype == EXPV_MI_C64) {
-      Mat<cd> M(m, m);
-      std::vector<cd> vv(m);
-      for (int j = 0; j < m; ++j)
-        for (int i = 0; i < m; ++i) M(i, j) = reinterpret_cast<const cd *>(A)[(size_t)j * lda + i];
-      for (int i = 0; i < m; ++i) vv[i] = reinterpret_cast<const cd *>(v)[i];
-      Mat<cd> R = dense::phiv_dense(M, vv, k);
-      std::copy(R.a.begin(), R.a.end(), reinterpret_cast<cd *>(w));
-    } else {
-      Mat<double> M(m, m);
-      std::vector<double> vv(m);
-      for (int j = 0; j < m; ++j)
-        for (int i = 0; i < m; ++i) M(i, j) = reinterpret_cast<const double *>(A)[(size_t)j * lda + i];
-      for (int i = 0; i < m; ++i) vv[i] = reinterpret_cast<const double *>(v)[i];
-      Mat<double> R = dense::phiv_dense(M, vv, k);
-      std::copy(R.a.begin(), R.a.end(), reinterpret_cast<double *>(w));
+    switch (dtype) {
+      case EXPV_MI_F64: host_phiv_dense_T<double>(m, k, A, lda, v, w); break;
+      case EXPV_MI_C64: host_phiv_dense_T<cd>(m, k, A, lda, v, w); break;
+      case EXPV_MI_F32: host_phiv_dense_T<float>(m, k, A, lda, v, w); break;
+      case EXPV_MI_C32: host_phiv_dense_T<dense::cf>(m, k, A, lda, v, w); break;
+      default: fail(EXPV_MI_ARGUMENT_ERROR, "host_phiv_dense: unknown dtype");
     }
   });
 }

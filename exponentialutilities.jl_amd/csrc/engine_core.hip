@@ -97,6 +97,11 @@ static void ks_alloc_aux(Ks &ks) {
 
 void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int augmented) {
   if (n < 0 || maxiter < 1 || augmented < 0) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: bad n/maxiter/augmented");
+  for (int dt : {dtT, dtU}) {
+    if (dt == EXPV_MI_F32 || dt == EXPV_MI_C32)
+      fail(EXPV_MI_UNSUPPORTED, "KrylovSubspace: the device path computes in fp64 / complex-fp64; promote 32-bit operands");
+    if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: unknown dtype");
+  }
   if (dtT == EXPV_MI_F64 && dtU == EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: U complex with T real");
   ctx->use();
   ks.ctx = ctx;
@@ -1094,8 +1099,22 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
   T *Hd = ks.Hdev.as<T>();
   std::vector<double> alpha, betas;
   std::vector<cd> cv;
-  std::vector<T> colbuf(ks.ldhd);
-  for (int j = 1; j <= m; ++j) {
+  // The stopping test of step j needs alpha_j, beta_j on the host (the j x j tridiagonal exponential, :58-68), but the
+  // device need not wait for the verdict: steps are enqueued LOOKAHEAD ahead, each followed by a two-word copy of its
+  // (alpha, beta) into pinned memory and an event; the host waits on the event of step j while steps j+1 .. j+LOOKAHEAD are
+  // already queued.  When step j satisfies the test the at most LOOKAHEAD extra steps are simply not used (Ks.m = j):
+  // same arithmetic, same result as the step-by-step form, no idle device between steps.
+  constexpr int LOOKAHEAD = 3;
+  const size_t pin_need = sizeof(T) * 2 * (size_t)(m + 1);
+  if (ks.pin_bytes < pin_need) {
+    if (ks.pin) (void)hipHostFree(ks.pin);
+    ks.pin = nullptr;
+    ks.pin_bytes = std::max(pin_need, sizeof(T) * (size_t)ks.ldhd * (ks.maxiter + 1) + sizeof(StepState));
+    HIPCHECK(hipHostMalloc(&ks.pin, ks.pin_bytes, hipHostMallocDefault));
+  }
+  T *ab = reinterpret_cast<T *>(ks.pin);
+  std::vector<hipEvent_t> ev(m + 1, nullptr);
+  auto enqueue = [&](int j) {
     const T *x = V + (size_t)(j - 1) * ks.ldv;
     T *y = V + (size_t)j * ks.ldv;
     op_apply_T<T>(op, x, y, nullptr, j);
@@ -1110,11 +1129,18 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
     u.ldh = ks.ldhd; u.jcol = j - 1; u.tol = -1.0; u.step = j;
     dev::update<T>(s, u);
     dev::scale_by_state<T>(s, y, ks.n, st, j);
-    HIPCHECK(hipMemcpyAsync(colbuf.data(), Hd + (size_t)(j - 1) * ks.ldhd, sizeof(T) * (j + 1), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    // alpha_j = H[j, j], beta_j = H[j+1, j]: two adjacent entries of column j
+    HIPCHECK(hipMemcpyAsync(ab + 2 * (size_t)j, Hd + (size_t)(j - 1) * ks.ldhd + (j - 1), sizeof(T) * 2, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ev[j], s));
+  };
+  int enq = 0;
+  for (int j = 1; j <= m; ++j) {
+    while (enq < std::min(m, j + LOOKAHEAD)) enqueue(++enq);
+    HIPCHECK(hipEventSynchronize(ev[j]));
     double aj, bj;
-    if constexpr (ST<T>::is_complex) { aj = colbuf[j - 1].re; bj = colbuf[j].re; }
-    else { aj = colbuf[j - 1]; bj = colbuf[j]; }
+    if constexpr (ST<T>::is_complex) { aj = ab[2 * j].re; bj = ab[2 * j + 1].re; }
+    else { aj = ab[2 * j]; bj = ab[2 * j + 1]; }
     setH(ks, j - 1, j - 1, cd(aj, 0));
     setH(ks, j, j - 1, cd(bj, 0));
     alpha.push_back(aj);
@@ -1124,6 +1150,8 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
     const double sigma = bj * ks.beta * std::abs(cv[j - 1]);           // Saad's Er2  (:197)
     if (sigma < eps_stop) { ks.m = j; break; }
   }
+  for (auto e : ev)
+    if (e) (void)hipEventDestroy(e);
   const int mm = ks.m;
   if (t.imag() == 0.0 && ks.dtypeT == EXPV_MI_F64) {
     std::vector<double> cr(mm);

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <limits>
 #include <stdexcept>
 #include <vector>
 
@@ -21,17 +22,25 @@ namespace expv_mi {
 namespace dense {
 
 using cd = std::complex<double>;
+using cf = std::complex<float>;
+// real type of a scalar: the norms, thresholds and balancing factors of a matrix of S live in it
+template <class S> struct real_of { typedef S type; };
+template <class R> struct real_of<std::complex<R>> { typedef R type; };
+template <class S> using real_t = typename real_of<S>::type;
 
 struct SingularError : std::runtime_error {
   SingularError() : std::runtime_error("SingularException(0): Pade denominator is singular") {}
 };
 
 inline double absv(double x) { return std::fabs(x); }
-inline double absv(const cd &x) { return std::abs(x); }
+inline float absv(float x) { return std::fabs(x); }
+template <class R> inline R absv(const std::complex<R> &x) { return std::abs(x); }
 inline double cabs1(double x) { return std::fabs(x); }
-inline double cabs1(const cd &x) { return std::fabs(x.real()) + std::fabs(x.imag()); }
+inline float cabs1(float x) { return std::fabs(x); }
+template <class R> inline R cabs1(const std::complex<R> &x) { return std::fabs(x.real()) + std::fabs(x.imag()); }
 inline bool nonzero(double x) { return x != 0.0; }
-inline bool nonzero(const cd &x) { return x.real() != 0.0 || x.imag() != 0.0; }
+inline bool nonzero(float x) { return x != 0.0f; }
+template <class R> inline bool nonzero(const std::complex<R> &x) { return x.real() != R(0) || x.imag() != R(0); }
 
 template <class S>
 struct Mat {  // tiny owning column-major matrix
@@ -80,10 +89,10 @@ inline void matmul(Mat<S> &C, const Mat<S> &A, const Mat<S> &B) {  // C = A*B (C
 }
 
 template <class S>
-inline double opnorm1(const Mat<S> &A) {
-  double best = 0;
+inline real_t<S> opnorm1(const Mat<S> &A) {
+  real_t<S> best = 0;
   for (int j = 0; j < A.c; ++j) {
-    double s = 0;
+    real_t<S> s = 0;
     for (int i = 0; i < A.r; ++i) s += absv(A(i, j));
     best = std::max(best, s);
   }
@@ -105,32 +114,36 @@ inline double opnorm1_raw(const S *H, int ld, int r, int c) {
 // ---- balancing: LAPACK xGEBAL job='B' (2-norm variant) --------------------------------------
 template <class S>
 struct Balance {
-  int ilo = 1, ihi = 0;        // 1-based like LAPACK
-  std::vector<double> scale;   // permutation indices outside [ilo,ihi], scale factors inside
+  int ilo = 1, ihi = 0;             // 1-based like LAPACK
+  std::vector<real_t<S>> scale;     // permutation indices outside [ilo,ihi], scale factors inside
 };
 
 inline double re_of(double x) { return x; }
 inline double im_of(double) { return 0.0; }
-inline double re_of(const cd &x) { return x.real(); }
-inline double im_of(const cd &x) { return x.imag(); }
+inline float re_of(float x) { return x; }
+inline float im_of(float) { return 0.0f; }
+template <class R> inline R re_of(const std::complex<R> &x) { return x.real(); }
+template <class R> inline R im_of(const std::complex<R> &x) { return x.imag(); }
 
 template <class S>
-inline double nrm2_strided(const S *x, int n, int inc) {
+inline real_t<S> nrm2_strided(const S *x, int n, int inc) {
+  typedef real_t<S> R;
   // plain sum of squares first (what balancing sees is O(|H|)); the scaled BLAS-style form only
   // when that over/underflows
-  double ss = 0.0;
+  R ss = 0;
   for (int i = 0; i < n; ++i) {
     const S v = x[(size_t)i * inc];
     ss += re_of(v) * re_of(v) + im_of(v) * im_of(v);
   }
-  if (ss > 1e-280 && ss < 1e280) return std::sqrt(ss);
-  double scale = 0, ssq = 1;
+  const R lo = sizeof(R) == 8 ? R(1e-280) : R(1e-30f), hi = sizeof(R) == 8 ? R(1e280) : R(1e30f);
+  if (ss > lo && ss < hi) return std::sqrt(ss);
+  R scale = 0, ssq = 1;
   for (int i = 0; i < n; ++i) {
     const S v = x[(size_t)i * inc];
-    const double parts[2] = {re_of(v), im_of(v)};
-    for (double p : parts) {
+    const R parts[2] = {re_of(v), im_of(v)};
+    for (R p : parts) {
       if (p != 0) {
-        const double a = std::fabs(p);
+        const R a = std::fabs(p);
         if (scale < a) {
           ssq = 1 + ssq * (scale / a) * (scale / a);
           scale = a;
@@ -145,13 +158,14 @@ inline double nrm2_strided(const S *x, int n, int inc) {
 
 template <class S>
 inline Balance<S> gebal(Mat<S> &A) {
+  typedef real_t<S> R;
   const int n = A.r;
   Balance<S> B;
-  B.scale.assign(n, 1.0);
+  B.scale.assign(n, R(1));
   if (n == 0) { B.ilo = 1; B.ihi = 0; return B; }
-  const double radix = 2.0, sclfac = 2.0, factor = 0.95;
+  const R radix = 2, sclfac = 2, factor = R(0.95);
   auto swap_rc = [&](int j, int m, int k, int l) {  // 1-based j<->m; cols over rows 1..l, rows over cols k..n
-    B.scale[m - 1] = j;
+    B.scale[m - 1] = R(j);
     if (j != m) {
       for (int i = 0; i < l; ++i) std::swap(A(i, j - 1), A(i, m - 1));
       for (int c = k - 1; c < n; ++c) std::swap(A(j - 1, c), A(m - 1, c));
@@ -187,27 +201,27 @@ inline Balance<S> gebal(Mat<S> &A) {
       }
     }
   }
-  for (int i = k; i <= l; ++i) B.scale[i - 1] = 1.0;
-  const double tiny = 2.2250738585072014e-308, eps = 2.220446049250313e-16;
-  const double sfmin1 = tiny / eps, sfmax1 = 1.0 / sfmin1;
-  const double sfmin2 = sfmin1 * sclfac, sfmax2 = 1.0 / sfmin2;
+  for (int i = k; i <= l; ++i) B.scale[i - 1] = R(1);
+  const R tiny = std::numeric_limits<R>::min(), eps = std::numeric_limits<R>::epsilon();     // xLAMCH('S'), xLAMCH('P')
+  const R sfmin1 = tiny / eps, sfmax1 = R(1) / sfmin1;
+  const R sfmin2 = sfmin1 * sclfac, sfmax2 = R(1) / sfmin2;
   noconv = true;
   while (noconv) {
     noconv = false;
     for (int i = k; i <= l; ++i) {
-      double c = nrm2_strided(&A(k - 1, i - 1), l - k + 1, 1);
-      double r = nrm2_strided(&A(i - 1, k - 1), l - k + 1, n);
+      R c = nrm2_strided(&A(k - 1, i - 1), l - k + 1, 1);
+      R r = nrm2_strided(&A(i - 1, k - 1), l - k + 1, n);
       int ica = 0;
-      double best = -1;
-      for (int q = 0; q < l; ++q) { double v = cabs1(A(q, i - 1)); if (v > best) { best = v; ica = q; } }
-      double ca = absv(A(ica, i - 1));
+      R best = -1;
+      for (int q = 0; q < l; ++q) { R v = cabs1(A(q, i - 1)); if (v > best) { best = v; ica = q; } }
+      R ca = absv(A(ica, i - 1));
       int ira = k - 1;
       best = -1;
-      for (int q = k - 1; q < n; ++q) { double v = cabs1(A(i - 1, q)); if (v > best) { best = v; ira = q; } }
-      double ra = absv(A(i - 1, ira));
-      if (c == 0.0 || r == 0.0) continue;
-      double g = r / radix, f = 1.0;
-      const double s = c + r;
+      for (int q = k - 1; q < n; ++q) { R v = cabs1(A(i - 1, q)); if (v > best) { best = v; ira = q; } }
+      R ra = absv(A(i - 1, ira));
+      if (c == R(0) || r == R(0)) continue;
+      R g = r / radix, f = 1;
+      const R s = c + r;
       while (c < g && std::max(f, std::max(c, ca)) < sfmax2 && std::min(r, std::min(g, ra)) > sfmin2) {
         f *= sclfac; c *= sclfac; ca *= sclfac; r /= sclfac; g /= sclfac; ra /= sclfac;
       }
@@ -216,9 +230,9 @@ inline Balance<S> gebal(Mat<S> &A) {
         f /= sclfac; c /= sclfac; g /= sclfac; ca /= sclfac; r *= sclfac; ra *= sclfac;
       }
       if ((c + r) >= factor * s) continue;
-      if (f < 1.0 && B.scale[i - 1] < 1.0 && f * B.scale[i - 1] <= sfmin1) continue;
-      if (f > 1.0 && B.scale[i - 1] > 1.0 && B.scale[i - 1] >= sfmax1 / f) continue;
-      g = 1.0 / f;
+      if (f < R(1) && B.scale[i - 1] < R(1) && f * B.scale[i - 1] <= sfmin1) continue;
+      if (f > R(1) && B.scale[i - 1] > R(1) && B.scale[i - 1] >= sfmax1 / f) continue;
+      g = R(1) / f;
       B.scale[i - 1] *= f;
       noconv = true;
       for (int cidx = k - 1; cidx < n; ++cidx) A(i - 1, cidx) *= g;
@@ -235,7 +249,7 @@ template <class S>
 inline void unbalance(Mat<S> &X, const Balance<S> &B) {
   const int n = X.r;
   for (int j = B.ilo; j <= B.ihi; ++j) {
-    const double sj = B.scale[j - 1];
+    const real_t<S> sj = B.scale[j - 1];
     for (int i = 0; i < n; ++i) X(j - 1, i) *= sj;
     for (int i = 0; i < n; ++i) X(i, j - 1) /= sj;
   }
@@ -257,13 +271,13 @@ inline void lu_solve(Mat<S> &M, Mat<S> &X) {
   std::vector<int> piv(n);
   for (int k = 0; k < n; ++k) {
     int p = k;
-    double best = cabs1(M(k, k));
+    real_t<S> best = cabs1(M(k, k));
     for (int i = k + 1; i < n; ++i) {
-      const double v = cabs1(M(i, k));
+      const real_t<S> v = cabs1(M(i, k));
       if (v > best) { best = v; p = i; }
     }
     piv[k] = p;
-    if (best == 0.0 || std::isnan(best)) throw SingularError();
+    if (best == real_t<S>(0) || std::isnan(best)) throw SingularError();
     if (p != k) {
       for (int j = 0; j < n; ++j) std::swap(M(k, j), M(p, j));
       for (int j = 0; j < nrhs; ++j) std::swap(X(k, j), X(p, j));
@@ -315,7 +329,8 @@ inline Mat<S> pade_evaluate(const Mat<S> &A, const double *C, int N) {
   const int n = A.r;
   Mat<S> A2, P(n, n), U(n, n), V(n, n), tmp;
   matmul(A2, A, A);
-  for (int i = 0; i < n; ++i) { P(i, i) = S(1); U(i, i) = S(C[1]); V(i, i) = S(C[0]); }
+  typedef real_t<S> R;    // the coefficients are stored once as doubles and converted to the element type (exp_baseexp.jl:65-77, :88)
+  for (int i = 0; i < n; ++i) { P(i, i) = S(1); U(i, i) = S(R(C[1])); V(i, i) = S(R(C[0])); }
   for (int k = 1; k <= N / 2 - 1; ++k) {
     const int k2 = 2 * k;
     if (k == 1) {
@@ -324,7 +339,7 @@ inline Mat<S> pade_evaluate(const Mat<S> &A, const double *C, int N) {
       matmul(tmp, P, A2);
       std::swap(P.a, tmp.a);
     }
-    const S cu = S(C[k2 + 1]), cv = S(C[k2]);
+    const S cu = S(R(C[k2 + 1])), cv = S(R(C[k2]));
     for (size_t i = 0; i < P.a.size(); ++i) { U.a[i] += cu * P.a[i]; V.a[i] += cv * P.a[i]; }
   }
   matmul(tmp, A, U);
@@ -349,25 +364,26 @@ static const double PADE_C13[] = {64764752532480000.0, 32382376266240000.0, 7771
 // exponential!(A, ExpMethodHigham2005Base())  -- in place
 template <class S>
 inline void expm_higham2005base(Mat<S> &A) {
+  typedef real_t<S> R;
   const int n = A.r;
   if (n == 0) return;
   for (const auto &v : A.a)   // LAPACK.gebal!'s chkfinite: balancing never terminates on NaN input
-    if (!std::isfinite(std::real(cd(v))) || !std::isfinite(std::imag(cd(v))))
+    if (!std::isfinite(re_of(v)) || !std::isfinite(im_of(v)))
       throw std::invalid_argument("ArgumentError: matrix contains Infs or NaNs");
   Balance<S> bal = gebal(A);
-  const double nA = opnorm1(A);
+  const R nA = opnorm1(A);
   Mat<S> X;
-  if (nA <= 2.1) {
-    if (nA > 0.95) X = pade_evaluate(A, PADE_C9, 10);
-    else if (nA > 0.25) X = pade_evaluate(A, PADE_C7, 8);
-    else if (nA > 0.015) X = pade_evaluate(A, PADE_C5, 6);
+  if (nA <= R(2.1)) {
+    if (nA > R(0.95)) X = pade_evaluate(A, PADE_C9, 10);
+    else if (nA > R(0.25)) X = pade_evaluate(A, PADE_C7, 8);
+    else if (nA > R(0.015)) X = pade_evaluate(A, PADE_C5, 6);
     else X = pade_evaluate(A, PADE_C3, 4);
   } else {
-    const double s = std::log2(nA / 5.4);
+    const R s = std::log2(nA / R(5.4));
     int si = 0;
     if (s > 0) {
       si = (int)std::ceil(s);
-      const double sc = std::ldexp(1.0, si);
+      const R sc = std::ldexp(R(1), si);
       for (auto &v : A.a) v /= sc;
     }
     X = pade_evaluate(A, PADE_C13, 14);

@@ -44,7 +44,11 @@ typedef enum {
   EXPV_MI_BOUNDS = 8              /* BoundsError (kiops.jl:303 with several output times)    */
 } expv_mi_status;
 
-typedef enum { EXPV_MI_F64 = 0, EXPV_MI_C64 = 1 } expv_mi_dtype;
+/* F64 / C64: every entry point.  F32 / C32: the HOST small-dense functions (expv_mi_host_expm, expv_mi_host_phiv_dense:
+ * exponential!(A, ExpMethodHigham2005Base()) for every BlasFloat, test/basictests.jl:952-974).  The device path computes in
+ * fp64 / complex-fp64: entry points that take device data answer EXPV_MI_UNSUPPORTED for F32 / C32, and the host mirrors
+ * promote 32-bit operands on upload and round the result back to the reference's promote_type. */
+typedef enum { EXPV_MI_F64 = 0, EXPV_MI_C64 = 1, EXPV_MI_F32 = 2, EXPV_MI_C32 = 3 } expv_mi_dtype;
 typedef enum { EXPV_MI_HOST = 0, EXPV_MI_DEVICE = 1 } expv_mi_loc;
 
 /* Orthogonalisation arithmetic of arnoldi_step! (arnoldi.jl:301-304).

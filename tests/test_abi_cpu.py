@@ -235,3 +235,24 @@ def test_julia_shim_calls_match_the_header():
                  "expv_mi_timestep_caches_create", "expv_mi_expv_error_estimate", "expv_mi_expv", "expv_mi_expv_batch_multi",
                  "expv_mi_abi_sizeof", "expv_mi_ks_resize"):
         assert must in used, must
+
+
+@pytest.mark.parametrize("T,tol", [(np.float64, 1e-11), (np.float32, 1e-4), (np.complex128, 1e-11), (np.complex64, 1e-4)])
+@pytest.mark.parametrize("scale", [3.0, 1.5, 0.5, 0.1, 0.005])
+def test_host_expm_across_blasfloat_types(eu, T, tol, scale):
+    """test/basictests.jl:952-974: exponential!(_, ExpMethodHigham2005Base) for every BlasFloat across every Pade norm
+    range (C13 with scaling-squaring, C9, C7, C5, C3), against a high-precision reference; the result keeps the type."""
+    rng = np.random.default_rng(7)
+    n = 40
+    A0 = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if np.dtype(T).kind == "c" else 0)
+    A = (scale * A0 / np.linalg.norm(A0, 1)).astype(T)
+    ref = sl.expm(A.astype(np.complex128))
+    E = eu.host_expm(A)
+    assert E.dtype == np.dtype(T)
+    assert np.linalg.norm(E.astype(np.complex128) - ref) / np.linalg.norm(ref) < tol
+    if scale == 3.0:     # phiv_dense through the same routine, same element type
+        v = A[:, 0].copy()
+        w = eu.host_phiv_dense(A, v, 2)
+        assert w.dtype == np.dtype(T)
+        w64 = eu.host_phiv_dense(A.astype(np.complex128), v.astype(np.complex128), 2)
+        assert np.linalg.norm(w.astype(np.complex128) - w64) / np.linalg.norm(w64) < 10 * tol

@@ -414,3 +414,25 @@ def test_basis_reuse_across_tau_only_retries_is_bit_identical(eu):
         if vs_oracle:
             assert (s_re["num_timesteps"], s_re["matvecs"], s_re["m"]) == (so["num_timesteps"], so["matvecs"], so["m"]), (s_re, so)
             close(U_re, Uo, 1e-12, "phiv_timestep with basis reuse (n=%d m=%d t=%g, %d tau-only retries) vs oracle" % (n, m, t, s_re["arnoldi_reused"]))
+
+
+@pytest.mark.parametrize("T", [np.float32, np.complex64])
+def test_32bit_operands_follow_the_reference_result_type(eu, T):
+    """Float32 / ComplexF32 operands: the reference computes and returns in that type (BlasFloat, ExponentialUtilities.jl:19);
+    the build promotes to fp64 on upload, computes there and rounds the result of expv to the reference's promote_type."""
+    rng = np.random.default_rng(3)
+    n = 200
+    A = (c2_operator(n).toarray() * (1 + (0.25j if np.dtype(T).kind == "c" else 0))).astype(T)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(T).kind == "c" else 0)).astype(T)
+    w = eu.expv(0.5, A, b, m=30)
+    assert w.dtype == np.dtype(T)
+    truth = sl.expm(0.5 * A.astype(np.complex128)) @ b.astype(np.complex128)
+    close(w.astype(np.complex128), truth, 2e-6, "expv with %s operands vs dense truth (fp32 rounding of inputs and result)" % np.dtype(T).name)
+    w64 = eu.expv(0.5, A.astype(np.complex128 if np.dtype(T).kind == "c" else np.float64), b, m=30)
+    assert w64.dtype.itemsize == 2 * np.dtype(T).itemsize
+    with pytest.raises(eu.ExpvMIError) as ei:                      # the C ABI itself says so, instead of misreading the bytes
+        import ctypes as C
+        from exponentialutilities_jl_amd import _lib as L
+        h = C.c_void_p()
+        L.check(L.load().expv_mi_ks_create(eu.default_context()._h, L.F32, L.F32, 10, 5, 0, C.byref(h)), eu.default_context()._h)
+    assert ei.value.kind == "Unsupported"
