@@ -87,6 +87,15 @@ class Context:
         """Device-resident results stream-ordered (True) or complete on return (False, the C-ABI default)."""
         _check(L.load().expv_mi_ctx_set_async_outputs(self._h, int(bool(on))), self._h)
 
+    def set_option(self, name, value):
+        """Engine option of this context by name (expv_mi_ctx_set_option; see include/expv_mi.h for the list)."""
+        _check(L.load().expv_mi_ctx_set_option(self._h, name.encode(), int(value)), self._h)
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        _check(L.load().expv_mi_ctx_get_option(self._h, name.encode(), C.byref(v)), self._h)
+        return int(v.value)
+
     def counters(self):
         """Cumulative counters of the context (expv_mi_ctx_counters)."""
         out = (C.c_int64 * 8)()

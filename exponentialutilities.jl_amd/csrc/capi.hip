@@ -365,6 +365,7 @@ int expv_mi_ctx_create(int device_id, void *stream, expv_mi_ctx_t *out) {
     if (device_id < 0 || device_id >= count) fail(EXPV_MI_ARGUMENT_ERROR, "ctx_create: device id out of range");
     std::unique_ptr<expv_mi_ctx_s> c(new expv_mi_ctx_s());
     c->device = device_id;
+    c->opt = Options::from_env();
     HIPCHECK(hipSetDevice(device_id));
     if (stream) {
       c->stream = reinterpret_cast<hipStream_t>(stream);
@@ -401,6 +402,24 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on) {
   if (!ctx) return EXPV_MI_ARGUMENT_ERROR;
   ctx->pipe_overlap = (on != 0);
   return EXPV_MI_OK;
+}
+int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value) {
+  if (!ctx) return EXPV_MI_ARGUMENT_ERROR;
+  return guarded(ctx, [&] {
+    int *slot = ctx->opt.find(name);
+    if (!slot) fail(EXPV_MI_ARGUMENT_ERROR, std::string("unknown option: ") + (name ? name : "(null)"));
+    if (value < 0 || value > INT_MAX) fail(EXPV_MI_ARGUMENT_ERROR, "option value out of range");
+    *slot = (int)value;
+    if (slot == &ctx->opt.batch_rounds && *slot < 1) *slot = 1;
+  });
+}
+int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value) {
+  if (!ctx || !value) return EXPV_MI_ARGUMENT_ERROR;
+  return guarded(ctx, [&] {
+    int *slot = ctx->opt.find(name);
+    if (!slot) fail(EXPV_MI_ARGUMENT_ERROR, std::string("unknown option: ") + (name ? name : "(null)"));
+    *value = *slot;
+  });
 }
 int expv_mi_ctx_counters(expv_mi_ctx_t ctx, int64_t out[8]) {
   if (!ctx || !out) return EXPV_MI_ARGUMENT_ERROR;

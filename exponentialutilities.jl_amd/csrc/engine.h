@@ -44,8 +44,26 @@ struct ProfSlot {
   double total_ms = 0.0;
 };
 
+// Engine options of a context (expv_mi_ctx_set_option).  The environment variables named below only provide the DEFAULTS of
+// a new context (read once, when it is created) so that A/B runs of an unmodified program stay possible; library
+// behaviour is per context, never per process.
+struct Options {
+  int pipeline = 1;        // single-pass step for banded / structured-grid operators        (EXPV_MI_NO_PIPE=1 -> 0)
+  int wave = 1;            // ... its wave form for operators wider than a cheap halo          (EXPV_MI_NO_WAVE=1 -> 0)
+  int fused = 1;           // single-reduction two-kernel step for regular-row sparse operators (EXPV_MI_NO_FUSED=1 -> 0)
+  int fused_two_reductions = 0;   // the older two-reduction form of that step (A/B only)      (EXPV_MI_FUSED_V1=1 -> 1)
+  int dia = 1;             // diagonal storage forms (DIA / general DIA) instead of SELL slots (EXPV_MI_NO_DIA=1 -> 0)
+  int mailbox = 1;         // H / state to the host through host-mapped memory, no copy + sync (EXPV_MI_NO_MAILBOX=1 -> 0)
+  int pipeline_serial = 0; // single-pass step: one launch after the other even if overlap is on (EXPV_MI_PIPE_SERIAL=1 -> 1)
+  int spin_limit = 400000; // polls (~1 us each) before a waiting kernel gives up               (EXPV_MI_PIPE_SPIN_LIMIT)
+  int batch_rounds = 2;    // batched single-pass step: resident rounds of fat workgroups       (EXPV_MI_BATCH_ROUNDS)
+  static Options from_env();
+  int *find(const char *name);
+};
+
 struct Ctx {
   int device = 0;
+  Options opt;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   std::string last_error;

@@ -176,7 +176,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       pb.V = strideV; pb.y = ldv; pb.part = (int64_t)dev::MAX_GRID * 64; pb.gpart = ngpart; pb.Hdev = strideH;
       pb.gram = (int64_t)ldg * ldg; pb.hcoef = m + 2; pb.scales = m + 2; pb.dia = dia_words; pb.st = 1; pb.u0 = ldb;
       ProfScope ps(ctx, EXPV_MI_K_BATCH);
-      dev::pipe_step(s, pa, pc);
+      dev::pipe_step(s, pa, pc, ctx->opt.batch_rounds);
     }
     HIPCHECK(hipMemcpyAsync(Hh.data(), dH.p, sizeof(double) * (size_t)strideH * pc, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(sth.data(), dst.p, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
@@ -250,8 +250,7 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
   if (!herm && std::min(iop, m) > dev::LOWSYNC_MAX) fail(EXPV_MI_UNSUPPORTED, "expv_batch: window longer than 64 columns");
   if (m > dev::LOWSYNC_MAX * 2) fail(EXPV_MI_UNSUPPORTED, "expv_batch: m > 128");
   if constexpr (std::is_same<T, double>::value) {
-    static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
-    if (!no_pipe && m <= dev::PIPE_CH && m >= 1) {
+    if (ctx->opt.pipeline && m <= dev::PIPE_CH && m >= 1) {
       const DiaPattern P = dia_pattern(n, rowptr_h, colind_h, nnz);
       if (P.ndiag > 0) {
         expv_batch_pipe(ctx, n, nprob, P, vals_dev, nnz, t, b_dev, ldb, w_dev, ldw, o, m_used, m, herm, iop);

@@ -223,9 +223,8 @@ static MailboxView mailbox_view(const Ks &ks, void *base) {
   return MailboxView{m, m + hw, m + hw + sw, reinterpret_cast<unsigned long long *>(m + hw + sw + 4)};
 }
 static bool mailbox_arm(Ks &ks, int m) {
-  static const bool no_mbox = std::getenv("EXPV_MI_NO_MAILBOX") != nullptr;
   ks.mbox_armed = false;
-  if (no_mbox) return false;
+  if (!ks.ctx->opt.mailbox) return false;
   const size_t need = sizeof(double) * (mailbox_hwords(ks) + (size_t)(ks.maxiter + 2) + 8);
   if (ks.mbox_bytes < need) {
     if (ks.mbox) (void)hipHostFree(ks.mbox);
@@ -244,6 +243,35 @@ static bool mailbox_arm(Ks &ks, int m) {
   return true;
 }
 
+Options Options::from_env() {
+  Options o;
+  auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
+  if (flag("EXPV_MI_NO_PIPE")) o.pipeline = 0;
+  if (flag("EXPV_MI_NO_WAVE")) o.wave = 0;
+  if (flag("EXPV_MI_NO_FUSED")) o.fused = 0;
+  if (flag("EXPV_MI_FUSED_V1")) o.fused_two_reductions = 1;
+  if (flag("EXPV_MI_NO_DIA")) o.dia = 0;
+  if (flag("EXPV_MI_NO_MAILBOX")) o.mailbox = 0;
+  if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
+  if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
+  if (const char *v = std::getenv("EXPV_MI_BATCH_ROUNDS")) o.batch_rounds = std::max(1, std::atoi(v));
+  return o;
+}
+int *Options::find(const char *name) {
+  const std::string n(name ? name : "");
+  if (n == "pipeline") return &pipeline;
+  if (n == "wave") return &wave;
+  if (n == "fused") return &fused;
+  if (n == "fused_two_reductions") return &fused_two_reductions;
+  if (n == "dia") return &dia;
+  if (n == "mailbox") return &mailbox;
+  if (n == "pipeline_serial") return &pipeline_serial;
+  if (n == "spin_limit") return &spin_limit;
+  if (n == "batch_rounds") return &batch_rounds;
+  return nullptr;
+}
+
+// host-side phase timing is a developer diagnostic (process-wide, printed when a context is destroyed), not library behaviour
 static const bool g_ht_on = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
 static double g_ht_sum[16];
 static long g_ht_cnt[16];
@@ -262,58 +290,98 @@ void ht_report() {
     if (g_ht_cnt[i]) std::fprintf(stderr, "[host timing] %-28s %8.2f us avg over %ld\n", names[i], g_ht_sum[i] / g_ht_cnt[i], g_ht_cnt[i]);
 }
 template <class T>
-static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos) {
-  Ctx *c = ks.ctx;
-  c->use();
-  hipStream_t s = c->stream;
-  const bool isaug = aug != nullptr;
-  int m = o.m > 0 ? o.m : (int)std::min<int64_t>(ks.maxiter, op.n);
-  const double tol = o.tol;
-  int init = o.init;
-  ks.wasbreakdown = false;
-  if (init == 0) { ks.scale_pending = false; ks.scale_cols = 0; }   // a fresh factorisation overwrites the stored basis
-  if (m > ks.maxiter) ks_resize(ks, m);
-  else ks.m = m;
-  // checkdims (arnoldi.jl:207-220)
-  const int p = isaug ? aug->p : 0;
-  if (op.n != ks.n || p != ks.augmented)
-    fail(EXPV_MI_DIMENSION_MISMATCH, "length(b') == size(A,1) == size(A,2) == size(V,1)-p doesn't hold");
-  if (op.dtype != ks.dtypeT) fail(EXPV_MI_ARGUMENT_ERROR, "operator dtype must equal the subspace dtype T");
-  const int64_t rows = ks.rows();
-  T *V = ks.V.as<T>();
-  StepState *st = ks.state.as<StepState>();
-  const bool real_coeff = (ks.dtypeT == EXPV_MI_C64 && ks.dtypeU == EXPV_MI_F64);
-  const int hview_rows = m + 1, hview_cols = m + (isaug ? 1 : 0);
-  bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
-  int64_t wave_reach = 0;
+static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos);
 
-  const bool fresh = (init == 0);
-  // ---- which step form runs ----------------------------------------------------------------
-  static const bool no_fused = std::getenv("EXPV_MI_NO_FUSED") != nullptr;   // A/B switches for profiling
-  static const bool fused_v1 = std::getenv("EXPV_MI_FUSED_V1") != nullptr;   // two reductions per step
-  single_red = !fused_v1;
-  // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
-  //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
-  use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
-              o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
-  // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
-  static const bool no_pipe = std::getenv("EXPV_MI_NO_PIPE") != nullptr;
-  static const bool no_dia_env = std::getenv("EXPV_MI_NO_DIA") != nullptr;   // A/B: SELL operator slots
-  {
-    // the update window of a pass is the projection window of the step before it: at most min(m - 1, iop) columns
-    // (2 for Lanczos), min(m, iop) for the closing pass that produces v_{m+1}
-    const int iopw = lanczos ? 2 : (o.iop == 0 ? m : std::min(o.iop, m));
-    const int wstep = std::min(m - 1, iopw);
-    const bool have_dia = op.ndiag > 0 && !no_dia_env;
-    use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
-               wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
-               (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
-               (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
+// One arnoldi! / lanczos! call.  The three step forms share the call's state; each lives in its own
+// member function:
+//   steps_single_pass()                 pipe.hip     one launch per Krylov step (banded / structured-grid operators)
+//   steps_two_kernel()                  fused.hip    single-reduction two-kernel step (regular-row sparse operators)
+//   steps_two_kernel_two_reductions()   fused.hip    its older two-reduction form (A/B only)
+//   steps_modular()                     kernels.hip  operator apply + dots + update + scale launches (dense, callback, strict MGS)
+template <class T>
+struct ArnoldiCall {
+  Ks &ks;
+  Op &op;
+  const T *b;
+  const expv_mi_arnoldi_opts &o;
+  const ArnoldiAug *aug;
+  const bool lanczos;
+  Ctx *c;
+  hipStream_t s;
+  const bool isaug, real_coeff, no_dia_env;
+  const int p;
+  const double tol;
+  int init;
+  const bool fresh;
+  int m = 0, iop = 0, jstart = 1, hview_rows = 0, hview_cols = 0;
+  int64_t rows = 0, wave_reach = 0;
+  T *V = nullptr, *Hd = nullptr, *hcoef = nullptr;
+  StepState *st = nullptr;
+  double *part = nullptr, *gpart = nullptr;
+  bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
+
+  ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
+      : ks(ks_), op(op_), b(b_), o(o_), aug(aug_), lanczos(lanczos_), c(ks_.ctx), s(ks_.ctx->stream), isaug(aug_ != nullptr),
+        real_coeff(ks_.dtypeT == EXPV_MI_C64 && ks_.dtypeU == EXPV_MI_F64), no_dia_env(!ks_.ctx->opt.dia),
+        p(aug_ ? aug_->p : 0), tol(o_.tol), init(o_.init), fresh(o_.init == 0) {}
+
+  int run() {
+    c->use();
+    m = o.m > 0 ? o.m : (int)std::min<int64_t>(ks.maxiter, op.n);
+    ks.wasbreakdown = false;
+    if (init == 0) { ks.scale_pending = false; ks.scale_cols = 0; }   // a fresh factorisation overwrites the stored basis
+    if (m > ks.maxiter) ks_resize(ks, m);
+    else ks.m = m;
+    // checkdims (arnoldi.jl:207-220)
+    if (op.n != ks.n || p != ks.augmented)
+      fail(EXPV_MI_DIMENSION_MISMATCH, "length(b') == size(A,1) == size(A,2) == size(V,1)-p doesn't hold");
+    if (op.dtype != ks.dtypeT) fail(EXPV_MI_ARGUMENT_ERROR, "operator dtype must equal the subspace dtype T");
+    rows = ks.rows();
+    V = ks.V.as<T>();
+    st = ks.state.as<StepState>();
+    hview_rows = m + 1;
+    hview_cols = m + (isaug ? 1 : 0);
+
+    choose_step_form();
+    if (fresh) first_step();
+    if (ks.beta == 0.0) return 0;
+    iop = o.iop;
+    if (iop == 0) iop = m;
+    jstart = lanczos ? 1 : init;     // lanczos!: loop is always 1:m (arnoldi.jl:480)
+    if (jstart > m) return 0;
+    reset_device_state();
+    if (use_pipe) steps_single_pass();
+    else if (use_fused && single_red) steps_two_kernel();
+    else if (use_fused) steps_two_kernel_two_reductions();
+    else steps_modular();
+    return read_back();
+  }
+
+  // ---- which step form runs ------------------------------------------------------------------
+  void choose_step_form() {
+    const bool no_fused = !c->opt.fused;
+    single_red = !c->opt.fused_two_reductions;
+    // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
+    //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
+    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
+                o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
+    // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
+    const bool no_pipe = !c->opt.pipeline;
+    {
+      // the update window of a pass is the projection window of the step before it: at most min(m - 1, iop) columns
+      // (2 for Lanczos), min(m, iop) for the closing pass that produces v_{m+1}
+      const int iopw = lanczos ? 2 : (o.iop == 0 ? m : std::min(o.iop, m));
+      const int wstep = std::min(m - 1, iopw);
+      const bool have_dia = op.ndiag > 0 && !no_dia_env;
+      use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+                 wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
+                 (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
+                 (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
   }
   if constexpr (!ST<T>::is_complex) {
     // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
     // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
-    static const bool no_wave = std::getenv("EXPV_MI_NO_WAVE") != nullptr;
+    const bool no_wave = !c->opt.wave;
     const int64_t ntiles_w = (ks.n + 511) / 512;
     if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
     const bool wave_dia = op.gndiag > 0 && !no_dia_env;
@@ -338,7 +406,10 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
     // every other path needs them normalised
     if (!use_pipe) ks_materialize(ks);
   }
-  if (init == 0) {  // firststep!  (arnoldi.jl:230-250 / :257-279)
+  }
+
+  // ---- firststep!  (arnoldi.jl:230-250 / :257-279) -------------------------------------------------------------------
+  void first_step() {
     for (int j = 0; j < hview_cols; ++j)
       std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
     HIPCHECK(hipMemsetAsync(st, 0, ks.state.bytes, s));   // step state and (behind it) the pipeline's arrival counters
@@ -356,253 +427,252 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
         extra += aug->w_aug_host[k - 1] * aug->w_aug_host[k - 1];
       }
       src = reinterpret_cast<const T *>(aug->w);
-    }
-    if (use_pipe) {
-      // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
-    } else if (use_fused && single_red) {
-      // u_1 = b goes to V[:, 0] unnormalised; ||b|| comes out of the first fused half-step's reduction
-      HIPCHECK(hipMemcpyAsync(V, src, sizeof(T) * (size_t)ks.n, hipMemcpyDeviceToDevice, s));
-      if (isaug) {   // u_1 = [bl; w_aug]  (arnoldi.jl:257-279), unnormalised like the rest of it
-        std::vector<T> tail(p);
-        for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
-        HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipStreamSynchronize(s));   // `tail` is pageable and local
-      }
-    } else {
-      ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
-      dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
-    }
-    ks.gram_rows = 0;
-    if (use_fused) {
-      ks.beta = 1.0;   // placeholder: the true value is read back with H after the loop (no sync here)
-    } else {
-      StepState h;
-      read_state<T>(ks, &h);
-      ks.beta = std::sqrt(h.sumsq + extra);
-    }
-    if (ks.beta != 0.0 && use_fused) {
-      ks.gram_rows = 1;   // v_1 = b / beta is produced by the first fused half-step
-    } else if (ks.beta != 0.0) {
-      ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
-      if (isaug) {
-        dev::scale_copy<T>(s, V, src, ks.n, ks.beta, 1);  // @. V[1:n,1] = bl / beta
-        std::vector<T> tail(p);
-        for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k] / ks.beta);
-        HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipStreamSynchronize(s));
-      } else {
-        dev::scale_copy<T>(s, V, src, ks.n, 1.0 / ks.beta, 0);  // V[i,1] = b[i] * inv(beta)
-      }
-      ks.gram_rows = 1;
-    }
-    init = 1;
   }
-  if (ks.beta == 0.0) return 0;
-  int iop = o.iop;
-  if (iop == 0) iop = m;
-  const int jstart = lanczos ? 1 : init;     // lanczos!: loop is always 1:m (arnoldi.jl:480)
-  if (jstart > m) return 0;
-
-  // reset the device step state; zero the columns of Hdev this call will fill
-  {
-    if (!use_fused || !fresh) {   // fresh fused path: the first pass leaves {hnorm = beta_0, m_done = 0} on the device itself
-      StepState &z = ks.state_host;   // (member: the copy below is asynchronous)
-      std::memset(&z, 0, sizeof(z));
-      z.m_done = jstart - 1;
-      z.hnorm = ks.beta;
-      z.inv = 1.0;
-      z.beta0sq = ks.beta * ks.beta;
-      HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
-    }
-    HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
-                            sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
-  }
-  T *Hd = ks.Hdev.as<T>();
-  T *hcoef = ks.hcoef.as<T>();
-  double *part = ks.part.as<double>();
-  double *gpart = ks.gpart.as<double>();
-  const int ortho = o.ortho;
-
   if (use_pipe) {
-    {
-      // ---- single-pass banded pipeline: ONE launch, ONE reduction, ONE read of V per step (pipe.hip) --
-      const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
-      if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
-      if (ks.hcoef2.bytes < ks.hcoef.bytes) ks.hcoef2.alloc(ks.hcoef.bytes);
-      if (ks.colscale.bytes < sizeof(double) * (size_t)(ks.maxiter + 2)) ks.colscale.alloc(sizeof(double) * (size_t)(ks.maxiter + 2));
-      T *ya = ks.ybuf.as<T>(), *yb2 = ks.ubuf.as<T>();
-      T *hca = ks.hcoef.as<T>(), *hcb = ks.hcoef2.as<T>();
-      dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
-      // Overlapped form (default): consecutive steps on two streams, the next step's kernel starts while this one
-      // finishes (pipe.hip).  EXPV_MI_PIPE_SERIAL=1 / profiling / a previous expired wait: one stream, one launch
-      // after the other.
-      ht_mark(1);
-      static const bool serial_env = std::getenv("EXPV_MI_PIPE_SERIAL") != nullptr;
-      // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
-      static const int spin_limit = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT") ? std::atoi(std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) : 400000;
-      if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
-      const int nsteps = m - jstart + 1;
-      const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && nsteps >= 2;
-      const int iopw = lanczos ? 2 : iop;
-      // overlapped form with the tail requested: one more (closing) pass produces v_{m+1}, H[m+1, m] and the
-      // breakdown test of step m instead of the update2 + norm_final launches below
-      const bool closing = live && !ks.skip_tail && std::min(m, iopw) <= dev::pipe_max_window<T>();
-      hipStream_t s2 = nullptr;
-      auto next_seq = [&]() {
-        ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;
-        if (ks.pipe_seq == 0) ks.pipe_seq = 1;
-      };
-      if (!fresh) {
-        // continuation: the stored columns keep their scales (all 1 when the basis has been materialised since); the
-        // arrival counters of the steps of this call start at 0
-        if (!ks.scale_pending || (int)ks.colscale_host.size() < ks.maxiter + 2) ks.colscale_host.assign(ks.maxiter + 2, 1.0);
-        HIPCHECK(hipMemcpyAsync(ks.colscale.p, ks.colscale_host.data(), sizeof(double) * (size_t)jstart, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemsetAsync(ks.state.as<char>() + sizeof(StepState), 0, ks.state.bytes - sizeof(StepState), s));
-      }
-      if (live) {
-        c->ensure_aux();
-        s2 = c->stream2;
-        if (!ks.flags.p) {
-          ks.flags.alloc(sizeof(uint32_t) * (size_t)dev::PIPE_FLAG_COPIES * dev::PIPE_FLAG_STRIDE);
-          HIPCHECK(hipMemsetAsync(ks.flags.p, 0, ks.flags.bytes, s));
-        }
-        // the last kernel mirrors H, the scales and the final state into host-mapped memory and raises a flag there,
-        // so the host continues the moment the last step is done (no copy engine, no stream sync)
-        ks.mbox_armed = false;
-        if (ks.skip_tail || closing) (void)mailbox_arm(ks, m);
-        if (!ks.mbox_armed) next_seq();   // the flags still need a fresh sequence number
-        HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
-        HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
-      }
-      if (use_wave) {
-        const size_t tb = sizeof(uint32_t) * (size_t)((ks.n + 511) / 512 + 1);
-        if (ks.tflags.bytes < tb) {
-          ks.tflags.alloc(tb);
-          HIPCHECK(hipMemsetAsync(ks.tflags.p, 0, tb, s));
-        }
-        if (!live) {   // (the overlapped form arms the mailbox and takes its sequence number above)
-          ks.mbox_armed = false;
-          if (ks.skip_tail) (void)mailbox_arm(ks, m);
-          if (!ks.mbox_armed) next_seq();
-        }
-      }
-      {
-        // overlapped kernels have no separate durations: one scope over the sequence, counted as its launches
-        ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? nsteps : 0);
-        int prev_grid = 0;
-        ks.pipe_closed = closing;
-        for (int j = jstart; j <= m + (closing ? 1 : 0); ++j) {
-          const int i0 = lanczos ? j : std::max(1, j - iop + 1);
-          const int nd = j - i0 + 1;
-          const bool cont = (!fresh && j == jstart);
-          dev::PipeArgsT<T> pa{};
-          pa.final = (j == m + 1) ? 1 : 0;
-          pa.cont = cont ? 1 : 0;
-          pa.cont_inv = cont ? ks.colscale_host[j - 1] : 1.0;
-          pa.A = A;
-          if constexpr (!ST<T>::is_complex) {
-            if (use_wave) {
-              if (op.gndiag > 0 && !no_dia_env) {
-                pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
-                pa.gdia_off = op.gdia_off.as<int32_t>();
-              } else {   // SELL slots + the per-tile column ranges
-                pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
-              }
-              pa.tile_flags = ks.tflags.as<uint32_t>();
-              pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
-              pa.spin_limit = spin_limit;
-            }
-          }
-          if (!use_wave && op.ndiag > 0 && !no_dia_env) {
-            pa.dia_val = op.dia_val.as<T>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
-            for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
-          }
-          pa.w = (int)op.bandwidth;
-          pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
-          pa.ybuf = (j & 1) ? ya : yb2;
-          pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
-          if (isaug) {
-            pa.aug_p = p; pa.n_op = ks.n; pa.B = reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;
-            if (j == 1 && fresh)
-              for (int k = 0; k < p; ++k) pa.u0_tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
-          }
-          dev::DotsArgs<T> &d = pa.d;
-          d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
-          d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
-          d.part = part; d.gpart = gpart; d.st = st;
-          d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
-          d.real_coeff = real_coeff;
-          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
-          d.hcoef = nullptr;
-          if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
-          else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
-          else if (cont) { pa.uc0 = i0 - 1; pa.udir = 1; pa.und = nd - 1; }   // the older columns of this step's own window (zero coefficients)
-          else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
-          pa.hcoef_in = (j & 1) ? hcb : hca;
-          pa.hcoef_out = (j & 1) ? hca : hcb;
-          pa.scales = ks.colscale.as<double>();
-          pa.step = j;
-          pa.tol = tol;
-          if (live) {
-            hipStream_t sj = (j & 1) ? s : s2;
-            uint32_t *arr = reinterpret_cast<uint32_t *>(ks.state.as<char>() + sizeof(StepState));   // zeroed with the state
-            pa.flags = ks.flags.as<uint32_t>();
-            pa.seq = ks.pipe_seq;
-            pa.spin_limit = spin_limit;
-            pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
-            if (ks.mbox_armed) {
-              const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-              d.Hhost = reinterpret_cast<T *>(mv.H);
-              pa.mb_scales = mv.scales;
-              pa.mb_state = mv.state;
-              pa.mb_done = mv.done;
-              pa.last_step = m + (closing ? 1 : 0);
-            }
-            if (j > jstart) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-            if constexpr (!ST<T>::is_complex) {
-              prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
-            } else {
-              prev_grid = dev::pipe_step_live(sj, pa);
-            }
-            if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
-          } else if (use_wave) {
-            if constexpr (!ST<T>::is_complex) {
-              ProfScope ps1(c, EXPV_MI_K_FUSED_A);
-              if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
-            }
-          } else {
-            ProfScope ps1(c, EXPV_MI_K_FUSED_A);
-            dev::pipe_step(s, pa);
-          }
-        }
-        if (live) {
-          HIPCHECK(hipEventRecord(c->ev_join, s2));
-          HIPCHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-        }
-      }
-      ks.pipe_live_used = live;
-      if (use_wave && !live && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
-        const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-        dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)ks.ldhd * m, st, mv.H, mv.state, mv.done, ks.pipe_seq,
-                          ks.colscale.as<double>(), m, mv.scales);
-        mbox_generic = true;
-      }
-      ht_mark(2);
-      if (!ks.skip_tail && !ks.pipe_closed) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
-        dev::UpdateArgs<T> u{};
-        u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
-        if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }
-        else { const int i0 = std::max(1, m - iop + 1); u.c0 = i0 - 1; u.dir = 1; u.nd = m - i0 + 1; }
-        u.hcoef = (m & 1) ? hca : hcb; u.do_norm = 0; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
-        u.jcol = m - 1; u.tol = tol; u.step = m + 1;
-        { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, -1); }
-        ProfScope ps(c, EXPV_MI_K_SCALE);
-        dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol, dev::BatchStrides{}, 1,
-                           ks.colscale.as<double>() + m);
-      }
-      ks.gram_rows = lanczos ? 1 : m;
-    }
+    // single-pass banded pipeline: b is consumed in place by the first pass (pipe.hip)
   } else if (use_fused && single_red) {
+    // u_1 = b goes to V[:, 0] unnormalised; ||b|| comes out of the first fused half-step's reduction
+    HIPCHECK(hipMemcpyAsync(V, src, sizeof(T) * (size_t)ks.n, hipMemcpyDeviceToDevice, s));
+    if (isaug) {   // u_1 = [bl; w_aug]  (arnoldi.jl:257-279), unnormalised like the rest of it
+      std::vector<T> tail(p);
+      for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
+      HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));   // `tail` is pageable and local
+    }
+  } else {
+    ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
+    dev::sumsq<T>(s, src, ks.n, ks.part.as<double>(), ks.gpart.as<double>(), st);
+  }
+  ks.gram_rows = 0;
+  if (use_fused) {
+    ks.beta = 1.0;   // placeholder: the true value is read back with H after the loop (no sync here)
+  } else {
+    StepState h;
+    read_state<T>(ks, &h);
+    ks.beta = std::sqrt(h.sumsq + extra);
+  }
+  if (ks.beta != 0.0 && use_fused) {
+    ks.gram_rows = 1;   // v_1 = b / beta is produced by the first fused half-step
+  } else if (ks.beta != 0.0) {
+    ProfScope ps(c, EXPV_MI_K_FIRSTSTEP);
+    if (isaug) {
+      dev::scale_copy<T>(s, V, src, ks.n, ks.beta, 1);  // @. V[1:n,1] = bl / beta
+      std::vector<T> tail(p);
+      for (int k = 0; k < p; ++k) tail[k] = ST<T>::from_real(aug->w_aug_host[k] / ks.beta);
+      HIPCHECK(hipMemcpyAsync(V + ks.n, tail.data(), sizeof(T) * p, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    } else {
+      dev::scale_copy<T>(s, V, src, ks.n, 1.0 / ks.beta, 0);  // V[i,1] = b[i] * inv(beta)
+    }
+    ks.gram_rows = 1;
+  }
+  init = 1;
+  }
+
+  void reset_device_state() {
+    // reset the device step state; zero the columns of Hdev this call will fill
+    {
+      if (!use_fused || !fresh) {   // fresh fused path: the first pass leaves {hnorm = beta_0, m_done = 0} on the device itself
+        StepState &z = ks.state_host;   // (member: the copy below is asynchronous)
+        std::memset(&z, 0, sizeof(z));
+        z.m_done = jstart - 1;
+        z.hnorm = ks.beta;
+        z.inv = 1.0;
+        z.beta0sq = ks.beta * ks.beta;
+        HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
+      }
+      HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
+                              sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
+  }
+  Hd = ks.Hdev.as<T>();
+  hcoef = ks.hcoef.as<T>();
+  part = ks.part.as<double>();
+  gpart = ks.gpart.as<double>();
+
+  }
+
+  // ---- single-pass step: ONE launch, ONE reduction, ONE read of V per Krylov step (pipe.hip) -------------------------
+  void steps_single_pass() {
+    // ---- single-pass banded pipeline: ONE launch, ONE reduction, ONE read of V per step (pipe.hip) --
+    const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
+    if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
+    if (ks.hcoef2.bytes < ks.hcoef.bytes) ks.hcoef2.alloc(ks.hcoef.bytes);
+    if (ks.colscale.bytes < sizeof(double) * (size_t)(ks.maxiter + 2)) ks.colscale.alloc(sizeof(double) * (size_t)(ks.maxiter + 2));
+    T *ya = ks.ybuf.as<T>(), *yb2 = ks.ubuf.as<T>();
+    T *hca = ks.hcoef.as<T>(), *hcb = ks.hcoef2.as<T>();
+    dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+    // Overlapped form (default): consecutive steps on two streams, the next step's kernel starts while this one
+    // finishes (pipe.hip).  EXPV_MI_PIPE_SERIAL=1 / profiling / a previous expired wait: one stream, one launch
+    // after the other.
+    ht_mark(1);
+    const bool serial_env = c->opt.pipeline_serial != 0;
+    // polls (~1 us each) before a waiting kernel gives up; EXPV_MI_PIPE_SPIN_LIMIT=1 exercises the serial redo
+    const int spin_limit = c->opt.spin_limit;
+    if (ks.pipe_serial && ++ks.pipe_serial_calls > 64) { ks.pipe_serial = false; ks.pipe_serial_calls = 0; }   // the device may be ours again
+    const int nsteps = m - jstart + 1;
+    const bool live = !serial_env && c->pipe_overlap && !ks.pipe_serial && nsteps >= 2;
+    const int iopw = lanczos ? 2 : iop;
+    // overlapped form with the tail requested: one more (closing) pass produces v_{m+1}, H[m+1, m] and the
+    // breakdown test of step m instead of the update2 + norm_final launches below
+    const bool closing = live && !ks.skip_tail && std::min(m, iopw) <= dev::pipe_max_window<T>();
+    hipStream_t s2 = nullptr;
+    auto next_seq = [&]() {
+      ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;
+      if (ks.pipe_seq == 0) ks.pipe_seq = 1;
+    };
+    if (!fresh) {
+      // continuation: the stored columns keep their scales (all 1 when the basis has been materialised since); the
+      // arrival counters of the steps of this call start at 0
+      if (!ks.scale_pending || (int)ks.colscale_host.size() < ks.maxiter + 2) ks.colscale_host.assign(ks.maxiter + 2, 1.0);
+      HIPCHECK(hipMemcpyAsync(ks.colscale.p, ks.colscale_host.data(), sizeof(double) * (size_t)jstart, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipMemsetAsync(ks.state.as<char>() + sizeof(StepState), 0, ks.state.bytes - sizeof(StepState), s));
+  }
+  if (live) {
+    c->ensure_aux();
+    s2 = c->stream2;
+    if (!ks.flags.p) {
+      ks.flags.alloc(sizeof(uint32_t) * (size_t)dev::PIPE_FLAG_COPIES * dev::PIPE_FLAG_STRIDE);
+      HIPCHECK(hipMemsetAsync(ks.flags.p, 0, ks.flags.bytes, s));
+    }
+    // the last kernel mirrors H, the scales and the final state into host-mapped memory and raises a flag there,
+    // so the host continues the moment the last step is done (no copy engine, no stream sync)
+    ks.mbox_armed = false;
+    if (ks.skip_tail || closing) (void)mailbox_arm(ks, m);
+    if (!ks.mbox_armed) next_seq();   // the flags still need a fresh sequence number
+    HIPCHECK(hipEventRecord(c->ev_fork, s));          // everything queued so far (state reset, H zeroing) ...
+    HIPCHECK(hipStreamWaitEvent(s2, c->ev_fork, 0));  // ... precedes the even steps too
+  }
+  if (use_wave) {
+    const size_t tb = sizeof(uint32_t) * (size_t)((ks.n + 511) / 512 + 1);
+    if (ks.tflags.bytes < tb) {
+      ks.tflags.alloc(tb);
+      HIPCHECK(hipMemsetAsync(ks.tflags.p, 0, tb, s));
+    }
+    if (!live) {   // (the overlapped form arms the mailbox and takes its sequence number above)
+      ks.mbox_armed = false;
+      if (ks.skip_tail) (void)mailbox_arm(ks, m);
+      if (!ks.mbox_armed) next_seq();
+    }
+  }
+  {
+    // overlapped kernels have no separate durations: one scope over the sequence, counted as its launches
+    ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? nsteps : 0);
+    int prev_grid = 0;
+    ks.pipe_closed = closing;
+    for (int j = jstart; j <= m + (closing ? 1 : 0); ++j) {
+      const int i0 = lanczos ? j : std::max(1, j - iop + 1);
+      const int nd = j - i0 + 1;
+      const bool cont = (!fresh && j == jstart);
+      dev::PipeArgsT<T> pa{};
+      pa.final = (j == m + 1) ? 1 : 0;
+      pa.cont = cont ? 1 : 0;
+      pa.cont_inv = cont ? ks.colscale_host[j - 1] : 1.0;
+      pa.A = A;
+      if constexpr (!ST<T>::is_complex) {
+        if (use_wave) {
+          if (op.gndiag > 0 && !no_dia_env) {
+            pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
+            pa.gdia_off = op.gdia_off.as<int32_t>();
+          } else {   // SELL slots + the per-tile column ranges
+            pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
+          }
+          pa.tile_flags = ks.tflags.as<uint32_t>();
+          pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
+          pa.spin_limit = spin_limit;
+        }
+      }
+      if (!use_wave && op.ndiag > 0 && !no_dia_env) {
+        pa.dia_val = op.dia_val.as<T>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
+        for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+      }
+      pa.w = (int)op.bandwidth;
+      pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
+      pa.ybuf = (j & 1) ? ya : yb2;
+      pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
+      if (isaug) {
+        pa.aug_p = p; pa.n_op = ks.n; pa.B = reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;
+        if (j == 1 && fresh)
+          for (int k = 0; k < p; ++k) pa.u0_tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
+      }
+      dev::DotsArgs<T> &d = pa.d;
+      d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = nullptr; d.x = nullptr;
+      d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+      d.part = part; d.gpart = gpart; d.st = st;
+      d.mode = lanczos ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
+      d.real_coeff = real_coeff;
+      d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
+      d.hcoef = nullptr;
+      if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
+      else if (lanczos) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
+      else if (cont) { pa.uc0 = i0 - 1; pa.udir = 1; pa.und = nd - 1; }   // the older columns of this step's own window (zero coefficients)
+      else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
+      pa.hcoef_in = (j & 1) ? hcb : hca;
+      pa.hcoef_out = (j & 1) ? hca : hcb;
+      pa.scales = ks.colscale.as<double>();
+      pa.step = j;
+      pa.tol = tol;
+      if (live) {
+        hipStream_t sj = (j & 1) ? s : s2;
+        uint32_t *arr = reinterpret_cast<uint32_t *>(ks.state.as<char>() + sizeof(StepState));   // zeroed with the state
+        pa.flags = ks.flags.as<uint32_t>();
+        pa.seq = ks.pipe_seq;
+        pa.spin_limit = spin_limit;
+        pa.arrive = arr + (size_t)j * dev::PIPE_ARRIVE_STEP;
+        if (ks.mbox_armed) {
+          const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+          d.Hhost = reinterpret_cast<T *>(mv.H);
+          pa.mb_scales = mv.scales;
+          pa.mb_state = mv.state;
+          pa.mb_done = mv.done;
+          pa.last_step = m + (closing ? 1 : 0);
+        }
+        if (j > jstart) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
+        if constexpr (!ST<T>::is_complex) {
+          prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
+        } else {
+          prev_grid = dev::pipe_step_live(sj, pa);
+        }
+        if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+      } else if (use_wave) {
+        if constexpr (!ST<T>::is_complex) {
+          ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+          if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+        }
+      } else {
+        ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+        dev::pipe_step(s, pa);
+      }
+    }
+    if (live) {
+      HIPCHECK(hipEventRecord(c->ev_join, s2));
+      HIPCHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+  }
+  ks.pipe_live_used = live;
+  if (use_wave && !live && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
+    const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)ks.ldhd * m, st, mv.H, mv.state, mv.done, ks.pipe_seq,
+                      ks.colscale.as<double>(), m, mv.scales);
+    mbox_generic = true;
+  }
+  ht_mark(2);
+  if (!ks.skip_tail && !ks.pipe_closed) {  // u_{m+1} = y~_m / beta_{m-1} - sum_i (h_i s_i) raw_i  ->  column m (raw), then its norm
+    dev::UpdateArgs<T> u{};
+    u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = V + (size_t)m * ks.ldv; u.yin = (m & 1) ? ya : yb2;
+    if (lanczos) { u.c0 = m - 1; u.dir = -1; u.nd = (m > 1) ? 2 : 1; }
+    else { const int i0 = std::max(1, m - iop + 1); u.c0 = i0 - 1; u.dir = 1; u.nd = m - i0 + 1; }
+    u.hcoef = (m & 1) ? hca : hcb; u.do_norm = 0; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+    u.jcol = m - 1; u.tol = tol; u.step = m + 1;
+    { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, -1); }
+    ProfScope ps(c, EXPV_MI_K_SCALE);
+    dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol, dev::BatchStrides{}, 1,
+                       ks.colscale.as<double>() + m);
+  }
+  ks.gram_rows = lanczos ? 1 : m;
+  }
+
+  // ---- single-reduction two-kernel step: 2 launches and ONE grid reduction per Krylov step (fused.hip) ----------------
+  void steps_two_kernel() {
     // ---- single-reduction path: 2 launches and ONE grid reduction per Krylov step (fused.hip) --
     const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
     if (ks.ybuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
@@ -618,8 +688,7 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       fa.step = j;
       fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
-      static const bool no_gdia = std::getenv("EXPV_MI_NO_DIA") != nullptr;
-      if (op.gndiag > 0 && !no_gdia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
+      if (op.gndiag > 0 && c->opt.dia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
         fa.dia_val = op.gdia_ptr<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();
         fa.n_dia = ks.n;
       }
@@ -639,19 +708,22 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       u.hcoef = hcoef; u.do_norm = 0; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
       u.jcol = j - 1; u.tol = tol; u.step = j;
       { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update2<T>(s, u, j - 1); }
-    }
-    if (!ks.skip_tail) {
-      ProfScope ps(c, EXPV_MI_K_SCALE);
-      dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol);
-      dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
-    } else if (mailbox_arm(ks, m)) {   // whole-call expv: H and the final state go to the host through the mailbox
-      const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-      dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)(dtype_size(ks.dtypeT) / 8) * ks.ldhd * m, st, mv.H,
-                        mv.state, mv.done, ks.pipe_seq);
-      mbox_generic = true;
-    }
-    ks.gram_rows = lanczos ? 1 : m;
-  } else if (use_fused) {
+  }
+  if (!ks.skip_tail) {
+    ProfScope ps(c, EXPV_MI_K_SCALE);
+    dev::norm_final<T>(s, V + (size_t)m * ks.ldv, rows, part, gpart, st, Hd, ks.ldhd, m, tol);
+    dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
+  } else if (mailbox_arm(ks, m)) {   // whole-call expv: H and the final state go to the host through the mailbox
+    const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)(dtype_size(ks.dtypeT) / 8) * ks.ldhd * m, st, mv.H,
+                      mv.state, mv.done, ks.pipe_seq);
+    mbox_generic = true;
+  }
+  ks.gram_rows = lanczos ? 1 : m;
+  }
+
+  // ---- two-reduction form: 2 launches per Krylov step, lagged normalisation (fused.hip) ------------------------------
+  void steps_two_kernel_two_reductions() {
     // ---- fused path: 2 launches per Krylov step, lagged normalisation (fused.hip) ------------
     const size_t vbytes = sizeof(T) * (size_t)ks.ldv;
     if (ks.ubuf.bytes < vbytes) { ks.ubuf.alloc(vbytes); ks.ybuf.alloc(vbytes); }
@@ -681,75 +753,82 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
       u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
       u.jcol = j - 1; u.tol = tol; u.step = j;
       { ProfScope ps(c, EXPV_MI_K_FUSED_B); dev::update<T>(s, u); }
-    }
-    { ProfScope ps(c, EXPV_MI_K_SCALE); dev::finalize_last<T>(s, V, ks.ldv, rows, ub, st); }
-    ks.gram_rows = lanczos ? 1 : m;
   }
-  for (int j = jstart; j <= m && !use_fused; ++j) {
-    const T *x = V + (size_t)(j - 1) * ks.ldv;
-    T *y = V + (size_t)j * ks.ldv;
-    op_apply_T<T>(op, x, y, st, j);
-    if (isaug) {
-      ProfScope ps(c, EXPV_MI_K_AUG);
-      dev::aug_apply<T>(s, ks.n, p, reinterpret_cast<const T *>(aug->B), aug->ldb, x, y, st, j);
-    }
-    if (lanczos) {  // lanczos_step!  (arnoldi.jl:388-403)
-      dev::DotsArgs<T> d{};
-      d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
-      d.c0 = j - 1; d.dir = 1; d.nd = 1;
-      d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = real_coeff;
-      d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
-      { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
-      dev::UpdateArgs<T> u{};
-      u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
-      u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
-      u.tol = tol; u.step = j;
-      { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
-    } else {  // arnoldi_step!  (arnoldi.jl:289-308)
-      const int i0 = std::max(1, j - iop + 1);
-      const int nd = j - i0 + 1;
-      bool lowsync = (ortho != EXPV_MI_ORTHO_MGS) && nd >= 2 && nd <= dev::LOWSYNC_MAX;
-      if (lowsync && nd >= 3 && ks.gram_rows < j - 1) lowsync = false;  // Gram rows of older vectors missing
-      if (lowsync) {
+  { ProfScope ps(c, EXPV_MI_K_SCALE); dev::finalize_last<T>(s, V, ks.ldv, rows, ub, st); }
+  ks.gram_rows = lanczos ? 1 : m;
+  }
+
+  // ---- modular launches: operator apply, projections, update, scale (kernels.hip) ------------------------------------
+  void steps_modular() {
+    const int ortho = o.ortho;
+    for (int j = jstart; j <= m; ++j) {
+      const T *x = V + (size_t)(j - 1) * ks.ldv;
+      T *y = V + (size_t)j * ks.ldv;
+      op_apply_T<T>(op, x, y, st, j);
+      if (isaug) {
+        ProfScope ps(c, EXPV_MI_K_AUG);
+        dev::aug_apply<T>(s, ks.n, p, reinterpret_cast<const T *>(aug->B), aug->ldb, x, y, st, j);
+      }
+      if (lanczos) {  // lanczos_step!  (arnoldi.jl:388-403)
         dev::DotsArgs<T> d{};
-        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = x;
-        d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
-        d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LOWSYNC; d.real_coeff = real_coeff;
-        d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
-        d.hcoef = hcoef;
+        d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
+        d.c0 = j - 1; d.dir = 1; d.nd = 1;
+        d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LANCZOS; d.real_coeff = real_coeff;
+        d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
         { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
         dev::UpdateArgs<T> u{};
-        u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i0 - 1; u.dir = 1; u.nd = nd;
+        u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = j - 1; u.dir = -1; u.nd = (j > 1) ? 2 : 1;
         u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
         u.tol = tol; u.step = j;
         { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
-        if (ks.gram_rows >= j - 1) ks.gram_rows = std::max(ks.gram_rows, j);
-      } else {  // literal MGS: dot -> axpy per column, then the norm
-        for (int i = i0; i <= j; ++i) {
+      } else {  // arnoldi_step!  (arnoldi.jl:289-308)
+        const int i0 = std::max(1, j - iop + 1);
+        const int nd = j - i0 + 1;
+        bool lowsync = (ortho != EXPV_MI_ORTHO_MGS) && nd >= 2 && nd <= dev::LOWSYNC_MAX;
+        if (lowsync && nd >= 3 && ks.gram_rows < j - 1) lowsync = false;  // Gram rows of older vectors missing
+        if (lowsync) {
           dev::DotsArgs<T> d{};
-          d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
-          d.c0 = i - 1; d.dir = 1; d.nd = 1;
-          d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_STRICT; d.real_coeff = real_coeff;
-          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
+          d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = x;
+          d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
+          d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_LOWSYNC; d.real_coeff = real_coeff;
+          d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = ks.gram.as<T>(); d.ldg = ks.ldg; d.jrow = j - 1;
+          d.hcoef = hcoef;
           { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
           dev::UpdateArgs<T> u{};
-          u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i - 1; u.dir = 1; u.nd = 1;
-          u.hcoef = hcoef; u.do_norm = (i == j) ? 1 : 0; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
-          u.jcol = j - 1; u.tol = tol; u.step = j;
+          u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i0 - 1; u.dir = 1; u.nd = nd;
+          u.hcoef = hcoef; u.do_norm = 1; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd; u.jcol = j - 1;
+          u.tol = tol; u.step = j;
           { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
+          if (ks.gram_rows >= j - 1) ks.gram_rows = std::max(ks.gram_rows, j);
+        } else {  // literal MGS: dot -> axpy per column, then the norm
+          for (int i = i0; i <= j; ++i) {
+            dev::DotsArgs<T> d{};
+            d.V = V; d.ldv = ks.ldv; d.n = rows; d.y = y; d.x = nullptr;
+            d.c0 = i - 1; d.dir = 1; d.nd = 1;
+            d.part = part; d.gpart = gpart; d.st = st; d.mode = dev::DOTS_STRICT; d.real_coeff = real_coeff;
+            d.Hdev = Hd; d.ldh = ks.ldhd; d.jcol = j - 1; d.gram = nullptr; d.ldg = 0; d.jrow = 0; d.hcoef = hcoef;
+            { ProfScope ps(c, EXPV_MI_K_DOTS); dev::dots<T>(s, d); }
+            dev::UpdateArgs<T> u{};
+            u.V = V; u.ldv = ks.ldv; u.n = rows; u.y = y; u.c0 = i - 1; u.dir = 1; u.nd = 1;
+            u.hcoef = hcoef; u.do_norm = (i == j) ? 1 : 0; u.part = part; u.gpart = gpart; u.st = st; u.Hdev = Hd; u.ldh = ks.ldhd;
+            u.jcol = j - 1; u.tol = tol; u.step = j;
+            { ProfScope ps(c, EXPV_MI_K_UPDATE); dev::update<T>(s, u); }
+          }
         }
       }
-    }
-    { ProfScope ps(c, EXPV_MI_K_SCALE); dev::scale_by_state<T>(s, y, rows, st, j); }
+      { ProfScope ps(c, EXPV_MI_K_SCALE); dev::scale_by_state<T>(s, y, rows, st, j); }
   }
 
-  // ---- one host synchronisation per factorisation: state + Hessenberg --------------------
-  const size_t hbytes = sizeof(T) * (size_t)ks.ldhd * (m + 1);
-  if (ks.pin_bytes < hbytes + sizeof(StepState)) {
-    if (ks.pin) (void)hipHostFree(ks.pin);
-    ks.pin = nullptr;
-    ks.pin_bytes = sizeof(T) * (size_t)ks.ldhd * (ks.maxiter + 1) + sizeof(StepState);
-    HIPCHECK(hipHostMalloc(&ks.pin, ks.pin_bytes, hipHostMallocDefault));
+  }
+
+  // ---- one host synchronisation per factorisation: state + Hessenberg ------------------------------------------------
+  int read_back() {
+    const size_t hbytes = sizeof(T) * (size_t)ks.ldhd * (m + 1);
+    if (ks.pin_bytes < hbytes + sizeof(StepState)) {
+      if (ks.pin) (void)hipHostFree(ks.pin);
+      ks.pin = nullptr;
+      ks.pin_bytes = sizeof(T) * (size_t)ks.ldhd * (ks.maxiter + 1) + sizeof(StepState);
+      HIPCHECK(hipHostMalloc(&ks.pin, ks.pin_bytes, hipHostMallocDefault));
   }
   const T *Hh = reinterpret_cast<const T *>(ks.pin);   // Hessenberg columns as the device left them
   StepState &h = *reinterpret_cast<StepState *>(reinterpret_cast<char *>(ks.pin) + ks.pin_bytes - sizeof(StepState));
@@ -858,6 +937,13 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
                           : (use_fused ? EXPV_MI_PATH_TWO_KERNEL : EXPV_MI_PATH_MODULAR);
   if (use_pipe) { ++c->cnt_pipe; if (ks.pipe_live_used) ++c->cnt_live; }
   return jlast - jstart + 1;
+  }
+};
+
+template <class T>
+static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos) {
+  ArnoldiCall<T> call(ks, op, b, o, aug, lanczos);
+  return call.run();
 }
 
 int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug,

@@ -355,22 +355,13 @@ void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
   constexpr int CH = DotChunk<T>::CH;
   constexpr int SHL = 64 * Pack<T>::N;
   const int64_t nslices = a.aug_p ? (a.d.n + SHL - 1) / SHL : a.A.nslices;   // augmented: slices over n_op + p rows
-  // measured on C2 (profiles/r01_ab_variants.txt): the 2x-accumulator variant is slower (56 vs 48 us per launch),
-  // so it is opt-in for experiments only
-  static const bool wide_ok = std::getenv("EXPV_MI_WIDE") != nullptr;
+  // (a 2x-accumulator variant for windows of 17..32 columns measured slower -- 56 vs 48 us per launch, profiles/
+  //  r01_ab_variants.txt -- and is not in the tree)
   int nb, spw;
   if (a.d.mode == DOTS_LOWSYNC) {
-    if (wide_ok && a.d.nd > CH && a.d.nd <= 2 * CH) {
-      // windows of 17..32 columns (fp64): one pass with twice the accumulators (2 workgroups/CU)
-      // instead of a second sweep over y, v_j and a second workgroup reduction
-      auto k = k_fused_a2<T, true, 2 * CH, 2>;
-      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
-      hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
-    } else {
-      auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
-      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
-      hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
-    }
+    auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
+    plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);
+    hipLaunchKernelGGL(k, dim3(nb, nbatch), dim3(BLOCK), 0, s, a, spw, tol);
   } else {
     auto k = k_fused_a2<T, false, CH, DOTS_WAVES>;
     plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);

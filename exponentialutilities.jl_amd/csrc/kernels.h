@@ -216,8 +216,8 @@ struct PipeArgsT {
   T u0_tail[PIPE_AUG_MAX];     // step 1 of an augmented factorisation: rows n_op.. of u_1 (by value: no staging copy)
 };
 using PipeArgs = PipeArgsT<double>;
-void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1);
-void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch = 1);
+void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1, int batch_rounds = 2);
+void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch = 1, int batch_rounds = 2);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // operator form: pa.ndiag > 0 ? DIA : SELL
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused

@@ -696,13 +696,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
 template <class T> constexpr int pipe_tile_rows() { return Pack<T>::N * BLOCK; }
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
-static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch) {
+static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int batch_rounds = 2) {
   const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
   const int maxb = resident_blocks((const void *)k_pipe<T, CH, WAVES, PS, DIA, AUG>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   // batch: workgroups of all problems share the chip; a few resident rounds of fat workgroups instead of one tile each
   // (start-up round trips and the ticket are per workgroup)
-  static const int batch_rounds = std::getenv("EXPV_MI_BATCH_ROUNDS") ? std::atoi(std::getenv("EXPV_MI_BATCH_ROUNDS")) : 2;
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
@@ -713,39 +712,39 @@ static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 
 // CU.  (The fp64 analogue at 5 workgroups per CU measured 1.5 % SLOWER than the 8-column variant on the Lanczos input:
 // profiles/r02_ab_variants.txt.)
 static bool pipe_small(int und, int nbatch) { return und <= 3 && nbatch == 1; }
-void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch) {
+void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch_rounds) {
   // the register budget follows the window: short windows run with more workgroups per CU
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {   // augmented operator (kiops): DIA form, windows <= 7
-    if (pa.und <= 3) pipe_launch<double, 4, 4, 6, true, true>(s, pa, nbatch);
-    else pipe_launch<double, 8, 4, 6, true, true>(s, pa, nbatch);
+    if (pa.und <= 3) pipe_launch<double, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
+    else pipe_launch<double, 8, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
     return;
   }
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: pipe_launch<double, 8, 4, 6, true>(s, pa, nbatch); break;
-      case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch); break;
-      case 2: pipe_launch<double, 24, 3, 0, true>(s, pa, nbatch); break;
-      default: pipe_launch<double, 32, 2, 5, true>(s, pa, nbatch); break;
+      case 0: pipe_launch<double, 8, 4, 6, true>(s, pa, nbatch, batch_rounds); break;
+      case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
+      case 2: pipe_launch<double, 24, 3, 0, true>(s, pa, nbatch, batch_rounds); break;
+      default: pipe_launch<double, 32, 2, 5, true>(s, pa, nbatch, batch_rounds); break;
     }
     return;
   }
   switch (v) {
-    case 0: pipe_launch<double, 8, 4, 6, false>(s, pa, nbatch); break;
-    case 1: pipe_launch<double, 16, 3, 6, false>(s, pa, nbatch); break;
-    case 2: pipe_launch<double, 24, 3, 0, false>(s, pa, nbatch); break;
-    default: pipe_launch<double, 32, 2, 5, false>(s, pa, nbatch); break;
+    case 0: pipe_launch<double, 8, 4, 6, false>(s, pa, nbatch, batch_rounds); break;
+    case 1: pipe_launch<double, 16, 3, 6, false>(s, pa, nbatch, batch_rounds); break;
+    case 2: pipe_launch<double, 24, 3, 0, false>(s, pa, nbatch, batch_rounds); break;
+    default: pipe_launch<double, 32, 2, 5, false>(s, pa, nbatch, batch_rounds); break;
   }
 }
-void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch) {   // complex: DIA form, windows <= 15
+void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_rounds) {   // complex: DIA form, windows <= 15
   if (pa.aug_p > 0) {
-    if (pa.und <= 3) pipe_launch<cplx, 4, 4, 6, true, true>(s, pa, nbatch);
-    else pipe_launch<cplx, 8, 3, 6, true, true>(s, pa, nbatch);
+    if (pa.und <= 3) pipe_launch<cplx, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
+    else pipe_launch<cplx, 8, 3, 6, true, true>(s, pa, nbatch, batch_rounds);
     return;
   }
-  if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch);
-  else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch);
-  else pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch);
+  if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
+  else pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
 }
 
 template <int CH, int WAVES, int PS, bool DIA>

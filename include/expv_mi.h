@@ -74,6 +74,21 @@ int expv_mi_ctx_set_async_outputs(expv_mi_ctx_t ctx, int on);
  * one finishes (default on).  Off: one launch after the other on the context's stream -- same results; per-kernel
  * durations are then meaningful to a profiler. */
 int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
+/* Engine options of a context, by name (A/B switches and limits; every one has a default that is right for production):
+ *   "pipeline" 1        single-pass Krylov step for banded / structured-grid operators (0: two-kernel step instead)
+ *   "wave" 1            its wave form for operators too wide for a halo recompute
+ *   "fused" 1           single-reduction two-kernel step for regular-row sparse operators (0: modular launches)
+ *   "fused_two_reductions" 0   the older two-reduction form of that step
+ *   "dia" 1             diagonal storage forms instead of SELL slots where the pattern allows
+ *   "mailbox" 1         Hessenberg / state to the host through host-mapped memory instead of a copy + stream sync
+ *   "pipeline_serial" 0 single-pass step one launch after the other (like expv_mi_ctx_set_pipeline_overlap(ctx, 0))
+ *   "spin_limit" 400000 polls before a waiting kernel gives up and the host redoes the factorisation without waits
+ *   "batch_rounds" 2    batched single-pass step: resident rounds of fat workgroups
+ * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS (read once, at creation) -- nothing reads the environment later.
+ * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
+int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
+int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
 /* Cumulative counters of a context: out[0] Krylov steps (operator applications inside arnoldi!/lanczos!), [1] factorisations,
  * [2] of those on the single-pass pipeline, [3] of those with overlapped steps, [4] factorisations redone one launch after
  * the other because a bounded device wait expired (device shared with other work), [5] redone on the two-kernel step because

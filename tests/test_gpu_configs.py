@@ -436,3 +436,35 @@ def test_32bit_operands_follow_the_reference_result_type(eu, T):
         h = C.c_void_p()
         L.check(L.load().expv_mi_ks_create(eu.default_context()._h, L.F32, L.F32, 10, 5, 0, C.byref(h)), eu.default_context()._h)
     assert ei.value.kind == "Unsupported"
+
+
+def test_context_options_select_the_step_form(eu):
+    """Engine switches are context options (expv_mi_ctx_set_option), not process environment: the same operator and vector
+    through the three step forms give the same result, and the context reports which one ran."""
+    n, m = 30_000, 20
+    A = c2_operator(n)
+    b = np.random.default_rng(2).standard_normal(n)
+    wo = ko.expv(0.8, A, b, m=m, ishermitian=False)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    assert ctx.get_option("pipeline") == 1 and ctx.get_option("spin_limit") == 400000
+    seen = []
+    for opts, want in (({}, "pipeline"), ({"pipeline": 0}, "two_kernel"), ({"pipeline": 0, "fused": 0}, "modular"),
+                       ({"pipeline": 0, "dia": 0}, "two_kernel"), ({"pipeline": 0, "fused_two_reductions": 1}, "two_kernel"),
+                       ({"mailbox": 0}, "pipeline"), ({"pipeline_serial": 1}, "pipeline")):
+        for k in ("pipeline", "fused", "dia", "mailbox"):
+            ctx.set_option(k, 1)
+        for k in ("fused_two_reductions", "pipeline_serial"):
+            ctx.set_option(k, 0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        w = eu.expv(0.8, op, b, m=m, ishermitian=False)
+        path = eu.expv.last_stats["path"]
+        assert want in path, (opts, path)
+        assert ("overlapped" in path) == (want == "pipeline" and not opts.get("pipeline_serial")), (opts, path)
+        close(w, wo, 1e-12, "expv through options %s (%s)" % (opts, "+".join(path)))
+        seen.append(path)
+    with pytest.raises(eu.ExpvMIError):
+        ctx.set_option("no_such_option", 1)
+    c = ctx.counters()
+    assert c["redo_serial"] == 0 and c["redo_wave_off"] == 0 and c["factorisations"] == len(seen)
