@@ -95,6 +95,11 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     DevBuf perm, V, Ya, Yb, Dia, H, G, hca, hcb, sc, part, gpart, st, coef, beta, mcols;
     int64_t n = -1;
     int m = -1;
+    // pinned host mirrors of what comes back per sub-chunk (H, step states, column scales): a copy into pageable memory
+    // would block the host until the sub-chunk's kernels have run, and nothing would overlap
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+    ~BatchWs() { if (pin) (void)hipHostFree(pin); }
   };
   BatchWs *ws = reinterpret_cast<BatchWs *>(ctx->ws_batch);
   if (!ws) {
@@ -138,38 +143,55 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   DevBuf &dhca = ws->hca, &dhcb = ws->hcb, &dsc = ws->sc, &dpart = ws->part, &dgpart = ws->gpart, &dst = ws->st;
   DevBuf &dcoef = ws->coef, &dbeta = ws->beta, &dmcols = ws->mcols;
   HIPCHECK(hipMemcpyAsync(d_perm.p, P.perm.data(), sizeof(int32_t) * P.perm.size(), hipMemcpyHostToDevice, s));
-  std::vector<double> Hh((size_t)strideH * PC), coefh((size_t)(m + 1) * PC), betah(PC), sch((size_t)(m + 2) * PC);
-  std::vector<StepState> sth(PC);
+  const size_t pin_need = sizeof(double) * ((size_t)strideH * PC + (size_t)(m + 2) * PC) + sizeof(StepState) * (size_t)PC + 64;
+  if (ws->pin_bytes < pin_need) {
+    if (ws->pin) (void)hipHostFree(ws->pin);
+    ws->pin = nullptr;
+    HIPCHECK(hipHostMalloc(&ws->pin, pin_need, hipHostMallocDefault));
+    ws->pin_bytes = pin_need;
+  }
+  struct Span { double *p; double *data() const { return p; } };
+  const Span Hh{reinterpret_cast<double *>(ws->pin)}, sch{Hh.p + (size_t)strideH * PC};
+  struct SSpan { StepState *p; StepState *data() const { return p; } StepState &operator[](size_t i) const { return p[i]; } };
+  const SSpan sth{reinterpret_cast<StepState *>(sch.p + (size_t)(m + 2) * PC)};
+  std::vector<double> coefh((size_t)(m + 1) * PC), betah(PC);
   std::vector<int32_t> mch(PC);
   if (tm) { HIPCHECK(hipStreamSynchronize(s)); std::fprintf(stderr, "[batch timing] alloc+memset %.1f ms (PC=%d)\n", std::chrono::duration<double, std::milli>(now() - t_begin).count(), PC); }
-  for (int p0 = 0; p0 < nprob; p0 += PC) {
-    auto t_chunk = now();
-    const int pc = std::min(PC, nprob - p0);
-    dev::permute_values<double>(s, dDia.as<double>(), dia_words, vals_dev + (int64_t)p0 * nnz, nnz, d_perm.as<int32_t>(), dia_words, pc);
-    HIPCHECK(hipMemsetAsync(dst.p, 0, sizeof(StepState) * (size_t)pc, s));
-    HIPCHECK(hipMemsetAsync(dH.p, 0, sizeof(double) * (size_t)strideH * pc, s));
+  // A chunk (the problems whose vectors fit the workspace together) is cut into SUB-CHUNKS that are pipelined: while the host
+  // runs the m x m exponentials of sub-chunk k (all cores) the device already factorises sub-chunk k+1; the combine of k is
+  // queued behind it.  Sub-chunks are slices of the same chunk buffers, so no extra memory is needed.
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
+  for (auto &e : ev_done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{ev_done};
+  auto factorise = [&](int p0, int q0, int pc) {   // problems [p0 + q0, p0 + q0 + pc) of the call = slots [q0, q0 + pc) of the chunk
+    dev::permute_values<double>(s, dDia.as<double>() + (int64_t)q0 * dia_words, dia_words, vals_dev + (int64_t)(p0 + q0) * nnz, nnz,
+                                d_perm.as<int32_t>(), dia_words, pc);
+    HIPCHECK(hipMemsetAsync(dst.as<StepState>() + q0, 0, sizeof(StepState) * (size_t)pc, s));
+    HIPCHECK(hipMemsetAsync(dH.as<double>() + (int64_t)q0 * strideH, 0, sizeof(double) * (size_t)strideH * pc, s));
     for (int j = 1; j <= m; ++j) {
       const int i0 = herm ? j : std::max(1, j - iop + 1);
       const int nd = j - i0 + 1;
       dev::PipeArgs pa{};
-      pa.dia_val = dDia.as<double>(); pa.dia_ld = P.ld; pa.ndiag = P.ndiag;
+      pa.dia_val = dDia.as<double>() + (int64_t)q0 * dia_words; pa.dia_ld = P.ld; pa.ndiag = P.ndiag;
       for (int d = 0; d < P.ndiag; ++d) pa.dia_off[d] = P.off[d];
       pa.w = P.bandwidth;
-      pa.yprev = (j & 1) ? dYb.as<double>() : dYa.as<double>();
-      pa.ybuf = (j & 1) ? dYa.as<double>() : dYb.as<double>();
-      pa.u0 = (j == 1) ? b_dev + (int64_t)p0 * ldb : nullptr;
+      pa.yprev = ((j & 1) ? dYb.as<double>() : dYa.as<double>()) + (int64_t)q0 * ldv;
+      pa.ybuf = ((j & 1) ? dYa.as<double>() : dYb.as<double>()) + (int64_t)q0 * ldv;
+      pa.u0 = (j == 1) ? b_dev + (int64_t)(p0 + q0) * ldb : nullptr;
       dev::DotsArgs<double> &d = pa.d;
-      d.V = dV.as<double>(); d.ldv = ldv; d.n = n;
+      d.V = dV.as<double>() + (int64_t)q0 * strideV; d.ldv = ldv; d.n = n;
       d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
-      d.part = dpart.as<double>(); d.gpart = dgpart.as<double>(); d.st = dst.as<StepState>();
+      d.part = dpart.as<double>() + (int64_t)q0 * dev::MAX_GRID * 64; d.gpart = dgpart.as<double>() + (int64_t)q0 * ngpart;
+      d.st = dst.as<StepState>() + q0;
       d.mode = herm ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
-      d.Hdev = dH.as<double>(); d.ldh = ldhd; d.jcol = j - 1; d.gram = dG.as<double>(); d.ldg = ldg; d.jrow = j - 1;
+      d.Hdev = dH.as<double>() + (int64_t)q0 * strideH; d.ldh = ldhd; d.jcol = j - 1;
+      d.gram = dG.as<double>() + (int64_t)q0 * ldg * ldg; d.ldg = ldg; d.jrow = j - 1;
       if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
       else if (herm) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
       else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
-      pa.hcoef_in = (j & 1) ? dhcb.as<double>() : dhca.as<double>();
-      pa.hcoef_out = (j & 1) ? dhca.as<double>() : dhcb.as<double>();
-      pa.scales = dsc.as<double>();
+      pa.hcoef_in = ((j & 1) ? dhcb.as<double>() : dhca.as<double>()) + (int64_t)q0 * (m + 2);
+      pa.hcoef_out = ((j & 1) ? dhca.as<double>() : dhcb.as<double>()) + (int64_t)q0 * (m + 2);
+      pa.scales = dsc.as<double>() + (int64_t)q0 * (m + 2);
       pa.step = j;
       pa.tol = tol;
       dev::PipeBatch &pb = pa.pb;
@@ -178,12 +200,13 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       ProfScope ps(ctx, EXPV_MI_K_BATCH);
       dev::pipe_step(s, pa, pc, ctx->opt.batch_rounds);
     }
-    HIPCHECK(hipMemcpyAsync(Hh.data(), dH.p, sizeof(double) * (size_t)strideH * pc, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(sth.data(), dst.p, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(sch.data(), dsc.p, sizeof(double) * (size_t)(m + 2) * pc, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    if (tm) std::fprintf(stderr, "[batch timing] chunk factorisation %.1f ms\n", std::chrono::duration<double, std::milli>(now() - t_chunk).count());
-    t_chunk = now();
+    HIPCHECK(hipMemcpyAsync(Hh.data() + (size_t)q0 * strideH, dH.as<double>() + (int64_t)q0 * strideH, sizeof(double) * (size_t)strideH * pc,
+                            hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(sth.data() + q0, dst.as<StepState>() + q0, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(sch.data() + (size_t)q0 * (m + 2), dsc.as<double>() + (int64_t)q0 * (m + 2), sizeof(double) * (size_t)(m + 2) * pc,
+                            hipMemcpyDeviceToHost, s));
+  };
+  auto finish = [&](int p0, int q0, int pc) {   // host exponentials of a factorised sub-chunk, then its combine
     auto solve_one = [&](int q) {
       const StepState &h = sth[q];
       const double beta = std::sqrt(h.beta0sq);
@@ -212,29 +235,53 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       for (int i = 0; i < mm; ++i) cq[i] *= sq[i];
     };
     {
-      const int nth = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+      // a few problems per thread: creating a thread costs about as much as one 30 x 30 exponential
+      const int nth = (int)std::max(1u, std::min(std::min(std::thread::hardware_concurrency(), 16u), (unsigned)((pc + 7) / 8)));
       std::vector<std::thread> th;
       std::vector<std::string> errs(nth);
       for (int w = 0; w < nth; ++w)
         th.emplace_back([&, w] {
           try {
-            for (int q = w; q < pc; q += nth) solve_one(q);
+            for (int q = q0 + w; q < q0 + pc; q += nth) solve_one(q);
           } catch (const std::exception &e) { errs[w] = e.what(); }
         });
       for (auto &x : th) x.join();
       for (auto &e : errs)
         if (!e.empty()) fail(EXPV_MI_SINGULAR, e);
     }
-    HIPCHECK(hipMemcpyAsync(dcoef.p, coefh.data(), sizeof(double) * (size_t)(m + 1) * pc, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(dbeta.p, betah.data(), sizeof(double) * pc, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(dmcols.p, mch.data(), sizeof(int32_t) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dcoef.as<double>() + (size_t)q0 * (m + 1), coefh.data() + (size_t)q0 * (m + 1), sizeof(double) * (size_t)(m + 1) * pc,
+                            hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dbeta.as<double>() + q0, betah.data() + q0, sizeof(double) * pc, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dmcols.as<int32_t>() + q0, mch.data() + q0, sizeof(int32_t) * pc, hipMemcpyHostToDevice, s));
     {
       ProfScope ps(ctx, EXPV_MI_K_COMBINE);
-      dev::combine_batch<double>(s, n, dV.as<double>(), ldv, strideV, dcoef.as<double>(), m + 1, dbeta.as<double>(),
-                                 dmcols.as<int32_t>(), w_dev + (int64_t)p0 * ldw, ldw, pc);
+      dev::combine_batch<double>(s, n, dV.as<double>() + (int64_t)q0 * strideV, ldv, strideV, dcoef.as<double>() + (size_t)q0 * (m + 1), m + 1,
+                                 dbeta.as<double>() + q0, dmcols.as<int32_t>() + q0, w_dev + (int64_t)(p0 + q0) * ldw, ldw, pc);
     }
+  };
+  for (int p0 = 0; p0 < nprob; p0 += PC) {
+    auto t_chunk = now();
+    const int pc_all = std::min(PC, nprob - p0);
+    const int nsub = pc_all >= 64 ? (pc_all >= 256 ? 4 : 2) : 1;
+    const int per = (pc_all + nsub - 1) / nsub;
+    int prev_q0 = -1, prev_pc = 0;
+    for (int k = 0; k < nsub; ++k) {
+      const int q0 = k * per, pc = std::min(per, pc_all - q0);
+      if (pc <= 0) break;
+      factorise(p0, q0, pc);
+      HIPCHECK(hipEventRecord(ev_done[k & 1], s));
+      if (prev_q0 >= 0) {                       // the previous sub-chunk: its exponentials run while this one factorises
+        HIPCHECK(hipEventSynchronize(ev_done[(k - 1) & 1]));
+        finish(p0, prev_q0, prev_pc);
+      }
+      prev_q0 = q0;
+      prev_pc = pc;
+    }
+    HIPCHECK(hipStreamSynchronize(s));          // the last sub-chunk's results, and the buffers are free for the next chunk afterwards
+    finish(p0, prev_q0, prev_pc);
     HIPCHECK(hipStreamSynchronize(s));
-    if (tm) std::fprintf(stderr, "[batch timing] chunk host exp + combine %.1f ms\n", std::chrono::duration<double, std::milli>(now() - t_chunk).count());
+    if (tm) std::fprintf(stderr, "[batch timing] chunk of %d problems in %d pipelined sub-chunk(s): %.1f ms\n", pc_all, nsub,
+                         std::chrono::duration<double, std::milli>(now() - t_chunk).count());
   }
 }
 
