@@ -687,7 +687,7 @@ def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
     rows = np.repeat(np.arange(n), k)
     cols = rows + rng.integers(-band, band + 1, size=n * k)
     cols = np.clip(cols, 0, n - 1)
-    vals = rng.standard_normal(n * k) * 0.15
+    vals = rng.standard_normal(n * k) * 1.0      # (0.15 made the Krylov residual collapse below 1e-9 within 30 steps: H columns of pure rounding noise)
     A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
     A.sum_duplicates()
     A = (A - 2.0 * sp.eye(n)).tocsr()
@@ -695,10 +695,12 @@ def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
     Ks = eu.arnoldi(A, b, m=m, ishermitian=False)
     Km = eu.arnoldi(A, b, m=m, ishermitian=False, ortho="mgs")
     Vm = Km.getV()[:, : m + 1]
-    tol = max(TOL, 10 * float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1)))))
+    loss = float(np.max(np.abs(Vm.T @ Vm - np.eye(m + 1))))
+    print("[parity] %-90s loss of orthogonality of the strict-MGS basis: %.3e" % ("SELL wave form n=%d" % n, loss))
+    tol = max(TOL, 10 * loss)
     assert Ks.m == Km.m and Ks.wasbreakdown == Km.wasbreakdown
     close(Ks.H[: m + 1, :m], Km.H[: m + 1, :m], tol, "SELL wave form n=%d: H vs strict MGS" % n, mat=True)
     w = eu.expv(0.4, A, b, m=m, ishermitian=False)
-    close(w, eu.expv_(np.empty(n), 0.4, Km), tol, "SELL wave form n=%d: w vs strict MGS" % n)
+    close(w, eu.expv_(np.empty(n), 0.4, Km), TOL, "SELL wave form n=%d: w vs strict MGS" % n)
     if n <= 100_000:
-        close(w, ko.expv(0.4, A, b, m=m, ishermitian=False), tol, "SELL wave form n=%d: w vs oracle" % n)
+        close(w, ko.expv(0.4, A, b, m=m, ishermitian=False), TOL, "SELL wave form n=%d: w vs oracle" % n)
