@@ -237,7 +237,7 @@ static bool mailbox_arm(Ks &ks, int m) {
   const MailboxView v = mailbox_view(ks, ks.mbox);
   std::memset(v.H, 0, dtype_size(ks.dtypeT) * (size_t)ks.ldhd * (m + 1));   // columns this call fills
   std::memset(v.state, 0, sizeof(double) * 4);
-  ks.pipe_seq = (ks.pipe_seq + 1) & 0xffffffu;
+  ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;   // (the step flags carry it in 20 bits: a wider value would never match)
   if (ks.pipe_seq == 0) ks.pipe_seq = 1;
   ks.mbox_armed = true;
   return true;

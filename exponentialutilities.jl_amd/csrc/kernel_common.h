@@ -356,7 +356,24 @@ __device__ __forceinline__ void gram_prefetch(const DotsArgs<T> &a, T *gs_s) {
 // SHARED: the step results are read by the NEXT step's kernel, which is already running (overlapped pipeline), and
 // the Gram rows / H were written by other workgroups earlier in it: every global access goes through to memory
 // (sc1) instead of relying on a kernel boundary.  slot_scale_s (LDS, optional): factor folded into hcoef[k].
-template <class T, bool SHARED = false>
+#ifdef PIPE_TRACE
+__device__ unsigned long long g_epi_trace[40][8];
+#define EPI_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 40) g_epi_trace[step][slot] = wall_clock64(); } while (0)
+#else
+#define EPI_STAMP(step, slot) do { } while (0)
+#endif
+// value of lane k (wave-uniform k) in every lane: v_readlane, a few cycles -- a shuffle goes through the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int k) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, k), hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <class T> __device__ __forceinline__ T readlane_T(T v, int k);
+template <> __device__ __forceinline__ double readlane_T<double>(double v, int k) { return readlane_f64(v, k); }
+template <> __device__ __forceinline__ cplx readlane_T<cplx>(cplx v, int k) { return make_cplx(readlane_f64(v.re, k), readlane_f64(v.im, k)); }
+
+// MAXND: longest window of the caller (rows of the triangular solve); <= 32 keeps a lane's row of the Gram triangle in registers
+template <class T, bool SHARED = false, int MAXND = LOWSYNC_MAX>
 __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const double *vals_s, T *gs_s,
                                                     double newest_scale = 1.0, const double *slot_scale_s = nullptr,
                                                     bool gram_ready = false, T *hcol_s = nullptr) {
@@ -387,6 +404,7 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     return;
   }
   const int nd = a.nd;  // <= LOWSYNC_MAX, dir == +1, newest column (v_j) is window index nd-1
+  EPI_STAMP(a.jcol + 1, 1);
   for (int e = threadIdx.x; e < nd * (nd - 1) / 2; e += BLOCK) {
     int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);   // unpack e -> (i, k), k < i
     while (i * (i - 1) / 2 > e) --i;
@@ -404,14 +422,33 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     gs_s[e] = g;
   }
   __syncthreads();
+  EPI_STAMP(a.jcol + 1, 2);
   if (wave == 0) {  // forward substitution, lane i owns row i
+    // The chain is nd - 1 dependent steps on the critical path of every Krylov step: h_k is broadcast with v_readlane
+    // (k is wave-uniform) and the Gram entries do not depend on the chain, so they are fetched ahead of it.
     T sv = (lane < nd) ? vals_to_T<T>(vals_s + lane * NR) : ST<T>::zero();
-    for (int k = 0; k < nd; ++k) {
-      T hk = shfl_T<T>(sv, k);
-      if (a.real_coeff) hk = ST<T>::real_only(hk);
-      if (lane > k && lane < nd) ST<T>::nfma(sv, hk, gs_s[lane * (lane - 1) / 2 + k]);
+    const int rowbase = lane * (lane - 1) / 2;
+    if constexpr (MAXND <= 32) {
+      T grow[MAXND - 1];
+#pragma unroll
+      for (int k = 0; k < MAXND - 1; ++k) grow[k] = (k < lane && lane < nd) ? gs_s[rowbase + k] : ST<T>::zero();
+#pragma unroll
+      for (int k = 0; k < MAXND - 1; ++k) {
+        if (k < nd - 1) {   // (wave-uniform; no early exit: the unrolled loop keeps grow[] in registers)
+          T hk = readlane_T<T>(sv, k);
+          if (a.real_coeff) hk = ST<T>::real_only(hk);
+          if (lane > k) ST<T>::nfma(sv, hk, grow[k]);     // (rows >= nd carry zeros)
+        }
+      }
+    } else {
+      for (int k = 0; k < nd - 1; ++k) {
+        T hk = readlane_T<T>(sv, k);
+        if (a.real_coeff) hk = ST<T>::real_only(hk);
+        if (lane > k && lane < nd) ST<T>::nfma(sv, hk, gs_s[rowbase + k]);
+      }
     }
     if (a.real_coeff) sv = ST<T>::real_only(sv);
+    EPI_STAMP(a.jcol + 1, 3);
     if (lane < nd) {
       sth(lane, sv);
       const double f = slot_scale_s ? slot_scale_s[lane] : ((lane == nd - 1) ? newest_scale : 1.0);

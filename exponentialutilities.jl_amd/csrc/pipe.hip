@@ -33,6 +33,7 @@
 //   continuation  (cont = 1) first pass of arnoldi!(...; init = j): starts from the stored, normalised v_j
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "kernel_common.h"
 
@@ -69,6 +70,7 @@ __device__ __forceinline__ double ld_shared_f64(const double *p) {   // value an
 #ifdef PIPE_TRACE
 // build-time tracing (tools/pipe_trace.py): per step and workgroup {pass begin, main loop end, reduced, published}
 __device__ unsigned long long g_pipe_trace[33][1024][6];
+__device__ unsigned g_pipe_hw[33][1024];   // HW_ID | XCC_ID << 16 of thread 0's wave
 #define PIPE_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 33 && blockIdx.x < 1024) g_pipe_trace[step][blockIdx.x][slot] = wall_clock64(); } while (0)
 #else
 #define PIPE_STAMP(step, slot) do { } while (0)
@@ -171,6 +173,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   }
   if (!LIVE && step_skipped(a.st, pa.step)) return 0;
   PIPE_STAMP(pa.step, 0);
+#ifdef PIPE_TRACE
+  if (threadIdx.x == 0 && pa.step < 33 && blockIdx.x < 1024)
+    g_pipe_hw[pa.step][blockIdx.x] = (__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xffffu) | ((__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 16);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = pa.w, jcol = a.jcol, und = pa.und;
   if constexpr (DIA && !WAVE) {
@@ -274,20 +280,30 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         vp += cstep;
       }
     }
+    Pack<T> u;                 // u_j on this lane's rows (overlapped form, first tile: y~ of the previous step is loaded into it right behind the flag)
+#pragma unroll
+    for (int e = 0; e < N; ++e) u.v[e] = ST<T>::zero();
+    bool have_ypre = false;
     if constexpr (LIVE) {
       if (!ready) {   // first tile: everything above is in flight; now the previous step must be complete
         const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
         if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
         PIPE_STAMP(pa.step, 4);
+        // everything that only waited for the previous step goes in flight TOGETHER -- its coefficients and 1/beta, the
+        // column it wrote and its y~ on this tile: one memory round trip between the flag and the first product, not two
         inv = consume_f64(&a.st->inv);
-        if (tid < 32) hs[tid] = (tid < und) ? consume_T<T>(hcoef_in + tid) : ST<T>::zero();
-        __syncthreads();
-        tail_of_u();
+        T hc = ST<T>::zero();
+        if (tid < und && tid < 32) hc = consume_T<T>(hcoef_in + tid);
         if (wload) {
 #pragma unroll
           for (int k = 0; k < CH - 1; ++k)
             if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * cstep);
+          u = *reinterpret_cast<const Pack<T> *>(yprev + i);
+          have_ypre = true;
         }
+        if (tid < 32) hs[tid] = hc;
+        __syncthreads();
+        tail_of_u();
         ready = true;
       }
     }
@@ -315,9 +331,6 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
     }
     }
-    Pack<T> u;
-#pragma unroll
-    for (int e = 0; e < N; ++e) u.v[e] = ST<T>::zero();
     if (first) {
       if (AUG) {
 #pragma unroll
@@ -334,7 +347,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         u = ld_pack_user(u0, i, a.n, is_al16(u0));
       }
     } else if (act) {
-      u = *reinterpret_cast<const Pack<T> *>(yprev + i);
+      if (!(LIVE && have_ypre)) u = *reinterpret_cast<const Pack<T> *>(yprev + i);
 #pragma unroll
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
 #pragma unroll
@@ -550,6 +563,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   };
   if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
   PIPE_STAMP(pa.step, 2);
+  EPI_STAMP(pa.step, 0);
 
   // ---- last workgroup: finish step j-1, produce the Hessenberg column of step j ------------------
   // (LIVE: what the last workgroups of earlier steps wrote -- scales, Gram rows, H -- is read through to
@@ -607,7 +621,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   if (a.mode == DOTS_LANCZOS && threadIdx.x == 0) sh.cs_s[0] = pa.cont ? pa.cont_inv : invj;    // cs_s[1]: pf()
   __syncthreads();
   a.hcoef = hcoef_out;
-  projection_epilogue<T, LIVE>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
+  projection_epilogue<T, LIVE, CH>(a, std_s, gs_s, 1.0, sh.cs_s, gram_pf);
   return 1;
 }
 
@@ -662,6 +676,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
                                  __HIP_MEMORY_SCOPE_AGENT);
   const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
+    PIPE_STAMP(pa.step, 5);
+    EPI_STAMP(pa.step, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < PIPE_FLAG_COPIES)
@@ -669,6 +685,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
                          (pa.seq << PIPE_SEQ_SHIFT) | (r == 2 ? PIPE_STOP_BIT : 0u) | (uint32_t)pa.step, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     PIPE_STAMP(pa.step, 3);
+    EPI_STAMP(pa.step, 5);
     if (pa.mb_done && (r == 2 || pa.step == pa.last_step)) {
       // The factorisation ends here: copy what the host reads -- the Hessenberg columns, the column scales, the
       // final state -- from device memory (every step stored them through before raising its flag) into the
@@ -876,6 +893,27 @@ extern "C" void expv_mi_pipe_trace_dump(const char *path) {
       const unsigned long long *r = &h[((size_t)st * 1024 + b) * 6];
       if (r[0]) std::fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu\n", st, b, r[0], r[1], r[2], r[3], r[4], r[5]);
     }
+  std::fclose(f);
+  {   // where each workgroup ran
+    std::vector<unsigned> hw((size_t)33 * 1024);
+    (void)hipMemcpyFromSymbol(hw.data(), HIP_SYMBOL(g_pipe_hw), hw.size() * 4);
+    const std::string p3 = std::string(path) + ".hw";
+    FILE *g = std::fopen(p3.c_str(), "w");
+    if (g) {
+      for (int st = 1; st < 33; ++st)
+        for (int b = 0; b < 1024; ++b)
+          if (h[((size_t)st * 1024 + b) * 6]) std::fprintf(g, "%d %d %u\n", st, b, hw[(size_t)st * 1024 + b]);
+      std::fclose(g);
+    }
+  }
+  // phases of the last workgroup's epilogue: reduced -> sums rescaled -> Gram row stored -> triangular solve -> stores issued -> flag
+  unsigned long long e[40][8];
+  (void)hipMemcpyFromSymbol(e, HIP_SYMBOL(g_epi_trace), sizeof(e));
+  const std::string p2 = std::string(path) + ".epi";
+  f = std::fopen(p2.c_str(), "w");
+  if (!f) return;
+  for (int st = 1; st < 34; ++st)
+    if (e[st][0]) std::fprintf(f, "%d %.2f %.2f %.2f %.2f %.2f\n", st, (e[st][1] - e[st][0]) * 0.01, (e[st][2] - e[st][1]) * 0.01, (e[st][3] - e[st][2]) * 0.01, (e[st][4] - e[st][3]) * 0.01, (e[st][5] - e[st][4]) * 0.01);
   std::fclose(f);
 }
 #endif

@@ -22,7 +22,7 @@ d = np.loadtxt(sys.argv[1], dtype=np.int64)
 step, blk, t0, t1, t2, t3, t4, t5 = d.T
 prev_pub = None
 print("per step, us relative to the previous step's publish (step 1: to its own first start):")
-print("step nblk | kernel start first/median/last | released (after wait) median/last | main end median/last | reduced | published  [= step time]")
+print("step nblk | kernel start first/median/last | released (after wait) median/last | main end median/last | reduced | epilogue stored | published  [= step time]")
 for q in sorted(set(step)):
     mk = step == q
     ref = prev_pub if prev_pub is not None else t0[mk].min()
@@ -30,6 +30,8 @@ for q in sorted(set(step)):
     rel = t4[mk][t4[mk] > 0]
     pub = t3[mk].max()
     red = t2[mk].max()
+    epi = t5[mk].max()
     print(q, mk.sum(), "|", r(t0[mk].min()), r(np.median(t0[mk])), r(t0[mk].max()), "|",
-          (r(np.median(rel)), r(rel.max())) if len(rel) else "-", "|", r(np.median(t1[mk])), r(t1[mk].max()), "|", r(red), "|", r(pub))
+          (float(r(np.median(rel))), float(r(rel.max()))) if len(rel) else "-", "|", r(np.median(t1[mk])), r(t1[mk].max()), "|", r(red), "|",
+          (r(epi) if epi > 0 else "-"), "|", r(pub))
     prev_pub = pub
