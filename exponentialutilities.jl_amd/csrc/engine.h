@@ -57,6 +57,8 @@ struct Options {
   int pipeline_serial = 0; // single-pass step: one launch after the other even if overlap is on (EXPV_MI_PIPE_SERIAL=1 -> 1)
   int spin_limit = 400000; // polls (~1 us each) before a waiting kernel gives up               (EXPV_MI_PIPE_SPIN_LIMIT)
   int batch_rounds = 2;    // batched single-pass step: resident rounds of fat workgroups       (EXPV_MI_BATCH_ROUNDS)
+  int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
+                           // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();
   int *find(const char *name);
 };
@@ -209,6 +211,7 @@ struct Ks {
   DevBuf flags;                      // ... the step flags of its overlapped form (arrival counters: behind `state`)
   DevBuf tflags;                     // ... the per-tile flags of its wave form
   uint32_t pipe_seq = 0;
+  bool pipe_resident_used = false;   // the last factorisation ran as one resident kernel
   bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait ...
   int pipe_serial_calls = 0;                           // ... and tried again after this many serial factorisations
   bool wave_off = false;                               // wave form switched off after an expired wait (two-kernel step instead)

@@ -252,6 +252,7 @@ Options Options::from_env() {
   if (flag("EXPV_MI_FUSED_V1")) o.fused_two_reductions = 1;
   if (flag("EXPV_MI_NO_DIA")) o.dia = 0;
   if (flag("EXPV_MI_NO_MAILBOX")) o.mailbox = 0;
+  if (flag("EXPV_MI_RESIDENT")) o.resident = 1;
   if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
   if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
   if (const char *v = std::getenv("EXPV_MI_BATCH_ROUNDS")) o.batch_rounds = std::max(1, std::atoi(v));
@@ -265,6 +266,7 @@ int *Options::find(const char *name) {
   if (n == "fused_two_reductions") return &fused_two_reductions;
   if (n == "dia") return &dia;
   if (n == "mailbox") return &mailbox;
+  if (n == "resident") return &resident;
   if (n == "pipeline_serial") return &pipeline_serial;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
@@ -554,7 +556,32 @@ struct ArnoldiCall {
       if (!ks.mbox_armed) next_seq();
     }
   }
-  {
+  // Resident form: the whole factorisation as ONE cooperative kernel that keeps operator diagonals and y~ on the chip
+  // (pipe.hip).  Shape: fp64 banded DIA operator, fresh call, full window, everything else as in the overlapped form.
+  bool resident_done = false;
+  ks.pipe_resident_used = false;
+  if constexpr (!ST<T>::is_complex) {
+    if (live && c->opt.resident && fresh && !use_wave && !isaug && !lanczos && op.ndiag > 0 && !no_dia_env && iop >= m &&
+        m + (closing ? 1 : 0) <= dev::PIPE_CH && (ks.skip_tail || closing) && ks.mbox_armed) {
+      dev::ResArgs ra{};
+      ra.dia_val = op.dia_val.as<double>(); ra.dia_ld = op.dia_ld; ra.ndiag = op.ndiag;
+      for (int d = 0; d < op.ndiag; ++d) ra.dia_off[d] = op.dia_off[d];
+      ra.w = (int)op.bandwidth;
+      ra.V = V; ra.ldv = ks.ldv; ra.n = rows;
+      ra.ya = ya; ra.yb = yb2; ra.u0 = b;
+      ra.part = part; ra.gpart = gpart; ra.st = st;
+      ra.Hdev = Hd; ra.ldh = ks.ldhd; ra.gram = ks.gram.as<double>(); ra.ldg = ks.ldg;
+      ra.hca = hca; ra.hcb = hcb; ra.scales = ks.colscale.as<double>();
+      ra.flags = ks.flags.as<uint32_t>(); ra.seq = ks.pipe_seq; ra.spin_limit = spin_limit;
+      ra.m = m; ra.closing = closing ? 1 : 0; ra.tol = tol; ra.real_coeff = real_coeff;
+      const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
+      ra.Hhost = mv.H; ra.mb_scales = mv.scales; ra.mb_state = mv.state; ra.mb_done = mv.done;
+      ProfScope ps(c, EXPV_MI_K_FUSED_A, nsteps);
+      resident_done = dev::pipe_resident(s, ra);
+      if (resident_done) { ks.pipe_closed = closing; ks.pipe_resident_used = true; }
+    }
+  }
+  if (!resident_done) {
     // overlapped kernels have no separate durations: one scope over the sequence, counted as its launches
     ProfScope ps(c, EXPV_MI_K_FUSED_A, live ? nsteps : 0);
     int prev_grid = 0;
@@ -933,7 +960,7 @@ struct ArnoldiCall {
   }
   c->cnt_steps += jlast - jstart + 1;
   ++c->cnt_fact;
-  c->last_path = use_pipe ? (EXPV_MI_PATH_PIPELINE | (use_wave ? EXPV_MI_PATH_WAVE : 0) | (ks.pipe_live_used ? EXPV_MI_PATH_OVERLAPPED : 0))
+  c->last_path = use_pipe ? (EXPV_MI_PATH_PIPELINE | (use_wave ? EXPV_MI_PATH_WAVE : 0) | (ks.pipe_live_used ? EXPV_MI_PATH_OVERLAPPED : 0) | (ks.pipe_resident_used ? EXPV_MI_PATH_RESIDENT : 0))
                           : (use_fused ? EXPV_MI_PATH_TWO_KERNEL : EXPV_MI_PATH_MODULAR);
   if (use_pipe) { ++c->cnt_pipe; if (ks.pipe_live_used) ++c->cnt_live; }
   return jlast - jstart + 1;

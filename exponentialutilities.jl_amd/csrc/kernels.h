@@ -216,6 +216,21 @@ struct PipeArgsT {
   T u0_tail[PIPE_AUG_MAX];     // step 1 of an augmented factorisation: rows n_op.. of u_1 (by value: no staging copy)
 };
 using PipeArgs = PipeArgsT<double>;
+// resident form (pipe.hip): one cooperative launch per factorisation
+struct ResArgs {
+  const double *dia_val; int64_t dia_ld; int ndiag; int dia_off[PIPE_DIA_MAX]; int w;
+  double *V; int64_t ldv; int64_t n;
+  double *ya, *yb;              // y~ of the odd / even steps (the memory copies: halo rows of the neighbours)
+  const double *u0;             // the starting vector
+  double *part, *gpart; StepState *st;
+  double *Hdev; int ldh; double *gram; int ldg;
+  double *hca, *hcb; double *scales;
+  uint32_t *flags; uint32_t seq; int spin_limit;
+  int m, closing; double tol; int real_coeff;
+  double *Hhost; double *mb_scales, *mb_state; unsigned long long *mb_done;
+};
+bool pipe_resident(hipStream_t s, const ResArgs &ra);   // false: not launched (shape outside the resident form's scope)
+int pipe_resident_capacity();
 void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1, int batch_rounds = 2);
 void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch = 1, int batch_rounds = 2);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid

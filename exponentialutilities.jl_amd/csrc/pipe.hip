@@ -710,6 +710,325 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
   }
 }
 
+
+// ---- resident form: the whole factorisation in ONE kernel, part of the operand kept on the chip (experimental, off) ------
+// Every step of the forms above reads the operator diagonals and y~ of the previous step from HBM again.  Here the grid is
+// launched once per factorisation (cooperative launch: all workgroups resident, two per CU) and loops over the Krylov
+// steps itself; a workgroup owns the same RES_TILES tiles of 512 rows in every step, so RES_DL operator diagonals and
+// y~_{j-1} of its rows stay in its LDS (64 of the 80 KB a workgroup can have at two per CU).  Steps are separated by the
+// same grid reduction + step flag as in the overlapped form.
+// Measured (profiles/r02_ab_variants.txt, item 6): correct (3.6e-16 against the step-wise result) and 15 % SLOWER on config 2
+// although it moves 17 % fewer bytes: the window columns of a tile must stay in registers between the update and the
+// projection sums (124 of 256 VGPRs at two workgroups per CU), which leaves no registers for resident basis columns and
+// pins every step to the occupancy of the widest window, where the step-wise kernels run 4 / 3 workgroups per CU for the
+// first 24 steps.  Kept behind the context option "resident" (default 0) as the A/B of that design.
+// Scope: fp64, DIA form, fresh factorisation with the full window (no IOP, not Lanczos), m <= PIPE_CH - 1,
+// rows <= grid x RES_TILES x 512.
+constexpr int RES_TILES = 4, RES_DL = 3;
+struct ResShared {
+  double us[2 * BLOCK + 2 * PIPE_WMAX];
+  double dia_s[RES_DL][RES_TILES * 2 * BLOCK];
+  double y_s[RES_TILES * 2 * BLOCK];
+  double hs[32];
+  double red_s[BLOCK / 64][64];
+  double vals_s[64];
+  double std_s[MAX_RED_VALUES];
+  double gs_s[PIPE_CH * (PIPE_CH - 1) / 2];
+  double cs_s[PIPE_CH];
+  int doff[PIPE_DIA_MAX];
+  int flag_s;
+};
+__global__ __launch_bounds__(BLOCK, 2) void k_pipe_resident(const ResArgs ra) {
+  extern __shared__ __align__(16) unsigned char res_smem[];
+  ResShared &sh = *reinterpret_cast<ResShared *>(res_smem);
+  using T = double;
+  constexpr int CH = PIPE_CH, N = 2, TR = N * BLOCK;
+  constexpr int K = 16, P = CH / K, NSETS = 2 * P;
+  static_assert(CH == 32 && NSETS == 4, "value layout of the resident form");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = ra.w;
+  double(&us)[2 * BLOCK + 2 * PIPE_WMAX] = sh.us;
+  double(&hs)[32] = sh.hs;
+  double(&red_s)[BLOCK / 64][64] = sh.red_s;
+  double(&vals_s)[64] = sh.vals_s;
+  double(&std_s)[MAX_RED_VALUES] = sh.std_s;
+  int &flag_s = sh.flag_s;
+  const int64_t n = ra.n, nb = (n + 127) & ~(int64_t)127;
+  const int64_t ntiles = (n + TR - 1) / TR;
+  const int64_t tq = ntiles / gridDim.x, trem = ntiles % gridDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * tq + ((int64_t)blockIdx.x < trem ? blockIdx.x : trem);
+  const int ntl = (int)(tq + ((int64_t)blockIdx.x < trem ? 1 : 0));      // <= RES_TILES (checked by the launcher)
+  if (tid < PIPE_DIA_MAX) {
+    int v = 0;
+#pragma unroll
+    for (int q = 0; q < PIPE_DIA_MAX; ++q)
+      if (tid == q) v = ra.dia_off[q];
+    sh.doff[tid] = v;
+  }
+  // ---- resident operand: the first RES_DL diagonals of this workgroup's rows, loaded once ---------------------------------
+  for (int tl = 0; tl < ntl; ++tl) {
+    const int64_t i = (t0 + tl) * TR + N * (int64_t)tid;
+    const bool act = i < nb;
+#pragma unroll
+    for (int d = 0; d < RES_DL; ++d) {
+      Pack<T> v;
+      v.v[0] = v.v[1] = 0.0;
+      if (act && d < ra.ndiag) v = *reinterpret_cast<const Pack<T> *>(ra.dia_val + (int64_t)d * ra.dia_ld + i);
+      *reinterpret_cast<Pack<T> *>(&sh.dia_s[d][tl * TR + N * tid]) = v;
+    }
+  }
+  __syncthreads();
+  const int last_step = ra.m + (ra.closing ? 1 : 0);
+  double *scales = ra.scales;
+  for (int j = 1; j <= last_step; ++j) {
+    const bool first = (j == 1), final = (j == ra.m + 1);
+    const int und = j - 1, jcol = j - 1, knew = j - 2;
+    const T *yprev = (j & 1) ? ra.yb : ra.ya;
+    T *ybuf = (j & 1) ? ra.ya : ra.yb;
+    const T *hcoef_in = (j & 1) ? ra.hcb : ra.hca;
+    T *hcoef_out = (j & 1) ? ra.hca : ra.hcb;
+    DotsArgs<T> a{};
+    a.V = ra.V; a.ldv = ra.ldv; a.n = n; a.c0 = 0; a.dir = 1; a.nd = j;
+    a.part = ra.part; a.gpart = ra.gpart; a.st = ra.st;
+    a.mode = (j >= 2) ? DOTS_LOWSYNC : DOTS_STRICT;
+    a.real_coeff = ra.real_coeff;
+    a.Hdev = ra.Hdev; a.ldh = ra.ldh; a.jcol = j - 1; a.gram = ra.gram; a.ldg = ra.ldg; a.jrow = j - 1;
+    a.hcoef = hcoef_out; a.Hhost = ra.Hhost;
+    bool ready = first;
+    double inv = 1.0;
+    double acc = 0.0;
+    auto await_previous = [&]() -> int {   // the previous step must be complete: its flag, then its coefficients and 1/beta
+      const int bd = wait_step(ra.st, ra.flags, ra.seq, j - 1, &flag_s, ra.spin_limit);
+      if (bd != 0) return bd;
+      inv = consume_f64(&ra.st->inv);
+      T hc = 0.0;
+      if (tid < und && tid < 32) hc = consume_f64(hcoef_in + tid);
+      if (tid < 32) hs[tid] = hc;
+      return 0;
+    };
+    if (first) {
+      if (tid < 32) hs[tid] = 0.0;
+      __syncthreads();
+    }
+    for (int tl = 0; tl < ntl; ++tl) {
+      {
+        const int64_t r0 = (t0 + tl) * TR, i = r0 + N * (int64_t)tid;
+        const bool act = i < nb;
+        // ---- operator diagonals beyond the resident ones, and the window columns of this lane's rows ------------------------
+        Pack<T> avx[PIPE_DIA_MAX - RES_DL];
+#pragma unroll
+        for (int d = RES_DL; d < PIPE_DIA_MAX; ++d) {
+          avx[d - RES_DL].v[0] = avx[d - RES_DL].v[1] = 0.0;
+          if (!final && act && d < ra.ndiag) avx[d - RES_DL] = *reinterpret_cast<const Pack<T> *>(ra.dia_val + (int64_t)d * ra.dia_ld + i);
+        }
+        Pack<T> vreg[CH - 1];
+#pragma unroll
+        for (int k = 0; k < CH - 1; ++k) vreg[k].v[0] = vreg[k].v[1] = 0.0;
+        const bool wload = !first && act;
+        const T *vp0 = ra.V + i;
+        if (wload) {
+          const T *vp = vp0;
+#pragma unroll
+          for (int k = 0; k < CH - 1; ++k) {
+            if (k < und && (ready || k != knew)) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp);
+            vp += ra.ldv;
+          }
+        }
+        if (!ready) {   // first tile of the step: the loads above are in flight; now the previous step must be complete
+          const int bd = await_previous();
+          if (bd != 0) return;
+          if (wload) {
+#pragma unroll
+            for (int k = 0; k < CH - 1; ++k)
+              if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * ra.ldv);
+          }
+          __syncthreads();
+          ready = true;
+        }
+        // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row -----------------------
+        for (int e = tid; e < 2 * w * 32; e += BLOCK) {
+          const int hrow = e >> 5, k = e & 31;
+          const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
+          T val = 0.0;
+          if (hr >= 0 && hr < n) {
+            if (k == 31) val = first ? ra.u0[hr] : consume_f64(yprev + hr) * inv;     // (a neighbour wrote it during this launch)
+            else if (!first && k < und) val = -hs[k] * ra.V[hr + (int64_t)k * ra.ldv];   // (columns never change once written)
+          }
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+          if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
+        }
+        // ---- phase 1: u_j on the tile rows --------------------------------------------------------------------------------
+        Pack<T> u;
+        u.v[0] = u.v[1] = 0.0;
+        if (first) {
+          u = ld_pack_user(ra.u0, i, n, is_al16(ra.u0));
+        } else if (act) {
+          u = *reinterpret_cast<const Pack<T> *>(&sh.y_s[tl * TR + N * tid]);     // y~_{j-1} of these rows: this lane's own store
+          u.v[0] *= inv;
+          u.v[1] *= inv;
+#pragma unroll
+          for (int k = 0; k < CH - 1; ++k)
+            if (k < und) {                          // MGS axpy order
+              const T h = hs[k];
+              u.v[0] = fma(-h, vreg[k].v[0], u.v[0]);
+              u.v[1] = fma(-h, vreg[k].v[1], u.v[1]);
+            }
+        }
+        us[w + N * tid] = u.v[0];
+        us[w + N * tid + 1] = u.v[1];
+        if (act) st_tile<true, T>(ra.V + (int64_t)jcol * ra.ldv + i, u);      // raw u_j -> column j-1
+        __syncthreads();
+        // ---- phase 2: y~ = A u_j for this lane's rows, u from LDS, the diagonals from LDS / registers -------------------
+        Pack<T> y;
+        y.v[0] = y.v[1] = 0.0;
+        if (!final && act) {
+          const int base = w + N * tid;
+#pragma unroll
+          for (int d = 0; d < PIPE_DIA_MAX; ++d)
+            if (d < ra.ndiag) {
+              Pack<T> av;
+              if (d < RES_DL) av = *reinterpret_cast<const Pack<T> *>(&sh.dia_s[d < RES_DL ? d : 0][tl * TR + N * tid]);
+              else av = avx[d >= RES_DL ? d - RES_DL : 0];
+              const int o = base + sh.doff[d];
+              y.v[0] = fma(av.v[0], us[o], y.v[0]);
+              y.v[1] = fma(av.v[1], us[o + 1], y.v[1]);
+            }
+          *reinterpret_cast<Pack<T> *>(&sh.y_s[tl * TR + N * tid]) = y;
+          st_tile<true, T>(ybuf + i, y);
+        }
+        // ---- phase 3: this tile's products, summed across the wave at once (layout: see pipe_pass) ----------------------
+        const bool slot_dots = !first;
+        auto tile_set = [&](int sidx, const Pack<T> &o) {
+          const int part = sidx % P;
+          double arr[K];
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int q = part * K + k;                 // window slot, or the self term (q == CH - 1)
+            if (q < CH - 1) {
+              arr[k] = (slot_dots && q < und) ? pack_prod(vreg[q < CH - 1 ? q : 0], o, 0) : 0.0;
+            } else {
+              arr[k] = pack_prod(u, o, 0);
+            }
+          }
+          wave_reduce_multi<K>(arr);
+          if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
+        };
+#pragma unroll
+        for (int sidx = 0; sidx < NSETS; ++sidx) tile_set(sidx, sidx < P ? y : u);
+        __syncthreads();   // us is rewritten by the next tile
+      }
+    }
+    if (!ready) {   // (a workgroup without tiles still takes part in the reduction of every step, in step order)
+      const int bd = await_previous();
+      if (bd != 0) return;
+      __syncthreads();
+      ready = true;
+    }
+    // ---- workgroup: 4 waves -> one partial per value (compact layout, see pipe_pass) -------------------------------------
+    const int o_self = 2 * und, o_nrm = 2 * und + 1;
+    {
+      constexpr int COPIES = 64 / K;
+      const int idx = wave_multi_index<K>(lane);
+      const int sidx = lane & (NSETS - 1);
+      if ((lane & (COPIES - 1)) == sidx) {
+        const int part = sidx % P, t = sidx / P;
+        const int q = part * K + idx;
+        if (q == CH - 1) {
+          if (t == 0) red_s[wave][o_self] = acc;
+          else red_s[wave][o_nrm] = acc;
+        } else if (q < und) red_s[wave][t * und + q] = acc;
+      }
+    }
+    __syncthreads();
+    const int nvals = o_nrm + 1;
+    if (tid < nvals) publish_f64(a.part + (size_t)tid * MAX_GRID + blockIdx.x, red_s[0][tid] + red_s[1][tid] + red_s[2][tid] + red_s[3][tid]);
+    const bool gram_pf = (a.mode == DOTS_LOWSYNC);
+    auto pf = [&]() {
+      if (gram_pf) gram_prefetch<T, true>(a, sh.gs_s);
+      for (int k = threadIdx.x; k < a.nd; k += BLOCK)
+        if (k != jcol) sh.cs_s[k] = consume_f64(scales + k);
+    };
+    if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) continue;
+    // ---- last workgroup of the step: finish step j-1, produce the Hessenberg column of step j, raise the flag ----------
+    const double beta = sqrt(vals_s[o_nrm]);
+    const double invj = 1.0 / beta;
+    const bool stop = first ? (beta == 0.0) : (beta < ra.tol);
+    if (tid == 0) {
+      publish_f64(&a.st->hnorm, beta);
+      publish_f64(&a.st->inv, invj);
+      a.st->m_done = j - 1;
+      publish_f64(&scales[jcol], invj);
+      if (first) publish_f64(&a.st->beta0sq, vals_s[o_nrm]);
+      else publish_f64(&a.Hdev[jcol + (int64_t)(jcol - 1) * a.ldh], beta);      // H[j, j-1] = ||u_j||
+      if (stop) a.st->breakdown = first ? 2 : 1;
+    }
+    if (!stop && !final) {
+      const int nd = a.nd;
+      for (int k = tid; k < nd; k += BLOCK) {
+        double f, sc;
+        int src_d, src_g = -1;
+        if (k == jcol) {
+          f = invj * invj;
+          src_d = o_self;
+          sc = invj;
+        } else {
+          sc = sh.cs_s[k];
+          f = sc * invj;
+          src_d = k;
+          src_g = und + k;
+        }
+        std_s[k] = vals_s[src_d] * f;
+        std_s[nd + k] = (src_g >= 0) ? vals_s[src_g] * f : 0.0;
+        sh.cs_s[k] = sc;
+      }
+      __syncthreads();
+      projection_epilogue<T, true, CH>(a, std_s, sh.gs_s, 1.0, sh.cs_s, gram_pf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < PIPE_FLAG_COPIES)
+      __hip_atomic_store(ra.flags + (size_t)tid * PIPE_FLAG_STRIDE, (ra.seq << PIPE_SEQ_SHIFT) | (stop ? PIPE_STOP_BIT : 0u) | (uint32_t)j,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ra.mb_done && (stop || j == last_step)) {   // the factorisation ends here: what the host reads goes to the mailbox
+      const int ncols = j;
+      double *hh = ra.Hhost;
+      const double *hd = ra.Hdev;
+      for (int e = tid; e < a.ldh * ncols; e += BLOCK) publish_host_f64(&hh[e], consume_f64(&hd[e]));
+      for (int k = tid; k < j; k += BLOCK) publish_host_f64(&ra.mb_scales[k], consume_f64(&scales[k]));
+      if (tid == 0) {
+        publish_host_f64(&ra.mb_state[0], consume_f64(&a.st->beta0sq));
+        publish_host_f64(&ra.mb_state[1], stop ? (j == 1 ? 2.0 : 1.0) : 0.0);
+        publish_host_f64(&ra.mb_state[2], (double)(j - 1));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(ra.mb_done, (unsigned long long)ra.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (stop) return;
+  }
+}
+int pipe_resident_capacity() {   // rows a resident launch can take (0: the kernel cannot be made resident here)
+  static int cap = -1;
+  if (cap >= 0) return cap;
+  cap = 0;
+  if (hipFuncSetAttribute((const void *)k_pipe_resident, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ResShared)) != hipSuccess) return cap;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pipe_resident, BLOCK, sizeof(ResShared)) != hipSuccess) return cap;
+  if (per_cu < 2) return cap;
+  cap = 2 * device_cus();      // workgroups
+  return cap;
+}
+bool pipe_resident(hipStream_t s, const ResArgs &ra) {
+  const int grid = pipe_resident_capacity();
+  const int64_t ntiles = (ra.n + 2 * BLOCK - 1) / (2 * BLOCK);
+  if (grid <= 0 || grid > MAX_GRID || ntiles > (int64_t)grid * RES_TILES) return false;
+  if (ra.ndiag < 1 || ra.ndiag > PIPE_DIA_MAX || ra.w > PIPE_WMAX || ra.m + (ra.closing ? 1 : 0) > PIPE_CH) return false;
+  ResArgs args = ra;
+  void *kargs[] = {&args};
+  return hipLaunchCooperativeKernel((const void *)k_pipe_resident, dim3(grid), dim3(BLOCK), kargs, sizeof(ResShared), s) == hipSuccess;
+}
+
 template <class T> constexpr int pipe_tile_rows() { return Pack<T>::N * BLOCK; }
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>

@@ -468,3 +468,39 @@ def test_context_options_select_the_step_form(eu):
         ctx.set_option("no_such_option", 1)
     c = ctx.counters()
     assert c["redo_serial"] == 0 and c["redo_wave_off"] == 0 and c["factorisations"] == len(seen)
+
+
+def test_resident_form_matches_stepwise_and_oracle(eu):
+    """Context option "resident" = 1: the whole factorisation as one cooperative kernel (pipe.hip, k_pipe_resident).  Same
+    algorithm as the step-wise single-pass form with another partition of the rows: agreement to rounding with it and with
+    the C oracle, happy breakdown included, and the path flag says that it ran."""
+    rng = np.random.default_rng(77)
+    for n, m in ((200_000, 30), (70_001, 12)):
+        A = c2_operator(n)
+        b = rng.standard_normal(n)
+        ctx = eu.Context()
+        op = eu.MIOperator(A, ctx)
+        w_step = eu.expv(0.7, op, b, m=m, ishermitian=False)
+        assert "resident" not in eu.expv.last_stats["path"]
+        ctx.set_option("resident", 1)
+        w_res = eu.expv(0.7, op, b, m=m, ishermitian=False)
+        assert "resident" in eu.expv.last_stats["path"], eu.expv.last_stats
+        w_ref, _ = co.expv_csr(0.7, A, b, m=m)
+        close(w_res, w_step, 1e-13, "resident form vs step-wise form (n=%d, m=%d)" % (n, m))
+        close(w_res, w_ref, 1e-12, "resident form vs C oracle (n=%d, m=%d)" % (n, m))
+    # happy breakdown inside the resident kernel: b is a combination of 8 eigenvectors of a tridiagonal Toeplitz operator
+    # (full diagonals, so the operator takes the DIA form the resident kernel needs)
+    n = 4096
+    A = sp.diags([0.5, 1.5, 0.5], [-1, 0, 1], shape=(n, n), format="csc")
+    i = np.arange(1, n + 1)
+    b = sum((1.0 + 1e-3 * k) * np.sin(np.pi * k * i / (n + 1)) / 64.0 for k in (300, 800, 1300, 1800, 2300, 2800, 3300, 3800))
+    ctx = eu.Context()
+    ctx.set_option("resident", 1)
+    op = eu.MIOperator(A, ctx)
+    w = eu.expv(0.3, op, b, m=20, ishermitian=False)
+    st = dict(eu.expv.last_stats)
+    assert "resident" in st["path"] and st["wasbreakdown"] and st["m"] <= 9, st
+    lam = 1.5 + np.cos(np.pi * np.array([300, 800, 1300, 1800, 2300, 2800, 3300, 3800]) / (n + 1))
+    w_exact = sum(np.exp(0.3 * l) * (1.0 + 1e-3 * k) * np.sin(np.pi * k * i / (n + 1)) / 64.0
+                  for l, k in zip(lam, (300, 800, 1300, 1800, 2300, 2800, 3300, 3800)))
+    close(w, w_exact, 1e-10, "resident form, happy breakdown")
