@@ -57,6 +57,7 @@ struct Options {
   int pipeline_serial = 0; // single-pass step: one launch after the other even if overlap is on (EXPV_MI_PIPE_SERIAL=1 -> 1)
   int spin_limit = 400000; // polls (~1 us each) before a waiting kernel gives up               (EXPV_MI_PIPE_SPIN_LIMIT)
   int batch_rounds = 2;    // batched single-pass step: resident rounds of fat workgroups       (EXPV_MI_BATCH_ROUNDS)
+  int nontemporal = -1;    // non-temporal loads in the single-pass step: -1 by footprint, 0 never, 1 always  (EXPV_MI_NONTEMPORAL=0|1)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();

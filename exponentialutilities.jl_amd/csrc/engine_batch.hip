@@ -194,6 +194,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       pa.scales = dsc.as<double>() + (int64_t)q0 * (m + 2);
       pa.step = j;
       pa.tol = tol;
+      pa.nt_mode = ctx->opt.nontemporal < 0 ? 0 : (ctx->opt.nontemporal ? 2 : 1);
       dev::PipeBatch &pb = pa.pb;
       pb.V = strideV; pb.y = ldv; pb.part = (int64_t)dev::MAX_GRID * 64; pb.gpart = ngpart; pb.Hdev = strideH;
       pb.gram = (int64_t)ldg * ldg; pb.hcoef = m + 2; pb.scales = m + 2; pb.dia = dia_words; pb.st = 1; pb.u0 = ldb;

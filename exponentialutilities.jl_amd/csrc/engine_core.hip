@@ -253,6 +253,7 @@ Options Options::from_env() {
   if (flag("EXPV_MI_NO_DIA")) o.dia = 0;
   if (flag("EXPV_MI_NO_MAILBOX")) o.mailbox = 0;
   if (flag("EXPV_MI_RESIDENT")) o.resident = 1;
+  if (const char *e = std::getenv("EXPV_MI_NONTEMPORAL")) o.nontemporal = std::atoi(e) ? 1 : 0;
   if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
   if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
   if (const char *v = std::getenv("EXPV_MI_BATCH_ROUNDS")) o.batch_rounds = std::max(1, std::atoi(v));
@@ -267,6 +268,7 @@ int *Options::find(const char *name) {
   if (n == "dia") return &dia;
   if (n == "mailbox") return &mailbox;
   if (n == "resident") return &resident;
+  if (n == "nontemporal") return &nontemporal;
   if (n == "pipeline_serial") return &pipeline_serial;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
@@ -638,6 +640,7 @@ struct ArnoldiCall {
       pa.scales = ks.colscale.as<double>();
       pa.step = j;
       pa.tol = tol;
+      pa.nt_mode = c->opt.nontemporal < 0 ? 0 : (c->opt.nontemporal ? 2 : 1);
       if (live) {
         hipStream_t sj = (j & 1) ? s : s2;
         uint32_t *arr = reinterpret_cast<uint32_t *>(ks.state.as<char>() + sizeof(StepState));   // zeroed with the state

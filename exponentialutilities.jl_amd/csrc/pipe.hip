@@ -62,6 +62,25 @@ __device__ __forceinline__ void st_tile(T *p, const Pack<T> &v) {
   if constexpr (WT) st_pack_wt<T>(p, v);
   else *reinterpret_cast<Pack<T> *>(p) = v;
 }
+// 16-byte load of a stream a pass reads exactly once (window columns, operator diagonals).  NTL: non-temporal form.
+// Measured (profiles/r02_ab_variants.txt items 4 and 7): while the basis + operator fit the 256 MiB Infinity Cache plain
+// loads are 6-12 % faster (re-reads of the next step hit the cache, nt loads do not allocate there); once the footprint of a
+// step is well beyond it nt loads stream 7-9 % faster (n = 6.4e6: 4.47 -> 4.88 TB/s, config 5: 222 -> 237 k matvecs/s).
+// The launchers pick the form per step from the step's footprint (pipe_nontemporal).
+template <bool NTL, class T>
+__device__ __forceinline__ Pack<T> ld_stream(const T *p) {
+  if constexpr (NTL) {
+    typedef double vec2d __attribute__((ext_vector_type(2)));
+    const vec2d d = __builtin_nontemporal_load(reinterpret_cast<const vec2d *>(p));
+    Pack<T> r;
+    double *dst = reinterpret_cast<double *>(&r);
+    dst[0] = d.x;
+    dst[1] = d.y;
+    return r;
+  } else {
+    return *reinterpret_cast<const Pack<T> *>(p);
+  }
+}
 template <bool FRESH>
 __device__ __forceinline__ double ld_shared_f64(const double *p) {   // value another workgroup wrote during this launch
   if constexpr (FRESH) return consume_f64(p);
@@ -127,7 +146,7 @@ __device__ __forceinline__ double pack_prod(const Pack<cplx> &v, const Pack<cplx
 }
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
-template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false>
+template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
   static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
   constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64) or 1 (complex)
@@ -247,7 +266,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         avp = dia_val + i;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
-          if (sl < L) av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld);
+          if (sl < L) av[sl] = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
       }
     } else if (i < a.n) {
       if constexpr (!ST<T>::is_complex) {
@@ -276,7 +295,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       const T *vp = vp0;                                  // one running pointer, stepped per column
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k) {
-        if (k < und && (ready || k != knew)) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp);
+        if (k < und && (ready || k != knew)) vreg[k] = ld_stream<NT, T>(vp);
         vp += cstep;
       }
     }
@@ -347,7 +366,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         u = ld_pack_user(u0, i, a.n, is_al16(u0));
       }
     } else if (act) {
-      if (!(LIVE && have_ypre)) u = *reinterpret_cast<const Pack<T> *>(yprev + i);
+      if (!(LIVE && have_ypre)) u = ld_stream<false, T>(yprev + i);
 #pragma unroll
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
 #pragma unroll
@@ -461,7 +480,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) term(av[sl], sl);
-        for (int sl = PS; sl < L; ++sl) term(*reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld), sl);
+        for (int sl = PS; sl < L; ++sl) term(ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld), sl);
       }
       }
     } else if constexpr (DIA) {
@@ -475,7 +494,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], av[sl].v[e], us[o + e]);     // rows beyond n and absent entries carry value 0
           }
         for (int sl = PS; sl < L; ++sl) {
-          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * pa.dia_ld);
+          const Pack<T> v2 = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
           const int o = base + sh.doff[sl];
 #pragma unroll
           for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], v2.v[e], us[o + e]);
@@ -625,10 +644,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   return 1;
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgsT<T> pa, int tiles_per_block) {
   __shared__ PipeSharedT<T> sh;
-  (void)pipe_pass<T, CH, PS, false, DIA, false, AUG>(pa, tiles_per_block, sh);
+  (void)pipe_pass<T, CH, PS, false, DIA, false, AUG, NT>(pa, tiles_per_block, sh);
 }
 
 // ---- wave form: single-pass step for operators made of a few diagonals with ARBITRARY offsets (structured grids) ----
@@ -668,13 +687,13 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
   hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
   __shared__ PipeSharedT<T> sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG>(pa, tiles_per_block, sh);
+  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG, NT>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
     PIPE_STAMP(pa.step, 5);
     EPI_STAMP(pa.step, 4);
@@ -1031,6 +1050,17 @@ bool pipe_resident(hipStream_t s, const ResArgs &ra) {
 
 template <class T> constexpr int pipe_tile_rows() { return Pack<T>::N * BLOCK; }
 
+// Non-temporal loads for the once-per-pass streams of this step?  nt_mode: 0 = by footprint (what the step touches: window
+// columns, operator diagonals, y~ in and out, u_j out -- for all problems of a batched launch), 1 = never, 2 = always.
+constexpr int64_t PIPE_NT_FOOTPRINT = (int64_t)480 << 20;   // ~1.9 x the Infinity Cache (crossover measured at n ~ 2.2e6, m = 30)
+template <class T>
+static bool pipe_nontemporal(const PipeArgsT<T> &pa, int nbatch) {
+  if (pa.nt_mode == 1) return false;
+  if (pa.nt_mode == 2) return true;
+  const int64_t streams = pa.und + pa.ndiag + 3;
+  return (int64_t)nbatch * pa.d.n * (int64_t)sizeof(T) * streams > PIPE_NT_FOOTPRINT;
+}
+
 template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
 static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int batch_rounds = 2) {
   const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
@@ -1041,6 +1071,12 @@ static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int b
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
+  if constexpr (DIA && !AUG && !ST<T>::is_complex) {
+    if (pipe_nontemporal(pa, nbatch)) {
+      hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, true>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
 static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
@@ -1112,6 +1148,12 @@ static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
+  if constexpr (DIA && !AUG && !ST<T>::is_complex) {
+    if (pipe_nontemporal(pa, 1)) {
+      hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+      return nb;
+    }
+  }
   hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }

@@ -504,3 +504,33 @@ def test_resident_form_matches_stepwise_and_oracle(eu):
     w_exact = sum(np.exp(0.3 * l) * (1.0 + 1e-3 * k) * np.sin(np.pi * k * i / (n + 1)) / 64.0
                   for l, k in zip(lam, (300, 800, 1300, 1800, 2300, 2800, 3300, 3800)))
     close(w, w_exact, 1e-10, "resident form, happy breakdown")
+
+
+def test_nontemporal_loads_change_nothing_but_the_cache_policy(eu):
+    """Context option "nontemporal" (-1: by the footprint of a step, 0 never, 1 always): the single-pass step reads the window
+    columns and operator diagonals with non-temporal loads when a step's footprint is far beyond the Infinity Cache.  Only the
+    cache policy of the loads differs: results are bitwise equal, for the single problem (overlapped and serial) and the batch."""
+    n, m = 60_000, 24
+    A = c2_operator(n)
+    b = np.random.default_rng(5).standard_normal(n)
+    res = {}
+    for nt in (0, 1):
+        for serial in (0, 1):
+            ctx = eu.Context()
+            ctx.set_option("nontemporal", nt)
+            ctx.set_option("pipeline_serial", serial)
+            op = eu.MIOperator(A, ctx)
+            res[(nt, serial)] = eu.expv(0.9, op, b, m=m, ishermitian=False)
+            assert "pipeline" in eu.expv.last_stats["path"]
+    assert np.array_equal(res[(0, 0)], res[(1, 0)]) and np.array_equal(res[(0, 1)], res[(1, 1)])
+    A0 = A.tocsr(); A0.sort_indices()
+    vals = np.stack([A0.data * s for s in (1.0, 1.05, 0.97)])
+    B = np.asfortranarray(np.random.default_rng(6).standard_normal((n, 3)))
+    B[:, 0] = b
+    W = []
+    for nt in (0, 1):
+        ctx = eu.Context()
+        ctx.set_option("nontemporal", nt)
+        W.append(np.asarray(eu.expv_batch(0.9, A0, vals, B, m=m, ctx=ctx)))
+    assert np.array_equal(W[0], W[1])
+    close(W[0][:, 0], res[(0, 1)], 1e-13, "batch column 0 vs single expv (nontemporal test)")

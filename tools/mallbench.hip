@@ -71,7 +71,7 @@ int main() {
   const size_t MB = 1 << 20;
   double* out;
   CK(hipMalloc(&out, 64));
-  size_t cap = 2048 * MB;
+  size_t cap = 2048 * MB;   // x holds up to 40 columns of 51.2 MB
   d2 *x, *z;
   CK(hipMalloc(&x, cap));
   CK(hipMalloc(&z, cap));
@@ -119,6 +119,19 @@ int main() {
       double tot = (double)(ncol + 7) * 8 * MB;
       printf("ncol %2d (%3d MB): plain/plain %7.1f   x plain z nt %7.1f   x nt z plain %7.1f  nt/nt %7.1f GB/s  (%6.2f us)\n", ncol,
              (ncol + 7) * 8, tot / t0 * 1e-9, tot / t1 * 1e-9, tot / t2 * 1e-9, tot / t3 * 1e-9, t0 * 1e6);
+    }
+  }
+  printf("== tile-ordered, LARGE columns (51.2 MB each = n 6.4e6): ncol columns (x) + 7 streams (z); working set >> Infinity Cache\n");
+  {
+    size_t n = (size_t)6400000 * 8 / 16;  // d2 per column
+    for (int ncol : {4, 12, 20, 31}) {
+      if ((size_t)ncol * n * 16 > cap) break;
+      double t0 = timeit([&] { hipLaunchKernelGGL((k_tiles<0, 0>), dim3(grid), dim3(256), 0, 0, x, n, ncol, z, 7, out); }, 10);
+      double t1 = timeit([&] { hipLaunchKernelGGL((k_tiles<0, 1>), dim3(grid), dim3(256), 0, 0, x, n, ncol, z, 7, out); }, 10);
+      double t3 = timeit([&] { hipLaunchKernelGGL((k_tiles<1, 1>), dim3(grid), dim3(256), 0, 0, x, n, ncol, z, 7, out); }, 10);
+      double tot = (double)(ncol + 7) * n * 16;
+      printf("ncol %2d (%5.0f MB): plain/plain %7.1f   x plain z nt %7.1f   nt/nt %7.1f GB/s\n", ncol, tot / 1048576.0, tot / t0 * 1e-9,
+             tot / t1 * 1e-9, tot / t3 * 1e-9);
     }
   }
   return 0;
