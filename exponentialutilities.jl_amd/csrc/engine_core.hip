@@ -322,6 +322,7 @@ struct ArnoldiCall {
   T *V = nullptr, *Hd = nullptr, *hcoef = nullptr;
   StepState *st = nullptr;
   double *part = nullptr, *gpart = nullptr;
+  bool h_zeroed = false;   // first_step() zeroed this call's columns of Hdev together with the step state
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
 
   ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
@@ -416,7 +417,9 @@ struct ArnoldiCall {
   void first_step() {
     for (int j = 0; j < hview_cols; ++j)
       std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
-    HIPCHECK(hipMemsetAsync(st, 0, ks.state.bytes, s));   // step state and (behind it) the pipeline's arrival counters
+    // step state and (behind it) the pipeline's arrival counters, and the columns of Hdev this call will fill: one launch
+    dev::zero_two(s, st, ks.state.bytes, ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1));
+    h_zeroed = true;
     double extra = 0.0;
     const T *src = b;
     if (isaug) {
@@ -485,8 +488,9 @@ struct ArnoldiCall {
         z.beta0sq = ks.beta * ks.beta;
         HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
       }
-      HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
-                              sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
+      if (!h_zeroed)
+        HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
+                                sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
   }
   Hd = ks.Hdev.as<T>();
   hcoef = ks.hcoef.as<T>();

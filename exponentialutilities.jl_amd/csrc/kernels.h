@@ -76,6 +76,7 @@ template <class T> void sumsq(hipStream_t s, const T *x, int64_t n, double *part
 template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t n, double scal, int divide);
 template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);
 template <class T> void fill_zero(hipStream_t s, T *dst, int64_t n);
+void zero_two(hipStream_t s, void *a, size_t abytes, void *b, size_t bbytes);   // both multiples of 8 bytes
 
 template <class T>
 void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *col, const T *val, const T *x,

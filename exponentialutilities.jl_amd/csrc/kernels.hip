@@ -207,6 +207,23 @@ __global__ __launch_bounds__(BLOCK) void k_fill_zero(T *__restrict__ dst, int64_
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
     dst[i] = ST<T>::zero();
 }
+// two small device ranges (8-byte words) zeroed by ONE launch: the per-call resets of the step state and of the Hessenberg
+// columns were two rocclr fill kernels of 7 + 4 us on the critical path between two factorisations
+__global__ __launch_bounds__(BLOCK) void k_zero_two(unsigned long long *a, size_t na, unsigned long long *b, size_t nb) {
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < na + nb; i += stride) {
+    if (i < na) a[i] = 0ull;
+    else b[i - na] = 0ull;
+  }
+}
+void zero_two(hipStream_t s, void *a, size_t abytes, void *b, size_t bbytes) {
+  const size_t words = abytes / 8 + bbytes / 8;
+  if (!words) return;
+  const int g = (int)std::min<size_t>(64, (words + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_zero_two, dim3(g), dim3(BLOCK), 0, s, reinterpret_cast<unsigned long long *>(a), abytes / 8,
+                     reinterpret_cast<unsigned long long *>(b), bbytes / 8);
+}
+
 template <class T>
 void fill_zero(hipStream_t s, T *dst, int64_t n) {
   hipLaunchKernelGGL(k_fill_zero<T>, dim3(grid_for(n, BLOCK * 4)), dim3(BLOCK), 0, s, dst, n);
