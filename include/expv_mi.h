@@ -84,8 +84,12 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *   "pipeline_serial" 0 single-pass step one launch after the other (like expv_mi_ctx_set_pipeline_overlap(ctx, 0))
  *   "spin_limit" 400000 polls before a waiting kernel gives up and the host redoes the factorisation without waits
  *   "batch_rounds" 2    batched single-pass step: resident rounds of fat workgroups
+ *   "nontemporal" -1    single-pass step: non-temporal loads of the streamed operands: -1 when a step's footprint is far
+ *                       beyond the 256 MiB Infinity Cache (> 480 MB), 0 never, 1 always; results do not depend on it
+ *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
+ *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
- * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS (read once, at creation) -- nothing reads the environment later.
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT (read once, at creation) -- nothing reads the environment later.
  * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
 int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
 int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
