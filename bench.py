@@ -270,6 +270,19 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     sec["lanczos"] = entry("expv, symmetric 5-diagonal operator (Lanczos, window 2), n=%d m=%d" % (n, m),
                            timed(lan, args.steps, 2, env.sync), m, alg_bytes_expv_window(n, As.nnz, m, 2))
     del ops, As
+    # (3b) structured-grid operator: the same five values per row on the offsets of a 2-D 5-point stencil (-k, -1, 0, 1, k with
+    # k = sqrt(n)): too wide for a halo recompute, so the single-pass step runs in its wave form (per-tile flags)
+    import scipy.sparse as sp
+    k = int(round(np.sqrt(n)))
+    Ag = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csc")
+    opg = eu.MIOperator(Ag, ctx)
+    grid = lambda: eu.expv(T_FINAL, opg, b, m=m, ishermitian=False, out=w)
+    grid()
+    e = entry("expv, 5-point grid stencil offsets (-%d,-1,0,1,%d) (wave form of the single-pass step), n=%d m=%d" % (k, k, n, m),
+              timed(grid, args.steps, 2, env.sync), m, alg_bytes_expv(n, Ag.nnz, m))
+    e["path"] = list(eu.expv.last_stats["path"])
+    sec["grid_stencil_wave_form"] = e
+    del opg, Ag
     # (4) BASELINE configs[3]: kiops, complex sparse, iop = 2 (the build's extension)
     Ac = (c2_operator(n) * (1 + 0.25j)).tocsc()
     opc = eu.MIOperator(Ac, ctx)
