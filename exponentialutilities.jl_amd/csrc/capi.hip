@@ -252,6 +252,8 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
   op.gndiag = nd;
   op.gdia_ld = ld;
   op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)P.offsets.front()), std::llabs((long long)P.offsets.back()));
+  op.gdia_near = false;
+  for (int d = 0; d < nd; ++d) op.gdia_near = op.gdia_near || std::llabs((long long)P.offsets[d]) <= dev::PIPE_WMAX;
   op.gdia_alias = true;
 }
 // General DIA form (any offsets): structured-grid stencils whose bandwidth is too wide for the banded pipeline.  Same
@@ -280,6 +282,8 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
   op.gndiag = nd;
   op.gdia_ld = ld;
   op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)offs.front()), std::llabs((long long)offs.back()));
+  op.gdia_near = false;
+  for (int d = 0; d < nd; ++d) op.gdia_near = op.gdia_near || std::llabs((long long)offs[d]) <= dev::PIPE_WMAX;
 }
 
 template <class V>

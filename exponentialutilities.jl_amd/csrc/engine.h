@@ -171,6 +171,7 @@ struct Op {
   template <class T> const T *gdia_ptr() const { return reinterpret_cast<const T *>(gdia_alias ? dia_val.p : gdia_val.p); }
   int gndiag = 0;
   int64_t gdia_ld = 0, gdia_maxoff = 0;
+  bool gdia_near = false;        // some offset of the general DIA form is within PIPE_WMAX of the diagonal (wave form: LDS + halo rows)
   DevBuf dense;              // owned copy when created from host
   const void *dense_ptr = nullptr;
   int64_t lda = 0;

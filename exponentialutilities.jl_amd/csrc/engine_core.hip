@@ -606,6 +606,7 @@ struct ArnoldiCall {
           if (op.gndiag > 0 && !no_dia_env) {
             pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
             pa.gdia_off = op.gdia_off.as<int32_t>();
+            pa.wave_near = op.gdia_near ? 1 : 0;
           } else {   // SELL slots + the per-tile column ranges
             pa.tile_lo = op.tile_lo.as<int32_t>(); pa.tile_hi = op.tile_hi.as<int32_t>();
           }

@@ -193,6 +193,7 @@ struct PipeArgsT {
   const int32_t *tile_lo, *tile_hi;   // device: first / last tile the columns of a tile's rows lie in (SELL operators)
   uint32_t *tile_flags;        // device: one word per tile, = tile_stamp when u_j of the tile is in memory
   uint32_t tile_stamp;
+  int wave_near;               // DIA wave form: some diagonal has |offset| <= PIPE_WMAX (its halo rows are read after the flag wait)
   uint32_t *flags;             // overlapped form: PIPE_FLAG_COPIES step flags, PIPE_FLAG_STRIDE words apart
   uint32_t seq;                // ... and the sequence number of this factorisation that stamps them
   uint32_t *arrive;            // ... and this step's arrival counters (residency gate)

@@ -396,6 +396,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
       // u_j of the tiles their diagonals reach into, so wait for those flags (bounded)
       if (act) st_tile<true, T>(Vw + (int64_t)jcol * a.ldv + i, u);
+      if constexpr (DIA) {   // near diagonals (|offset| <= PIPE_WMAX) take u_j of this tile from LDS, like the halo form
+#pragma unroll
+        for (int e = 0; e < N; ++e) us[PIPE_WMAX + N * tid + e] = u.v[e];
+      }
       // the sums against u_j do not need the operator: they fill the time the store takes to reach memory
 #pragma unroll
       for (int sidx = P; sidx < NSETS; ++sidx) tile_set(sidx, u);
@@ -435,6 +439,15 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
         __syncthreads();
         if (flag_s != 0) return 3;
+        if constexpr (DIA && !ST<T>::is_complex) {
+          // PIPE_WMAX rows above and below the tile (their tiles' flags were part of the wait whenever a near diagonal exists)
+          if (tid < 2 * PIPE_WMAX) {
+            const int64_t hr = (tid < PIPE_WMAX) ? r0 - PIPE_WMAX + tid : r0 + TR + (tid - PIPE_WMAX);
+            const T *ucol = a.V + (int64_t)jcol * a.ldv;
+            us[(tid < PIPE_WMAX) ? tid : TR + tid] = (pa.wave_near && hr >= 0 && hr < a.n) ? consume_T<T>(ucol + hr) : ST<T>::zero();
+          }
+          __syncthreads();
+        }
       }
     } else {
 #pragma unroll
@@ -471,9 +484,23 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
         const T *ucol = a.V + (int64_t)jcol * a.ldv;
         auto term = [&](const Pack<T> &v2, int sl) {
-          const int64_t c0 = i + pa.gdia_off[sl];
-          const double x0 = (c0 >= 0 && c0 < a.n) ? ucol[c0] : 0.0;
-          const double x1 = (c0 + 1 >= 0 && c0 + 1 < a.n) ? ucol[c0 + 1] : 0.0;
+          const int off = pa.gdia_off[sl];
+          double x0, x1;
+          if (off >= -PIPE_WMAX && off <= PIPE_WMAX) {      // near: LDS (tile + PIPE_WMAX rows either side; rows outside the matrix hold 0)
+            const int o = PIPE_WMAX + N * tid + off;
+            x0 = us[o];
+            x1 = us[o + 1];
+          } else {
+            const int64_t c0 = i + off;
+            if ((off & 1) == 0 && c0 >= 0 && c0 + 1 < a.n) {   // even offset: the pair is one aligned 16-byte load
+              const Pack<T> xx = *reinterpret_cast<const Pack<T> *>(ucol + c0);
+              x0 = xx.v[0];
+              x1 = xx.v[1];
+            } else {
+              x0 = (c0 >= 0 && c0 < a.n) ? ucol[c0] : 0.0;
+              x1 = (c0 + 1 >= 0 && c0 + 1 < a.n) ? ucol[c0 + 1] : 0.0;
+            }
+          }
           y.v[0] = fma(v2.v[0], x0, y.v[0]);
           y.v[1] = fma(v2.v[1], x1, y.v[1]);
         };
