@@ -248,6 +248,20 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
   op.ndiag = nd;
   op.dia_ld = ld;
   for (int d = 0; d < nd; ++d) op.dia_off[d] = (int)P.offsets[d];
+  // constant-coefficient stencil?  (every entry a diagonal can have is stored and they are all equal; fp64 only)
+  op.dia_is_const = false;
+  if constexpr (std::is_same<V, double>::value) {
+    bool cst = true;
+    for (int d = 0; d < nd && cst; ++d) {
+      const int64_t o = P.offsets[d], rlo = o < 0 ? -o : 0, rhi = o > 0 ? n - o : n;   // rows whose column r + o exists
+      if (rhi <= rlo) { cst = false; break; }
+      const double c0 = dv[(size_t)d * (size_t)ld + (size_t)rlo];
+      for (int64_t r = rlo; r < rhi; ++r)
+        if (dv[(size_t)d * (size_t)ld + (size_t)r] != c0) { cst = false; break; }
+      op.dia_const[d] = c0;
+    }
+    op.dia_is_const = cst;
+  }
   // the two-kernel step reads the same [ndiag][ld] array through its "general DIA" arguments (device offsets)
   op.gndiag = nd;
   op.gdia_ld = ld;

@@ -57,6 +57,7 @@ struct Options {
   int pipeline_serial = 0; // single-pass step: one launch after the other even if overlap is on (EXPV_MI_PIPE_SERIAL=1 -> 1)
   int spin_limit = 400000; // polls (~1 us each) before a waiting kernel gives up               (EXPV_MI_PIPE_SPIN_LIMIT)
   int batch_rounds = 2;    // batched single-pass step: resident rounds of fat workgroups       (EXPV_MI_BATCH_ROUNDS)
+  int stencil = 0;         // constant-coefficient banded operators: pass the diagonals as scalars, do not stream them (EXPV_MI_STENCIL=1 -> 1)
   int nontemporal = -1;    // non-temporal loads in the single-pass step: -1 by footprint, 0 never, 1 always  (EXPV_MI_NONTEMPORAL=0|1)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
@@ -160,6 +161,8 @@ struct Op {
   int64_t bandwidth = -1;   // max |col - row| (CSR operators)
   DevBuf dia_val;           // DIA form of a narrow-banded fp64 operator (pipe.hip): [ndiag][dia_ld], ascending offsets
   int ndiag = 0;
+  bool dia_is_const = false;      // every stored diagonal of the DIA form holds one value (constant-coefficient stencil)
+  double dia_const[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t dia_ld = 0;
   int dia_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // general DIA form (fp64, any offsets, <= GDIA_MAX diagonals, <= 30 % zero fill): structured-grid stencils; read by

@@ -253,6 +253,7 @@ Options Options::from_env() {
   if (flag("EXPV_MI_NO_DIA")) o.dia = 0;
   if (flag("EXPV_MI_NO_MAILBOX")) o.mailbox = 0;
   if (flag("EXPV_MI_RESIDENT")) o.resident = 1;
+  if (flag("EXPV_MI_STENCIL")) o.stencil = 1;
   if (const char *e = std::getenv("EXPV_MI_NONTEMPORAL")) o.nontemporal = std::atoi(e) ? 1 : 0;
   if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
   if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
@@ -268,6 +269,7 @@ int *Options::find(const char *name) {
   if (n == "dia") return &dia;
   if (n == "mailbox") return &mailbox;
   if (n == "resident") return &resident;
+  if (n == "stencil") return &stencil;
   if (n == "nontemporal") return &nontemporal;
   if (n == "pipeline_serial") return &pipeline_serial;
   if (n == "spin_limit") return &spin_limit;
@@ -618,6 +620,10 @@ struct ArnoldiCall {
       if (!use_wave && op.ndiag > 0 && !no_dia_env) {
         pa.dia_val = op.dia_val.as<T>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;
         for (int d = 0; d < op.ndiag; ++d) pa.dia_off[d] = op.dia_off[d];
+        if (!ST<T>::is_complex && c->opt.stencil && op.dia_is_const && !isaug) {   // constant-coefficient stencil: scalars instead of streams
+          pa.dia_const = 1;
+          for (int d = 0; d < op.ndiag; ++d) pa.dia_c[d] = op.dia_const[d];
+        }
       }
       pa.w = (int)op.bandwidth;
       pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);

@@ -205,6 +205,8 @@ struct PipeArgsT {
   int last_step;
   int final;                   // 1: closing pass of a factorisation: u_{m+1} and its norm only (no operator apply, no sums)
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
+  int dia_const;               // DIA form, fp64: the diagonals are constants (dia_c), nothing is read from dia_val
+  double dia_c[PIPE_DIA_MAX];
   int nt_mode;                 // non-temporal loads for the streamed operands: 0 by footprint, 1 never, 2 always (pipe.hip)
   // continuation (arnoldi!(...; init = j), arnoldi.jl:350,368): the first pass of the call takes the stored, normalised
   // v_j (yprev = its column, inv = 1, zero coefficients): its norm is 1 by construction, H[j, j-1] is already known

@@ -100,6 +100,7 @@ struct PipeSharedT {
   T hs[32];                        // update coefficients (h_i s_i): LDS broadcast, no SGPRs
   T ut[PIPE_AUG_MAX];              // augmented operator: rows n_op.. of u_j
   int doff[PIPE_DIA_MAX];          // DIA offsets (a dynamically indexed kernel argument would be copied to scratch)
+  double dcoef[PIPE_DIA_MAX];      // ... and the diagonal constants of a constant-coefficient operator
   double red_s[BLOCK / 64][64];
   double vals_s[64];
   double std_s[MAX_RED_VALUES];
@@ -205,6 +206,13 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int q = 0; q < PIPE_DIA_MAX; ++q)
         if (tid == q) v = pa.dia_off[q];
       sh.doff[tid] = v;      // (read after the barrier that follows the LDS copy of u_j)
+      if constexpr (!ST<T>::is_complex) {
+        double cst = 0.0;
+#pragma unroll
+        for (int q = 0; q < PIPE_DIA_MAX; ++q)
+          if (tid == q) cst = pa.dia_c[q];
+        sh.dcoef[tid] = cst;
+      }
     }
   }
   const bool first = (pa.step == 1) && !pa.cont;
@@ -266,7 +274,12 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         avp = dia_val + i;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
-          if (sl < L) av[sl] = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
+          if (sl < L) {
+            if constexpr (!ST<T>::is_complex && !AUG) {
+              if (pa.dia_const) { av[sl].v[0] = av[sl].v[1] = pa.dia_c[sl]; continue; }   // constant-coefficient stencil: nothing to load
+            }
+            av[sl] = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
+          }
       }
     } else if (i < a.n) {
       if constexpr (!ST<T>::is_complex) {
@@ -521,10 +534,22 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], av[sl].v[e], us[o + e]);     // rows beyond n and absent entries carry value 0
           }
         for (int sl = PS; sl < L; ++sl) {
-          const Pack<T> v2 = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
+          Pack<T> v2;
+          bool have = false;
+          if constexpr (!ST<T>::is_complex && !AUG) {
+            if (pa.dia_const) { v2.v[0] = v2.v[1] = sh.dcoef[sl]; have = true; }
+          }
+          if (!have) v2 = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
           const int o = base + sh.doff[sl];
 #pragma unroll
           for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], v2.v[e], us[o + e]);
+        }
+        if constexpr (!ST<T>::is_complex && !AUG) {
+          if (pa.dia_const) {   // (the stored diagonals are zero on the padding rows; the constants are not)
+#pragma unroll
+            for (int e = 0; e < N; ++e)
+              if (i + e >= a.n) y.v[e] = ST<T>::zero();
+          }
         }
       }
     } else if (i < a.n) {

@@ -534,3 +534,42 @@ def test_nontemporal_loads_change_nothing_but_the_cache_policy(eu):
         W.append(np.asarray(eu.expv_batch(0.9, A0, vals, B, m=m, ctx=ctx)))
     assert np.array_equal(W[0], W[1])
     close(W[0][:, 0], res[(0, 1)], 1e-13, "batch column 0 vs single expv (nontemporal test)")
+
+
+def test_constant_coefficient_stencil_option_is_bitwise_neutral(eu):
+    """Context option "stencil" = 1: a banded operator whose stored diagonals are constant (constant-coefficient finite
+    differences) is applied from scalars instead of streamed diagonals.  Same products in the same order: results are
+    bitwise equal to the general DIA path, overlapped and serial, ragged size included; an operator that is NOT constant
+    along its diagonals takes the general path unchanged."""
+    rng = np.random.default_rng(99)
+    for n, m in ((100_003, 30), (7_001, 12)):
+        A = c2_operator(n)
+        b = rng.standard_normal(n)
+        res = {}
+        for stencil in (0, 1):
+            for serial in (0, 1):
+                ctx = eu.Context()
+                ctx.set_option("stencil", stencil)
+                ctx.set_option("pipeline_serial", serial)
+                op = eu.MIOperator(A, ctx)
+                Ks = eu.KrylovSubspace(np.float64, np.float64, n, m, 0, ctx)
+                eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+                res[(stencil, serial)] = (Ks.H.copy(), Ks.getV().copy(), np.asarray(eu.expv(0.6, op, b, m=m, ishermitian=False)).copy())
+        for serial in (0, 1):
+            for x0, x1 in zip(res[(0, serial)], res[(1, serial)]):
+                assert np.array_equal(x0, x1), (n, m, serial)
+        wo, _ = co.expv_csr(0.6, A, b, m=m)
+        close(res[(1, 0)][2], wo, 1e-12, "stencil option vs C oracle (n=%d, m=%d)" % (n, m))
+    # not constant along the diagonals: same pattern, one entry changed
+    n = 20_000
+    A = c2_operator(n).tolil()
+    A[5000, 5001] = 0.75
+    A = A.tocsc()
+    b = rng.standard_normal(n)
+    w = []
+    for stencil in (0, 1):
+        ctx = eu.Context()
+        ctx.set_option("stencil", stencil)
+        w.append(np.asarray(eu.expv(0.6, eu.MIOperator(A, ctx), b, m=20, ishermitian=False)))
+    assert np.array_equal(w[0], w[1])
+    close(w[1], co.expv_csr(0.6, A, b, m=20)[0], 1e-12, "stencil option on a non-constant operator vs C oracle")
