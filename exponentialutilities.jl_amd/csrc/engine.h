@@ -224,6 +224,11 @@ struct Ks {
   void *mbox = nullptr, *mbox_dev = nullptr;           // result mailbox (host-mapped) of the whole-call expv
   size_t mbox_bytes = 0;
   bool mbox_armed = false;
+  // Deferred closing pass: a driver that only needs H[1:m, 1:m] next (kiops: the small exponential) asks arnoldi_run to
+  // return at the EARLY mailbox flag; H[m+1, m], the scale of column m and the breakdown test of step m are filled in by
+  // ks_finish_tail() once the closing pass has raised the final flag (it runs under the host's exponential meanwhile).
+  bool defer_tail_req = false;
+  struct TailPending { bool pending = false, lanczos = false; int m = 0; uint32_t seq = 0; void *stream = nullptr; } tail;
   bool pipe_closed = false;   // the overlapped pipeline produced v_{m+1} / H[m+1, m] itself (closing pass)
   std::vector<double> colscale_host; // ... and their host copy
   bool scale_pending = false;        // stored columns are v_c / s_c until materialised
@@ -232,6 +237,7 @@ struct Ks {
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
   int64_t rows() const { return n + augmented; }
 };
+void ks_finish_tail(Ks &ks);   // engine_core.hip
 }  // namespace expv_mi
 struct expv_mi_ks_s : expv_mi::Ks {};
 namespace expv_mi {

@@ -324,7 +324,8 @@ struct ArnoldiCall {
   T *V = nullptr, *Hd = nullptr, *hcoef = nullptr;
   StepState *st = nullptr;
   double *part = nullptr, *gpart = nullptr;
-  bool h_zeroed = false;   // first_step() zeroed this call's columns of Hdev together with the step state
+  bool h_zeroed = false;
+  bool tail_deferred = false;   // read_back() returned at the early mailbox flag (Ks::defer_tail_req)   // first_step() zeroed this call's columns of Hdev together with the step state
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
 
   ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
@@ -666,6 +667,7 @@ struct ArnoldiCall {
           pa.mb_state = mv.state;
           pa.mb_done = mv.done;
           pa.last_step = m + (closing ? 1 : 0);
+          pa.early_step = (ks.defer_tail_req && closing) ? m : 0;
         }
         if (j > jstart) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
         if constexpr (!ST<T>::is_complex) {
@@ -880,7 +882,10 @@ struct ArnoldiCall {
     const MailboxView mvh = mailbox_view(ks, ks.mbox);
     const double *mh = mvh.H;
     const size_t hwords = mailbox_hwords(ks), swords = (size_t)ks.maxiter + 2;
-    const volatile unsigned long long *done = mvh.done;
+    // (deferred closing pass: wait for the early flag, raised by the last workgroup of step m)
+    const bool defer = ks.defer_tail_req && use_pipe && ks.pipe_live_used && ks.pipe_closed && !ks.pipe_resident_used && !mbox_generic;
+    const volatile unsigned long long *done = defer ? mvh.done + 1 : mvh.done;
+    tail_deferred = false;
     for (long it = 1;; ++it) {
       if (*done == (unsigned long long)ks.pipe_seq) { from_mbox = true; break; }
       __builtin_ia32_pause();
@@ -900,6 +905,7 @@ struct ArnoldiCall {
       h.beta0sq = mh[hwords + swords];
       h.breakdown = (int32_t)mh[hwords + swords + 1];
       h.m_done = (int32_t)mh[hwords + swords + 2];
+      tail_deferred = defer && h.breakdown == 0;     // (a stop ended the factorisation: nothing is pending)
     }
   }
   if (!from_mbox) {
@@ -933,7 +939,7 @@ struct ArnoldiCall {
     if (ks.beta == 0.0) { ks.gram_rows = 0; return 0; }   // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
   }
   if (use_pipe) {   // the stored columns are v_c / s_c: keep the scales for the combine / a later materialisation
-    const int ncol = ((h.breakdown == 1) ? h.m_done + 1 : (ks.skip_tail ? m : m + 1));
+    const int ncol = ((h.breakdown == 1) ? h.m_done + 1 : ((ks.skip_tail || tail_deferred) ? m : m + 1));
     ks.colscale_host.assign(ks.maxiter + 2, 1.0);
     if (from_mbox) {
       const double *ms = mailbox_view(ks, ks.mbox).scales;
@@ -954,7 +960,7 @@ struct ArnoldiCall {
   if (lanczos) {
     for (int j = 1; j <= jlast; ++j) {
       setH(ks, j - 1, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + (j - 1)]));            // u[j] = alpha
-      setH_realpart(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]).real());       // v[j] = beta
+      if (!(tail_deferred && j == m)) setH_realpart(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]).real());       // v[j] = beta
     }
     // copyto!(@diagview(H, 1), v[1:end-1]) on the pre-breakdown view  (arnoldi.jl:488)
     const int nsub = std::min(hview_rows - 1, hview_cols);
@@ -965,9 +971,11 @@ struct ArnoldiCall {
     for (int j = jstart; j <= jlast; ++j) {
       const int i0 = std::max(1, j - iopw + 1);
       for (int i = i0; i <= j; ++i) setH(ks, i - 1, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + (i - 1)]));
-      setH(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]));
+      if (!(tail_deferred && j == m)) setH(ks, j, j - 1, toc(Hh[(size_t)(j - 1) * ks.ldhd + j]));
     }
   }
+  ks.tail.pending = tail_deferred;
+  if (tail_deferred) { ks.tail.lanczos = lanczos; ks.tail.m = m; ks.tail.seq = ks.pipe_seq; ks.tail.stream = (void *)s; }
   if (h.breakdown == 1) {
     ks.m = h.m_done;
     ks.wasbreakdown = true;
@@ -987,8 +995,44 @@ static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, 
   return call.run();
 }
 
+// The closing pass of a deferred factorisation: H[m+1, m], the scale of column m, the breakdown test of step m.
+void ks_finish_tail(Ks &ks) {
+  if (!ks.tail.pending) return;
+  ks.tail.pending = false;
+  const int m = ks.tail.m;
+  const MailboxView mv = mailbox_view(ks, ks.mbox);
+  const volatile unsigned long long *done = mv.done;
+  hipStream_t s = (hipStream_t)ks.tail.stream;
+  for (long it = 1;; ++it) {
+    if (*done == (unsigned long long)ks.tail.seq) break;
+    __builtin_ia32_pause();
+    if ((it & 0xfff) == 0) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess) {
+        if (*done == (unsigned long long)ks.tail.seq) break;
+        fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: the closing pass ended without its result (bounded wait expired)");
+      }
+      if (q != hipErrorNotReady) HIPCHECK(q);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const size_t hwords = mailbox_hwords(ks), swords = (size_t)ks.maxiter + 2;
+  const double *mh = mv.H;
+  const size_t e = (size_t)(m - 1) * ks.ldhd + m;     // H[m+1, m]
+  if (ks.dtypeT == EXPV_MI_C64) {
+    const cd v(mh[2 * e], mh[2 * e + 1]);
+    if (ks.tail.lanczos) setH_realpart(ks, m, m - 1, v.real()); else setH(ks, m, m - 1, v);
+  } else {
+    if (ks.tail.lanczos) setH_realpart(ks, m, m - 1, mh[e]); else setH(ks, m, m - 1, cd(mh[e], 0.0));
+  }
+  if ((int)ks.colscale_host.size() > m) ks.colscale_host[m] = mv.scales[m];
+  ks.scale_cols = m + 1;
+  if ((int32_t)mh[hwords + swords + 1] == 1) ks.wasbreakdown = true;      // beta_m < tol: Ks.m stays m (arnoldi.jl:370-374)
+}
+
 int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug,
                 bool force_lanczos) {
+  ks_finish_tail(ks);   // (a deferred closing pass nobody asked for yet)
   int herm = o.ishermitian;
   if (herm < 0) herm = op.ishermitian;
   const bool lanczos = force_lanczos || herm != 0;

@@ -413,17 +413,27 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
     ao.m = m;
     ao.init = j;
     aug.t = tau_now;
+    // the exponential below needs H[1:j, 1:j] only (H[j+1, j] is zeroed for it): let arnoldi return before the closing pass
+    // (v_{j+1}, H[j+1, j]) has finished -- it runs on the device while the host exponentiates
+    ks.defer_tail_req = true;
+    struct DeferOff { Ks &k; ~DeferOff() { k.defer_tail_req = false; } } defer_off{ks};
     arnoldi_run(ks, op, nullptr, ao, &aug, false);
+    ks.defer_tail_req = false;
     j = ks.m;
     bool happy = j < oldj;
     const double beta = ks.beta;
     setH(ks, 0, j, cd(1.0, 0.0));                  // H[1, j+1] = 1
-    const cd nrm = getH(ks, j, j - 1);             // save h_{j+1,j}
+    cd nrm = getH(ks, j, j - 1);                   // save h_{j+1,j}  (deferred: arrives below)
     setH(ks, j, j - 1, cd(0.0, 0.0));
     Mat<S> F = hblock<S>(ks, j + 1, sgn * tau);    // exp(sgn*tau*H[1:j+1, 1:j+1])
     dense::expm_higham2005base(F);
     ++exps;
-    setH(ks, j, j - 1, nrm);
+    if (ks.tail.pending) {
+      ks_finish_tail(ks);
+      nrm = getH(ks, j, j - 1);
+    } else {
+      setH(ks, j, j - 1, nrm);
+    }
     double tau_new;
     int m_new;
     if (happy) {

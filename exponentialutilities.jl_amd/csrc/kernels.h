@@ -203,6 +203,8 @@ struct PipeArgsT {
   double *mb_state;            // {beta_0^2, breakdown, m_done}
   unsigned long long *mb_done; // = seq when everything above is complete
   int last_step;
+  int early_step;              // > 0: the step whose last workgroup ALSO mirrors H / scales / state and raises mb_done[1] (the host
+                               //      continues with H[1:m,1:m] while the closing pass still runs); the final flag stays mb_done[0]
   int final;                   // 1: closing pass of a factorisation: u_{m+1} and its norm only (no operator apply, no sums)
   int spin_limit;              // polls before a waiting kernel gives up (status 99 -> the host redoes the call serially)
   int dia_const;               // DIA form, fp64: the diagonals are constants (dia_c), nothing is read from dia_val

@@ -757,7 +757,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
                          __HIP_MEMORY_SCOPE_AGENT);
     PIPE_STAMP(pa.step, 3);
     EPI_STAMP(pa.step, 5);
-    if (pa.mb_done && (r == 2 || pa.step == pa.last_step)) {
+    const bool mb_final = (r == 2 || pa.step == pa.last_step);
+    const bool mb_early = pa.early_step > 0 && pa.step == pa.early_step;
+    if (pa.mb_done && (mb_final || mb_early)) {
       // The factorisation ends here: copy what the host reads -- the Hessenberg columns, the column scales, the
       // final state -- from device memory (every step stored them through before raising its flag) into the
       // host-mapped mailbox, then raise its flag.  One short copy per factorisation, formally ordered.
@@ -776,7 +778,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid == 0) {
+        // early flag: everything but H[m+1, m], the scale of column m and the breakdown test of step m is final (a stop
+        // ends the factorisation: both flags)
+        if (pa.early_step > 0) __hip_atomic_store(pa.mb_done + 1, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mb_final) __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
