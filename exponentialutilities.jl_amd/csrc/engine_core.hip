@@ -325,6 +325,7 @@ struct ArnoldiCall {
   StepState *st = nullptr;
   double *part = nullptr, *gpart = nullptr;
   bool h_zeroed = false;
+  bool cont_reset_done = false; // reset_device_state() did the whole reset of a continued single-pass factorisation in one launch
   bool tail_deferred = false;   // read_back() returned at the early mailbox flag (Ks::defer_tail_req)   // first_step() zeroed this call's columns of Hdev together with the step state
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
 
@@ -482,7 +483,15 @@ struct ArnoldiCall {
   void reset_device_state() {
     // reset the device step state; zero the columns of Hdev this call will fill
     {
-      if (!use_fused || !fresh) {   // fresh fused path: the first pass leaves {hnorm = beta_0, m_done = 0} on the device itself
+      if (use_pipe && !fresh && jstart <= dev::CONT_SCALES_MAX && ks.colscale.bytes >= sizeof(double) * (size_t)(ks.maxiter + 2)) {
+        // continued single-pass factorisation: everything that has to be reset, in one launch.  The stored columns keep
+        // their scales (all 1 when the basis has been materialised since); tickets and arrival counters start at 0.
+        if (!ks.scale_pending || (int)ks.colscale_host.size() < ks.maxiter + 2) ks.colscale_host.assign(ks.maxiter + 2, 1.0);
+        dev::cont_reset(s, st, ks.state.bytes, ks.beta, 1.0, ks.beta * ks.beta, jstart - 1, ks.colscale.as<double>(),
+                        ks.colscale_host.data(), jstart, ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd,
+                        sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1));
+        cont_reset_done = true;
+      } else if (!use_fused || !fresh) {   // fresh fused path: the first pass leaves {hnorm = beta_0, m_done = 0} on the device itself
         StepState &z = ks.state_host;   // (member: the copy below is asynchronous)
         std::memset(&z, 0, sizeof(z));
         z.m_done = jstart - 1;
@@ -491,7 +500,7 @@ struct ArnoldiCall {
         z.beta0sq = ks.beta * ks.beta;
         HIPCHECK(hipMemcpyAsync(st, &z, sizeof(z), hipMemcpyHostToDevice, s));
       }
-      if (!h_zeroed)
+      if (!h_zeroed && !cont_reset_done)
         HIPCHECK(hipMemsetAsync(ks.Hdev.as<T>() + (size_t)(jstart - 1) * ks.ldhd, 0,
                                 sizeof(T) * (size_t)ks.ldhd * (m - jstart + 1), s));
   }
@@ -531,7 +540,7 @@ struct ArnoldiCall {
       ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;
       if (ks.pipe_seq == 0) ks.pipe_seq = 1;
     };
-    if (!fresh) {
+    if (!fresh && !cont_reset_done) {
       // continuation: the stored columns keep their scales (all 1 when the basis has been materialised since); the
       // arrival counters of the steps of this call start at 0
       if (!ks.scale_pending || (int)ks.colscale_host.size() < ks.maxiter + 2) ks.colscale_host.assign(ks.maxiter + 2, 1.0);

@@ -77,6 +77,10 @@ template <class T> void scale_copy(hipStream_t s, T *dst, const T *src, int64_t 
 template <class T> void scale_by_state(hipStream_t s, T *y, int64_t n, const StepState *st, int step);
 template <class T> void fill_zero(hipStream_t s, T *dst, int64_t n);
 void zero_two(hipStream_t s, void *a, size_t abytes, void *b, size_t bbytes);   // both multiples of 8 bytes
+constexpr int CONT_SCALES_MAX = 160;
+struct ContScales { double v[CONT_SCALES_MAX]; };
+void cont_reset(hipStream_t s, StepState *st, size_t state_bytes, double hnorm, double inv, double beta0sq, int m_done,
+                double *colscale, const double *scales_host, int ncs, void *H, size_t hbytes);
 
 template <class T>
 void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *col, const T *val, const T *x,

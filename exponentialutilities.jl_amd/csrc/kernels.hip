@@ -216,6 +216,31 @@ __global__ __launch_bounds__(BLOCK) void k_zero_two(unsigned long long *a, size_
     else b[i - na] = 0ull;
   }
 }
+// the resets in front of a CONTINUED single-pass factorisation in one launch: step state {hnorm, inv, beta0^2, m_done}, zeroed
+// tickets and arrival counters, the scales of the stored columns (by value), zeroed Hessenberg columns of the new steps
+// (were: two staged host-to-device copies and two fills, ~20 us on the path of every kiops continuation)
+__global__ __launch_bounds__(BLOCK) void k_cont_reset(StepState *st, size_t state_words, double hnorm, double inv, double beta0sq,
+                                                      int m_done, double *colscale, ContScales cv, int ncs, unsigned long long *H,
+                                                      size_t hwords) {
+  unsigned long long *sw = reinterpret_cast<unsigned long long *>(st);
+  const size_t head = sizeof(StepState) / 8;
+  if (blockIdx.x == 0) {   // the struct itself: zero, then its fields (one workgroup: ordered by the barrier)
+    for (size_t i = threadIdx.x; i < head; i += BLOCK) sw[i] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) { st->hnorm = hnorm; st->inv = inv; st->beta0sq = beta0sq; st->m_done = m_done; }
+    for (int k = threadIdx.x; k < ncs; k += BLOCK) colscale[k] = cv.v[k];
+  }
+  const size_t stride = (size_t)gridDim.x * BLOCK, i0 = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  for (size_t i = head + i0; i < state_words; i += stride) sw[i] = 0ull;
+  for (size_t i = i0; i < hwords; i += stride) H[i] = 0ull;
+}
+void cont_reset(hipStream_t s, StepState *st, size_t state_bytes, double hnorm, double inv, double beta0sq, int m_done,
+                double *colscale, const double *scales_host, int ncs, void *H, size_t hbytes) {
+  ContScales cv;
+  for (int k = 0; k < ncs; ++k) cv.v[k] = scales_host[k];
+  hipLaunchKernelGGL(k_cont_reset, dim3(32), dim3(BLOCK), 0, s, st, state_bytes / 8, hnorm, inv, beta0sq, m_done, colscale, cv, ncs,
+                     reinterpret_cast<unsigned long long *>(H), hbytes / 8);
+}
 void zero_two(hipStream_t s, void *a, size_t abytes, void *b, size_t bbytes) {
   const size_t words = abytes / 8 + bbytes / 8;
   if (!words) return;
