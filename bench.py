@@ -162,6 +162,84 @@ def c5_problem(n, p, A0_data):
     return A0_data * scale, np.random.default_rng(1000 + p).standard_normal(n)
 
 
+def c3_rows(torch, device, n, lo, hi, chunk=4096):
+    """Rows [lo, hi) of the config-3 operator A = -2 I + randn(n, n) / sqrt(n), generated on the device block by block with a
+    per-block seed, so any partition of the rows over ranks produces the same matrix."""
+    rows = torch.empty((hi - lo, n), dtype=torch.float64, device=device)
+    r = lo
+    while r < hi:
+        b0 = (r // chunk) * chunk                      # blocks are aligned to `chunk` rows of the GLOBAL matrix
+        b1 = min(b0 + chunk, n)
+        g = torch.Generator(device=device)
+        g.manual_seed(40_000 + b0 // chunk)
+        blk = torch.randn((b1 - b0, n), dtype=torch.float64, device=device, generator=g)
+        blk.mul_(1.0 / np.sqrt(n))
+        idx = torch.arange(b0, b1, device=device)
+        blk[idx - b0, idx] -= 2.0
+        e = min(b1, hi)
+        rows[r - lo: e - lo].copy_(blk[r - b0: e - b0])
+        r = e
+        del blk
+    return rows
+
+
+def run_c3(args, eu, env):
+    """BASELINE configs[2]: phiv_timestep, adaptive, K = 4, dense fp64.  n = 2e5 (320 GB) does not fit one MI355X: with
+    --gpus >= 2 the rows of A are sharded over the ranks (dist.RowShardedDense: local GEMV + one all-gather of the n-vector per
+    operator application, the Krylov iteration replicated); at --gpus 1 the largest n that fits is used unless --n3 says
+    otherwise.  Unit: operator applications (all mul! calls of the reference: p + m per sub-step + m per retry)."""
+    torch, D = env.torch, load_dist_module()
+    world, rank = env.world, env.rank
+    n = args.n3 if args.n3 > 0 else (200_000 if world > 1 else 163_840)
+    lo, hi = D.shard_range(n, world, rank)
+    rows = c3_rows(torch, env.device, n, lo, hi)
+    sh = D.RowShardedDense(rows, n)
+    op = sh.operator(eu, env.ctx)
+    g = torch.Generator(device=env.device)
+    g.manual_seed(5)
+    B = torch.randn((5, n), dtype=torch.float64, device=env.device, generator=g).t()      # K = 4: five coefficient columns
+    st = {}
+
+    def step():
+        return eu.phiv_timestep(1.0, op, B, adaptive=True, tol=1e-7, m=10, stats=st)
+    for _ in range(max(1, args.warmup)):
+        u = step()
+    env.barrier()
+    a0 = sh.applications
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        u = step()
+    env.barrier()
+    elapsed_local = time.perf_counter() - t0
+    apps = sh.applications - a0
+    units, elapsed = D.aggregate_throughput(apps, elapsed_local, device=env.device)
+    units /= world                                     # every rank counts the same (replicated) applications
+    # every rank holds the full result of the replicated iteration: they must agree to the last bit
+    chk = torch.stack([u.abs().sum(), (u * torch.arange(n, device=env.device, dtype=torch.float64)).sum()])
+    lo_chk, hi_chk = chk.clone(), chk.clone()
+    if world > 1:
+        env.dist.all_reduce(lo_chk, op=env.dist.ReduceOp.MIN)
+        env.dist.all_reduce(hi_chk, op=env.dist.ReduceOp.MAX)
+    same = bool(torch.equal(lo_chk, hi_chk))
+    bytes_per_app = 8.0 * n * n
+    gbps_per_gpu = bytes_per_app * units / elapsed / 1e9 / world
+    out = {"metric": "phiv_timestep operator applications/s, adaptive, K=4, dense fp64 n=%d" % n, "value": units / elapsed,
+           "unit": "matvecs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: phiv_timestep(1.0, A, B; adaptive, tol=1e-7, m0=10), dense A n=%d (%.1f GB), "
+                                  "rows sharded over %d GPU(s)" % (n, 8e-9 * n * n, world), "n": n, "K": 4},
+           "stats": {k: st.get(k) for k in ("num_timesteps", "matvecs", "m")}, "applications_per_call": apps / args.steps,
+           "ranks_seen": env.ranks_seen(), "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "verified": {"replicas_bitwise_equal": same},
+           "roofline": {"bound": "hbm", "achieved": gbps_per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps_per_gpu / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "local GEMV (rocBLAS through torch.mv) + all_gather of n*8 B",
+                        "alg_bytes_per_launch": bytes_per_app / world}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return out
+
+
 def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
     """BASELINE configs[4]: nprob independent expv problems (n = 1e5, C2 diagonals scaled per problem, m = 30), problems
     sharded over the ranks, one final gather of the results.  After the timed region two random columns
@@ -390,8 +468,10 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra non-overlapped profiling pass")
     ap.add_argument("--sync-outputs", action="store_true", help="every call returns only when its device result is complete")
     ap.add_argument("--split-api", action="store_true", help="time arnoldi!(Ks,A,b) + expv!(w,t,Ks) instead of expv(t,A,b)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
-                    help="c2 (default, the headline metric) or c5: batch of --nprob independent n=1e5 problems")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5", "c3"],
+                    help="c2 (default, the headline metric), c5: batch of --nprob independent n=1e5 problems, or c3: adaptive "
+                         "phiv_timestep on a dense operator whose rows are sharded over the ranks")
+    ap.add_argument("--n3", type=int, default=0, help="c3: operator size (default 2e5 on >= 2 GPUs, 163840 on one)")
     ap.add_argument("--nprob", type=int, default=1024, help="c5: total number of problems over all GPUs")
     args = ap.parse_args()
     import torch
@@ -415,6 +495,11 @@ def main():
     env = Env(torch, dist, world, rank, torch.device("cuda", local_rank), ctx)
     if args.config == "c5":
         run_c5(args, eu, env)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.config == "c3":
+        run_c3(args, eu, env)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -4,6 +4,10 @@ The Krylov path shards only across independent (A, b) problems: one process per 
 runs its own contiguous block of problems through the HIP path, and the ONLY collective is the final
 gather of the result block (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
 torch.distributed is plumbing here -- nothing in this file computes.
+
+One exception, for BASELINE config 3 at its literal size (SURVEY.md §8d "C3 fit"): a dense operator that does not fit one
+GPU is ROW-SHARDED (RowShardedDense): the only multi-GPU exchange inside a problem is one all-gather of the n-vector per
+operator application; everything else of the Krylov iteration runs replicated and identically on every rank.
 """
 import time
 
@@ -66,3 +70,62 @@ def run_sharded(nprob, solve_one, make_block, group=None, rank=None, world_size=
     elapsed = time.perf_counter() - t0
     block = make_block(cols)
     return gather_columns(block, nprob, group), hi - lo, elapsed
+
+
+class RowShardedDense:
+    """y = A x for a dense n x n operator whose ROWS are spread over the ranks of `group` (config 3: n = 2e5 fp64 is 320 GB,
+    more than the 288 GB of one MI355X).  Rank r holds rows [lo_r, hi_r) of A (shard_range(n, world, r)) as a row-major
+    torch tensor `rows` of shape (hi_r - lo_r, n); an application is the local GEMV (a plain library GEMV: rocBLAS through
+    torch.mv) followed by ONE all-gather of the result pieces (n * 8 B = 1.6 MB at n = 2e5; RCCL over xGMI with backend
+    "nccl").  Every rank then holds the same y, so a Krylov iteration driven by this operator runs replicated: the same
+    kernels on the same data on every rank (deterministic), no other communication, and every rank ends with the full
+    result.  `operator(eu, ctx)` wraps it as the library's matrix-free operator (expv_mi_op_create_callback)."""
+
+    def __init__(self, rows, n, group=None, stage_through_host=False):
+        import torch
+        import torch.distributed as dist
+        self.rows = rows
+        self.n = int(n)
+        self.group = group
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.lo, self.hi = shard_range(self.n, self.world, self.rank)
+        if tuple(rows.shape) != (self.hi - self.lo, self.n):
+            raise ValueError("rank %d holds rows [%d, %d): expected a (%d, %d) block, got %s"
+                             % (self.rank, self.lo, self.hi, self.hi - self.lo, self.n, tuple(rows.shape)))
+        self.width = max(shard_sizes(self.n, self.world))          # equal-size pieces for ONE fixed-size collective
+        self.stage = bool(stage_through_host)                      # gloo has no device all-gather: CPU tests / fallback
+        self._send = torch.zeros(self.width, dtype=rows.dtype, device=rows.device)
+        self._recv = torch.empty(self.world * self.width, dtype=rows.dtype, device=rows.device)
+        self.applications = 0
+
+    def matvec(self, x):
+        import torch
+        self.applications += 1
+        yl = torch.mv(self.rows, x)
+        if self.world == 1:
+            return yl
+        self._send[: yl.shape[0]].copy_(yl)
+        if self.stage:
+            send, recv = self._send.cpu(), torch.empty(self.world * self.width, dtype=self._send.dtype)
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            self._recv.copy_(recv)
+        else:
+            self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+        if self.n == self.world * self.width:
+            return self._recv
+        sizes = shard_sizes(self.n, self.world)
+        return torch.cat([self._recv[r * self.width: r * self.width + sizes[r]] for r in range(self.world)])
+
+    def operator(self, eu, ctx=None, ishermitian=False):
+        """The library operator (device vectors in, device vectors out, on the library's stream)."""
+        return eu.MIOperator(None, ctx, dtype=_np_dtype(self.rows.dtype), ishermitian=ishermitian, matvec=self.matvec,
+                             shape=(self.n, self.n))
+
+
+def _np_dtype(torch_dtype):
+    import numpy as np
+    import torch
+    return {torch.float64: np.float64, torch.complex128: np.complex128, torch.float32: np.float32,
+            torch.complex64: np.complex64}[torch_dtype]

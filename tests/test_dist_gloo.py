@@ -156,3 +156,69 @@ def test_bench_byte_contracts_match_survey():
     assert abs(bench.alg_bytes_kiops(n, nnz, 1, 0, 0) - 184.0e6) < 0.1e6
     sym = bench.c2_operator(50, sym=True)
     assert (sym != sym.T).nnz == 0 and (bench.c2_operator(50) != bench.c2_operator(50).T).nnz > 0
+
+
+# ---- BASELINE config 3 at its literal size: dense operator row-sharded over the ranks (dist.RowShardedDense) -----------------
+def _c3_inputs(n, K=4):
+    A = -2.0 * np.eye(n) + np.random.default_rng(4).standard_normal((n, n)) / np.sqrt(n)
+    B = np.asfortranarray(np.random.default_rng(5).standard_normal((n, K + 1)))
+    return A, B
+
+
+class _ShardedAsMatrixFree:
+    """The operator contract of docs/src/interfaces.md:7-36 (eltype / size / mul! / ishermitian) on top of the sharded matvec."""
+
+    def __init__(self, sh):
+        self.sh, self.shape, self.dtype, self.ishermitian = sh, (sh.n, sh.n), np.dtype(np.float64), False
+
+    def __matmul__(self, x):
+        return self.sh.matvec(torch.as_tensor(np.ascontiguousarray(x))).numpy().copy()
+
+
+def _worker_rows(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(ROOT, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    from oracle import krylov_oracle as ko
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, B = _c3_inputs(n)
+        lo, hi = D.shard_range(n, world, rank)
+        sh = D.RowShardedDense(torch.as_tensor(np.ascontiguousarray(A[lo:hi])), n)      # this rank never touches the other rows
+        x = np.random.default_rng(11).standard_normal(n)
+        y = sh.matvec(torch.as_tensor(x)).numpy().copy()
+        st = {}
+        U = ko.phiv_timestep(np.array([0.5, 1.0]), _ShardedAsMatrixFree(sh), B, adaptive=True, tol=1e-7, stats=st)
+        np.save(os.path.join(out_dir, f"y_{rank}.npy"), y)
+        np.save(os.path.join(out_dir, f"U_{rank}.npy"), U)
+        np.save(os.path.join(out_dir, f"st_{rank}.npy"), np.array([st["num_timesteps"], st["matvecs"], st["m"], sh.applications]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64])
+def test_row_sharded_dense_operator_two_ranks(tmp_path, n):
+    """Config 3 row-sharded over 2 ranks (ragged and even split): the sharded matvec equals A x on every rank, and the adaptive
+    phiv_timestep driven by it (the oracle's controller here; the device engine on the GPU) takes the same steps and gives the
+    same snapshots on both ranks as the unsharded operator."""
+    world = 2
+    mp.spawn(_worker_rows, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    from oracle import krylov_oracle as ko
+    A, B = _c3_inputs(n)
+    x = np.random.default_rng(11).standard_normal(n)
+    y0, y1 = np.load(tmp_path / "y_0.npy"), np.load(tmp_path / "y_1.npy")
+    np.testing.assert_array_equal(y0, y1)
+    np.testing.assert_allclose(y0, A @ x, rtol=0, atol=1e-13 * np.abs(A @ x).max())
+    so = {}
+    Uo = ko.phiv_timestep(np.array([0.5, 1.0]), A, B, adaptive=True, tol=1e-7, stats=so)
+    U0, U1 = np.load(tmp_path / "U_0.npy"), np.load(tmp_path / "U_1.npy")
+    np.testing.assert_array_equal(U0, U1)                      # replicated iteration: bitwise the same on every rank
+    s0, s1 = np.load(tmp_path / "st_0.npy"), np.load(tmp_path / "st_1.npy")
+    np.testing.assert_array_equal(s0, s1)
+    assert tuple(s0[:3]) == (so["num_timesteps"], so["matvecs"], so["m"])
+    assert s0[3] >= so["matvecs"]                              # every operator application went through the collective
+    assert np.linalg.norm(U0 - Uo) <= 1e-12 * np.linalg.norm(Uo)

@@ -573,3 +573,73 @@ def test_constant_coefficient_stencil_option_is_bitwise_neutral(eu):
         w.append(np.asarray(eu.expv(0.6, eu.MIOperator(A, ctx), b, m=20, ishermitian=False)))
     assert np.array_equal(w[0], w[1])
     close(w[1], co.expv_csr(0.6, A, b, m=20)[0], 1e-12, "stencil option on a non-constant operator vs C oracle")
+
+
+def test_row_sharded_dense_operator_on_the_device(eu):
+    """dist.RowShardedDense at world size 1 (the multi-rank exchange is covered by the gloo test on CPU): the adaptive
+    phiv_timestep driven by the sharded matrix-free operator takes the controller decisions of the dense operator path and
+    gives the same snapshots."""
+    import importlib.util, os, torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(root, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    n = 1500
+    A, B = c3_inputs(n)
+    ctx = eu.Context()
+    sh = D.RowShardedDense(torch.as_tensor(np.ascontiguousarray(A), device="cuda"), n)
+    op = sh.operator(eu, ctx)
+    st, sd = {}, {}
+    ts = np.array([3.0, 12.0, 7.5])
+    U = eu.phiv_timestep(ts.copy(), op, B, adaptive=True, tol=1e-9, stats=st)
+    Ud = eu.phiv_timestep(ts.copy(), eu.MIOperator(A, ctx), B, adaptive=True, tol=1e-9, stats=sd)
+    assert (st["num_timesteps"], st["matvecs"], st["m"]) == (sd["num_timesteps"], sd["matvecs"], sd["m"]), (st, sd)
+    assert sh.applications >= st["matvecs"]
+    close(U, Ud, 1e-12, "phiv_timestep through the row-sharded operator vs the dense operator (n=%d)" % n)
+
+
+def _rows_worker(rank, world, port, n, out_dir):
+    import os, sys, importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    import expv_mi_loader
+    eu = expv_mi_loader.load()
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(root, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A, B = c3_inputs(n)
+        lo, hi = D.shard_range(n, world, rank)
+        # both ranks share the one GPU of the test box; gloo has no device all-gather, so the pieces are staged through the host
+        sh = D.RowShardedDense(torch.as_tensor(np.ascontiguousarray(A[lo:hi]), device="cuda"), n, stage_through_host=True)
+        st = {}
+        U = eu.phiv_timestep(np.array([3.0, 7.5]), sh.operator(eu, eu.Context()), B, adaptive=True, tol=1e-9, stats=st)
+        np.save(os.path.join(out_dir, "U_%d.npy" % rank), np.asarray(U))
+        np.save(os.path.join(out_dir, "st_%d.npy" % rank), np.array([st["num_timesteps"], st["matvecs"], st["m"], sh.applications]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_dense_operator_two_processes_one_gpu(eu, tmp_path):
+    """Two processes (gloo, both on the test box's single GPU), each holding half of the rows of the config-3 operator: the
+    device engine of each process drives the all-gather from inside its operator callback; both replicas take the same
+    sub-steps and end with the same snapshots as the unsharded dense operator."""
+    import socket
+    import torch.multiprocessing as mp
+    n, world = 1200, 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rows_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    A, B = c3_inputs(n)
+    sd = {}
+    Ud = np.asarray(eu.phiv_timestep(np.array([3.0, 7.5]), A, B, adaptive=True, tol=1e-9, stats=sd))
+    U0, U1 = np.load(tmp_path / "U_0.npy"), np.load(tmp_path / "U_1.npy")
+    s0, s1 = np.load(tmp_path / "st_0.npy"), np.load(tmp_path / "st_1.npy")
+    assert np.array_equal(U0, U1) and np.array_equal(s0, s1)
+    assert tuple(s0[:3]) == (sd["num_timesteps"], sd["matvecs"], sd["m"]), (s0, sd)
+    close(U0, Ud, 1e-12, "row-sharded operator, 2 processes on one GPU, vs the dense operator (n=%d)" % n)
