@@ -112,6 +112,21 @@ end
 const CTX = Ref{Ctx}()
 ctx() = (isassigned(CTX) || (check_abi(); CTX[] = Ctx()); CTX[])
 sync() = check(ccall((:expv_mi_ctx_sync, lib), Cint, (Ptr{Cvoid},), ctx().h), ctx().h)
+# engine options of the context by name ("pipeline", "wave", "fused", "dia", "mailbox", "nontemporal", "stencil", ...: expv_mi.h)
+set_option!(name::AbstractString, value::Integer) =
+    check(ccall((:expv_mi_ctx_set_option, lib), Cint, (Ptr{Cvoid}, Cstring, Int64), ctx().h, name, value), ctx().h)
+function get_option(name::AbstractString)
+    v = Ref{Int64}(0)
+    check(ccall((:expv_mi_ctx_get_option, lib), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), ctx().h, name, v), ctx().h)
+    v[]
+end
+# cumulative counters: Krylov steps, factorisations, on the single-pass step, overlapped, redone serially, redone without the
+# wave form, operator applications outside a factorisation, reserved
+function counters()
+    out = zeros(Int64, 8)
+    check(ccall((:expv_mi_ctx_counters, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx().h, out), ctx().h)
+    out
+end
 
 function check(code::Integer, h)
     code == 0 && return nothing
@@ -196,6 +211,41 @@ function MIOperator(A::MIMatrix{T}) where {T}                                   
     check(ccall((:expv_mi_op_create_dense, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Cint, Ref{Ptr{Cvoid}}),
                 ctx().h, dtype(T), size(A, 1), A.ptr, ld(A), DEVICE, r), ctx().h)
     wrap_operator(T, r[])
+end
+# Matrix-free operator: anything that implements the reference's operator contract (docs/src/interfaces.md:7-36, exercised by
+# test/basictests.jl:786-816): eltype, size, LinearAlgebra.mul!(y, A, x) on device vectors, ishermitian.  The library calls
+# back with device pointers on its stream; the Julia object is kept alive by the operator that wraps it.
+struct MatVecBox
+    A::Any
+    T::DataType
+    n::Int
+end
+const MATVEC_ROOTS = IdDict{Ptr{Cvoid}, Any}()                # callback user pointer -> boxed operator (rooted while the handle lives)
+function matvec_trampoline(user::Ptr{Cvoid}, xp::Ptr{Cvoid}, yp::Ptr{Cvoid}, stream::Ptr{Cvoid})::Cint
+    try
+        box = unsafe_pointer_to_objref(user)::Base.RefValue{MatVecBox}
+        b = box[]
+        x = MIArray{b.T, 1}(xp, (b.n,), false)
+        y = MIArray{b.T, 1}(yp, (b.n,), false)
+        LinearAlgebra.mul!(y, b.A, x)                          # the user's method, on MIVector arguments
+        return Cint(0)
+    catch
+        return Cint(1)                                         # surfaces as ArgumentError from the library call
+    end
+end
+function MIOperator(A, ::Type{T} = eltype(A); ishermitian::Bool = LinearAlgebra.ishermitian(A), nnz_hint::Integer = 0) where {T <: MIScalar}
+    n = size(A, 1)
+    box = Ref(MatVecBox(A, T, n))
+    user = pointer_from_objref(box)
+    fn = @cfunction(matvec_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:expv_mi_op_create_callback, lib), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ref{Ptr{Cvoid}}),
+                ctx().h, dtype(T), n, fn, user, ishermitian ? 1 : 0, nnz_hint, r), ctx().h)
+    MATVEC_ROOTS[r[]] = box
+    op = wrap_operator(T, r[])
+    finalizer(o -> delete!(MATVEC_ROOTS, o.h), op)
+    op
 end
 Base.eltype(::MIOperator{T}) where {T} = T
 Base.size(A::MIOperator) = (A.n, A.n)

@@ -233,7 +233,8 @@ def test_julia_shim_calls_match_the_header():
     used = set(re.findall(r":(expv_mi_[a-z0-9_]+), lib", src))
     for must in ("expv_mi_arnoldi", "expv_mi_lanczos", "expv_mi_expv_ks", "expv_mi_phiv_ks", "expv_mi_phiv_timestep", "expv_mi_kiops",
                  "expv_mi_timestep_caches_create", "expv_mi_expv_error_estimate", "expv_mi_expv", "expv_mi_expv_batch_multi",
-                 "expv_mi_abi_sizeof", "expv_mi_ks_resize"):
+                 "expv_mi_abi_sizeof", "expv_mi_ks_resize", "expv_mi_op_create_callback", "expv_mi_ctx_set_option",
+                 "expv_mi_ctx_get_option", "expv_mi_ctx_counters"):
         assert must in used, must
 
 
