@@ -212,6 +212,13 @@ __device__ __forceinline__ bool hier_reduce(StepState *st, double *part, double 
     reduce_flat(part, nblk, nvals, vals_s, red2_s);
     return true;
   }
+  if (nblk <= GROUP_SIZE) {   // one group: its last workgroup reduces straight into LDS -- one ticket, one gather
+    pf();
+    if (!take_ticket(&st->ticket, (uint32_t)nblk, flag_s)) return false;
+    reduce_stage(part, MAX_GRID, nblk, nvals, vals_s, 1, true);
+    __syncthreads();
+    return true;
+  }
   const int g = blockIdx.x / GROUP_SIZE;
   const int ng = (nblk + GROUP_SIZE - 1) / GROUP_SIZE;
   const int gsize = (nblk - g * GROUP_SIZE < GROUP_SIZE) ? nblk - g * GROUP_SIZE : GROUP_SIZE;
