@@ -1098,9 +1098,10 @@ int pipe_resident_capacity() {   // rows a resident launch can take (0: the kern
   return cap;
 }
 bool pipe_resident(hipStream_t s, const ResArgs &ra) {
-  const int grid = pipe_resident_capacity();
+  const int cap = pipe_resident_capacity();
   const int64_t ntiles = (ra.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  if (grid <= 0 || grid > MAX_GRID || ntiles > (int64_t)grid * RES_TILES) return false;
+  if (cap <= 0 || cap > MAX_GRID || ntiles > (int64_t)cap * RES_TILES) return false;
+  const int grid = (int)std::min<int64_t>(cap, std::max<int64_t>(1, ntiles));   // small problems: one tile per workgroup, a short reduction
   if (ra.ndiag < 1 || ra.ndiag > PIPE_DIA_MAX || ra.w > PIPE_WMAX || ra.m + (ra.closing ? 1 : 0) > PIPE_CH) return false;
   ResArgs args = ra;
   void *kargs[] = {&args};
