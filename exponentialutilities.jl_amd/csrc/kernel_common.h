@@ -71,10 +71,66 @@ __device__ __forceinline__ void st_pack(T *p, int64_t i, int64_t n, bool al, con
 }
 __device__ __forceinline__ bool is_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-__device__ __forceinline__ double wave_sum(double v) {  // total lands in lane 0
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+// ---- cross-lane exchange in the VALU (no LDS round trip) ---------------------------------------------------------
+// ds_bpermute (what __shfl_xor compiles to) goes through the LDS pipe: ~40 cycles each once four waves share it, and the
+// sums of a 32-column step take 130 of them per tile -- 1 to 3.7 us per step on the critical path of a small problem
+// (profiles/r02_trace_small_n.txt).  gfx950 swaps 32- and 16-lane rows between two registers in one VALU instruction
+// (v_permlane32_swap / v_permlane16_swap), and DPP moves cover the distances inside a 16-lane row.  Every routine
+// below adds the same two operands per lane as its __shfl form did, so results are bit-for-bit unchanged.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// OFF = 32 / 16: the odd OFF-lane rows of a trade places with the even rows of b
+template <int OFF>
+__device__ __forceinline__ void rows_swap(double &a, double &b) {
+  static_assert(OFF == 32 || OFF == 16, "row swaps exist for 32 and 16 lanes");
+  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  u32x2_t lo, hi;
+  if constexpr (OFF == 32) {
+    lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  }
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_mov(double old, double v) {   // lanes outside BANKS keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+// v of lane ^ OFF, OFF = 8, 4, 2, 1 (inside a 16-lane row)
+template <int OFF>
+__device__ __forceinline__ double lane_xor(double v) {
+  static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "DPP reaches inside a row of 16 lanes");
+  if constexpr (OFF == 8) return dpp_mov<0x128, 0xf>(v, v);                    // row_ror:8
+  else if constexpr (OFF == 4) return dpp_mov<0x114, 0xa>(dpp_mov<0x104, 0x5>(v, v), v);   // row_shl:4 into banks 0,2; row_shr:4 into banks 1,3
+  else if constexpr (OFF == 2) return dpp_mov<0x4e, 0xf>(v, v);                // quad_perm [2,3,0,1]
+  else return dpp_mov<0xb1, 0xf>(v, v);                                        // quad_perm [1,0,3,2]
+}
+// v + v[lane ^ OFF] in every lane
+template <int OFF>
+__device__ __forceinline__ double xor_sum(double v) {
+  if constexpr (OFF >= 16) {
+    double a = v, b = v;
+    rows_swap<OFF>(a, b);     // a = even rows of v twice, b = odd rows twice
+    return a + b;
+  } else {
+    return v + lane_xor<OFF>(v);
+  }
+}
+// butterfly over lane distances FROM, FROM/2 .. 1: every lane of a 2*FROM group ends with the group's total
+template <int FROM>
+__device__ __forceinline__ double xor_reduce(double v) {
+  v = xor_sum<FROM>(v);
+  if constexpr (FROM > 1) return xor_reduce<FROM / 2>(v);
+  else return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {  // wave total (lane 0 reads it; the tree is the one of a shift-down reduction)
+  return xor_reduce<32>(v);
 }
 
 __device__ __forceinline__ void publish_f64(double *p, double v) {
@@ -131,18 +187,24 @@ __device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected
 // value index ((lane >> (6 - log2 K)) ... ) -- see wave_multi_index.
 template <int HALF, int OFF, int K>
 __device__ __forceinline__ void wave_halve(double (&a)[K], int lane) {
-  const bool hi = (lane & OFF) != 0;
+  if constexpr (OFF >= 16) {
+    // one row swap leaves the two halves of a pair side by side: no select, no LDS
 #pragma unroll
-  for (int i = 0; i < HALF; ++i) {
-    const double send = hi ? a[i] : a[i + HALF];
-    const double keep = hi ? a[i + HALF] : a[i];
-    a[i] = keep + __shfl_xor(send, OFF, 64);
+    for (int i = 0; i < HALF; ++i) {
+      rows_swap<OFF>(a[i], a[i + HALF]);
+      a[i] = a[i] + a[i + HALF];
+    }
+  } else {
+    const bool hi = (lane & OFF) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const double send = hi ? a[i] : a[i + HALF];
+      const double keep = hi ? a[i + HALF] : a[i];
+      a[i] = keep + lane_xor<OFF>(send);
+    }
   }
   if constexpr (HALF > 1) wave_halve<HALF / 2, OFF / 2, K>(a, lane);
-  else {
-#pragma unroll
-    for (int off = OFF / 2; off >= 1; off >>= 1) a[0] += __shfl_xor(a[0], off, 64);
-  }
+  else if constexpr (OFF > 1) a[0] = xor_reduce<OFF / 2>(a[0]);
 }
 template <int K>
 __device__ __forceinline__ void wave_reduce_multi(double (&a)[K]) {

@@ -88,7 +88,7 @@ __device__ __forceinline__ double ld_shared_f64(const double *p) {   // value an
 }
 #ifdef PIPE_TRACE
 // build-time tracing (tools/pipe_trace.py): per step and workgroup {pass begin, main loop end, reduced, published}
-__device__ unsigned long long g_pipe_trace[33][1024][6];
+__device__ unsigned long long g_pipe_trace[33][1024][12];
 __device__ unsigned g_pipe_hw[33][1024];   // HW_ID | XCC_ID << 16 of thread 0's wave
 #define PIPE_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 33 && blockIdx.x < 1024) g_pipe_trace[step][blockIdx.x][slot] = wall_clock64(); } while (0)
 #else
@@ -335,6 +335,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
         if (tid < 32) hs[tid] = hc;
         __syncthreads();
+        PIPE_STAMP(pa.step, 6);
         tail_of_u();
         ready = true;
       }
@@ -354,15 +355,15 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
       }
       if constexpr (ST<T>::is_complex) {
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) { val.re += __shfl_xor(val.re, o, 64); val.im += __shfl_xor(val.im, o, 64); }
+        val.re = xor_reduce<16>(val.re);
+        val.im = xor_reduce<16>(val.im);
       } else {
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+        val = xor_reduce<16>(val);
       }
       if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
     }
     }
+    if (tl == 0) PIPE_STAMP(pa.step, 7);
     if (first) {
       if (AUG) {
 #pragma unroll
@@ -467,6 +468,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int e = 0; e < N; ++e) us[w + N * tid + e] = u.v[e];
       if (act && !pa.cont) st_tile<LIVE, T>(Vw + (int64_t)jcol * a.ldv + i, u);      // raw u_j -> column j-1 (a continuation's is there already)
       __syncthreads();
+      if (tl == 0) PIPE_STAMP(pa.step, 8);
     }
     // ---- phase 2: y~ = A u_j for this lane's rows, u from LDS ---------------------------------------
     Pack<T> y;
@@ -587,6 +589,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
     }
     if (act && !pa.final) st_tile<LIVE, T>(ybuf + i, y);
+    if (tl == 0) PIPE_STAMP(pa.step, 9);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The LSET values of a set (CH-1 window slots + the self term, NR reals each) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -632,6 +635,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         if (a.c0 + k != jcol) sh.cs_s[k] = ld_shared_f64<LIVE>(scales + a.c0 + k);
     }
   };
+  PIPE_STAMP(pa.step, 10);
   if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
   PIPE_STAMP(pa.step, 2);
   EPI_STAMP(pa.step, 0);
@@ -932,8 +936,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pipe_resident(const ResArgs ra) {
             if (k == 31) val = first ? ra.u0[hr] : consume_f64(yprev + hr) * inv;     // (a neighbour wrote it during this launch)
             else if (!first && k < und) val = -hs[k] * ra.V[hr + (int64_t)k * ra.ldv];   // (columns never change once written)
           }
-#pragma unroll
-          for (int o = 16; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+          val = xor_reduce<16>(val);
           if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
         }
         // ---- phase 1: u_j on the tile rows --------------------------------------------------------------------------------
@@ -1304,15 +1307,15 @@ template void scale_columns<cplx>(hipStream_t, cplx *, int64_t, int64_t, const d
 #include <vector>
 extern "C" void expv_mi_pipe_trace_dump(const char *path) {
   using namespace expv_mi::dev;
-  std::vector<unsigned long long> h((size_t)33 * 1024 * 6);
+  std::vector<unsigned long long> h((size_t)33 * 1024 * 12);
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pipe_trace), h.size() * 8);
   FILE *f = std::fopen(path, "w");
   if (!f) return;
   for (int st = 1; st < 33; ++st)
     for (int b = 0; b < 1024; ++b) {
-      const unsigned long long *r = &h[((size_t)st * 1024 + b) * 6];
-      if (r[0]) std::fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu\n", st, b, r[0], r[1], r[2], r[3], r[4], r[5]);
+      const unsigned long long *r = &h[((size_t)st * 1024 + b) * 12];
+      if (r[0]) std::fprintf(f, "%d %d %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", st, b, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]);
     }
   std::fclose(f);
   {   // where each workgroup ran
@@ -1323,7 +1326,7 @@ extern "C" void expv_mi_pipe_trace_dump(const char *path) {
     if (g) {
       for (int st = 1; st < 33; ++st)
         for (int b = 0; b < 1024; ++b)
-          if (h[((size_t)st * 1024 + b) * 6]) std::fprintf(g, "%d %d %u\n", st, b, hw[(size_t)st * 1024 + b]);
+          if (h[((size_t)st * 1024 + b) * 12]) std::fprintf(g, "%d %d %u\n", st, b, hw[(size_t)st * 1024 + b]);
       std::fclose(g);
     }
   }
