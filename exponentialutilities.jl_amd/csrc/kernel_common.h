@@ -506,7 +506,11 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
         if (k < nd - 1) {   // (wave-uniform; no early exit: the unrolled loop keeps grow[] in registers)
           T hk = readlane_T<T>(sv, k);
           if (a.real_coeff) hk = ST<T>::real_only(hk);
-          if (lane > k) ST<T>::nfma(sv, hk, grow[k]);     // (rows >= nd carry zeros)
+          if constexpr (ST<T>::is_complex) {
+            if (lane > k) ST<T>::nfma(sv, hk, grow[k]);   // (rows >= nd carry zeros)
+          } else {
+            ST<T>::nfma(sv, hk, grow[k]);                 // grow[k] = 0 for lane <= k: the product is a zero and sv stays (no select on the chain)
+          }
         }
       }
     } else {

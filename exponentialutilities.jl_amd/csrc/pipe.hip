@@ -160,6 +160,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
   static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
   static_assert(!(WAVE && ST<T>::is_complex), "the wave form is fp64 only");
+  static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
   static_assert(DIA || !ST<T>::is_complex, "complex operators use the DIA form");
   T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
   T(&hs)[32] = sh.hs;
@@ -316,6 +317,31 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
     for (int e = 0; e < N; ++e) u.v[e] = ST<T>::zero();
     bool have_ypre = false;
+    // halo rows of the first tile of an overlapped step: the elements of the older window columns are requested before the
+    // wait, those the previous step wrote (its column and its y~) right behind the flag with everything else -- the halo
+    // costs no memory round trip of its own between the flag and the first product
+    T hpre[2];
+    bool have_hpre = false;
+    auto halo_elem = [&](int e, int &k, int64_t &hr) {
+      const int hrow = e >> 5;
+      k = e & 31;
+      hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
+      return hr >= 0 && hr < n_op;
+    };
+    if constexpr (LIVE && !WAVE) {
+      if (!ready) {
+        have_hpre = true;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          hpre[it] = ST<T>::zero();
+          int k;
+          int64_t hr;
+          const int e = tid + it * BLOCK;
+          if (e < 2 * w * 32 && halo_elem(e, k, hr) && k < und && k != knew && k != 31)
+            hpre[it] = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+        }
+      }
+    }
     if constexpr (LIVE) {
       if (!ready) {   // first tile: everything above is in flight; now the previous step must be complete
         const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
@@ -333,6 +359,18 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           u = *reinterpret_cast<const Pack<T> *>(yprev + i);
           have_ypre = true;
         }
+        if constexpr (!WAVE) {
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            int k;
+            int64_t hr;
+            const int e = tid + it * BLOCK;
+            if (e < 2 * w * 32 && halo_elem(e, k, hr)) {
+              if (k == 31) hpre[it] = yprev[hr];
+              else if (k == knew && k < und) hpre[it] = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+            }
+          }
+        }
         if (tid < 32) hs[tid] = hc;
         __syncthreads();
         PIPE_STAMP(pa.step, 6);
@@ -342,14 +380,17 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     }
     if constexpr (!WAVE) {
     // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
-    for (int e = tid; e < 2 * w * 32; e += BLOCK) {
-      const int hrow = e >> 5, k = e & 31;
-      const int64_t hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {          // 2 w <= 16 halo rows x 32 lanes: at most two rounds
+      const int e = tid + it * BLOCK;
+      if (e >= 2 * w * 32) break;
+      int k;
+      int64_t hr;
       T val = ST<T>::zero();
-      if (hr >= 0 && hr < n_op) {        // (operator rows only read operator columns: rows of the augmentation never matter here)
-        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real(yprev[hr], inv);
+      if (halo_elem(e, k, hr)) {        // (operator rows only read operator columns: rows of the augmentation never matter here)
+        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real(have_hpre ? hpre[it] : yprev[hr], inv);
         else if (!first && k < und) {
-          const T hv = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+          const T hv = have_hpre ? hpre[it] : a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
           if constexpr (ST<T>::is_complex) ST<T>::nfma(val, hs[k], hv);
           else val = -hs[k] * hv;
         }
@@ -360,8 +401,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       } else {
         val = xor_reduce<16>(val);
       }
-      if (k == 0) us[(hrow < w) ? hrow : TR + hrow] = val;
+      if (k == 0) us[((e >> 5) < w) ? (e >> 5) : TR + (e >> 5)] = val;
     }
+    have_hpre = false;
     }
     if (tl == 0) PIPE_STAMP(pa.step, 7);
     if (first) {
@@ -383,9 +425,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       if (!(LIVE && have_ypre)) u = ld_stream<false, T>(yprev + i);
 #pragma unroll
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
+      // MGS axpy order.  fp64: slots k >= und hold h = +0 and v = +0, and fma(-0, 0, u) is u bit for bit (either zero sign
+      // included), so the chain runs unconditionally -- per column 2 FMAs instead of 2 FMAs + 4 selects on a spilled mask
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
-        if (k < und) {                          // MGS axpy order
+        if (!ST<T>::is_complex || k < und) {
           const T h = hs[k];
 #pragma unroll
           for (int e = 0; e < N; ++e) ST<T>::nfma(u.v[e], h, vreg[k].v[e]);
@@ -399,7 +443,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int k = 0; k < K; ++k) {
         const int qq = part * K + k;                // position in the LSET-long vector of the set
         const int q = qq / NR, r = qq % NR;         // window slot (or the self term), component
-        if (q < CH - 1) arr[k] = (slot_dots && q < und) ? pack_prod(vreg[q < CH - 1 ? q : 0], o, r) : 0.0;
+        if (q < CH - 1) arr[k] = slot_dots ? pack_prod(vreg[q < CH - 1 ? q : 0], o, r) : 0.0;   // (slots >= und hold zeros, and their sums are never stored)
         else if (q == CH - 1) arr[k] = pack_prod(u, o, r);
         else arr[k] = 0.0;
       }
