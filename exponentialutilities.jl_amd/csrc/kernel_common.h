@@ -178,7 +178,7 @@ __device__ __forceinline__ bool take_ticket(uint32_t *counter, uint32_t expected
     *flag_s = last;
   }
   __syncthreads();
-  return *flag_s != 0;
+  return __builtin_amdgcn_readfirstlane(*flag_s) != 0;   // (uniform by construction: scalar branch for the caller)
 }
 
 // Sum K (power of two, <= 32) per-lane values across the wave by recursive halving: at each step a

@@ -113,6 +113,9 @@ struct PipeSharedT {
 // between calls; a stop (happy breakdown / zero vector) releases every later step's kernel as well.
 constexpr uint32_t PIPE_STOP_BIT = 0x800u, PIPE_STEP_MASK = 0x7ffu;
 constexpr int PIPE_SEQ_SHIFT = 12;
+#ifndef PIPE_POLL_SLEEP
+#define PIPE_POLL_SLEEP 8     // x 64 cycles between two polls of a step flag
+#endif
 __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, uint32_t seq, int step, int *flag_s,
                                          int spin_limit) {
   if (threadIdx.x == 0) {
@@ -129,12 +132,12 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
         res = 99;
         break;
       }
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP);
     }
     *flag_s = res;
   }
   __syncthreads();
-  const int bd = *flag_s;
+  const int bd = __builtin_amdgcn_readfirstlane(*flag_s);   // workgroup-uniform, and the compiler should know: everything behind the wait stays scalar control flow
   __syncthreads();
   return bd;
 }
@@ -320,7 +323,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     // halo rows of the first tile of an overlapped step: the elements of the older window columns are requested before the
     // wait, those the previous step wrote (its column and its y~) right behind the flag with everything else -- the halo
     // costs no memory round trip of its own between the flag and the first product
-    T hpre[2];
+    T hpre = ST<T>::zero();      // (first round of the halo loop: all of it for w <= 4; a wider band loads its second round behind the wait)
     bool have_hpre = false;
     auto halo_elem = [&](int e, int &k, int64_t &hr) {
       const int hrow = e >> 5;
@@ -331,15 +334,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     if constexpr (LIVE && !WAVE) {
       if (!ready) {
         have_hpre = true;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          hpre[it] = ST<T>::zero();
-          int k;
-          int64_t hr;
-          const int e = tid + it * BLOCK;
-          if (e < 2 * w * 32 && halo_elem(e, k, hr) && k < und && k != knew && k != 31)
-            hpre[it] = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
-        }
+        int k;
+        int64_t hr;
+        if (tid < 2 * w * 32 && halo_elem(tid, k, hr) && k < und && k != knew && k != 31)
+          hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
     }
     if constexpr (LIVE) {
@@ -360,15 +358,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           have_ypre = true;
         }
         if constexpr (!WAVE) {
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            int k;
-            int64_t hr;
-            const int e = tid + it * BLOCK;
-            if (e < 2 * w * 32 && halo_elem(e, k, hr)) {
-              if (k == 31) hpre[it] = yprev[hr];
-              else if (k == knew && k < und) hpre[it] = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
-            }
+          int k;
+          int64_t hr;
+          if (tid < 2 * w * 32 && halo_elem(tid, k, hr)) {
+            if (k == 31) hpre = yprev[hr];
+            else if (k == knew && k < und) hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
           }
         }
         if (tid < 32) hs[tid] = hc;
@@ -388,9 +382,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       int64_t hr;
       T val = ST<T>::zero();
       if (halo_elem(e, k, hr)) {        // (operator rows only read operator columns: rows of the augmentation never matter here)
-        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real(have_hpre ? hpre[it] : yprev[hr], inv);
+        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real((have_hpre && it == 0) ? hpre : yprev[hr], inv);
         else if (!first && k < und) {
-          const T hv = have_hpre ? hpre[it] : a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+          const T hv = (have_hpre && it == 0) ? hpre : a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
           if constexpr (ST<T>::is_complex) ST<T>::nfma(val, hs[k], hv);
           else val = -hs[k] * hv;
         }
@@ -496,7 +490,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           }
         }
         __syncthreads();
-        if (flag_s != 0) return 3;
+        if (__builtin_amdgcn_readfirstlane(flag_s) != 0) return 3;
         if constexpr (DIA && !ST<T>::is_complex) {
           // PIPE_WMAX rows above and below the tile (their tiles' flags were part of the wait whenever a near diagonal exists)
           if (tid < 2 * PIPE_WMAX) {
@@ -1196,12 +1190,12 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {   // augmented operator (kiops): DIA form, windows <= 7
     if (pa.und <= 3) pipe_launch<double, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
-    else pipe_launch<double, 8, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
+    else pipe_launch<double, 8, 4, 5, true, true>(s, pa, nbatch, batch_rounds);
     return;
   }
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: pipe_launch<double, 8, 4, 6, true>(s, pa, nbatch, batch_rounds); break;
+      case 0: pipe_launch<double, 8, 4, 5, true>(s, pa, nbatch, batch_rounds); break;
       case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
       case 2: pipe_launch<double, 24, 3, 0, true>(s, pa, nbatch, batch_rounds); break;
       default: pipe_launch<double, 32, 2, 5, true>(s, pa, nbatch, batch_rounds); break;
@@ -1289,11 +1283,11 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns th
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {
     if (pa.und <= 3) return pipe_live_launch<double, 4, 4, 6, true, true>(s, pa);
-    return pipe_live_launch<double, 8, 4, 6, true, true>(s, pa);
+    return pipe_live_launch<double, 8, 4, 5, true, true>(s, pa);
   }
   if (pa.ndiag > 0) {
     switch (v) {
-      case 0: return pipe_live_launch<double, 8, 4, 6, true>(s, pa);
+      case 0: return pipe_live_launch<double, 8, 4, 5, true>(s, pa);
       case 1: return pipe_live_launch<double, 16, 3, 6, true>(s, pa);
       case 2: return pipe_live_launch<double, 24, 3, 0, true>(s, pa);
       default: return pipe_live_launch<double, 32, 2, 5, true>(s, pa);
