@@ -474,6 +474,14 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
   }
   const int nd = a.nd;  // <= LOWSYNC_MAX, dir == +1, newest column (v_j) is window index nd-1
   EPI_STAMP(a.jcol + 1, 1);
+  if (gram_ready) {   // the older rows are in gs_s already (gram_prefetch): only the row computed in this pass is new
+    const int rb = (nd - 1) * (nd - 2) / 2;
+    for (int k = threadIdx.x; k < nd - 1; k += BLOCK) {
+      const T g = ST<T>::conj(vals_to_T<T>(vals_s + nd * NR + k * NR));
+      stg(&a.gram[a.jrow + (int64_t)(a.c0 + k) * a.ldg], g);
+      gs_s[rb + k] = g;
+    }
+  } else
   for (int e = threadIdx.x; e < nd * (nd - 1) / 2; e += BLOCK) {
     int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);   // unpack e -> (i, k), k < i
     while (i * (i - 1) / 2 > e) --i;
