@@ -678,7 +678,13 @@ struct ArnoldiCall {
           pa.last_step = m + (closing ? 1 : 0);
           pa.early_step = (ks.defer_tail_req && closing) ? m : 0;
         }
-        if (j > jstart) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
+        // The gate keeps step j from being dispatched before step j-1 is completely resident.  Two grids that together have
+        // no more workgroups than the device has CUs are resident together whatever the order: no gate, half the launches
+        // (a small problem is bound by the host's launch rate: profiles/r02_trace_small_n.txt)
+        const int64_t tile_rows = (ST<T>::is_complex ? 1 : 2) * (int64_t)dev::BLOCK;   // pipe.hip: 16-byte packs, one per thread
+        const int64_t live_tiles = (rows + tile_rows - 1) / tile_rows;
+        const bool gate = use_wave || 2 * live_tiles > dev::device_cus();
+        if (j > jstart && gate) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
         if constexpr (!ST<T>::is_complex) {
           prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
         } else {
