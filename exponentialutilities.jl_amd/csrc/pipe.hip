@@ -1180,6 +1180,11 @@ static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int b
   }
   hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
+#ifndef PIPE_V2_CH     // the 16..23-column step of a banded (DIA) operator: columns / workgroups per CU / operator slots in registers
+#define PIPE_V2_CH 24
+#define PIPE_V2_WAVES 3
+#define PIPE_V2_PS 0
+#endif
 static int pipe_variant(int und) { return und <= 7 ? 0 : und <= 15 ? 1 : und <= 23 ? 2 : 3; }
 // complex windows of <= 3 columns (Hermitian Lanczos, iop <= 3): a leaner variant that stays spill-free at 4 workgroups per
 // CU.  (The fp64 analogue at 5 workgroups per CU measured 1.5 % SLOWER than the 8-column variant on the Lanczos input:
@@ -1197,7 +1202,7 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
     switch (v) {
       case 0: pipe_launch<double, 8, 4, 5, true>(s, pa, nbatch, batch_rounds); break;
       case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
-      case 2: pipe_launch<double, 24, 3, 0, true>(s, pa, nbatch, batch_rounds); break;
+      case 2: pipe_launch<double, PIPE_V2_CH, PIPE_V2_WAVES, PIPE_V2_PS, true>(s, pa, nbatch, batch_rounds); break;
       default: pipe_launch<double, 32, 2, 5, true>(s, pa, nbatch, batch_rounds); break;
     }
     return;
@@ -1289,7 +1294,7 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns th
     switch (v) {
       case 0: return pipe_live_launch<double, 8, 4, 5, true>(s, pa);
       case 1: return pipe_live_launch<double, 16, 3, 6, true>(s, pa);
-      case 2: return pipe_live_launch<double, 24, 3, 0, true>(s, pa);
+      case 2: return pipe_live_launch<double, PIPE_V2_CH, PIPE_V2_WAVES, PIPE_V2_PS, true>(s, pa);
       default: return pipe_live_launch<double, 32, 2, 5, true>(s, pa);
     }
   }
