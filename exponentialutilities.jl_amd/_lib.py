@@ -69,6 +69,7 @@ PROTOTYPES = {
     "expv_mi_ctx_set_async_outputs": (_i, [_vp, _i]),
     "expv_mi_ctx_set_pipeline_overlap": (_i, [_vp, _i]),
     "expv_mi_ctx_counters": (_i, [_vp, _pi64]),
+    "expv_mi_ctx_selftest": (_i, [_vp, _pi64]),
     "expv_mi_ctx_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "expv_mi_ctx_get_option": (_i, [_vp, C.c_char_p, _pi64]),
     "expv_mi_last_error": (C.c_char_p, [_vp]),

@@ -96,6 +96,12 @@ class Context:
         _check(L.load().expv_mi_ctx_get_option(self._h, name.encode(), C.byref(v)), self._h)
         return int(v.value)
 
+    def selftest(self):
+        """Device self-test of the VALU lane exchanges (expv_mi_ctx_selftest): mismatch counts per class, all zero when healthy."""
+        out = (C.c_int64 * 8)()
+        _check(L.load().expv_mi_ctx_selftest(self._h, out), self._h)
+        return tuple(int(x) for x in out)
+
     def counters(self):
         """Cumulative counters of the context (expv_mi_ctx_counters)."""
         out = (C.c_int64 * 8)()

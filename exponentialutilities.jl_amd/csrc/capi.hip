@@ -445,6 +445,34 @@ int expv_mi_ctx_counters(expv_mi_ctx_t ctx, int64_t out[8]) {
   out[4] = ctx->cnt_serial_redo; out[5] = ctx->cnt_wave_redo; out[6] = ctx->cnt_opapply; out[7] = 0;
   return EXPV_MI_OK;
 }
+int expv_mi_ctx_selftest(expv_mi_ctx_t ctx, int64_t out[8]) {
+  if (!out) return EXPV_MI_ARGUMENT_ERROR;
+  return guarded(ctx, [&] {
+    ctx->use();
+    const size_t nin = (size_t)32 * dev::BLOCK;
+    std::vector<double> h(nin);
+    uint64_t x = 0x9e3779b97f4a7c15ull;           // values of mixed sign and scale: every rounding of every tree level matters
+    for (size_t i = 0; i < nin; ++i) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+      h[i] = std::ldexp(u, (int)((x >> 3) % 40) - 20);
+    }
+    double *din = nullptr;
+    unsigned long long *dout = nullptr;
+    HIPCHECK(hipMalloc((void **)&din, nin * sizeof(double)));
+    HIPCHECK(hipMalloc((void **)&dout, 8 * sizeof(unsigned long long)));
+    unsigned long long res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(din, h.data(), nin * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dout, 0, sizeof(res), ctx->stream);
+    if (e == hipSuccess) { dev::selftest_lanes(ctx->stream, din, dout); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(res, dout, sizeof(res), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    HIPCHECK(e);
+    for (int i = 0; i < 8; ++i) out[i] = (int64_t)res[i];
+  });
+}
 int expv_mi_ctx_sync(expv_mi_ctx_t ctx) {
   return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipStreamSynchronize(ctx->stream)); });
 }

@@ -76,7 +76,9 @@ __device__ __forceinline__ bool is_al16(const void *p) { return (reinterpret_cas
 // sums of a 32-column step take 130 of them per tile -- 1 to 3.7 us per step on the critical path of a small problem
 // (profiles/r02_trace_small_n.txt).  gfx950 swaps 32- and 16-lane rows between two registers in one VALU instruction
 // (v_permlane32_swap / v_permlane16_swap), and DPP moves cover the distances inside a 16-lane row.  Every routine
-// below adds the same two operands per lane as its __shfl form did, so results are bit-for-bit unchanged.
+// below adds the same two operands per lane as its __shfl form did, so results are bit-for-bit unchanged
+// (expv_mi_ctx_selftest checks exactly that on the device).  Like any cross-lane operation they must be reached by whole
+// waves: an inactive lane is read as garbage.
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // OFF = 32 / 16: the odd OFF-lane rows of a trade places with the even rows of b
 template <int OFF>

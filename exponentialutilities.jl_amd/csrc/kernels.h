@@ -67,6 +67,8 @@ void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepS
 struct RowPlan { int nblocks; int64_t rows_per_block; };
 RowPlan plan_rows(int64_t n, int unit, int max_blocks);
 int device_cus();
+// device self-test of the VALU lane exchanges: in = 32 * BLOCK doubles, out = 8 zeroed counters
+void selftest_lanes(hipStream_t s, const double *in, unsigned long long *out);
 // workgroups of BLOCK threads of `kernel` that fit on the chip at once (occupancy query, cached)
 int resident_blocks(const void *kernel);
 

@@ -777,5 +777,64 @@ template void combine<double, cplx>(hipStream_t, int64_t, const double *, int64_
 template void combine<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const cplx *, int, int, double,
                                   cplx *, int64_t);
 
+
+// ---- device self-test: the VALU lane exchanges (v_permlane32/16_swap + DPP) against the LDS-permute forms they replaced --
+// One workgroup, random per-lane values; out[c] = number of lanes whose result differs in any bit from the shuffle form
+// (classes: include/expv_mi.h, expv_mi_ctx_selftest).
+template <int K>
+__device__ __forceinline__ void ref_halve(double (&a)[K], int lane) {   // the recursive halving written with shuffles
+  int half = K / 2, off = 32;
+  for (; half >= 1; half >>= 1, off >>= 1) {
+    const bool hi = (lane & off) != 0;
+    for (int i = 0; i < half; ++i) {
+      const double send = hi ? a[i] : a[i + half];
+      const double keep = hi ? a[i + half] : a[i];
+      a[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  for (; off >= 1; off >>= 1) a[0] += __shfl_xor(a[0], off, 64);
+}
+template <int K>
+__device__ __forceinline__ int selftest_multi(const double *in, int lane, int tid) {
+  double a[K], b[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) a[k] = b[k] = in[(size_t)k * BLOCK + tid];
+  wave_reduce_multi<K>(a);
+  ref_halve<K>(b, lane);
+  return __double_as_longlong(a[0]) != __double_as_longlong(b[0]);
+}
+__global__ __launch_bounds__(BLOCK) void k_selftest_lanes(const double *in, unsigned long long *out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const double v = in[tid];
+  int bad0 = 0;
+  bad0 += __double_as_longlong(xor_sum<32>(v)) != __double_as_longlong(v + __shfl_xor(v, 32, 64));
+  bad0 += __double_as_longlong(xor_sum<16>(v)) != __double_as_longlong(v + __shfl_xor(v, 16, 64));
+  bad0 += __double_as_longlong(xor_sum<8>(v)) != __double_as_longlong(v + __shfl_xor(v, 8, 64));
+  bad0 += __double_as_longlong(xor_sum<4>(v)) != __double_as_longlong(v + __shfl_xor(v, 4, 64));
+  bad0 += __double_as_longlong(xor_sum<2>(v)) != __double_as_longlong(v + __shfl_xor(v, 2, 64));
+  bad0 += __double_as_longlong(xor_sum<1>(v)) != __double_as_longlong(v + __shfl_xor(v, 1, 64));
+  double r = v, q = v;
+  for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o, 64);       // the form wave_sum replaced: lane 0 only
+  const int bad1 = __double_as_longlong(xor_reduce<32>(v)) != __double_as_longlong(r);
+  double r16 = v;
+  for (int o = 16; o >= 1; o >>= 1) r16 += __shfl_xor(r16, o, 64);
+  const int bad2 = __double_as_longlong(xor_reduce<16>(v)) != __double_as_longlong(r16);
+  const double ws = wave_sum(v);       // (all lanes take part: lane exchanges read inactive lanes as garbage)
+  const int bad3 = (lane == 0) && __double_as_longlong(ws) != __double_as_longlong(q);
+  const int bad4 = selftest_multi<16>(in, lane, tid) + selftest_multi<8>(in + 16 * BLOCK, lane, tid) +
+                   selftest_multi<2>(in + 24 * BLOCK, lane, tid) + selftest_multi<4>(in + 26 * BLOCK, lane, tid);
+  const int bad5 = selftest_multi<32>(in, lane, tid);
+  if (bad0) atomicAdd(out + 0, (unsigned long long)bad0);
+  if (bad1) atomicAdd(out + 1, (unsigned long long)bad1);
+  if (bad2) atomicAdd(out + 2, (unsigned long long)bad2);
+  if (bad3) atomicAdd(out + 3, (unsigned long long)bad3);
+  if (bad4) atomicAdd(out + 4, (unsigned long long)bad4);
+  if (bad5) atomicAdd(out + 5, (unsigned long long)bad5);
+}
+void selftest_lanes(hipStream_t s, const double *in, unsigned long long *out) {
+  hipLaunchKernelGGL(k_selftest_lanes, dim3(1), dim3(BLOCK), 0, s, in, out);
+}
+
 }  // namespace dev
 }  // namespace expv_mi

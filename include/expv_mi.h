@@ -102,6 +102,12 @@ int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
  * the wave form's tile wait expired, [6] operator applications outside a factorisation (phiv_timestep!'s recurrence, mul!),
  * [7] reserved.  A non-zero [4] / [5] means the overlapped / wave form was switched off for the following 64 calls. */
 int expv_mi_ctx_counters(expv_mi_ctx_t ctx, int64_t out[8]);
+/* Device self-test: the cross-lane sums of the kernels run on v_permlane32/16_swap + DPP (no LDS round trip); this runs them
+ * against the LDS-permute (shuffle) forms on random values and returns the number of lanes whose result differs in ANY bit:
+ * out[0] single exchanges (distances 32 .. 1), [1] 64-lane butterfly total, [2] 32-lane butterfly total, [3] lane 0 of the
+ * wave total against the shift-down tree, [4] multi-value recursive halving (2, 4, 8, 16 values), [5] the same for 32
+ * values, [6..7] reserved.  All zero on a device the library is built for. */
+int expv_mi_ctx_selftest(expv_mi_ctx_t ctx, int64_t out[8]);
 /* path flags of the most recent factorisation (also returned in expv_mi_expv_stats.path_flags) */
 enum {
   EXPV_MI_PATH_MODULAR = 1, EXPV_MI_PATH_TWO_KERNEL = 2, EXPV_MI_PATH_PIPELINE = 4, EXPV_MI_PATH_WAVE = 8,

@@ -128,6 +128,13 @@ function counters()
     out
 end
 
+# device self-test of the kernels' cross-lane sums (mismatching lanes per class; all zero when healthy)
+function selftest()
+    out = zeros(Int64, 8)
+    check(ccall((:expv_mi_ctx_selftest, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx().h, out), ctx().h)
+    out
+end
+
 function check(code::Integer, h)
     code == 0 && return nothing
     msg = unsafe_string(ccall((:expv_mi_last_error, lib), Cstring, (Ptr{Cvoid},), h))

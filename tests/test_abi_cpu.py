@@ -69,6 +69,25 @@ def test_host_expm_every_pade_branch(eu, T, scale):
     assert np.linalg.norm(E - ko.exponential_(A)) / np.linalg.norm(E) < 1e-13
 
 
+@pytest.mark.parametrize("hessenberg", [False, True])
+def test_host_expm_fp64_block_remainders(eu, hessenberg):
+    """The fp64 products and triangular solves of host_dense.h run on 8-row x 6-column register blocks (masked rows,
+    1..5 remainder columns, zero tails of Hessenberg factors skipped): every size class against the oracle."""
+    rng = np.random.default_rng(11)
+    for n in [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16, 17, 23, 24, 25, 30, 31, 32, 33, 47, 48, 49, 65]:
+        A = rng.standard_normal((n, n))
+        if hessenberg:
+            A = np.triu(A, -1)
+        A *= 4.5 / max(np.linalg.norm(A, 1), 1e-300)          # Pade 13, no squaring: the longest chain of products
+        E = eu.host_expm(A)
+        R = ko.exponential_(A)
+        assert np.linalg.norm(E - R) / np.linalg.norm(R) < 1e-13, n
+        A *= 20.0                                              # ... and with squarings
+        E = eu.host_expm(A)
+        R = ko.exponential_(A)
+        assert np.linalg.norm(E - R) / np.linalg.norm(R) < 5e-12, n
+
+
 def test_host_expm_balancing(eu):
     rng = np.random.default_rng(3)
     A = np.triu(rng.standard_normal((8, 8))) * np.logspace(-3, 3, 8)[:, None] * 1e-2

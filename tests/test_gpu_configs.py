@@ -643,3 +643,11 @@ def test_row_sharded_dense_operator_two_processes_one_gpu(eu, tmp_path):
     assert np.array_equal(U0, U1) and np.array_equal(s0, s1)
     assert tuple(s0[:3]) == (sd["num_timesteps"], sd["matvecs"], sd["m"]), (s0, sd)
     close(U0, Ud, 1e-12, "row-sharded operator, 2 processes on one GPU, vs the dense operator (n=%d)" % n)
+
+
+@pytest.mark.gpu
+def test_device_selftest_lane_exchanges_match_the_lds_permute_forms(eu):
+    """kernel_common.h sums across a wave with v_permlane32/16_swap + DPP; the C ABI's self-test runs every such routine
+    against its __shfl_xor (ds_bpermute) form on random values and counts lanes that differ in any bit."""
+    ctx = eu.Context()
+    assert ctx.selftest() == (0,) * 8
