@@ -547,6 +547,13 @@ struct ArnoldiCall {
       HIPCHECK(hipMemcpyAsync(ks.colscale.p, ks.colscale_host.data(), sizeof(double) * (size_t)jstart, hipMemcpyHostToDevice, s));
       HIPCHECK(hipMemsetAsync(ks.state.as<char>() + sizeof(StepState), 0, ks.state.bytes - sizeof(StepState), s));
   }
+  if (live && !use_wave) {   // per-tile "previous pass done" flags of the overlapped banded form (pipe.hip: tiles_ready)
+    const size_t tb = sizeof(uint32_t) * (size_t)(rows / dev::BLOCK + 2);
+    if (ks.tflags.bytes < tb) {
+      ks.tflags.alloc(tb);
+      HIPCHECK(hipMemsetAsync(ks.tflags.p, 0, tb, s));
+    }
+  }
   if (live) {
     c->ensure_aux();
     s2 = c->stream2;
@@ -626,6 +633,10 @@ struct ArnoldiCall {
           pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
           pa.spin_limit = spin_limit;
         }
+      }
+      if (live && !use_wave) {
+        pa.tile_flags = ks.tflags.as<uint32_t>();
+        pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
       }
       if (!use_wave && op.ndiag > 0 && !no_dia_env) {
         pa.dia_val = op.dia_val.as<T>(); pa.dia_ld = op.dia_ld; pa.ndiag = op.ndiag;

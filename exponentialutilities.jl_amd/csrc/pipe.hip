@@ -141,6 +141,32 @@ __device__ __forceinline__ int wait_step(StepState *st, const uint32_t *flags, u
   __syncthreads();
   return bd;
 }
+// Overlapped banded form: have the workgroups that own tiles tA, tB, tC finished the previous step's pass (stamp `want` in
+// their per-tile flags: their rows of y~ and of the new basis column are in memory)?  A workgroup is resident several us
+// before the step flag; with this it fetches its first tile's share of what the previous step wrote BEFORE the flag, and only
+// the coefficients are left behind it.  Bounded, and it gives up as soon as the step flag itself is up (the ordinary path
+// then loads everything in one round).
+__device__ __forceinline__ bool tiles_ready(const uint32_t *tflags, int64_t tA, int64_t tB, int64_t tC, uint32_t want,
+                                            const uint32_t *flags, uint32_t seq, int step, int *flag_s, int spin_limit) {
+  if (threadIdx.x == 0) {
+    const uint32_t *f = flags + (size_t)(blockIdx.x % PIPE_FLAG_COPIES) * PIPE_FLAG_STRIDE;
+    int ok = 0;
+    for (int it = 0; it < spin_limit; ++it) {
+      const uint32_t a = __hip_atomic_load(tflags + tA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t b = __hip_atomic_load(tflags + tB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t c = __hip_atomic_load(tflags + tC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a == want && b == want && c == want) { ok = 1; break; }
+      if ((v >> PIPE_SEQ_SHIFT) == seq && ((v & PIPE_STOP_BIT) || (int)(v & PIPE_STEP_MASK) >= step)) break;
+      __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP);
+    }
+    *flag_s = ok;
+  }
+  __syncthreads();
+  const int ok = __builtin_amdgcn_readfirstlane(*flag_s);
+  __syncthreads();
+  return ok != 0;
+}
 // component r of conj(v) * o summed over the elements of a 16-byte pack (the two rows of a lane for fp64)
 __device__ __forceinline__ double pack_prod(const Pack<double> &v, const Pack<double> &o, int) {
   return fma(v.v[0], o.v[0], v.v[1] * o.v[1]);
@@ -340,31 +366,43 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
     }
+    auto fetch_prev = [&]() {   // what the previous step wrote on (and around) this tile: its column of V and its y~
+      if (wload) {
+#pragma unroll
+        for (int k = 0; k < CH - 1; ++k)
+          if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * cstep);
+        u = *reinterpret_cast<const Pack<T> *>(yprev + i);
+        have_ypre = true;
+      }
+      if constexpr (!WAVE) {
+        int k;
+        int64_t hr;
+        if (tid < 2 * w * 32 && halo_elem(tid, k, hr)) {
+          if (k == 31) hpre = yprev[hr];
+          else if (k == knew && k < und) hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+        }
+      }
+    };
+    bool prefetched = false;
+    if constexpr (LIVE && !WAVE) {
+      if (!ready && pa.tile_flags != nullptr) {   // the owners of this tile and its two neighbours are done: fetch now, before the flag
+        prefetched = tiles_ready(pa.tile_flags, tile > 0 ? tile - 1 : tile, tile, tile + 1 < ntiles ? tile + 1 : tile,
+                                 pa.tile_stamp - 1u, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
+        if (prefetched) fetch_prev();
+      }
+    }
     if constexpr (LIVE) {
       if (!ready) {   // first tile: everything above is in flight; now the previous step must be complete
         const int bd = wait_step(a.st, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
         if (bd != 0) return 4;          // breakdown earlier in the factorisation (or an expired wait): leave
         PIPE_STAMP(pa.step, 4);
-        // everything that only waited for the previous step goes in flight TOGETHER -- its coefficients and 1/beta, the
-        // column it wrote and its y~ on this tile: one memory round trip between the flag and the first product, not two
+        // everything that only waited for the previous step goes in flight TOGETHER -- its coefficients and 1/beta and, unless
+        // they were fetched before the flag, the column it wrote and its y~ on this tile: one memory round trip between the
+        // flag and the first product, not two
         inv = consume_f64(&a.st->inv);
         T hc = ST<T>::zero();
         if (tid < und && tid < 32) hc = consume_T<T>(hcoef_in + tid);
-        if (wload) {
-#pragma unroll
-          for (int k = 0; k < CH - 1; ++k)
-            if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * cstep);
-          u = *reinterpret_cast<const Pack<T> *>(yprev + i);
-          have_ypre = true;
-        }
-        if constexpr (!WAVE) {
-          int k;
-          int64_t hr;
-          if (tid < 2 * w * 32 && halo_elem(tid, k, hr)) {
-            if (k == 31) hpre = yprev[hr];
-            else if (k == knew && k < und) hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
-          }
-        }
+        if (!prefetched) fetch_prev();
         if (tid < 32) hs[tid] = hc;
         __syncthreads();
         PIPE_STAMP(pa.step, 6);
@@ -674,7 +712,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     }
   };
   PIPE_STAMP(pa.step, 10);
-  if (!hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf)) return 0;
+  const bool reducer = hier_reduce(a.st, a.part, a.gpart, nvals, vals_s, &flag_s, pf);
+  if constexpr (LIVE && !WAVE) {
+    // behind the ticket every store of this workgroup's tiles is acknowledged: the tiles are ready for the next step
+    if (pa.tile_flags != nullptr && !pa.final)
+      for (int64_t t = t0 + tid; t < t1; t += BLOCK)
+        __hip_atomic_store(pa.tile_flags + t, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!reducer) return 0;
   PIPE_STAMP(pa.step, 2);
   EPI_STAMP(pa.step, 0);
 
