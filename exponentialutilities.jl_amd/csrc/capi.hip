@@ -403,6 +403,7 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   ht_report();
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
   if (ctx->ws_kiops && ctx->ws_kiops_free) ctx->ws_kiops_free(ctx->ws_kiops);
+  if (ctx->ws_ts && ctx->ws_ts_free) ctx->ws_ts_free(ctx->ws_ts);
   if (ctx->ws_batch && ctx->ws_batch_free) ctx->ws_batch_free(ctx->ws_batch);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

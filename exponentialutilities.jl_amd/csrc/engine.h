@@ -78,6 +78,8 @@ struct Ctx {
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
   void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
   void (*ws_kiops_free)(void *) = nullptr;
+  void *ws_ts = nullptr;      // cached work arrays + KrylovSubspace of a phiv_timestep! call without caches (owned; engine_drivers.hip)
+  void (*ws_ts_free)(void *) = nullptr;
   void *ws_batch = nullptr;   // cached device buffers of expv_batch (owned; see engine_batch.hip)
   size_t ws_batch_bytes = 0;  // ... and how many bytes they hold
   void (*ws_batch_free)(void *) = nullptr;

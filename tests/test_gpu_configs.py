@@ -651,3 +651,27 @@ def test_device_selftest_lane_exchanges_match_the_lds_permute_forms(eu):
     against its __shfl_xor (ds_bpermute) form on random values and counts lanes that differ in any bit."""
     ctx = eu.Context()
     assert ctx.selftest() == (0,) * 8
+
+
+@pytest.mark.gpu
+def test_timestep_without_caches_reuses_the_context_work_set_like_a_fresh_one(eu):
+    """phiv_timestep! without caches keeps its work arrays and KrylovSubspace in the context between calls (allocation cost
+    more than the call): a sequence of DIFFERENT calls on one context -- other inputs, horizons, tolerances, a larger m, more
+    coefficient columns, a Hermitian operator -- must each equal the oracle, with the oracle's controller decisions."""
+    rng = np.random.default_rng(21)
+    n = 700
+    A = c2_operator(n)
+    As = c2_operator(n, sym=True)
+    ctx = eu.Context()
+    cases = [(A, 1, [1.0], 1e-6, None), (A, 1, [0.4, 2.5], 1e-9, None), (A, 3, [3.0], 1e-7, None), (As, 2, [1.5, 6.0], 1e-8, None),
+             (A, 1, [2.0], 1e-7, 24), (A, 4, [0.7], 1e-6, None), (A, 1, [5.0], 1e-10, None)]
+    for k, (M, ncoef, ts, tol, m) in enumerate(cases):
+        B = rng.standard_normal((n, ncoef))
+        kw = dict(adaptive=True, tol=tol)
+        if m is not None:
+            kw["m"] = m
+        st, so = {}, {}
+        U = eu.phiv_timestep(np.array(ts), eu.MIOperator(M, ctx), B, stats=st, **kw)
+        Uo = ko.phiv_timestep(np.array(ts), M, B, stats=so, **kw)
+        assert (st["num_timesteps"], st["matvecs"], st["m"]) == (so["num_timesteps"], so["matvecs"], so["m"]), (k, st, so)
+        close(U, Uo, 1e-12, "cache-less phiv_timestep, call %d of a sequence on one context vs oracle" % k)
