@@ -403,6 +403,7 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   ht_report();
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
   if (ctx->ws_kiops && ctx->ws_kiops_free) ctx->ws_kiops_free(ctx->ws_kiops);
+  delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
   if (ctx->ws_ts && ctx->ws_ts_free) ctx->ws_ts_free(ctx->ws_ts);
   if (ctx->ws_batch && ctx->ws_batch_free) ctx->ws_batch_free(ctx->ws_batch);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -735,6 +736,13 @@ int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_l
 int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, int maxiter, int augmented,
                       expv_mi_ks_t *out) {
   return guarded(ctx, [&] {
+    expv_mi_ks_s *spare = reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
+    if (spare && ctx->opt.recycle && spare->dtypeT == dtype_T && spare->dtypeU == dtype_U && spare->n == n && spare->maxiter == maxiter &&
+        spare->augmented == augmented) {       // same shape as the last destroyed one: take its storage (ks_recycle made it fresh)
+      ctx->ks_spare = nullptr;
+      *out = spare;
+      return;
+    }
     std::unique_ptr<expv_mi_ks_s> ks(new expv_mi_ks_s());
     ks_alloc(*ks, ctx, dtype_T, dtype_U, n, maxiter, augmented);
     *out = ks.release();
@@ -742,7 +750,17 @@ int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, in
 }
 int expv_mi_ks_destroy(expv_mi_ks_t ks) {
   if (ks) {
-    (void)hipSetDevice(ks->ctx->device);
+    Ctx *ctx = ks->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->opt.recycle) {      // keep the storage for the next create of the same shape (one per context)
+      try {
+        ks_recycle(*ks);
+        delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
+        ctx->ks_spare = ks;
+        return EXPV_MI_OK;
+      } catch (...) {
+      }
+    }
     delete ks;
   }
   return EXPV_MI_OK;

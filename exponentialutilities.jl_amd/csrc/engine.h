@@ -59,6 +59,7 @@ struct Options {
   int batch_rounds = 2;    // batched single-pass step: resident rounds of fat workgroups       (EXPV_MI_BATCH_ROUNDS)
   int stencil = 0;         // constant-coefficient banded operators: pass the diagonals as scalars, do not stream them (EXPV_MI_STENCIL=1 -> 1)
   int nontemporal = -1;    // non-temporal loads in the single-pass step: -1 by footprint, 0 never, 1 always  (EXPV_MI_NONTEMPORAL=0|1)
+  int recycle = 1;         // a destroyed KrylovSubspace's storage is kept (one per context) for the next create of the same shape (EXPV_MI_NO_RECYCLE=1 -> 0)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();
@@ -78,6 +79,7 @@ struct Ctx {
   void *ws_ks = nullptr;   // cached KrylovSubspace of the whole-call expv (owned; see capi.hip)
   void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
   void (*ws_kiops_free)(void *) = nullptr;
+  void *ks_spare = nullptr;   // storage of the last destroyed KrylovSubspace (expv_mi_ks_s *), handed to the next create of the same shape
   void *ws_ts = nullptr;      // cached work arrays + KrylovSubspace of a phiv_timestep! call without caches (owned; engine_drivers.hip)
   void (*ws_ts_free)(void *) = nullptr;
   void *ws_batch = nullptr;   // cached device buffers of expv_batch (owned; see engine_batch.hip)
@@ -240,6 +242,7 @@ struct Ks {
   int64_t rows() const { return n + augmented; }
 };
 void ks_finish_tail(Ks &ks);   // engine_core.hip
+void ks_recycle(Ks &ks);       // engine_core.hip: a used subspace back to what ks_alloc leaves (same shape, storage kept)
 }  // namespace expv_mi
 struct expv_mi_ks_s : expv_mi::Ks {};
 namespace expv_mi {

@@ -89,10 +89,13 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *   "stencil" 0         banded fp64 operators whose stored diagonals are constant (constant-coefficient finite differences): apply
  *                       them from scalars instead of streaming the diagonals (bitwise the same result, 40 % less operator-side
  *                       traffic on a 5-diagonal operator); off by default so that a general sparse operator is timed as one
+ *   "recycle" 1         expv_mi_ks_destroy keeps the storage of the subspace (one per context) and the next expv_mi_ks_create of
+ *                       the same shape takes it over, reset to the freshly built state: the create-use-destroy pattern of the
+ *                       convenience methods costs no hipMalloc / hipFree.  0: destroy frees at once
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
- * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL (read once, at creation) -- nothing reads the environment later.
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE (read once, at creation) -- nothing reads the environment later.
  * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
 int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
 int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);

@@ -675,3 +675,39 @@ def test_timestep_without_caches_reuses_the_context_work_set_like_a_fresh_one(eu
         Uo = ko.phiv_timestep(np.array(ts), M, B, stats=so, **kw)
         assert (st["num_timesteps"], st["matvecs"], st["m"]) == (so["num_timesteps"], so["matvecs"], so["m"]), (k, st, so)
         close(U, Uo, 1e-12, "cache-less phiv_timestep, call %d of a sequence on one context vs oracle" % k)
+
+
+@pytest.mark.gpu
+def test_recycled_krylov_subspace_is_indistinguishable_from_a_fresh_one(eu):
+    """expv_mi_ks_destroy keeps the storage (context option "recycle") and the next create of the same shape takes it over:
+    convenience calls that build a KrylovSubspace per call -- phiv(t, A, b, k), arnoldi(A, b) with changing inputs, a Lanczos
+    run after an Arnoldi run, a happy breakdown in between -- give what a context with recycling off gives, bit for bit,
+    and match the oracle."""
+    rng = np.random.default_rng(5)
+    n = 900
+    A = c2_operator(n)
+    As = c2_operator(n, sym=True)
+    ctxs = [eu.Context(), eu.Context()]
+    ctxs[1].set_option("recycle", 0)
+    ops = [(eu.MIOperator(A, c), eu.MIOperator(As, c)) for c in ctxs]
+    e1 = np.zeros(n); e1[0] = 1.0
+    calls = [("phiv", 0, 0.7, 3, 20), ("phiv", 0, 1.3, 1, 20), ("phiv", 1, 0.5, 2, 20), ("H", 0, None, None, 20),
+             ("phiv", 0, 2.0, 2, 20), ("H", 1, None, None, 20), ("phiv", 0, 0.3, 4, 12), ("phiv", 0, 0.9, 2, 20)]
+    for k, (kind, which, t, kk, m) in enumerate(calls):
+        b = rng.standard_normal(n)
+        M = (A, As)[which]
+        outs = []
+        for c, (opA, opS) in zip(ctxs, ops):
+            op = (opA, opS)[which]
+            if kind == "phiv":
+                outs.append(np.asarray(eu.phiv(t, op, b, kk, m=m)))
+            else:
+                Ks = eu.arnoldi(op, b, m=m)
+                outs.append(np.array(Ks.getH()))
+                del Ks
+        assert np.array_equal(outs[0], outs[1]), "call %d: recycled and freshly allocated subspace differ" % k
+        if kind == "phiv":
+            close(outs[0], ko.phiv(t, M, b, kk, m=m), 1e-11, "phiv through a recycled KrylovSubspace, call %d vs oracle" % k)
+        else:
+            Ko = ko.arnoldi(M, b, m=m)
+            close(outs[0], Ko.getH(), 1e-12, "H through a recycled KrylovSubspace, call %d vs oracle" % k)

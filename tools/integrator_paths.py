@@ -30,3 +30,17 @@ c0 = ctx.counters()
 t = timeit(lambda: eu.kiops(1.0, op, B, tol=1e-8))
 c1 = ctx.counters(); st = (c1["krylov_steps"] - c0["krylov_steps"]) / 13
 print("kiops real K=2 ms", t, "steps/call", st, "us/step", 1e3 * t / st)
+
+from tests._util import c2_operator as c2u
+As = eu.MIOperator(c2u(n, sym=True), ctx)
+def count(f, label):
+    c0 = ctx.counters(); t = timeit(f); c1 = ctx.counters(); st = (c1["krylov_steps"] - c0["krylov_steps"]) / 13
+    print(label, "ms", round(t, 4), "steps/call", st, "us/step", round(1e3 * t / max(st, 1), 1))
+count(lambda: eu.phiv(1.0, op, b, 3, m=30), "phiv k=3 m=30")
+if As is not None:
+    count(lambda: eu.expv(1.0, As, b, m=30), "expv hermitian (Lanczos)")
+    count(lambda: eu.expv(1.0, As, b, m=30, mode="error_estimate", rtol=1e-8), "expv hermitian error_estimate")
+    count(lambda: eu.expv_timestep([1.0], As, b, tol=1e-8, adaptive=True), "expv_timestep hermitian adaptive")
+Ks = eu.arnoldi(op, b, m=30)
+count(lambda: eu.arnoldi_(Ks, op, b, m=30) if hasattr(eu, "arnoldi_") else eu.arnoldi(op, b, m=30), "arnoldi! into an existing Ks")
+count(lambda: eu.arnoldi(op, b, m=30), "arnoldi (fresh Ks per call)")
