@@ -78,6 +78,27 @@ void csr_props(int64_t n, const std::vector<int32_t> &rp, const std::vector<int3
     best = std::max(best, s);
   }
   *opn = best;
+  // A cheap look first: rows with ascending columns allow (c, r) to be found in row c by bisection.  The first stored
+  // off-diagonal entry without its conjugate partner settles the question for a matrix that is not Hermitian (the common case:
+  // no transpose, no second pass); a matrix that passes goes through the full comparison below.
+  {
+    bool sorted = true, broken = false;
+    for (int64_t r = 0; r < n && sorted && !broken; ++r) {
+      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+        if (k > rp[r] && !(ci[k - 1] < ci[k])) { sorted = false; break; }
+        if (iszero(va[k]) || ci[k] == r) continue;
+        const int32_t c = ci[k];
+        const int32_t *lo = ci.data() + rp[c], *hi = ci.data() + rp[c + 1];
+        bool row_c_sorted = true;
+        for (const int32_t *q = lo + 1; q < hi; ++q) row_c_sorted = row_c_sorted && q[-1] < q[0];
+        if (!row_c_sorted) { sorted = false; break; }
+        const int32_t *it = std::lower_bound(lo, hi, (int32_t)r);
+        if (it == hi || *it != (int32_t)r || !(va[it - ci.data()] == conjd(va[k]))) { broken = true; break; }
+      }
+      if (ci.size() > 0 && r >= 4096 && !broken) break;     // a few thousand clean rows: leave the verdict to the full pass
+    }
+    if (broken) { *herm = 0; return; }
+  }
   // transpose by counting sort, then compare row by row
   std::vector<int32_t> tp(n + 1, 0);
   for (size_t k = 0; k < ci.size(); ++k)
@@ -94,13 +115,27 @@ void csr_props(int64_t n, const std::vector<int32_t> &rp, const std::vector<int3
         tv[d] = va[k];
       }
   bool h = true;
+  std::vector<std::pair<int32_t, V>> a;     // (only rows whose columns are not ascending need a sorted copy)
   for (int64_t r = 0; r < n && h; ++r) {
-    // entries of row r of A (sorted by column when built from CSC; sort a copy otherwise)
-    std::vector<std::pair<int32_t, V>> a;
+    const int32_t t0 = tp[r], t1 = tp[r + 1];
+    // entries of row r of A against row r of A^H: ascending columns (every CSR built from CSC, every sorted CSR) are walked in
+    // place -- a per-row vector + sort here was a third of the creation time of an n = 1e6 operator
+    bool ascending = true;
+    for (int32_t k = rp[r] + 1; k < rp[r + 1]; ++k) ascending = ascending && ci[k - 1] < ci[k];
+    if (ascending) {
+      int32_t q = t0;
+      for (int32_t k = rp[r]; k < rp[r + 1] && h; ++k) {
+        if (iszero(va[k])) continue;
+        if (q >= t1 || ci[k] != tc[q] || !(va[k] == conjd(tv[q]))) h = false;
+        ++q;
+      }
+      if (q != t1) h = false;
+      continue;
+    }
+    a.clear();
     for (int32_t k = rp[r]; k < rp[r + 1]; ++k)
       if (!iszero(va[k])) a.emplace_back(ci[k], va[k]);
     std::sort(a.begin(), a.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-    const int32_t t0 = tp[r], t1 = tp[r + 1];
     if ((int32_t)a.size() != t1 - t0) { h = false; break; }
     for (int32_t q = 0; q < t1 - t0; ++q)
       if (a[q].first != tc[t0 + q] || !(a[q].second == conjd(tv[t0 + q]))) { h = false; break; }
@@ -302,19 +337,34 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
 
 template <class V>
 void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+  static const bool tm = std::getenv("EXPV_MI_OP_TIMING") != nullptr;      // developer diagnostic: phases of an operator build
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tm) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[op build] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   op.kind = OP_CSR;
   op.n = n;
   op.nnz = (int64_t)ci.size();
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
+  lap("ishermitian + opnorm");
   int64_t bw = 0;
   for (int64_t r = 0; r < n; ++r)
     for (int32_t k = rp[r]; k < rp[r + 1]; ++k) bw = std::max<int64_t>(bw, std::llabs((long long)ci[k] - (long long)r));
   op.bandwidth = bw;
+  lap("bandwidth");
   upload_csr<V>(op, rp, ci, va);
+  lap("CSR upload");
   build_sell<V>(op, n, rp, ci, va);
+  lap("SELL build + upload");
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  lap("pattern analysis");
   if (op.sell_ok) build_dia<V>(op, n, rp, ci, va, P);
+  lap("DIA build + upload");
   if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va, P);
+  lap("general DIA");
   if (op.sell_ok && P.tile_reach >= 0) {
     // wave form on SELL slots: which tiles does a tile's piece of A read u from?
     const int64_t TR = 512, nt = (n + TR - 1) / TR;
