@@ -328,6 +328,8 @@ class MIOperator:
             n = A.shape[0]
             if A.shape[0] != A.shape[1]:
                 raise DimensionMismatch("operator must be square")
+            self._sp_format = "csr" if A.format == "csr" else "csc"
+            self._sp_sorted = bool(A.has_sorted_indices) if A.format in ("csr", "csc") else False
             if A.format == "csr":
                 M = A.astype(dt)
                 M.sort_indices()
@@ -376,6 +378,34 @@ class MIOperator:
         self.ishermitian = bool(herm.value) if ishermitian is None else bool(ishermitian)
         self.opnorm_inf = float(opn.value)
         self.dtype = np.dtype(np.complex128 if dtc.value == L.C64 else np.float64)
+
+    def update_values(self, A):
+        """New values on the same sparsity pattern (expv_mi_op_update_values): ``A`` is the matrix the operator was created
+        from after an in-place change of its values (same format, sorted indices), a device tensor or an array of nnz values
+        in that order.  The stored device forms are refilled and ishermitian / opnorm_inf re-evaluated, ~10x cheaper than a
+        new MIOperator."""
+        fmt = getattr(self, "_sp_format", None)
+        if fmt is None:
+            raise ValueError("update_values: sparse operators only")
+        if hasattr(A, "indptr"):
+            if A.format != fmt or not A.has_sorted_indices or A.nnz != self.nnz or A.shape != self.shape:
+                raise ValueError("update_values: same format, shape and (sorted) pattern as at creation required")
+            vals = A.data
+        else:
+            vals = A
+        arg = _Arg(vals if _is_torch(vals) else np.ascontiguousarray(vals, dtype=self.dtype), self.dtype)
+        if int(np.prod(arg.shape)) != self.nnz:
+            raise DimensionMismatch("update_values: nnz values expected")
+        _check(L.load().expv_mi_op_update_values(self._h, arg.ptr, arg.loc), self.ctx._h)
+        if hasattr(A, "indptr"):
+            self.src = A
+        n_, nnz, herm, opn, dtc = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
+        _check(L.load().expv_mi_op_info(self._h, C.byref(n_), C.byref(nnz), C.byref(herm), C.byref(opn), C.byref(dtc)))
+        self.ishermitian = bool(herm.value)
+        self.opnorm_inf = float(opn.value)
+        for key in [k for k in vars(self) if k.startswith("_as_")]:      # converted copies hold the old values
+            delattr(self, key)
+        return self
 
     def astype(self, dtype):
         dtype = _work_dtype(dtype)
@@ -449,7 +479,15 @@ def _as_operator(A, want_dtype=None, ctx=None):
         key = (id(A), id(cobj))
         fp = _fingerprint(A)
         ent = cache.get(key)
-        if ent is None or ent[0]() is not A or ent[2] != fp or ent[1].ctx is not cobj:
+        same_obj = ent is not None and ent[0]() is A and ent[1].ctx is cobj
+        if same_obj and ent[2] != fp and fp[0] == "sp" and ent[2][0] == "sp" and fp[1:8] == ent[2][1:8] and fp[9:] == ent[2][9:] \
+                and A.format in ("csr", "csc") and A.has_sorted_indices and getattr(ent[1], "_sp_format", None) == A.format \
+                and getattr(ent[1], "_sp_sorted", False) and ent[1].dtype == _work_dtype(A.dtype):
+            # same arrays, same pattern (index checksums), other values: an in-place A.data[:] = ... between calls -- refill
+            # the uploaded operator instead of building a new one
+            op = ent[1].update_values(A)
+            cache[key] = (ent[0], op, fp)
+        elif ent is None or ent[0]() is not A or ent[2] != fp or ent[1].ctx is not cobj:
             op = MIOperator(A, cobj)
             try:
                 cache[key] = (weakref.ref(A), op, fp)

@@ -39,7 +39,7 @@ int guarded(Ctx *ctx, F &&f) {
 // CSC (any index base) -> CSR32, rows sorted by column; also the transpose for the Hermitian test
 template <class V>
 void csc_to_csr(int64_t n, const int64_t *colptr, const int64_t *rowval, const V *nz, int base, std::vector<int32_t> &rp,
-                std::vector<int32_t> &ci, std::vector<V> &va) {
+                std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> *pos = nullptr) {
   const int64_t nnz = colptr[n] - base;
   rp.assign(n + 1, 0);
   ci.resize(nnz);
@@ -51,12 +51,14 @@ void csc_to_csr(int64_t n, const int64_t *colptr, const int64_t *rowval, const V
   }
   for (int64_t r = 0; r < n; ++r) rp[r + 1] += rp[r];
   std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+  if (pos) pos->resize(nnz);
   for (int64_t c = 0; c < n; ++c)
     for (int64_t k = colptr[c] - base; k < colptr[c + 1] - base; ++k) {
       const int64_t r = rowval[k] - base;
       const int32_t dst = fill[r]++;
       ci[dst] = (int32_t)c;
       va[dst] = nz[k];
+      if (pos) (*pos)[k] = dst;      // where entry k of the caller's arrays lives in CSR order (values-only updates)
     }
 }
 
@@ -360,6 +362,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   build_sell<V>(op, n, rp, ci, va);
   lap("SELL build + upload");
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  op.rows_sorted_unique = P.sorted_unique;
   lap("pattern analysis");
   if (op.sell_ok) build_dia<V>(op, n, rp, ci, va, P);
   lap("DIA build + upload");
@@ -418,6 +421,66 @@ void host_phiv_dense_T(int m, int k, const void *A, int lda, const void *v, void
   std::copy(R.a.begin(), R.a.end(), reinterpret_cast<S *>(w));
 }
 }  // namespace
+
+// New values on an unchanged pattern: the stored forms are refilled on the device (one staged copy of the values, one
+// thread per row), the value-dependent properties -- opnorm(A, Inf), ishermitian, constant diagonals -- re-evaluated there.
+template <class T, class V>
+static void op_update_values_T(Op &op, const void *vals, int loc) {
+  Ctx *c = op.ctx;
+  hipStream_t s = c->stream;
+  const int64_t nnz = op.nnz;
+  const T *src = reinterpret_cast<const T *>(vals);
+  if (loc == EXPV_MI_HOST) {
+    if (op.upd_stage.bytes < sizeof(T) * (size_t)nnz) op.upd_stage.alloc(sizeof(T) * (size_t)nnz + 16);
+    HIPCHECK(hipMemcpyAsync(op.upd_stage.p, vals, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice, s));
+    src = op.upd_stage.as<T>();
+  }
+  if (!op.csc_pos.empty()) {           // the caller's arrays are in CSC order
+    if (!op.csc_pos_dev.p) {
+      op.csc_pos_dev.alloc(sizeof(int32_t) * op.csc_pos.size());
+      HIPCHECK(hipMemcpyAsync(op.csc_pos_dev.p, op.csc_pos.data(), sizeof(int32_t) * op.csc_pos.size(), hipMemcpyHostToDevice, s));
+    }
+    dev::op_scatter_values<T>(s, op.val.as<T>(), src, op.csc_pos_dev.as<int32_t>(), nnz);
+  } else {
+    HIPCHECK(hipMemcpyAsync(op.val.p, src, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToDevice, s));
+  }
+  if (!op.upd_out.p) op.upd_out.alloc(sizeof(unsigned long long) * 32);
+  HIPCHECK(hipMemsetAsync(op.upd_out.p, 0, sizeof(unsigned long long) * 32, s));
+  dev::OpUpdateArgs<T> a{};
+  a.n = op.n;
+  a.rp = op.rowptr.as<int32_t>(); a.ci = op.col.as<int32_t>(); a.val = op.val.as<T>();
+  if (op.sell_ok) { a.sell_val = op.sell_val.as<T>(); a.sell_off = op.sell_off.as<int64_t>(); a.sell_rows = 64 * (16 / (int)sizeof(T)); }
+  if (op.ndiag > 0) { a.dia = op.dia_val.as<T>(); a.dia_ld = op.dia_ld; a.nd = op.ndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
+  else if (op.gndiag > 0 && !op.gdia_alias) { a.dia = op.gdia_val.as<T>(); a.dia_ld = op.gdia_ld; a.nd = op.gndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
+  a.check_herm = op.rows_sorted_unique ? 1 : 0;
+  a.out = op.upd_out.as<unsigned long long>();
+  dev::op_update_forms<T>(s, a);
+  unsigned long long out[32];
+  HIPCHECK(hipMemcpyAsync(out, op.upd_out.p, sizeof(out), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  double opn;
+  std::memcpy(&opn, &out[0], sizeof(double));
+  op.opnorm_inf = opn;
+  if (op.rows_sorted_unique) {
+    op.ishermitian = out[1] ? 0 : 1;
+  } else {                              // rows out of order: the host test on a downloaded copy (as at creation)
+    std::vector<int32_t> rp((size_t)op.n + 1), ci((size_t)nnz);
+    std::vector<V> va((size_t)nnz);
+    HIPCHECK(hipMemcpy(rp.data(), op.rowptr.p, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(ci.data(), op.col.p, sizeof(int32_t) * ci.size(), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(va.data(), op.val.p, sizeof(V) * va.size(), hipMemcpyDeviceToHost));
+    double dummy;
+    csr_props<V>(op.n, rp, ci, va, &op.ishermitian, &dummy);
+  }
+  if (op.ndiag > 0 && !ST<T>::is_complex) {
+    bool cst = true;
+    for (int d = 0; d < op.ndiag; ++d) {
+      cst = cst && out[2 + d] == 0;
+      std::memcpy(&op.dia_const[d], &out[16 + d], sizeof(double));
+    }
+    op.dia_is_const = cst;
+  }
+}
 
 extern "C" {
 
@@ -603,11 +666,11 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
     std::vector<int32_t> rp, ci;
     if (dtype == EXPV_MI_C64) {
       std::vector<cd> va;
-      csc_to_csr<cd>(n, colptr, rowval, reinterpret_cast<const cd *>(nzval), index_base, rp, ci, va);
+      csc_to_csr<cd>(n, colptr, rowval, reinterpret_cast<const cd *>(nzval), index_base, rp, ci, va, &op->csc_pos);
       make_csr_op<cd>(*op, n, rp, ci, va);
     } else {
       std::vector<double> va;
-      csc_to_csr<double>(n, colptr, rowval, reinterpret_cast<const double *>(nzval), index_base, rp, ci, va);
+      csc_to_csr<double>(n, colptr, rowval, reinterpret_cast<const double *>(nzval), index_base, rp, ci, va, &op->csc_pos);
       make_csr_op<double>(*op, n, rp, ci, va);
     }
     *out = op.release();
@@ -765,6 +828,19 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
   if (opnorm_inf) *opnorm_inf = op->opnorm_inf;
   if (dtype) *dtype = op->dtype;
   return EXPV_MI_OK;
+}
+
+int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc) {
+  if (!op) return EXPV_MI_ARGUMENT_ERROR;
+  return guarded(op->ctx, [&] {
+    op->ctx->use();
+    if (op->kind != OP_CSR) fail(EXPV_MI_ARGUMENT_ERROR, "op_update_values: sparse (CSR / CSC) operators only");
+    if (op->nnz > 0 && !vals) fail(EXPV_MI_ARGUMENT_ERROR, "op_update_values: null values");
+    if (loc != EXPV_MI_HOST && loc != EXPV_MI_DEVICE) fail(EXPV_MI_ARGUMENT_ERROR, "op_update_values: bad location");
+    if (op->nnz == 0) return;
+    if (op->dtype == EXPV_MI_C64) op_update_values_T<cplx, cd>(*op, vals, loc);
+    else op_update_values_T<double, double>(*op, vals, loc);
+  });
 }
 
 int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc) {

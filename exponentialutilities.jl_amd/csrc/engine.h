@@ -159,6 +159,12 @@ struct Op {
   int ishermitian = 0;
   double opnorm_inf = 0.0;
   DevBuf rowptr, col, val;   // CSR32
+  // values-only update (expv_mi_op_update_values): where entry j of the caller's CSC arrays went in CSR order (empty for an
+  // operator created from CSR), its device copy (uploaded at the first update), a staging buffer, and whether every row has
+  // strictly ascending columns (the device-side Hermitian test bisects rows)
+  std::vector<int32_t> csc_pos;
+  DevBuf csc_pos_dev, upd_stage, upd_out;
+  bool rows_sorted_unique = false;
   DevBuf sell_off, sell_col, sell_val;   // SELL-C (C = 128 rows fp64 / 64 complex), built when padding is small
   int64_t nslices = 0;
   bool sell_ok = false;

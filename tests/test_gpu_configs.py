@@ -711,3 +711,62 @@ def test_recycled_krylov_subspace_is_indistinguishable_from_a_fresh_one(eu):
         else:
             Ko = ko.arnoldi(M, b, m=m)
             close(outs[0], Ko.getH(), 1e-12, "H through a recycled KrylovSubspace, call %d vs oracle" % k)
+
+
+@pytest.mark.gpu
+def test_values_only_update_equals_a_new_operator(eu):
+    """expv_mi_op_update_values: new values on an unchanged pattern refill every stored form on the device.  For each storage
+    class -- banded DIA (the single-pass step), grid stencil (general DIA / wave form), regular rows (SELL only), irregular rows
+    (plain CSR), complex, created from CSR and from CSC -- the updated operator must behave bit for bit like one built from the
+    new matrix, and report its ishermitian / opnorm."""
+    rng = np.random.default_rng(17)
+    def perturb(A, herm=False):
+        B = A.copy()
+        B.data = B.data * (1.0 + 0.3 * rng.standard_normal(B.nnz))
+        if herm:
+            B = ((B + B.conj().T) * 0.5).asformat(A.format)
+            B.sort_indices()
+        return B
+    n = 3000
+    banded = c2_operator(n)
+    gx = 50
+    grid = (sp.kron(sp.eye(n // gx), sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(gx, gx))) +
+            sp.kron(sp.diags([0.7, -1.0, 0.9], [-1, 0, 1], shape=(n // gx, n // gx)), sp.eye(gx)))
+    reg = sp.random(n, n, density=6.0 / n, random_state=3, format="csr") + sp.diags(np.full(n, -3.0))
+    irr = sp.random(n, n, density=4.0 / n, random_state=4, format="lil")
+    irr[7, :200] = 0.01
+    irr = irr.tocsr() + sp.diags(np.full(n, -2.0))
+    cases = [("banded csc", banded.tocsc(), False), ("banded csr", banded.tocsr(), False), ("banded symmetric pattern -> Hermitian", banded.tocsc(), True),
+             ("grid stencil", grid.tocsc(), False), ("regular rows", reg.tocsc(), False), ("irregular rows", irr.tocsc(), False),
+             ("complex banded", (banded * (1.0 + 0.2j)).tocsc(), False), ("complex -> Hermitian", (banded * (1.0 + 0.2j)).tocsc(), True)]
+    ctx = eu.Context()
+    for name, A0, herm in cases:
+        A0.sort_indices()
+        A1 = perturb(A0, herm)
+        assert A1.nnz == A0.nnz and np.array_equal(A1.indices, A0.indices) and np.array_equal(A1.indptr, A0.indptr), name
+        b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if A0.dtype.kind == "c" else 0)
+        op = eu.MIOperator(A0, ctx)
+        w_before = np.asarray(eu.expv(0.4, op, b, m=20))
+        op.update_values(A1)
+        fresh = eu.MIOperator(A1, ctx)
+        assert op.ishermitian == fresh.ishermitian == herm, (name, op.ishermitian, fresh.ishermitian)
+        # (complex: |a| is a hypot on either side, device and host libm may differ in the last bit)
+        assert abs(op.opnorm_inf - fresh.opnorm_inf) <= (0 if A0.dtype.kind != "c" else 1e-14 * fresh.opnorm_inf), (name, op.opnorm_inf, fresh.opnorm_inf)
+        for kw in ({}, {"ishermitian": False}):
+            w_upd = np.asarray(eu.expv(0.4, op, b, m=20, **kw))
+            w_new = np.asarray(eu.expv(0.4, fresh, b, m=20, **kw))
+            assert np.array_equal(w_upd, w_new), "%s: updated operator and new operator differ" % name
+        assert not np.array_equal(w_upd, w_before), name
+        close(w_upd, ko.expv(0.4, A1, b, m=20, ishermitian=False), 1e-12, "expv on a values-updated operator (%s) vs oracle" % name)
+        y_upd, y_new = np.asarray(op.apply(b)) if hasattr(op, "apply") else None, np.asarray(fresh.apply(b)) if hasattr(fresh, "apply") else None
+        if y_upd is not None:
+            assert np.array_equal(y_upd, y_new), name
+    # the convenience form: the same scipy object mutated in place between calls is refilled, not rebuilt
+    A = banded.tocsc(); A.sort_indices()
+    b = rng.standard_normal(n)
+    eu.clear_operator_cache()
+    w0 = np.asarray(eu.expv(0.4, A, b, m=20, ishermitian=False))
+    A.data[:] = A.data * 1.5
+    w1 = np.asarray(eu.expv(0.4, A, b, m=20, ishermitian=False))
+    close(w1, ko.expv(0.4, A, b, m=20, ishermitian=False), 1e-12, "expv after an in-place change of A.data (convenience form) vs oracle")
+    assert not np.array_equal(w0, w1)
