@@ -219,8 +219,7 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
 // SELL-C-sigma (sigma = 1: no row sorting) with C = 128 rows (fp64) / 64 rows (complex): slot-major
 // inside a slice so one wave reads 1 KiB of values per slot.  Built only when padding stays small.
 template <class V>
-void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                const std::vector<V> &va) {
+void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) {   // layout only: the slots are filled on the device (op_fill_forms)
   const int SH = 64 * (16 / (int)sizeof(V));
   const int64_t nsl = (n + SH - 1) / SH;
   std::vector<int64_t> off(nsl + 1, 0);
@@ -231,30 +230,16 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
   }
   const int64_t padded = off[nsl];
   op.sell_ok = false;
-  if (n == 0 || padded > (int64_t)(1.3 * (double)ci.size()) + 8 * SH) return;   // irregular rows: keep CSR
-  std::vector<V> sv((size_t)std::max<int64_t>(padded, 1), V(0));
-  std::vector<int32_t> sc((size_t)std::max<int64_t>(padded, 1), 0);
-  for (int64_t s = 0; s < nsl; ++s)
-    for (int64_t r = s * SH; r < std::min<int64_t>(n, (s + 1) * SH); ++r) {
-      const int q = (int)(r - s * SH);
-      const int L = (int)((off[s + 1] - off[s]) / SH);
-      int slot = 0;
-      for (int32_t k = rp[r]; k < rp[r + 1]; ++k, ++slot) {
-        sv[(size_t)(off[s] + (int64_t)slot * SH + q)] = va[k];
-        sc[(size_t)(off[s] + (int64_t)slot * SH + q)] = ci[k];
-      }
-      // padding slots (value 0) point at the row itself: whatever reads x[col] for them reads an entry that is as
-      // available as the row's own data (the wave form of the pipeline relies on that), never a far-away one
-      for (; slot < L; ++slot) sc[(size_t)(off[s] + (int64_t)slot * SH + q)] = (int32_t)r;
-    }
+  if (n == 0 || padded > (int64_t)(1.3 * (double)nnz) + 8 * SH) return;   // irregular rows: keep CSR
+  const size_t slots = (size_t)std::max<int64_t>(padded, 1);
   Ctx *c = op.ctx;
   op.sell_off.alloc(sizeof(int64_t) * off.size());
-  op.sell_col.alloc(sizeof(int32_t) * sc.size() + 16);
-  op.sell_val.alloc(sizeof(V) * sv.size() + 16);
+  op.sell_col.alloc(sizeof(int32_t) * slots + 16);
+  op.sell_val.alloc(sizeof(V) * slots + 16);
   HIPCHECK(hipMemcpyAsync(op.sell_off.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(op.sell_col.p, sc.data(), sizeof(int32_t) * sc.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(op.sell_val.p, sv.data(), sizeof(V) * sv.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));
+  HIPCHECK(hipMemsetAsync(op.sell_col.p, 0, op.sell_col.bytes, c->stream));     // slots of the rows beyond n: column 0, value 0
+  HIPCHECK(hipMemsetAsync(op.sell_val.p, 0, op.sell_val.bytes, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));      // (`off` leaves scope)
   op.nslices = nsl;
   op.sell_ok = true;
 }
@@ -263,42 +248,22 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::ve
 // PIPE_DIA_MAX of them, rows are free of duplicate entries and the zero fill stays below 30 %.  Absent entries are
 // explicit zeros, so a row's sum runs over the same terms, in ascending-column order, plus exact zeros.
 template <class V>
-inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                      const std::vector<V> &va, const PatternPlan &P) {
+inline void build_dia(Op &op, int64_t n, const PatternPlan &P) {   // layout only: absent entries are the zeros of the memset
   op.ndiag = 0;
   if (!P.pipe_dia) return;
-  const int W = dev::PIPE_WMAX;
   const int nd = (int)P.offsets.size();
   const int64_t ld = (n + 511) / 512 * 512;
-  int slot_of[2 * dev::PIPE_WMAX + 1];
-  for (int d = 0; d < nd; ++d) slot_of[P.offsets[d] + W] = d;
-  std::vector<V> dv((size_t)nd * (size_t)ld, V(0));
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) dv[(size_t)slot_of[ci[k] - r + W] * (size_t)ld + (size_t)r] = va[k];
   std::vector<int32_t> o32(nd);
   for (int d = 0; d < nd; ++d) o32[d] = (int32_t)P.offsets[d];
-  op.dia_val.alloc(sizeof(V) * dv.size());
+  op.dia_val.alloc(sizeof(V) * (size_t)nd * (size_t)ld);
   op.gdia_off.alloc(sizeof(int32_t) * nd);
-  HIPCHECK(hipMemcpyAsync(op.dia_val.p, dv.data(), sizeof(V) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemsetAsync(op.dia_val.p, 0, op.dia_val.bytes, op.ctx->stream));
   HIPCHECK(hipMemcpyAsync(op.gdia_off.p, o32.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
   op.ndiag = nd;
   op.dia_ld = ld;
   for (int d = 0; d < nd; ++d) op.dia_off[d] = (int)P.offsets[d];
-  // constant-coefficient stencil?  (every entry a diagonal can have is stored and they are all equal; fp64 only)
-  op.dia_is_const = false;
-  if constexpr (std::is_same<V, double>::value) {
-    bool cst = true;
-    for (int d = 0; d < nd && cst; ++d) {
-      const int64_t o = P.offsets[d], rlo = o < 0 ? -o : 0, rhi = o > 0 ? n - o : n;   // rows whose column r + o exists
-      if (rhi <= rlo) { cst = false; break; }
-      const double c0 = dv[(size_t)d * (size_t)ld + (size_t)rlo];
-      for (int64_t r = rlo; r < rhi; ++r)
-        if (dv[(size_t)d * (size_t)ld + (size_t)r] != c0) { cst = false; break; }
-      op.dia_const[d] = c0;
-    }
-    op.dia_is_const = cst;
-  }
+  op.dia_is_const = false;      // (decided by the fill: op_fill_forms)
   // the two-kernel step reads the same [ndiag][ld] array through its "general DIA" arguments (device offsets)
   op.gndiag = nd;
   op.gdia_ld = ld;
@@ -310,24 +275,16 @@ inline void build_dia(Op &op, int64_t n, const std::vector<int32_t> &rp, const s
 // General DIA form (any offsets): structured-grid stencils whose bandwidth is too wide for the banded pipeline.  Same
 // rules otherwise: rows sorted and free of duplicates, at most GDIA_MAX distinct offsets, zero fill below 30 %.
 template <class V>
-inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci,
-                       const std::vector<V> &va, const PatternPlan &P) {
+inline void build_gdia(Op &op, int64_t n, const PatternPlan &P) {   // layout only
   if (!P.general_dia) return;
   const std::vector<int64_t> &offs = P.offsets;
   const int nd = (int)offs.size();
   const int64_t ld = (n + 511) / 512 * 512;
-  std::vector<V> dv((size_t)nd * (size_t)ld, V(0));
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-      const int64_t o = (int64_t)ci[k] - r;
-      const int d = (int)(std::lower_bound(offs.begin(), offs.end(), o) - offs.begin());
-      dv[(size_t)d * (size_t)ld + (size_t)r] = va[k];
-    }
   std::vector<int32_t> o32(nd);
   for (int d = 0; d < nd; ++d) o32[d] = (int32_t)offs[d];
-  op.gdia_val.alloc(sizeof(V) * dv.size());
+  op.gdia_val.alloc(sizeof(V) * (size_t)nd * (size_t)ld);
   op.gdia_off.alloc(sizeof(int32_t) * nd);
-  HIPCHECK(hipMemcpyAsync(op.gdia_val.p, dv.data(), sizeof(V) * dv.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemsetAsync(op.gdia_val.p, 0, op.gdia_val.bytes, op.ctx->stream));
   HIPCHECK(hipMemcpyAsync(op.gdia_off.p, o32.data(), sizeof(int32_t) * nd, hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
   op.gndiag = nd;
@@ -335,6 +292,39 @@ inline void build_gdia(Op &op, int64_t n, const std::vector<int32_t> &rp, const 
   op.gdia_maxoff = std::max<int64_t>(std::llabs((long long)offs.front()), std::llabs((long long)offs.back()));
   op.gdia_near = false;
   for (int d = 0; d < nd; ++d) op.gdia_near = op.gdia_near || std::llabs((long long)offs[d]) <= dev::PIPE_WMAX;
+}
+
+// The stored forms of a CSR operator are filled ON THE DEVICE from its CSR arrays (kernels.hip: one thread per row): SELL
+// slots (+ their columns and the padding slots' columns at creation), the diagonal form, and on the way the value-dependent
+// properties -- opnorm(A, Inf), A == A^H when asked, constant diagonals.  Creation and expv_mi_op_update_values share it:
+// the host never builds or uploads a second or third copy of the values (creation of an n = 1e6 operator: 78 -> 50 ms).
+template <class T>
+static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long long out[32]) {
+  hipStream_t s = op.ctx->stream;
+  if (!op.upd_out.p) op.upd_out.alloc(sizeof(unsigned long long) * 32);
+  HIPCHECK(hipMemsetAsync(op.upd_out.p, 0, sizeof(unsigned long long) * 32, s));
+  dev::OpUpdateArgs<T> a{};
+  a.n = op.n;
+  a.rp = op.rowptr.as<int32_t>(); a.ci = op.col.as<int32_t>(); a.val = op.val.as<T>();
+  if (op.sell_ok) {
+    a.sell_val = op.sell_val.as<T>(); a.sell_off = op.sell_off.as<int64_t>(); a.sell_rows = 64 * (16 / (int)sizeof(T));
+    a.sell_col = creation ? op.sell_col.as<int32_t>() : nullptr;
+  }
+  if (op.ndiag > 0) { a.dia = op.dia_val.as<T>(); a.dia_ld = op.dia_ld; a.nd = op.ndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
+  else if (op.gndiag > 0 && !op.gdia_alias) { a.dia = op.gdia_val.as<T>(); a.dia_ld = op.gdia_ld; a.nd = op.gndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
+  a.check_herm = check_herm ? 1 : 0;
+  a.out = op.upd_out.as<unsigned long long>();
+  dev::op_update_forms<T>(s, a);
+  HIPCHECK(hipMemcpyAsync(out, op.upd_out.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  if (op.ndiag > 0 && !ST<T>::is_complex) {
+    bool cst = true;
+    for (int d = 0; d < op.ndiag; ++d) {
+      cst = cst && out[2 + d] == 0;
+      std::memcpy(&op.dia_const[d], &out[16 + d], sizeof(double));
+    }
+    op.dia_is_const = cst;
+  }
 }
 
 template <class V>
@@ -359,15 +349,21 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("bandwidth");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
-  build_sell<V>(op, n, rp, ci, va);
-  lap("SELL build + upload");
+  build_sell<V>(op, n, rp, (int64_t)ci.size());
+  lap("SELL layout");
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
   op.rows_sorted_unique = P.sorted_unique;
   lap("pattern analysis");
-  if (op.sell_ok) build_dia<V>(op, n, rp, ci, va, P);
-  lap("DIA build + upload");
-  if (op.sell_ok) build_gdia<V>(op, n, rp, ci, va, P);
+  if (op.sell_ok) build_dia<V>(op, n, P);
+  lap("DIA layout");
+  if (op.sell_ok) build_gdia<V>(op, n, P);
   lap("general DIA");
+  {
+    unsigned long long out[32];
+    if (std::is_same<V, cd>::value) op_fill_forms<cplx>(op, true, false, out);
+    else op_fill_forms<double>(op, true, false, out);
+  }
+  lap("device fill of the forms");
   if (op.sell_ok && P.tile_reach >= 0) {
     // wave form on SELL slots: which tiles does a tile's piece of A read u from?
     const int64_t TR = 512, nt = (n + TR - 1) / TR;
@@ -444,20 +440,8 @@ static void op_update_values_T(Op &op, const void *vals, int loc) {
   } else {
     HIPCHECK(hipMemcpyAsync(op.val.p, src, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToDevice, s));
   }
-  if (!op.upd_out.p) op.upd_out.alloc(sizeof(unsigned long long) * 32);
-  HIPCHECK(hipMemsetAsync(op.upd_out.p, 0, sizeof(unsigned long long) * 32, s));
-  dev::OpUpdateArgs<T> a{};
-  a.n = op.n;
-  a.rp = op.rowptr.as<int32_t>(); a.ci = op.col.as<int32_t>(); a.val = op.val.as<T>();
-  if (op.sell_ok) { a.sell_val = op.sell_val.as<T>(); a.sell_off = op.sell_off.as<int64_t>(); a.sell_rows = 64 * (16 / (int)sizeof(T)); }
-  if (op.ndiag > 0) { a.dia = op.dia_val.as<T>(); a.dia_ld = op.dia_ld; a.nd = op.ndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
-  else if (op.gndiag > 0 && !op.gdia_alias) { a.dia = op.gdia_val.as<T>(); a.dia_ld = op.gdia_ld; a.nd = op.gndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
-  a.check_herm = op.rows_sorted_unique ? 1 : 0;
-  a.out = op.upd_out.as<unsigned long long>();
-  dev::op_update_forms<T>(s, a);
   unsigned long long out[32];
-  HIPCHECK(hipMemcpyAsync(out, op.upd_out.p, sizeof(out), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  op_fill_forms<T>(op, false, op.rows_sorted_unique, out);
   double opn;
   std::memcpy(&opn, &out[0], sizeof(double));
   op.opnorm_inf = opn;
@@ -471,14 +455,6 @@ static void op_update_values_T(Op &op, const void *vals, int loc) {
     HIPCHECK(hipMemcpy(va.data(), op.val.p, sizeof(V) * va.size(), hipMemcpyDeviceToHost));
     double dummy;
     csr_props<V>(op.n, rp, ci, va, &op.ishermitian, &dummy);
-  }
-  if (op.ndiag > 0 && !ST<T>::is_complex) {
-    bool cst = true;
-    for (int d = 0; d < op.ndiag; ++d) {
-      cst = cst && out[2 + d] == 0;
-      std::memcpy(&op.dia_const[d], &out[16 + d], sizeof(double));
-    }
-    op.dia_is_const = cst;
   }
 }
 

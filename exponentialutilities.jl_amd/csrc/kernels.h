@@ -73,6 +73,7 @@ struct OpUpdateArgs {
   const int32_t *rp, *ci;
   const T *val;                 // CSR-ordered values (already updated)
   T *sell_val; const int64_t *sell_off; int sell_rows;     // SELL slices of sell_rows rows (nullptr: no SELL form)
+  int32_t *sell_col;            // creation only: the column of every slot is written too (padding slots: the row itself)
   T *dia; int64_t dia_ld; const int32_t *dia_off; int nd;   // [nd][dia_ld] diagonal form with device offsets (nullptr: none)
   int check_herm;               // rows have strictly ascending columns: test A == A^H (explicit zeros ignored) on the device
   unsigned long long *out;      // [0] bits of max_r sum_k |a_rk|, [1] != 0: not Hermitian, [2 + d] != 0: diagonal d not constant,

@@ -876,7 +876,11 @@ __global__ __launch_bounds__(BLOCK) void k_op_update_forms(const OpUpdateArgs<T>
       const T v = a.val[k];
       const int32_t c = a.ci[k];
       rowsum += upd_abs(v);
-      if (a.sell_val) a.sell_val[sbase + (int64_t)(k - k0) * a.sell_rows + q] = v;
+      if (a.sell_val) {
+        const int64_t e = sbase + (int64_t)(k - k0) * a.sell_rows + q;
+        a.sell_val[e] = v;
+        if (a.sell_col) a.sell_col[e] = c;
+      }
       if (a.dia) {
         const int32_t o = c - (int32_t)r;
         int lo = 0, hi = a.nd - 1;
@@ -895,6 +899,14 @@ __global__ __launch_bounds__(BLOCK) void k_op_update_forms(const OpUpdateArgs<T>
         if (lo >= a.rp[c + 1] || a.ci[lo] != (int32_t)r || !upd_eq_conj(a.val[lo], v)) bad = true;
       }
     }
+  }
+  if (r < a.n && a.sell_val && a.sell_col) {
+    // padding slots (value 0 from the memset) point at the row itself: whatever reads x[col] for them reads an entry that is
+    // as available as the row's own data (the wave form of the pipeline relies on that), never a far-away one
+    const int64_t sl = r / a.sell_rows;
+    const int q = (int)(r - sl * a.sell_rows);
+    const int L = (int)((a.sell_off[sl + 1] - a.sell_off[sl]) / a.sell_rows);
+    for (int slot = a.rp[r + 1] - a.rp[r]; slot < L; ++slot) a.sell_col[a.sell_off[sl] + (int64_t)slot * a.sell_rows + q] = (int32_t)r;
   }
   double m = rowsum;
   for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
