@@ -342,17 +342,13 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.nnz = (int64_t)ci.size();
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
   lap("ishermitian + opnorm");
-  int64_t bw = 0;
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) bw = std::max<int64_t>(bw, std::llabs((long long)ci[k] - (long long)r));
-  op.bandwidth = bw;
-  lap("bandwidth");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size());
   lap("SELL layout");
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
   op.rows_sorted_unique = P.sorted_unique;
+  op.bandwidth = P.bandwidth;      // max |col - row|
   lap("pattern analysis");
   if (op.sell_ok) build_dia<V>(op, n, P);
   lap("DIA layout");

@@ -159,7 +159,7 @@ int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_
 /* New values on the SAME sparsity pattern (a Jacobian refreshed every time step): `vals` holds nnz values of the operator's
  * dtype in the order of the arrays the operator was created from (nzval order for op_create_csc, vals order for
  * op_create_csr); loc = EXPV_MI_HOST or EXPV_MI_DEVICE.  The stored forms are refilled on the device and ishermitian /
- * opnorm(A, Inf) re-evaluated -- ~20x cheaper than destroy + create (n = 1e6, nnz = 5e6: 2.6 ms against 44-52 ms).  The reference
+ * opnorm(A, Inf) re-evaluated -- ~20x cheaper than destroy + create (n = 1e6, nnz = 5e6: 2.6 ms against 36-42 ms).  The reference
  * has no counterpart because it reads A at call time (mul!(y, A, x)); a caller that mutates A in place calls this instead. */
 int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc);
 int expv_mi_op_destroy(expv_mi_op_t op);
