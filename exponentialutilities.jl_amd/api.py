@@ -251,6 +251,13 @@ class _Arg:
                         raise TypeError("output matrix must be column-major (e.g. torch.empty(k, n).t())")
                     x = x.t().contiguous().t()
                 self.ld = x.stride(1) if x.shape[1] > 1 else max(x.shape[0], 1)
+            # The library works on its own (non-blocking) stream: whatever torch still has in flight for this tensor -- the
+            # kernel that produced it, the conversion / layout copy above -- must be complete before the library touches it.
+            # (A device-resident dense operator read its column-major copy while torch was still writing it: opnorm 65 instead
+            # of 74 at n = 8192.)  An idle stream costs a few microseconds.
+            st = torch.cuda.current_stream(x.device)
+            if not st.query():
+                st.synchronize()
             self.ptr, self.loc, self.shape, self.keep = x.data_ptr(), L.DEVICE, tuple(x.shape), x
         else:
             a = np.asarray(x)
@@ -359,12 +366,23 @@ class MIOperator:
             else:
                 M = np.asarray(A)
                 dt = _work_dtype(M.dtype if dtype is None else dtype)
-                M = np.asfortranarray(M, dtype=dt)
                 if M.ndim != 2 or M.shape[0] != M.shape[1]:
                     raise DimensionMismatch("operator must be square")
                 n = M.shape[0]
-                _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, M.ctypes.data, max(n, 1), L.HOST,
-                                                   C.byref(h)), self.ctx._h)
+                if n >= 256 and not M.flags.f_contiguous:
+                    # a row-major array would be transposed on the host first (numpy: 4 s at n = 8192): upload it as it lies
+                    # and lay it out column-major on the device (torch is the device-memory plumbing here)
+                    import torch
+                    Ad = torch.as_tensor(np.ascontiguousarray(M, dtype=dt), device="cuda:%d" % self.ctx.device)
+                    arg = _Arg(Ad, dt)
+                    del Ad
+                    _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, arg.ptr, arg.ld, L.DEVICE,
+                                                       C.byref(h)), self.ctx._h)
+                    self._keep = arg
+                else:
+                    M = np.asfortranarray(M, dtype=dt)
+                    _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, M.ctypes.data, max(n, 1), L.HOST,
+                                                       C.byref(h)), self.ctx._h)
         self._h = h
         self._finalizer = weakref.finalize(self, lib.expv_mi_op_destroy, h)
         try:            # element type the caller handed over (Float32 operands: see _ref_dtype)

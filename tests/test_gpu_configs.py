@@ -770,3 +770,29 @@ def test_values_only_update_equals_a_new_operator(eu):
     w1 = np.asarray(eu.expv(0.4, A, b, m=20, ishermitian=False))
     close(w1, ko.expv(0.4, A, b, m=20, ishermitian=False), 1e-12, "expv after an in-place change of A.data (convenience form) vs oracle")
     assert not np.array_equal(w0, w1)
+
+
+@pytest.mark.gpu
+def test_dense_operator_properties_do_not_depend_on_where_the_matrix_came_from(eu):
+    """A dense operator handed over as a row-major numpy array (uploaded as it lies, laid out column-major on the device), as
+    a column-major numpy array, or as a torch tensor already on the GPU reports the same opnorm(A, Inf) / ishermitian / nnz and
+    applies identically -- in particular the library must not read a torch tensor (or the layout copy made for it) before
+    torch has finished writing it."""
+    import torch
+    rng = np.random.default_rng(8)
+    n = 3000
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    A[5, 7] = 0.0
+    x = rng.standard_normal(n)
+    ref = float(np.abs(A).sum(axis=1).max())
+    for trial in range(3):
+        ops = [eu.MIOperator(A), eu.MIOperator(np.asfortranarray(A)), eu.MIOperator(torch.as_tensor(A, device="cuda")),
+               eu.MIOperator(torch.as_tensor(np.asfortranarray(A).T.copy(), device="cuda").t())]
+        for op in ops:
+            assert abs(op.opnorm_inf - ref) <= 4e-16 * ref * n ** 0.5, (trial, op.opnorm_inf, ref)
+            assert op.opnorm_inf == ops[0].opnorm_inf and op.ishermitian == ops[0].ishermitian is False and op.nnz == n * n - 1
+        ys = [np.asarray(eu.expv(0.3, op, x, m=12)) for op in ops]
+        for y in ys[1:]:
+            assert np.array_equal(y, ys[0]), trial
+    S = A + A.T
+    assert eu.MIOperator(torch.as_tensor(S, device="cuda")).ishermitian and eu.MIOperator(S).ishermitian
