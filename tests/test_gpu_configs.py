@@ -796,3 +796,40 @@ def test_dense_operator_properties_do_not_depend_on_where_the_matrix_came_from(e
             assert np.array_equal(y, ys[0]), trial
     S = A + A.T
     assert eu.MIOperator(torch.as_tensor(S, device="cuda")).ishermitian and eu.MIOperator(S).ishermitian
+
+
+@pytest.mark.gpu
+def test_ishermitian_of_sparse_operators_edge_cases(eu):
+    """LinearAlgebra.ishermitian on a sparse matrix ignores stored zeros.  The creation-time test looks for one stored entry
+    without its conjugate partner before it transposes anything, the update-time test runs on the device: both must agree
+    with the dense definition on the awkward cases."""
+    rng = np.random.default_rng(12)
+    n = 6000
+    def dense_herm(M):
+        D = M.toarray()
+        return bool(np.array_equal(D, D.conj().T))
+    base = sp.random(n, n, density=5.0 / n, random_state=9, format="csr")
+    H = (base + base.T).tocsr(); H.sort_indices()                       # Hermitian (real symmetric)
+    late = H.copy().tolil(); late[5000, 17] = 0.25; late = late.tocsr(); late.sort_indices()   # one asymmetric entry far down
+    zero_partner = H.copy().tolil(); zero_partner[40, 90] = 0.0; zero_partner[90, 40] = 0.0
+    zero_partner = zero_partner.tocsr()
+    stored_zero_only_one_side = H.copy().tolil(); stored_zero_only_one_side[7, 3000] = 1.0; stored_zero_only_one_side = stored_zero_only_one_side.tocsr()
+    stored_zero_only_one_side[7, 3000] = 0.0                                  # explicit zero without a partner: still Hermitian
+    Hc = (H + 1j * (sp.triu(H, 1) - sp.triu(H, 1).T)).tocsr(); Hc.sort_indices()   # complex Hermitian
+    bad_diag = Hc.copy().tolil(); bad_diag[11, 11] = 1.0 + 0.5j; bad_diag = bad_diag.tocsr()   # diagonal not real
+    cases = {"symmetric": H, "asymmetric entry in row 5000": late, "pair of stored zeros": zero_partner,
+             "stored zero without partner": stored_zero_only_one_side, "complex Hermitian": Hc, "complex, diagonal not real": bad_diag,
+             "plain non-symmetric": base.tocsr()}
+    for name, M in cases.items():
+        want = dense_herm(M)
+        for fmt in ("csr", "csc"):
+            Mf = M.asformat(fmt); Mf.sort_indices()
+            op = eu.MIOperator(Mf)
+            assert op.ishermitian == want, (name, fmt, op.ishermitian, want)
+            op.update_values(Mf)                                             # the device-side test on the same values
+            assert op.ishermitian == want, (name, fmt, "after update", op.ishermitian, want)
+    # an update can make a non-Hermitian operator Hermitian and back
+    A0 = H.copy(); A0.data = A0.data * (1.0 + 0.1 * rng.standard_normal(A0.nnz))
+    op = eu.MIOperator(A0)
+    assert not op.ishermitian
+    assert op.update_values(H).ishermitian and not op.update_values(A0).ishermitian
