@@ -490,6 +490,7 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   if (ctx->ws_kiops && ctx->ws_kiops_free) ctx->ws_kiops_free(ctx->ws_kiops);
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
   if (ctx->ws_ts && ctx->ws_ts_free) ctx->ws_ts_free(ctx->ws_ts);
+  if (ctx->ws_batch_pat && ctx->ws_batch_pat_free) ctx->ws_batch_pat_free(ctx->ws_batch_pat);
   if (ctx->ws_batch && ctx->ws_batch_free) ctx->ws_batch_free(ctx->ws_batch);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

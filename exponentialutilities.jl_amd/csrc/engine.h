@@ -82,6 +82,8 @@ struct Ctx {
   void *ks_spare = nullptr;   // storage of the last destroyed KrylovSubspace (expv_mi_ks_s *), handed to the next create of the same shape
   void *ws_ts = nullptr;      // cached work arrays + KrylovSubspace of a phiv_timestep! call without caches (owned; engine_drivers.hip)
   void (*ws_ts_free)(void *) = nullptr;
+  void *ws_batch_pat = nullptr;   // cached DIA layout of the last batch's shared pattern (owned; engine_batch.hip)
+  void (*ws_batch_pat_free)(void *) = nullptr;
   void *ws_batch = nullptr;   // cached device buffers of expv_batch (owned; see engine_batch.hip)
   size_t ws_batch_bytes = 0;  // ... and how many bytes they hold
   void (*ws_batch_free)(void *) = nullptr;

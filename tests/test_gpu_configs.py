@@ -833,3 +833,31 @@ def test_ishermitian_of_sparse_operators_edge_cases(eu):
     op = eu.MIOperator(A0)
     assert not op.ishermitian
     assert op.update_values(H).ishermitian and not op.update_values(A0).ishermitian
+
+
+@pytest.mark.gpu
+def test_batch_pattern_cache_follows_a_changed_pattern(eu):
+    """expv_batch keeps the DIA layout of the shared pattern (and its device permutation) in the context between calls.  Same
+    n and nnz, other column indices; a pattern that comes back; values passed again on the cached pattern: every call equals
+    the single-problem results."""
+    rng = np.random.default_rng(33)
+    n, nprob, m = 4000, 6, 20
+    ctx = eu.Context()
+    def pattern(offsets):
+        M = sp.diags([rng.standard_normal(n - abs(o)) * 0.4 - (2.0 if o == 0 else 0.0) for o in offsets], offsets, format="csr")
+        M.sort_indices()
+        return M
+    P1, P2 = pattern([-2, -1, 0, 1, 2]), pattern([-3, -1, 0, 1, 3])
+    P3 = P1.copy()                                   # same n, same nnz, one entry elsewhere: (10, 12) -> (10, 5)
+    k0 = P3.indptr[10]
+    assert list(P3.indices[k0:k0 + 5]) == [8, 9, 10, 11, 12]
+    P3.indices[k0:k0 + 5] = [5, 8, 9, 10, 11]
+    assert P3.nnz == P1.nnz and P3.has_canonical_format
+    for rnd, P in enumerate([P1, P2, P1, P3, P3, P1, P2]):
+        vals = np.stack([P.data * (1.0 + 0.2 * rng.standard_normal(P.nnz)) for _ in range(nprob)])
+        B = np.asfortranarray(rng.standard_normal((n, nprob)))
+        W = eu.expv_batch(0.7, P, vals, B, m=m, ctx=ctx)
+        for p in range(nprob):
+            Ap = P.copy()
+            Ap.data = vals[p].copy()
+            close(W[:, p], ko.expv(0.7, Ap, B[:, p], m=m, ishermitian=False), 1e-12, "batch call %d, column %d vs oracle" % (rnd, p))
