@@ -12,6 +12,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <future>
 #include <thread>
 #include <type_traits>
 
@@ -228,7 +230,9 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     HIPCHECK(hipMemcpyAsync(sch.data() + (size_t)q0 * (m + 2), dsc.as<double>() + (int64_t)q0 * (m + 2), sizeof(double) * (size_t)(m + 2) * pc,
                             hipMemcpyDeviceToHost, s));
   };
-  auto finish = [&](int p0, int q0, int pc) {   // host exponentials of a factorised sub-chunk, then its combine
+  // wait(): called by the caller's thread once the workers exist and before they may read the sub-chunk's H -- the last
+  // sub-chunk passes the stream synchronisation here, so its workers are created while the device is still factorising
+  auto finish = [&](int p0, int q0, int pc, const std::function<void()> &wait) {   // host exponentials of a factorised sub-chunk, then its combine
     auto solve_one = [&](int q) {
       const StepState &h = sth[q];
       const double beta = std::sqrt(h.beta0sq);
@@ -261,13 +265,20 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       const int nth = (int)std::max(1u, std::min(std::min(std::thread::hardware_concurrency(), 16u), (unsigned)((pc + 7) / 8)));
       std::vector<std::thread> th;
       std::vector<std::string> errs(nth);
+      std::promise<void> go;
+      std::shared_future<void> ready = go.get_future().share();
       for (int w = 0; w < nth; ++w)
-        th.emplace_back([&, w] {
+        th.emplace_back([&, w, ready] {
           try {
+            ready.wait();
             for (int q = q0 + w; q < q0 + pc; q += nth) solve_one(q);
           } catch (const std::exception &e) { errs[w] = e.what(); }
         });
+      std::string wait_err;
+      try { wait(); } catch (const std::exception &e) { wait_err = e.what(); pc = 0; }   // (the workers still have to be released and joined)
+      go.set_value();
       for (auto &x : th) x.join();
+      if (!wait_err.empty()) fail(EXPV_MI_HIP_ERROR, wait_err);
       for (auto &e : errs)
         if (!e.empty()) fail(EXPV_MI_SINGULAR, e);
     }
@@ -293,14 +304,12 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       factorise(p0, q0, pc);
       HIPCHECK(hipEventRecord(ev_done[k & 1], s));
       if (prev_q0 >= 0) {                       // the previous sub-chunk: its exponentials run while this one factorises
-        HIPCHECK(hipEventSynchronize(ev_done[(k - 1) & 1]));
-        finish(p0, prev_q0, prev_pc);
+        finish(p0, prev_q0, prev_pc, [&] { HIPCHECK(hipEventSynchronize(ev_done[(k - 1) & 1])); });
       }
       prev_q0 = q0;
       prev_pc = pc;
     }
-    HIPCHECK(hipStreamSynchronize(s));          // the last sub-chunk's results, and the buffers are free for the next chunk afterwards
-    finish(p0, prev_q0, prev_pc);
+    finish(p0, prev_q0, prev_pc, [&] { HIPCHECK(hipStreamSynchronize(s)); });          // the last sub-chunk's results
     HIPCHECK(hipStreamSynchronize(s));
     if (tm) std::fprintf(stderr, "[batch timing] chunk of %d problems in %d pipelined sub-chunk(s): %.1f ms\n", pc_all, nsub,
                          std::chrono::duration<double, std::milli>(now() - t_chunk).count());
