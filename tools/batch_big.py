@@ -1,3 +1,4 @@
+"""expv_batch on a few LARGE problems (n = 1e6): the command rocprofv3 traces for the batch timeline.  usage: python tools/batch_big.py [nprob]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

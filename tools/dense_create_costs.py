@@ -1,3 +1,4 @@
+"""Creation time of a dense operator from a host array and from a device-resident tensor, and whether both report the same properties."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Where the time of a dense operator built from a row-major numpy array goes (numpy transposing copy vs the library call vs a plain upload)."""
 import sys, time, ctypes as C
 sys.path.insert(0, ".")
 import numpy as np, torch

@@ -1,3 +1,5 @@
+"""Creation time of a sparse operator (n = 1e6, nnz = 5e6) from CSR / CSC / DIA-format scipy matrices and of the Python-side conversions;
+with EXPV_MI_OP_TIMING=1 the library prints the phases of each build."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch, scipy.sparse as sp

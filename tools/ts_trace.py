@@ -1,3 +1,4 @@
+"""A few adaptive expv_timestep calls at n = 1e6 (config-2 operator): the command rocprofv3 traces for the integrator-path timeline."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
