@@ -89,6 +89,12 @@ def alg_bytes_kernel(name, n, nnz, m, s=8):
     }.get(name)
 
 
+def pmc_traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return os.path.relpath(files[-1], ROOT) if files else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs, gfx950 x2 read correction applied: tools/pmc_summary.py).  PMC collection
@@ -123,8 +129,9 @@ class Env:
     """Where the bench runs: device of the torch tensors, the process group, and how to wait for the device.
     The gloo CPU test (tests/test_dist_gloo.py) drives run_c5 with device="cpu" and a stand-in solver."""
 
-    def __init__(self, torch, dist, world, rank, device, ctx):
+    def __init__(self, torch, dist, world, rank, device, ctx, standin=None):
         self.torch, self.dist, self.world, self.rank, self.device, self.ctx = torch, dist, world, rank, device, ctx
+        self.standin = standin          # name of the stand-in solver module (CPU plumbing tests only), or None
 
     def sync(self):
         if str(self.device).startswith("cuda"):
@@ -145,6 +152,32 @@ class Env:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(round(float(t.item())))
 
+    def device_ids(self):
+        """what every rank is bound to, in rank order: host + the GPU's uuid / PCI address (the stand-in: host + pid)."""
+        import socket
+        if str(self.device).startswith("cuda"):
+            idx = self.torch.device(self.device).index or 0
+            pr = self.torch.cuda.get_device_properties(idx)
+            ident = getattr(pr, "uuid", None)
+            if ident is None:
+                ident = "pci-%s:%s.%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", idx))
+            mine = "%s/%s" % (socket.gethostname(), ident)
+        else:
+            mine = "%s/pid%d" % (socket.gethostname(), os.getpid())
+        if self.world == 1:
+            return [mine]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return out
+
+    def check_ranks(self, want):
+        """Fail loudly unless `want` ranks took part and every one of them is bound to its own device."""
+        seen, ids = self.ranks_seen(), self.device_ids()
+        if seen != want or len(set(ids)) != want:
+            raise SystemExit("bench.py --gpus %d: %d rank(s) took part, bound to %d distinct device(s) %s -- refusing to report "
+                             "a %d-GPU number" % (want, seen, len(set(ids)), ids, want))
+        return seen, ids
+
     def per_rank(self, x):
         """every rank's value of a scalar, in rank order."""
         if self.world == 1:
@@ -164,8 +197,8 @@ def c5_problem(n, p, A0_data):
 
 def c3_rows(torch, device, n, lo, hi, chunk=4096):
     """Rows [lo, hi) of the config-3 operator A = -2 I + randn(n, n) / sqrt(n), generated on the device block by block with a
-    per-block seed, so any partition of the rows over ranks produces the same matrix."""
-    rows = torch.empty((hi - lo, n), dtype=torch.float64, device=device)
+    per-block seed, so any partition of the rows over ranks produces the same matrix.  Returned column-major."""
+    rows = torch.empty((n, hi - lo), dtype=torch.float64, device=device).t()     # column-major (hi - lo) x n: the library's layout
     r = lo
     while r < hi:
         b0 = (r // chunk) * chunk                      # blocks are aligned to `chunk` rows of the GLOBAL matrix
@@ -183,13 +216,14 @@ def c3_rows(torch, device, n, lo, hi, chunk=4096):
     return rows
 
 
-def run_c3(args, eu, env):
+def run_c3(args, eu, env, emit=True):
     """BASELINE configs[2]: phiv_timestep, adaptive, K = 4, dense fp64.  n = 2e5 (320 GB) does not fit one MI355X: with
     --gpus >= 2 the rows of A are sharded over the ranks (dist.RowShardedDense: local GEMV + one all-gather of the n-vector per
     operator application, the Krylov iteration replicated); at --gpus 1 the largest n that fits is used unless --n3 says
     otherwise.  Unit: operator applications (all mul! calls of the reference: p + m per sub-step + m per retry)."""
     torch, D = env.torch, load_dist_module()
     world, rank = env.world, env.rank
+    seen, ids = env.check_ranks(world)
     n = args.n3 if args.n3 > 0 else (200_000 if world > 1 else 163_840)
     lo, hi = D.shard_range(n, world, rank)
     rows = c3_rows(torch, env.device, n, lo, hi)
@@ -230,12 +264,17 @@ def run_c3(args, eu, env):
            "config": {"workload": "BASELINE configs[2]: phiv_timestep(1.0, A, B; adaptive, tol=1e-7, m0=10), dense A n=%d (%.1f GB), "
                                   "rows sharded over %d GPU(s)" % (n, 8e-9 * n * n, world), "n": n, "K": 4},
            "stats": {k: st.get(k) for k in ("num_timesteps", "matvecs", "m")}, "applications_per_call": apps / args.steps,
-           "ranks_seen": env.ranks_seen(), "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
            "verified": {"replicas_bitwise_equal": same},
            "roofline": {"bound": "hbm", "achieved": gbps_per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps_per_gpu / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "local GEMV (rocBLAS through torch.mv) + all_gather of n*8 B",
+                        "traffic": None, "kernel": "k_gemv_dense on the rank's column-major row block (expv_mi_gemv_block) + all_gather of n*8 B",
                         "alg_bytes_per_launch": bytes_per_app / world}}
-    if rank == 0:
+    if env.standin:
+        out["standin"] = env.standin
+        out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
+    if not same:
+        raise SystemExit("config 3: the replicated iteration differs between ranks")
+    if rank == 0 and emit:
         print(json.dumps(out), flush=True)
     return out
 
@@ -246,6 +285,7 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
     of the gathered result are recomputed on this rank through the single-problem entry point and compared."""
     torch, D = env.torch, load_dist_module()
     nprob, world, rank = args.nprob, env.world, env.rank
+    seen, ids = env.check_ranks(world)
     A0 = c2_operator(n).tocsr()
     A0.sort_indices()
     nnz = A0.nnz
@@ -255,9 +295,11 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
     Bh = np.stack([np.random.default_rng(1000 + p).standard_normal(n) for p in range(lo, hi)])
     B = torch.as_tensor(Bh, device=env.device).t()
 
+    local = {}
+
     def step():
-        W = eu.expv_batch(T_FINAL, A0, vals, B, m=m, ctx=env.ctx)
-        return D.gather_columns(W, nprob) if world > 1 else W
+        local["W"] = eu.expv_batch(T_FINAL, A0, vals, B, m=m, ctx=env.ctx)
+        return D.gather_columns(local["W"], nprob) if world > 1 else local["W"]
 
     for _ in range(args.warmup):
         step()
@@ -268,6 +310,15 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
     env.barrier()
     elapsed_local = time.perf_counter() - t0
     units, elapsed = D.aggregate_throughput((hi - lo) * m * args.steps, elapsed_local, device=env.device)
+    # ---- the final gather alone (untimed extra): the one collective of the path, n x nprob fp64 over all ranks ----
+    gather_ms = None
+    if world > 1:
+        env.barrier()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            D.gather_columns(local["W"], nprob)
+        env.barrier()
+        gather_ms = max(env.per_rank(1e3 * (time.perf_counter() - tg) / args.steps))
     # ---- verification (untimed): the gathered matrix against a rank-local recomputation of two random columns ----
     cols = sorted(set(int(c) for c in np.random.default_rng(4242 + rank).integers(0, nprob, size=2)))
     worst = 0.0
@@ -287,16 +338,21 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: %d independent expv, n=%d, 5-diagonal, m=%d, sharded over %d "
                                   "GPU(s), final gather" % (nprob, n, m, world), "nprob": nprob, "n": n, "m": m},
-           "ranks_seen": env.ranks_seen(), "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "gather": {"ms": gather_ms, "bytes_total": 8.0 * n * nprob,
+                      "what": "the final all_gather of the n x nprob result alone (inside ms_per_step too); null at one rank"},
            "verified": {"columns_per_rank": 2, "columns_rank0": cols, "max_rel_err": worst_all, "bar": 1e-12,
                         "how": "gathered W[:, p] vs expv(t, A_p, b_p) recomputed on the checking rank"},
            "roofline": {"bound": "hbm", "achieved": per_gpu_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": per_gpu_gbps / HBM_PEAK_GBS, "traffic": None,
                         "note": "whole-call algorithmic GB/s per GPU (V of a problem is cache-resident)"}}
+    if env.standin:
+        out["standin"] = env.standin
+        out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
     if worst_all > 1e-12:
         raise SystemExit("config 5: gathered result differs from the recomputed columns: %.3e" % worst_all)
     if rank == 0 and emit:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     return out
 
 
@@ -456,12 +512,33 @@ def cpu_baseline_block(A, b_host, w_dev, m, n):
     return out
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) of this same script under
+    torch.distributed.run on this node and hand back its exit status.  Rendezvous on 127.0.0.1."""
+    import subprocess
+    argv = ["--rows" if a == "--n" else a for a in argv]     # (torch.distributed.run's own parser would claim a bare --n)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ngpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    envv = dict(os.environ)
+    envv.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    envv.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=envv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_ROWS, help="override problem size (debug only; invalidates the metric)")
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=N_ROWS, help="override problem size (debug only; invalidates the metric)")
     ap.add_argument("--ortho", default="auto", choices=["auto", "mgs", "lowsync"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (split API, Lanczos, C4, C5)")
@@ -472,37 +549,64 @@ def main():
                     help="c2 (default, the headline metric), c5: batch of --nprob independent n=1e5 problems, or c3: adaptive "
                          "phiv_timestep on a dense operator whose rows are sharded over the ranks")
     ap.add_argument("--n3", type=int, default=0, help="c3: operator size (default 2e5 on >= 2 GPUs, 163840 on one)")
+    ap.add_argument("--n5", type=int, default=100_000, help="c5: problem size (debug only)")
     ap.add_argument("--nprob", type=int, default=1024, help="c5: total number of problems over all GPUs")
-    args = ap.parse_args()
+    ap.add_argument("--standin", default="", help="TESTING ONLY: module with the product's Python signatures run on CPU tensors "
+                                                  "under gloo (tests/standin_eu.py) -- exercises launch, sharding, collectives "
+                                                  "and verification of this script without a GPU; its output is labelled and "
+                                                  "is not a measurement")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (the driver's own form, torch.distributed.run, sets WORLD_SIZE)
+        raise SystemExit(launch_ranks(args.gpus, argv))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d: one rank per GPU is the contract" % (args.gpus, world))
+    if args.standin:
+        import importlib
+        eu = importlib.import_module(args.standin).StandIn
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        env = Env(torch, dist, world, rank, "cpu", None, standin=args.standin)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d wants GPU %d, the node shows %d" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import expv_mi_loader
+        eu = expv_mi_loader.load()
+        # device-resident results are stream-ordered (like any HIP library); barrier() below syncs the context
+        ctx = eu.Context(device=local_rank, async_outputs=not args.sync_outputs)
+        env = Env(torch, dist, world, rank, torch.device("cuda", local_rank), ctx)
+    try:
+        if args.config == "c5":
+            run_c5(args, eu, env, n=args.n5)
+        elif args.config == "c3":
+            run_c3(args, eu, env)
+        else:
+            run_c2(args, eu, env)
+    finally:
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
 
-    import expv_mi_loader
-    eu = expv_mi_loader.load()
-    # device-resident results are stream-ordered (like any HIP library); barrier() below syncs the context
-    ctx = eu.Context(device=local_rank, async_outputs=not args.sync_outputs)
-    env = Env(torch, dist, world, rank, torch.device("cuda", local_rank), ctx)
-    if args.config == "c5":
-        run_c5(args, eu, env)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    if args.config == "c3":
-        run_c3(args, eu, env)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+
+def run_c2(args, eu, env):
+    """BASELINE configs[1], the headline: one independent expv problem per rank (weak scaling, no data-path collective)."""
+    torch, dist, ctx = env.torch, env.dist, env.ctx
+    world, rank = env.world, env.rank
+    seen, ids = env.check_ranks(world)
     n, m = args.n, M_KRYLOV
     A = c2_operator(n)
     nnz = A.nnz
@@ -510,8 +614,8 @@ def main():
     op = eu.MIOperator(A, ctx)                      # CSR32 upload + properties: setup, not timed
     t_setup = time.perf_counter() - t_setup
     b_host = np.random.default_rng(3 + rank).standard_normal(n)
-    b = torch.as_tensor(b_host, device="cuda")
-    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    b = torch.as_tensor(b_host, device=env.device)
+    w = torch.empty(n, dtype=torch.float64, device=env.device)
     Ks = eu.KrylovSubspace(np.float64, np.float64, n, m, 0, ctx) if args.split_api else None
 
     def one_expv():
@@ -531,30 +635,28 @@ def main():
         units += one_expv()
     env.barrier()
     elapsed_local = time.perf_counter() - t0
-    elapsed = elapsed_local
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        uu = torch.tensor([units], dtype=torch.float64, device="cuda")
-        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
-        units_total = float(uu.item())
-    else:
-        units_total = float(units)
+    elapsed = max(env.per_rank(elapsed_local))                 # MAX over ranks
+    units_total = float(sum(env.per_rank(units)))              # SUM over ranks
     value = units_total / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
-    ranks_seen = env.ranks_seen()
     per_rank_ms = [1e3 * v / args.steps for v in env.per_rank(elapsed_local)]
     path = list(getattr(eu.expv, "last_stats", {}).get("path", [])) if not args.split_api else None
+    if world > 1:
+        # every rank ran its own problem: their results must all be finite and different (distinct right-hand sides)
+        chk = env.per_rank(float(w.abs().sum()))
+        if not (all(np.isfinite(chk)) and len(set(chk)) == world):
+            raise SystemExit("config 2 at %d ranks: per-rank results are not %d distinct finite vectors: %s" % (world, world, chk))
 
     # ---- per-kernel HIP-event timing of the same K steps (separate pass: events perturb the headline) ---
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    for _ in range(args.steps):
-        one_expv()
-    ctx.sync()
-    prof = ctx.prof_get()
-    ctx.prof_enable(False)
+    prof = {}
+    if ctx is not None:
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(args.steps):
+            one_expv()
+        ctx.sync()
+        prof = ctx.prof_get()
+        ctx.prof_enable(False)
     # the single-pass pipeline records its step kernel under "fused_a" and has no per-step "fused_b"
     pipeline = "fused_a" in prof and prof.get("fused_b", {"launches": 0})["launches"] < prof["fused_a"]["launches"] / 2
     if pipeline:
@@ -600,6 +702,9 @@ def main():
         "achieved": kern[dom]["alg_GBps"] if dom else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (kern[dom]["alg_GBps"] / HBM_PEAK_GBS) if dom and kern[dom]["alg_GBps"] else None,
         "traffic": traffic,
+        "traffic_source": ("replayed from the committed rocprofv3 PMC pass %s (FETCH_SIZE / WRITE_SIZE in separate runs of this "
+                           "command, gfx950 read correction; counters cannot be collected from inside the timed process)"
+                           % pmc_traffic_file()) if traffic is not None else None,
         "avg_launch_ms": kern[dom]["avg_ms"] if dom else None,
         "alg_bytes_per_launch": kern[dom]["alg_bytes_per_launch"] if dom else None,
         "expv_alg_GBps": expv_gbps, "expv_frac": expv_gbps / HBM_PEAK_GBS,
@@ -623,20 +728,22 @@ def main():
                    "n": n, "m": m, "nnz": int(nnz), "ortho": args.ortho, "setup_s": t_setup,
                    "entry": "arnoldi!+expv!" if args.split_api else "expv(t,A,b)", "path": path,
                    "outputs": "complete on return" if args.sync_outputs else "stream-ordered"},
-        "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
-        "counters": ctx.counters(),
+        "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": per_rank_ms,
+        "counters": ctx.counters() if ctx is not None else None,
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_secondary and n == N_ROWS and not args.split_api:
+    if rank == 0 and world == 1 and not args.no_secondary and n == N_ROWS and not args.split_api and ctx is not None:
         out["secondary"] = secondary_block(args, eu, env, op, b, w, n, nnz, m)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and ctx is not None:
         eu.expv(T_FINAL, op, b, m=m, ishermitian=False, ortho=args.ortho, out=w)
         env.sync()
         out["cpu_baseline"] = cpu_baseline_block(A, b_host, w.cpu().numpy(), m, n)
+    if env.standin:
+        out["standin"] = env.standin
+        out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == "__main__":

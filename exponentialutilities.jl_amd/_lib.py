@@ -90,6 +90,7 @@ PROTOTYPES = {
     "expv_mi_op_update_values": (_i, [_vp, _vp, _i]),
     "expv_mi_op_info": (_i, [_vp, _pi64, _pi64, _pi, _pd, _pi]),
     "expv_mi_op_apply": (_i, [_vp, _vp, _i, _vp, _i]),
+    "expv_mi_gemv_block": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i]),
     "expv_mi_ks_create": (_i, [_vp, _i, _i, _i64, _i, _i, _pvp]),
     "expv_mi_ks_destroy": (_i, [_vp]),
     "expv_mi_ks_resize": (_i, [_vp, _i]),

@@ -813,6 +813,26 @@ int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_l
   });
 }
 
+int expv_mi_gemv_block(expv_mi_ctx_t ctx, int dtype, int64_t nrows, int64_t ncols, const void *A, int64_t lda,
+                       const void *x, void *y, void *scratch, int nsplit) {
+  return guarded(ctx, [&] {
+    ctx->use();
+    check_device_dtype(dtype, "gemv_block");
+    if (nrows < 0 || ncols < 0 || lda < nrows) fail(EXPV_MI_ARGUMENT_ERROR, "gemv_block: bad nrows / ncols / lda");
+    if (nrows == 0) return;
+    if (!A || !x || !y) fail(EXPV_MI_ARGUMENT_ERROR, "gemv_block: null pointer");
+    if (nsplit > 1 && !scratch) fail(EXPV_MI_ARGUMENT_ERROR, "gemv_block: nsplit > 1 needs scratch");
+    ++ctx->cnt_opapply;
+    ProfScope ps(ctx, EXPV_MI_K_MATVEC);
+    if (dtype == EXPV_MI_C64)
+      dev::gemv_dense<cplx>(ctx->stream, nrows, reinterpret_cast<const cplx *>(A), lda, reinterpret_cast<const cplx *>(x),
+                            reinterpret_cast<cplx *>(y), reinterpret_cast<cplx *>(scratch), nsplit, nullptr, 0, ncols);
+    else
+      dev::gemv_dense<double>(ctx->stream, nrows, reinterpret_cast<const double *>(A), lda, reinterpret_cast<const double *>(x),
+                              reinterpret_cast<double *>(y), reinterpret_cast<double *>(scratch), nsplit, nullptr, 0, ncols);
+  });
+}
+
 // ------------------------------------------------------------------ KrylovSubspace ----------
 int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, int maxiter, int augmented,
                       expv_mi_ks_t *out) {

@@ -104,7 +104,7 @@ void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *co
               T *y, const StepState *st, int step);
 template <class T>
 void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
-                const StepState *st, int step);
+                const StepState *st, int step, int64_t ncols = -1);   // n rows x ncols columns (ncols < 0: square)
 // ishermitian / opnorm(A, Inf) / count(!iszero) of a device-resident dense matrix (kernels.hip); scratch: nsplit * n
 // doubles, res: 3 words {opnorm bits, nnz, "not Hermitian"} zeroed by the caller
 template <class T>

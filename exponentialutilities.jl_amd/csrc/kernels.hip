@@ -284,16 +284,16 @@ void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *co
 // Dense column-major GEMV: grid (row tiles, column splits).  Each lane owns 16 B of rows and streams
 // its column range with 8 independent 16-B loads in flight; x[c] is wave-uniform (scalar loads).
 template <class T>
-__global__ __launch_bounds__(BLOCK) void k_gemv_dense(int64_t n, const T *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(BLOCK) void k_gemv_dense(int64_t n, int64_t ncols, const T *__restrict__ A, int64_t lda,
                                                       const T *__restrict__ x, T *__restrict__ out, int64_t out_stride,
                                                       const StepState *st, int step) {
   if (step_skipped(st, step)) return;
   constexpr int N = Pack<T>::N;
   const int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N;
   const int nsplit = gridDim.y;
-  const int64_t cper = (n + nsplit - 1) / nsplit;
+  const int64_t cper = (ncols + nsplit - 1) / nsplit;
   const int64_t cbeg = (int64_t)blockIdx.y * cper;
-  const int64_t cend = (cbeg + cper < n) ? cbeg + cper : n;
+  const int64_t cend = (cbeg + cper < ncols) ? cbeg + cper : ncols;
   const bool al = is_al16(A) && ((lda * sizeof(T)) % 16 == 0);
   Pack<T> acc;
 #pragma unroll
@@ -335,13 +335,15 @@ __global__ __launch_bounds__(BLOCK) void k_sum_splits(int64_t n, const T *__rest
 }
 template <class T>
 void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
-                const StepState *st, int step) {
+                const StepState *st, int step, int64_t ncols) {
+  // n rows (16 B of them per lane), ncols columns (< 0: square); y = A x
+  if (ncols < 0) ncols = n;
   const int rows_per_block = BLOCK * Pack<T>::N;
   const int gx = (int)((n + rows_per_block - 1) / rows_per_block);
   if (nsplit <= 1 || scratch == nullptr) {
-    hipLaunchKernelGGL(k_gemv_dense<T>, dim3(gx, 1), dim3(BLOCK), 0, s, n, A, lda, x, y, (int64_t)0, st, step);
+    hipLaunchKernelGGL(k_gemv_dense<T>, dim3(gx, 1), dim3(BLOCK), 0, s, n, ncols, A, lda, x, y, (int64_t)0, st, step);
   } else {
-    hipLaunchKernelGGL(k_gemv_dense<T>, dim3(gx, nsplit), dim3(BLOCK), 0, s, n, A, lda, x, scratch, n, st, step);
+    hipLaunchKernelGGL(k_gemv_dense<T>, dim3(gx, nsplit), dim3(BLOCK), 0, s, n, ncols, A, lda, x, scratch, n, st, step);
     hipLaunchKernelGGL(k_sum_splits<T>, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, n, scratch, n, nsplit, y, st,
                        step);
   }
@@ -756,7 +758,7 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void spmv_csr<T>(hipStream_t, int64_t, const int32_t *, const int32_t *, const T *, const T *, T *,     \
                             const StepState *, int);                                                                    \
   template void gemv_dense<T>(hipStream_t, int64_t, const T *, int64_t, const T *, T *, T *, int,                  \
-                              const StepState *, int);                                                                  \
+                              const StepState *, int, int64_t);                                                                \
   template void aug_apply<T>(hipStream_t, int64_t, int, const T *, int64_t, const T *, T *, const StepState *,     \
                              int);                                                                                 \
   template void dots<T>(hipStream_t, const DotsArgs<T> &);                                                         \

@@ -74,12 +74,14 @@ def run_sharded(nprob, solve_one, make_block, group=None, rank=None, world_size=
 
 class RowShardedDense:
     """y = A x for a dense n x n operator whose ROWS are spread over the ranks of `group` (config 3: n = 2e5 fp64 is 320 GB,
-    more than the 288 GB of one MI355X).  Rank r holds rows [lo_r, hi_r) of A (shard_range(n, world, r)) as a row-major
-    torch tensor `rows` of shape (hi_r - lo_r, n); an application is the local GEMV (a plain library GEMV: rocBLAS through
-    torch.mv) followed by ONE all-gather of the result pieces (n * 8 B = 1.6 MB at n = 2e5; RCCL over xGMI with backend
-    "nccl").  Every rank then holds the same y, so a Krylov iteration driven by this operator runs replicated: the same
-    kernels on the same data on every rank (deterministic), no other communication, and every rank ends with the full
-    result.  `operator(eu, ctx)` wraps it as the library's matrix-free operator (expv_mi_op_create_callback)."""
+    more than the 288 GB of one MI355X).  Rank r holds rows [lo_r, hi_r) of A (shard_range(n, world, r)) as a tensor `rows`
+    of shape (hi_r - lo_r, n).  On the GPU the block must be COLUMN-MAJOR (``torch.empty(n, nloc).t()``: the library's layout,
+    krylov_phiv_adaptive.jl works on Julia matrices) and an application is the library's own dense GEMV on it
+    (expv_mi_gemv_block: the kernel of the dense operator's mul!, no vendor BLAS) followed by ONE all-gather of the result
+    pieces (n * 8 B = 1.6 MB at n = 2e5; RCCL over xGMI with backend "nccl").  Every rank then holds the same y, so a Krylov
+    iteration driven by this operator runs replicated: the same kernels on the same data on every rank (deterministic), no
+    other communication, and every rank ends with the full result.  `operator(eu, ctx)` wraps it as the library's matrix-free
+    operator (expv_mi_op_create_callback).  A CPU tensor (the gloo tests of the collective plumbing) takes torch.mv."""
 
     def __init__(self, rows, n, group=None, stage_through_host=False):
         import torch
@@ -94,19 +96,56 @@ class RowShardedDense:
         if tuple(rows.shape) != (self.hi - self.lo, self.n):
             raise ValueError("rank %d holds rows [%d, %d): expected a (%d, %d) block, got %s"
                              % (self.rank, self.lo, self.hi, self.hi - self.lo, self.n, tuple(rows.shape)))
+        self.on_gpu = bool(rows.is_cuda)
+        if self.on_gpu and self.hi > self.lo and not (rows.stride(0) == 1 and rows.stride(1) >= self.hi - self.lo):
+            raise ValueError("a device-resident row block must be column-major (torch.empty(n, nloc).t()): strides %s"
+                             % (tuple(rows.stride()),))
         self.width = max(shard_sizes(self.n, self.world))          # equal-size pieces for ONE fixed-size collective
         self.stage = bool(stage_through_host)                      # gloo has no device all-gather: CPU tests / fallback
         self._send = torch.zeros(self.width, dtype=rows.dtype, device=rows.device)
         self._recv = torch.empty(self.world * self.width, dtype=rows.dtype, device=rows.device)
         self.applications = 0
+        self._ctx = None
+        self._lib = None
+        if self.on_gpu:
+            # column splits like expv_mi_op_create_dense picks them: >= 1024 workgroups for a block with few row tiles
+            nloc = self.hi - self.lo
+            rows_per_block = 256 * (1 if rows.is_complex() else 2)
+            gx = max(1, -(-nloc // rows_per_block))
+            self._nsplit = 1 if nloc < 64 else min(64, max(1, -(-1024 // gx)))
+            self._scratch = torch.empty(max(1, self._nsplit * nloc), dtype=rows.dtype, device=rows.device) if self._nsplit > 1 else None
+
+    @staticmethod
+    def column_major(rows):
+        """a (nloc, n) tensor laid out column-major (one transposing copy; build large blocks in this layout directly)"""
+        return rows if rows.stride(0) == 1 else rows.t().contiguous().t()
+
+    def _local_gemv(self, x):
+        """rows [lo, hi) of A x into the head of the send buffer."""
+        import torch
+        nloc = self.hi - self.lo
+        if not self.on_gpu:
+            yl = torch.mv(self.rows, x)                            # CPU tensors: test plumbing only
+            self._send[:nloc].copy_(yl)
+            return
+        if self._ctx is None:
+            raise RuntimeError("RowShardedDense: call operator(eu, ctx) first (the local GEMV runs on the library's stream)")
+        code = 1 if self.rows.is_complex() else 0
+        if not x.is_contiguous():
+            x = x.contiguous()
+        rc = self._lib.expv_mi_gemv_block(self._ctx._h, code, nloc, self.n, self.rows.data_ptr(), self.rows.stride(1) if self.n > 1 else max(nloc, 1),
+                                          x.data_ptr(), self._send.data_ptr(),
+                                          self._scratch.data_ptr() if self._scratch is not None else None, self._nsplit)
+        if rc != 0:
+            msg = self._lib.expv_mi_last_error(self._ctx._h)
+            raise RuntimeError("expv_mi_gemv_block failed (%d): %s" % (rc, msg.decode() if msg else ""))
 
     def matvec(self, x):
         import torch
         self.applications += 1
-        yl = torch.mv(self.rows, x)
+        self._local_gemv(x)
         if self.world == 1:
-            return yl
-        self._send[: yl.shape[0]].copy_(yl)
+            return self._send[: self.hi - self.lo]
         if self.stage:
             send, recv = self._send.cpu(), torch.empty(self.world * self.width, dtype=self._send.dtype)
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
@@ -120,6 +159,9 @@ class RowShardedDense:
 
     def operator(self, eu, ctx=None, ishermitian=False):
         """The library operator (device vectors in, device vectors out, on the library's stream)."""
+        if self.on_gpu:
+            self._ctx = ctx or eu.default_context()
+            self._lib = eu._lib.load()
         return eu.MIOperator(None, ctx, dtype=_np_dtype(self.rows.dtype), ishermitian=ishermitian, matvec=self.matvec,
                              shape=(self.n, self.n))
 

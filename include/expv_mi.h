@@ -169,6 +169,15 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
 /* mul!(y, A, x)  (arnoldi.jl:185) */
 int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc);
 
+/* y[0:nrows] = A x for a DEVICE-RESIDENT column-major nrows x ncols block A (leading dimension lda >= nrows), x (ncols) and
+ * y (nrows) device vectors, enqueued on the context's stream (stream-ordered: nothing is synchronised).  The same kernel as the
+ * dense operator's mul! (arnoldi.jl:185).  This is the local half of an operator whose ROWS are spread over several GPUs
+ * (BASELINE configs[2] at n = 2e5 does not fit one device: exponentialutilities.jl_amd/dist.py RowShardedDense calls it from
+ * inside its matrix-free callback, then all-gathers the pieces); no reference counterpart (the reference is single-process).
+ * `scratch` (device, nsplit * nrows elements, or NULL with nsplit <= 1) holds the partial sums of a column-split launch. */
+int expv_mi_gemv_block(expv_mi_ctx_t ctx, int dtype, int64_t nrows, int64_t ncols, const void *A, int64_t lda,
+                       const void *x, void *y, void *scratch, int nsplit);
+
 /* ------------------------------------------------------------------ KrylovSubspace --- */
 /* KrylovSubspace{T,U}(n, maxiter, augmented)  (arnoldi.jl:63-76).  V lives in HBM,
  * (n+augmented) x (maxiter+1); H is host-resident, (maxiter+1) x (maxiter + (augmented != 0)),

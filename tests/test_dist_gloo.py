@@ -222,3 +222,62 @@ def test_row_sharded_dense_operator_two_ranks(tmp_path, n):
     assert tuple(s0[:3]) == (so["num_timesteps"], so["matvecs"], so["m"])
     assert s0[3] >= so["matvecs"]                              # every operator application went through the collective
     assert np.linalg.norm(U0 - Uo) <= 1e-12 * np.linalg.norm(Uo)
+
+
+# ---- `python bench.py --gpus N` with NO launcher around it must start N ranks itself.  Run as a subprocess
+#      with the CPU stand-in solver (tests/standin_eu.py): the launch / rendezvous / sharding / collective / verification code of
+#      bench.py is the product's; only the per-problem solver is replaced.
+def _run_bench(extra, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--standin",
+                        "tests.standin_eu"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None), lines
+
+
+@pytest.mark.parametrize("cfg", [["--config", "c2", "--n", "300"], ["--config", "c5", "--n5", "96", "--nprob", "5"],
+                                 ["--config", "c3", "--n3", "101"]])
+def test_bench_gpus_2_launches_two_ranks_by_itself(cfg):
+    r, out, lines = _run_bench(["--gpus", "2"] + cfg)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1                                       # rank 0 prints ONE JSON line
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert len(out["devices"]) == 2 and len(set(out["devices"])) == 2
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in out["per_rank_ms_per_step"])
+    assert out["standin"] == "tests.standin_eu" and "NOT a measurement" in out["data"]
+    if cfg[1] == "c5":
+        assert out["gather"]["ms"] > 0 and out["verified"]["max_rel_err"] <= 1e-12
+    if cfg[1] == "c3":
+        assert out["verified"]["replicas_bitwise_equal"] is True and out["config"]["n"] == 101
+    if cfg[1] == "c2":
+        assert out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """One rank per GPU is the contract: `--gpus 2` inside a 1-rank job must fail loudly, not print an n_gpus: 1 line."""
+    r, out, lines = _run_bench(["--gpus", "2", "--config", "c2", "--n", "300"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not lines
+    assert "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_rank_check_rejects_ranks_sharing_a_device():
+    import argparse
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class _Env(bench.Env):
+        def device_ids(self):
+            return ["host/gpu0", "host/gpu0"]
+
+        def ranks_seen(self):
+            return 2
+    with pytest.raises(SystemExit) as ei:
+        _Env(torch, dist, 2, 0, "cpu", None).check_ranks(2)
+    assert "distinct" in str(ei.value)

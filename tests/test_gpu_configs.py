@@ -587,7 +587,7 @@ def test_row_sharded_dense_operator_on_the_device(eu):
     n = 1500
     A, B = c3_inputs(n)
     ctx = eu.Context()
-    sh = D.RowShardedDense(torch.as_tensor(np.ascontiguousarray(A), device="cuda"), n)
+    sh = D.RowShardedDense(D.RowShardedDense.column_major(torch.as_tensor(np.ascontiguousarray(A), device="cuda")), n)
     op = sh.operator(eu, ctx)
     st, sd = {}, {}
     ts = np.array([3.0, 12.0, 7.5])
@@ -596,6 +596,37 @@ def test_row_sharded_dense_operator_on_the_device(eu):
     assert (st["num_timesteps"], st["matvecs"], st["m"]) == (sd["num_timesteps"], sd["matvecs"], sd["m"]), (st, sd)
     assert sh.applications >= st["matvecs"]
     close(U, Ud, 1e-12, "phiv_timestep through the row-sharded operator vs the dense operator (n=%d)" % n)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("shape", [(1, 7), (63, 200), (700, 1500), (1201, 64), (513, 513)])
+def test_gemv_block_rectangular(eu, dtype, shape):
+    """expv_mi_gemv_block: y = A x for a device-resident column-major nrows x ncols block (the local half of the row-sharded
+    config-3 operator), single launch and column-split form, against numpy."""
+    import ctypes as C
+    import torch
+    from exponentialutilities_jl_amd import _lib as L
+    nr, nc = shape
+    rng = np.random.default_rng(nr * 1000 + nc)
+    A = rng.standard_normal((nr, nc)).astype(dtype)
+    x = rng.standard_normal(nc).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((nr, nc))
+        x = x + 1j * rng.standard_normal(nc)
+    ctx = eu.Context()
+    Ad = torch.as_tensor(np.ascontiguousarray(A.T), device="cuda").t()          # column-major nr x nc
+    xd = torch.as_tensor(x, device="cuda")
+    torch.cuda.synchronize()
+    ref = A @ x
+    for nsplit in (1, 5):
+        yd = torch.zeros(nr, dtype=xd.dtype, device="cuda")
+        scr = torch.empty(nsplit * nr, dtype=xd.dtype, device="cuda")
+        torch.cuda.synchronize()
+        rc = L.load().expv_mi_gemv_block(ctx._h, 1 if np.dtype(dtype).kind == "c" else 0, nr, nc, Ad.data_ptr(), Ad.stride(1) if nc > 1 else nr,
+                                         xd.data_ptr(), yd.data_ptr(), scr.data_ptr() if nsplit > 1 else None, nsplit)
+        assert rc == 0
+        ctx.sync()
+        close(yd.cpu().numpy(), ref, 1e-13, "gemv_block %dx%d %s nsplit=%d vs numpy" % (nr, nc, np.dtype(dtype).name, nsplit))
 
 
 def _rows_worker(rank, world, port, n, out_dir):
@@ -615,7 +646,7 @@ def _rows_worker(rank, world, port, n, out_dir):
         A, B = c3_inputs(n)
         lo, hi = D.shard_range(n, world, rank)
         # both ranks share the one GPU of the test box; gloo has no device all-gather, so the pieces are staged through the host
-        sh = D.RowShardedDense(torch.as_tensor(np.ascontiguousarray(A[lo:hi]), device="cuda"), n, stage_through_host=True)
+        sh = D.RowShardedDense(D.RowShardedDense.column_major(torch.as_tensor(np.ascontiguousarray(A[lo:hi]), device="cuda")), n, stage_through_host=True)
         st = {}
         U = eu.phiv_timestep(np.array([3.0, 7.5]), sh.operator(eu, eu.Context()), B, adaptive=True, tol=1e-9, stats=st)
         np.save(os.path.join(out_dir, "U_%d.npy" % rank), np.asarray(U))
