@@ -1017,9 +1017,11 @@ def host_pattern_info(A, dtype=np.float64):
     _check(L.load().expv_mi_host_pattern_info(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), out.ctypes.data))
     info = {"sell": bool(out[0]), "bandwidth": int(out[1]), "pipeline_dia_diagonals": int(out[2]),
             "general_dia_diagonals": int(out[3]), "general_dia_max_offset": int(out[4]), "sell_wave_reach": int(out[5]),
-            "rows_sorted_unique": bool(out[6])}
+            "rows_sorted_unique": bool(out[6]), "sell_cut": int(out[7])}
     if not info["sell"]:
-        info["path"] = "modular (CSR32)"
+        info["path"] = "modular (empty operator)"
+    elif info["sell_cut"] > 0:
+        info["path"] = "two-kernel step, SELL slots up to the cut + overflow pass (irregular rows)"
     elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) == np.float64 and info["bandwidth"] <= 8):
         info["path"] = "pipeline, halo form"
     elif np.dtype(dtype) == np.float64 and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0):

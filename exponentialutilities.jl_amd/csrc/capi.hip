@@ -161,8 +161,74 @@ void upload_csr(Op &op, const std::vector<int32_t> &rp, const std::vector<int32_
 
 // ---- which storage forms a CSR pattern gets (host only: the same analysis backs the builders below and
 //      expv_mi_host_pattern_info, so the decisions are testable without a GPU) ---------------------------------
+// SELL slices with a slot cut-off for irregular rows.  A slice of SH rows stores min(longest row of the slice, cut) slots; what
+// a row holds beyond that stays in the CSR arrays and is applied by the overflow pass (kernels.hip: spmv_ovf), in segments of
+// at most OVF_SEG entries.  cut == 0: every slice keeps its longest row (padding <= 30 %: regular rows, no overflow).
+constexpr int OVF_SEG = 256;
+struct SellPlan {
+  int cut = 0;
+  int64_t padded = 0;             // SELL slots, padding included
+  int64_t ovf_entries = 0, ovf_rows = 0, ovf_segments = 0, ovf_multi_rows = 0;
+};
+static SellPlan plan_sell(int64_t n, const int32_t *rp, int64_t nnz, int SH) {
+  SellPlan S;
+  if (n <= 0) return S;
+  int maxlen = 0;
+  for (int64_t r = 0; r < n; ++r) maxlen = std::max(maxlen, rp[r + 1] - rp[r]);
+  std::vector<int64_t> hrow((size_t)maxlen + 2, 0), hmax((size_t)maxlen + 2, 0);   // rows of length l; slices whose longest row is l
+  for (int64_t s0 = 0; s0 < n; s0 += SH) {
+    int L = 0;
+    for (int64_t r = s0; r < std::min<int64_t>(n, s0 + SH); ++r) { const int l = rp[r + 1] - rp[r]; hrow[l]++; L = std::max(L, l); }
+    hmax[L]++;
+    S.padded += (int64_t)L * SH;
+  }
+  if (S.padded <= (int64_t)(1.3 * (double)nnz) + 8 * SH) return S;      // regular rows: plain SELL
+  // irregular rows: the cut that moves the fewest bytes.  slots(L) = SH sum_s min(max_s, L); over(L) = sum_r max(0, len_r - L);
+  // an overflow entry costs about twice a slot (8-lane groups, partial waves), an overflow row a handful of slots more
+  double best = 1e300;
+  int bestL = 1;
+  const int Lmax = std::min(maxlen, 4096);
+  // rows_longer[L] = #rows longer than L, ent_longer[L] = their entries, sl_longer[L] = #slices whose longest row exceeds L,
+  // sl_short[L] = sum over the other slices of their longest row
+  std::vector<int64_t> rows_longer((size_t)maxlen + 2, 0), ent_longer((size_t)maxlen + 2, 0), sl_longer((size_t)maxlen + 2, 0),
+      sl_short((size_t)maxlen + 2, 0);
+  for (int l = maxlen - 1; l >= 0; --l) {
+    rows_longer[l] = rows_longer[l + 1] + hrow[l + 1];
+    ent_longer[l] = ent_longer[l + 1] + hrow[l + 1] * (int64_t)(l + 1);
+    sl_longer[l] = sl_longer[l + 1] + hmax[l + 1];
+  }
+  int64_t acc_short = 0;
+  for (int l = 0; l <= maxlen; ++l) { acc_short += hmax[l] * (int64_t)l; sl_short[l] = acc_short; }
+  for (int L = 1; L <= Lmax; ++L) {
+    const double slots = (double)SH * ((double)sl_short[L] + (double)L * (double)sl_longer[L]);
+    const double ov = (double)(ent_longer[L] - (int64_t)L * rows_longer[L]);
+    const double cost = slots + 2.0 * ov + 6.0 * (double)rows_longer[L];
+    if (cost < best) { best = cost; bestL = L; }
+  }
+  S.cut = bestL;
+  S.padded = 0;
+  for (int64_t s0 = 0; s0 < n; s0 += SH) {
+    int L = 0;
+    for (int64_t r = s0; r < std::min<int64_t>(n, s0 + SH); ++r) {
+      const int l = rp[r + 1] - rp[r];
+      L = std::max(L, l);
+      if (l > bestL) {
+        const int64_t nseg = ((int64_t)(l - bestL) + OVF_SEG - 1) / OVF_SEG;
+        S.ovf_rows++;
+        S.ovf_entries += l - bestL;
+        S.ovf_segments += nseg;
+        if (nseg > 1) S.ovf_multi_rows++;
+      }
+    }
+    S.padded += (int64_t)std::min(L, bestL) * SH;
+  }
+  return S;
+}
+
 struct PatternPlan {
-  bool sell_ok = false;           // rows regular enough for SELL slices (padding <= 30 %)
+  bool sell_ok = false;           // SELL slices are built (always for n > 0; `overflow` says whether a cut-off was needed)
+  bool overflow = false;          // irregular rows: SELL slots up to a cut + overflow entries applied from the CSR arrays
+  int sell_cut = 0;
   int64_t bandwidth = 0;          // max |col - row|
   bool sorted_unique = true;      // every row: strictly ascending columns
   std::vector<int64_t> offsets;   // distinct col - row, ascending (empty when there are more than GDIA_MAX)
@@ -175,13 +241,10 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
   PatternPlan P;
   if (n <= 0) return P;
   const int SH = 64 * (16 / value_bytes);
-  int64_t padded = 0;
-  for (int64_t s0 = 0; s0 < n; s0 += SH) {
-    int L = 0;
-    for (int64_t r = s0; r < std::min<int64_t>(n, s0 + SH); ++r) L = std::max(L, rp[r + 1] - rp[r]);
-    padded += (int64_t)L * SH;
-  }
-  P.sell_ok = padded <= (int64_t)(1.3 * (double)nnz) + 8 * SH;
+  const SellPlan S = plan_sell(n, rp, nnz, SH);
+  P.sell_ok = true;
+  P.overflow = S.cut > 0;
+  P.sell_cut = S.cut;
   bool many = false;
   for (int64_t r = 0; r < n; ++r) {
     int32_t prev = -1;
@@ -199,10 +262,10 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
   std::sort(P.offsets.begin(), P.offsets.end());
   const int nd = (int)P.offsets.size();
   P.fill_ok = nd > 0 && (double)nd * (double)n <= 1.3 * (double)nnz + 1024.0;
-  const bool dia_base = P.sell_ok && P.sorted_unique && P.fill_ok;   // fp64 and complex-fp64
+  const bool dia_base = P.sell_ok && !P.overflow && P.sorted_unique && P.fill_ok;   // fp64 and complex-fp64
   P.pipe_dia = dia_base && P.bandwidth <= dev::PIPE_WMAX && nd <= dev::PIPE_DIA_MAX;
-  P.general_dia = !P.pipe_dia && P.sell_ok && P.sorted_unique && P.fill_ok && P.bandwidth <= INT32_MAX;   // fp64 and complex
-  if (P.sell_ok && value_bytes == 8 && !P.pipe_dia && !P.general_dia) {
+  P.general_dia = !P.pipe_dia && dia_base && P.bandwidth <= INT32_MAX;   // fp64 and complex
+  if (P.sell_ok && !P.overflow && value_bytes == 8 && !P.pipe_dia && !P.general_dia) {
     const int64_t TR = 512;
     P.tile_reach = 0;
     for (int64_t t0 = 0; t0 < n; t0 += TR) {
@@ -222,15 +285,19 @@ template <class V>
 void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) {   // layout only: the slots are filled on the device (op_fill_forms)
   const int SH = 64 * (16 / (int)sizeof(V));
   const int64_t nsl = (n + SH - 1) / SH;
+  op.sell_ok = false;
+  op.sell_cut = 0;
+  op.ovf_nseg = op.ovf_nmulti = 0;
+  if (n == 0) return;
+  const SellPlan S = plan_sell(n, rp.data(), nnz, SH);
+  const int cut = S.cut > 0 ? S.cut : INT_MAX;
   std::vector<int64_t> off(nsl + 1, 0);
   for (int64_t s = 0; s < nsl; ++s) {
     int L = 0;
     for (int64_t r = s * SH; r < std::min<int64_t>(n, (s + 1) * SH); ++r) L = std::max(L, rp[r + 1] - rp[r]);
-    off[s + 1] = off[s] + (int64_t)L * SH;
+    off[s + 1] = off[s] + (int64_t)std::min(L, cut) * SH;
   }
   const int64_t padded = off[nsl];
-  op.sell_ok = false;
-  if (n == 0 || padded > (int64_t)(1.3 * (double)nnz) + 8 * SH) return;   // irregular rows: keep CSR
   const size_t slots = (size_t)std::max<int64_t>(padded, 1);
   Ctx *c = op.ctx;
   op.sell_off.alloc(sizeof(int64_t) * off.size());
@@ -239,8 +306,41 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) 
   HIPCHECK(hipMemcpyAsync(op.sell_off.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipMemsetAsync(op.sell_col.p, 0, op.sell_col.bytes, c->stream));     // slots of the rows beyond n: column 0, value 0
   HIPCHECK(hipMemsetAsync(op.sell_val.p, 0, op.sell_val.bytes, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream));      // (`off` leaves scope)
+  // overflow: the entries of a row beyond the cut, in segments of <= OVF_SEG entries of the CSR arrays.  {row, first entry,
+  // entries, destination}: destination -1 = the row's only segment (its sum goes straight to ovf_y[row]); otherwise the index
+  // of its partial sum, added up per row in segment order by the combine pass {row, first partial, partials, 0}
+  std::vector<int32_t> seg, multi;
+  if (S.cut > 0) {
+    seg.reserve((size_t)S.ovf_segments * 4);
+    int32_t npart = 0;
+    for (int64_t r = 0; r < n; ++r) {
+      const int l = rp[r + 1] - rp[r];
+      if (l <= S.cut) continue;
+      const int over = l - S.cut;
+      const int nseg = (over + OVF_SEG - 1) / OVF_SEG;
+      if (nseg > 1) { multi.push_back((int32_t)r); multi.push_back(npart); multi.push_back(nseg); multi.push_back(0); }
+      for (int q = 0; q < nseg; ++q) {
+        seg.push_back((int32_t)r);
+        seg.push_back(rp[r] + S.cut + q * OVF_SEG);
+        seg.push_back(std::min(OVF_SEG, over - q * OVF_SEG));
+        seg.push_back(nseg > 1 ? npart++ : -1);
+      }
+    }
+    op.ovf_nseg = (int64_t)seg.size() / 4;
+    op.ovf_nmulti = (int64_t)multi.size() / 4;
+    op.ovf_seg.alloc(sizeof(int32_t) * std::max<size_t>(seg.size(), 4));
+    HIPCHECK(hipMemcpyAsync(op.ovf_seg.p, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice, c->stream));
+    if (!multi.empty()) {
+      op.ovf_multi.alloc(sizeof(int32_t) * multi.size());
+      HIPCHECK(hipMemcpyAsync(op.ovf_multi.p, multi.data(), sizeof(int32_t) * multi.size(), hipMemcpyHostToDevice, c->stream));
+      op.ovf_part.alloc(sizeof(V) * (size_t)npart);
+    }
+    op.ovf_y.alloc(sizeof(V) * (size_t)((n + 127) / 128 * 128));
+    HIPCHECK(hipMemsetAsync(op.ovf_y.p, 0, op.ovf_y.bytes, c->stream));     // rows without overflow stay zero for good
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));      // (`off`, `seg`, `multi` leave scope)
   op.nslices = nsl;
+  op.sell_cut = S.cut;
   op.sell_ok = true;
 }
 
@@ -309,6 +409,7 @@ static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long 
   if (op.sell_ok) {
     a.sell_val = op.sell_val.as<T>(); a.sell_off = op.sell_off.as<int64_t>(); a.sell_rows = 64 * (16 / (int)sizeof(T));
     a.sell_col = creation ? op.sell_col.as<int32_t>() : nullptr;
+    a.sell_cut = op.sell_cut;
   }
   if (op.ndiag > 0) { a.dia = op.dia_val.as<T>(); a.dia_ld = op.dia_ld; a.nd = op.ndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
   else if (op.gndiag > 0 && !op.gdia_alias) { a.dia = op.gdia_val.as<T>(); a.dia_ld = op.gdia_ld; a.nd = op.gndiag; a.dia_off = op.gdia_off.as<int32_t>(); }
@@ -350,9 +451,9 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.rows_sorted_unique = P.sorted_unique;
   op.bandwidth = P.bandwidth;      // max |col - row|
   lap("pattern analysis");
-  if (op.sell_ok) build_dia<V>(op, n, P);
+  if (op.sell_ok && op.sell_cut == 0) build_dia<V>(op, n, P);
   lap("DIA layout");
-  if (op.sell_ok) build_gdia<V>(op, n, P);
+  if (op.sell_ok && op.sell_cut == 0) build_gdia<V>(op, n, P);
   lap("general DIA");
   {
     unsigned long long out[32];
@@ -1116,7 +1217,7 @@ int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *c
     out[4] = P.general_dia ? std::max<int64_t>(std::llabs((long long)P.offsets.front()), std::llabs((long long)P.offsets.back())) : 0;
     out[5] = P.tile_reach;
     out[6] = P.sorted_unique;
-    out[7] = 0;
+    out[7] = P.sell_cut;                     // > 0: irregular rows, SELL slots up to this many per row + overflow pass
   });
 }
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {

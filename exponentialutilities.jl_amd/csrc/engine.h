@@ -170,6 +170,11 @@ struct Op {
   DevBuf sell_off, sell_col, sell_val;   // SELL-C (C = 128 rows fp64 / 64 complex), built when padding is small
   int64_t nslices = 0;
   bool sell_ok = false;
+  // irregular rows: SELL slots up to sell_cut per row (0: no cut), the rest applied from the CSR arrays by the overflow pass
+  // (kernels.hip: spmv_ovf) into ovf_y, a dense vector that is zero on every row without overflow
+  int sell_cut = 0;
+  int64_t ovf_nseg = 0, ovf_nmulti = 0;
+  DevBuf ovf_seg, ovf_multi, ovf_part, ovf_y;
   int64_t bandwidth = -1;   // max |col - row| (CSR operators)
   DevBuf dia_val;           // DIA form of a narrow-banded fp64 operator (pipe.hip): [ndiag][dia_ld], ascending offsets
   int ndiag = 0;

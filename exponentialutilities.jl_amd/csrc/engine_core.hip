@@ -200,6 +200,11 @@ void ks_materialize(Ks &ks) {
 // operator application (mul!)                                          arnoldi.jl:185
 // ------------------------------------------------------------------------------------------
 template <class T>
+static dev::OvfView<T> ovf_view(const Op &op) {
+  return dev::OvfView<T>{op.ovf_seg.as<int32_t>(), op.ovf_nseg, op.ovf_multi.as<int32_t>(), op.ovf_nmulti, op.ovf_part.as<T>(),
+                         op.col.as<int32_t>(), op.val.as<T>(), op.ovf_y.as<T>()};
+}
+template <class T>
 static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) {
   Ctx *c = op.ctx;
   ProfScope ps(c, EXPV_MI_K_MATVEC);
@@ -207,9 +212,10 @@ static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) 
     case OP_CSR:
       if (op.sell_ok) {
         dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
-        dev::spmv_sell<T>(c->stream, op.n, A, x, y, st, step);
-      } else {
-        dev::spmv_csr<T>(c->stream, op.n, op.rowptr.as<int32_t>(), op.col.as<int32_t>(), op.val.as<T>(), x, y, st, step);
+        if (op.ovf_nseg > 0) dev::spmv_ovf<T>(c->stream, ovf_view<T>(op), x, st, step);      // irregular rows: entries beyond the slot cut-off
+        dev::spmv_sell<T>(c->stream, op.n, A, x, y, st, step, op.ovf_nseg > 0 ? op.ovf_y.as<T>() : nullptr);
+      } else if (op.n > 0) {
+        fail(EXPV_MI_ARGUMENT_ERROR, "sparse operator without its SELL form");
       }
       break;
     case OP_DENSE:
@@ -399,7 +405,7 @@ struct ArnoldiCall {
     single_red = !c->opt.fused_two_reductions;
     // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
     //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
-    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
+    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (single_red || op.sell_cut == 0) && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
                 o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
     // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
     const bool no_pipe = !c->opt.pipeline;
@@ -409,7 +415,7 @@ struct ArnoldiCall {
       const int iopw = lanczos ? 2 : (o.iop == 0 ? m : std::min(o.iop, m));
       const int wstep = std::min(m - 1, iopw);
       const bool have_dia = op.ndiag > 0 && !no_dia_env;
-      use_pipe = use_fused && single_red && !no_pipe && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+      use_pipe = use_fused && single_red && !no_pipe && op.sell_cut == 0 && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
                  (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
@@ -784,6 +790,11 @@ struct ArnoldiCall {
       fa.step = j;
       fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
+      if (op.ovf_nseg > 0) {               // irregular rows: the entries beyond the SELL slot cut-off, from the CSR arrays
+        ProfScope ps(c, EXPV_MI_K_MATVEC);
+        dev::spmv_ovf<T>(s, ovf_view<T>(op), fa.u, st, j);
+        fa.ovf_y = op.ovf_y.as<T>();
+      }
       if (op.gndiag > 0 && c->opt.dia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
         fa.dia_val = op.gdia_ptr<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();
         fa.n_dia = ks.n;

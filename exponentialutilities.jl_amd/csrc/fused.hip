@@ -106,7 +106,7 @@ __device__ __forceinline__ void sell_rows(const SellView<T> &A, int64_t slice, i
 // ---- stand-alone SELL SpMV (mul!) ---------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int64_t n, SellView<T> A, const T *__restrict__ x,
-                                                     T *__restrict__ y, const StepState *st, int step) {
+                                                     T *__restrict__ y, const StepState *st, int step, const T *__restrict__ ovf_y) {
   if (step_skipped(st, step)) return;
   constexpr int N = Pack<T>::N;
   constexpr int SH = 64 * N;
@@ -116,15 +116,20 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int64_t n, SellView<T> A, c
        slice += (int64_t)gridDim.x * (BLOCK / 64)) {
     Pack<T> acc;
     sell_rows<T>(A, slice, lane, x, acc.v);
+    if (ovf_y) {   // irregular rows: what the overflow pass summed for these rows (library vector, padded: whole packs)
+      const Pack<T> o = *reinterpret_cast<const Pack<T> *>(ovf_y + slice * SH + (int64_t)lane * N);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc.v[k] = ST<T>::add(acc.v[k], o.v[k]);
+    }
     st_pack_user(y, slice * SH + (int64_t)lane * N, n, al, acc);
   }
 }
 template <class T>
-void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step) {
+void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step, const T *ovf_y) {
   int64_t g = (A.nslices + (BLOCK / 64) - 1) / (BLOCK / 64);
   if (g > MAX_GRID) g = MAX_GRID;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_spmv_sell<T>, dim3((int)g), dim3(BLOCK), 0, s, n, A, x, y, st, step);
+  hipLaunchKernelGGL(k_spmv_sell<T>, dim3((int)g), dim3(BLOCK), 0, s, n, A, x, y, st, step, ovf_y);
 }
 
 // ---- fused half-step A ----------------------------------------------------------------------
@@ -282,8 +287,14 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
       const Pack<T> xv = ld_pack(u, i, a.n, al);
       if (cb == 0) {
         if (fa.ndiag > 0 && i < fa.n_dia) dia_rows<T>(fa.dia_val, fa.dia_ld, fa.ndiag, fa.dia_off, i, fa.n_dia, u, yv.v);   // y~ = A u_j
-        else if (fa.ndiag == 0 && slice < fa.A.nslices) sell_rows<T>(fa.A, slice, lane, u, yv.v);
-        else {
+        else if (fa.ndiag == 0 && slice < fa.A.nslices) {
+          sell_rows<T>(fa.A, slice, lane, u, yv.v);
+          if (fa.ovf_y) {   // irregular rows: + what the overflow pass summed for these rows (spmv_ovf ran on the same u)
+            const Pack<T> o = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + i);
+#pragma unroll
+            for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::add(yv.v[k], o.v[k]);
+          }
+        } else {
 #pragma unroll
           for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::zero();
         }
@@ -537,7 +548,7 @@ void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *cs
 }
 
 #define INSTF(T)                                                                                               \
-  template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int); \
+  template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int, const T *); \
   template void fused_a<T>(hipStream_t, const FusedAArgs<T> &);                                                \
   template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double, int);                                  \
   template void update2<T>(hipStream_t, const UpdateArgs<T> &, int, int);                                      \

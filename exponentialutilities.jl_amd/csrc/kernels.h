@@ -73,6 +73,7 @@ struct OpUpdateArgs {
   const int32_t *rp, *ci;
   const T *val;                 // CSR-ordered values (already updated)
   T *sell_val; const int64_t *sell_off; int sell_rows;     // SELL slices of sell_rows rows (nullptr: no SELL form)
+  int sell_cut;                 // > 0: a row keeps at most this many entries in its SELL slots (the rest: overflow pass)
   int32_t *sell_col;            // creation only: the column of every slot is written too (padding slots: the row itself)
   T *dia; int64_t dia_ld; const int32_t *dia_off; int nd;   // [nd][dia_ld] diagonal form with device offsets (nullptr: none)
   int check_herm;               // rows have strictly ascending columns: test A == A^H (explicit zeros ignored) on the device
@@ -99,9 +100,19 @@ struct ContScales { double v[CONT_SCALES_MAX]; };
 void cont_reset(hipStream_t s, StepState *st, size_t state_bytes, double hnorm, double inv, double beta0sq, int m_done,
                 double *colscale, const double *scales_host, int ncs, void *H, size_t hbytes);
 
+// Overflow pass of a SELL operator with a slot cut-off (irregular rows): the entries of a row beyond the cut, taken from the
+// CSR arrays in segments of <= 256 entries; ovf_y[row] = their sum (rows without overflow are never written and stay zero).
+// seg: int32 x 4 per segment {row, first entry, entries, partial index or -1}; multi: {row, first partial, partials, 0}.
 template <class T>
-void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *col, const T *val, const T *x,
-              T *y, const StepState *st, int step);
+struct OvfView {
+  const int32_t *seg; int64_t nseg;
+  const int32_t *multi; int64_t nmulti;
+  T *part;
+  const int32_t *col; const T *val;   // the CSR arrays
+  T *y;                               // dense, zero outside the overflow rows
+};
+template <class T> void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride = 0,
+                                 int nbatch = 1);
 template <class T>
 void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
                 const StepState *st, int step, int64_t ncols = -1);   // n rows x ncols columns (ncols < 0: square)
@@ -123,7 +134,8 @@ struct SellView {
   int64_t nslices;
 };
 template <class T>
-void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step);
+void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step,
+               const T *ovf_y = nullptr);   // ovf_y: added to the SELL part (spmv_ovf ran on the same x before)
 
 // fused Krylov half-step A: v_j = u / beta_{j-1};  y = A v_j;  projection sums of y (and the Gram row
 // of v_j) against the window of V -- one pass, one grid reduction (arnoldi.jl:185, :302, :306 fused)
@@ -147,6 +159,7 @@ struct FusedAArgs {
   int ndiag;
   const int32_t *dia_off;   // device, ascending
   int64_t n_dia;            // operator rows (the DIA arrays cover rows < n_dia, padded to 512)
+  const T *ovf_y;           // SELL with a slot cut-off: what the overflow pass left for these rows (nullptr: none)
 };
 constexpr int FUSED_AUG_MAX = 8;
 constexpr int GDIA_MAX = 32;       // most diagonals of the general DIA form   // widest augmentation the fused step handles (kiops: p = number of extra columns)

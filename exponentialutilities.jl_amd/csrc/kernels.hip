@@ -10,7 +10,7 @@
 //
 // Reference call sites replaced:
 //   K1  arnoldi.jl:233,241-246   sumsq + scale_copy
-//   K2  arnoldi.jl:185           spmv_csr / gemv_dense
+//   K2  arnoldi.jl:185           spmv_ovf (+ spmv_sell in fused.hip) / gemv_dense
 //   K3  arnoldi.jl:302           dots            (all window columns in one pass)
 //   K4  arnoldi.jl:303           update          (all window columns in one pass)
 //   K5  arnoldi.jl:305           update (norm epilogue)
@@ -257,28 +257,73 @@ void fill_zero(hipStream_t s, T *dst, int64_t n) {
 // ------------------------------------------------------------------------------------------
 // K2: operator application
 // ------------------------------------------------------------------------------------------
-// CSR, 32-bit indices, one row per lane.  (Round-1 form; the fused CSR path lives in fused.hip.)
+// Overflow pass of the SELL form with a slot cut-off (irregular rows; capi.hip: build_sell).  A segment is <= 256 consecutive
+// entries of one row in the CSR arrays; 8 lanes share a segment (coalesced 8-entry chunks of val / col, 4 chunks in flight),
+// their sums are combined in a fixed order (lane pairs at distance 4, 2, 1), so the result is reproducible run to run.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void k_spmv_csr(int64_t n, const int32_t *__restrict__ rowptr,
-                                                    const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                    const T *__restrict__ x, T *__restrict__ y, const StepState *st,
-                                                    int step) {
+__device__ __forceinline__ T group8_sum(T v);
+template <>
+__device__ __forceinline__ double group8_sum<double>(double v) {
+  v += lane_xor<4>(v);
+  v += lane_xor<2>(v);
+  v += lane_xor<1>(v);
+  return v;
+}
+template <>
+__device__ __forceinline__ cplx group8_sum<cplx>(cplx v) { return make_cplx(group8_sum<double>(v.re), group8_sum<double>(v.im)); }
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_spmv_ovf(OvfView<T> o, const T *__restrict__ x, const StepState *st, int step,
+                                                    int64_t x_stride) {
+  if (blockIdx.y != 0) { x += (int64_t)blockIdx.y * x_stride; if (st) st += blockIdx.y; }
   if (step_skipped(st, step)) return;
-  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK) {
-    const int32_t k0 = rowptr[r], k1 = rowptr[r + 1];
+  const int t = threadIdx.x & 7;
+  for (int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3; g < o.nseg; g += ((int64_t)gridDim.x * BLOCK) >> 3) {
+    const int4 sg = reinterpret_cast<const int4 *>(o.seg)[g];      // (the 8 lanes of a group share g: a group is in the loop as a whole)
+    const int32_t *cp = o.col + sg.y;
+    const T *vp = o.val + sg.y;
     T acc = ST<T>::zero();
-    for (int32_t k = k0; k < k1; ++k) ST<T>::fma_(acc, val[k], x[col[k]]);
-    y[r] = acc;
+    for (int k = t; k < sg.z; k += 32) {              // 4 chunks of 8 entries in flight per group; entries beyond the segment: value 0
+      T v[4], xv[4];
+      int32_t c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = k + 8 * q < sg.z;
+        const int e = in ? k + 8 * q : 0;             // (entry 0 of the segment: a column this group reads anyway)
+        c[q] = cp[e];
+        v[q] = in ? vp[e] : ST<T>::zero();
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[q] = x[c[q]];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ST<T>::fma_(acc, v[q], xv[q]);
+    }
+    acc = group8_sum<T>(acc);
+    if (t == 0) {
+      if (sg.w < 0) o.y[sg.x] = acc;
+      else o.part[sg.w] = acc;
+    }
   }
 }
 template <class T>
-void spmv_csr(hipStream_t s, int64_t n, const int32_t *rowptr, const int32_t *col, const T *val, const T *x, T *y,
-              const StepState *st, int step) {
-  // one row per lane and no grid cap below n/BLOCK: short rows want many waves in flight
-  int64_t g = (n + BLOCK - 1) / BLOCK;
-  if (g > 8 * MAX_GRID) g = 8 * MAX_GRID;
-  hipLaunchKernelGGL(k_spmv_csr<T>, dim3((int)g), dim3(BLOCK), 0, s, n, rowptr, col, val, x, y, st,
-                     step);
+__global__ __launch_bounds__(BLOCK) void k_ovf_combine(OvfView<T> o, const StepState *st, int step) {
+  if (blockIdx.y != 0 && st) st += blockIdx.y;
+  if (step_skipped(st, step)) return;
+  for (int64_t m = (int64_t)blockIdx.x * BLOCK + threadIdx.x; m < o.nmulti; m += (int64_t)gridDim.x * BLOCK) {
+    const int4 d = reinterpret_cast<const int4 *>(o.multi)[m];
+    T s = o.part[d.y];
+    for (int q = 1; q < d.z; ++q) s = ST<T>::add(s, o.part[d.y + q]);
+    o.y[d.x] = s;
+  }
+}
+template <class T>
+void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride, int nbatch) {
+  if (o.nseg <= 0) return;
+  int64_t g = (o.nseg * 8 + BLOCK - 1) / BLOCK;
+  if (g > 4 * MAX_GRID) g = 4 * MAX_GRID;
+  hipLaunchKernelGGL(k_spmv_ovf<T>, dim3((unsigned)g, nbatch), dim3(BLOCK), 0, s, o, x, st, step, x_stride);
+  if (o.nmulti > 0)
+    hipLaunchKernelGGL(k_ovf_combine<T>, dim3((unsigned)std::min<int64_t>(MAX_GRID, (o.nmulti + BLOCK - 1) / BLOCK), nbatch), dim3(BLOCK), 0, s, o,
+                       st, step);
 }
 
 // Dense column-major GEMV: grid (row tiles, column splits).  Each lane owns 16 B of rows and streams
@@ -755,8 +800,7 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void scale_copy<T>(hipStream_t, T *, const T *, int64_t, double, int);                                  \
   template void scale_by_state<T>(hipStream_t, T *, int64_t, const StepState *, int);                              \
   template void fill_zero<T>(hipStream_t, T *, int64_t);                                                           \
-  template void spmv_csr<T>(hipStream_t, int64_t, const int32_t *, const int32_t *, const T *, const T *, T *,     \
-                            const StepState *, int);                                                                    \
+  template void spmv_ovf<T>(hipStream_t, const OvfView<T> &, const T *, const StepState *, int, int64_t, int);      \
   template void gemv_dense<T>(hipStream_t, int64_t, const T *, int64_t, const T *, T *, T *, int,                  \
                               const StepState *, int, int64_t);                                                                \
   template void aug_apply<T>(hipStream_t, int64_t, int, const T *, int64_t, const T *, T *, const StepState *,     \
@@ -878,7 +922,7 @@ __global__ __launch_bounds__(BLOCK) void k_op_update_forms(const OpUpdateArgs<T>
       const T v = a.val[k];
       const int32_t c = a.ci[k];
       rowsum += upd_abs(v);
-      if (a.sell_val) {
+      if (a.sell_val && (a.sell_cut <= 0 || k - k0 < a.sell_cut)) {
         const int64_t e = sbase + (int64_t)(k - k0) * a.sell_rows + q;
         a.sell_val[e] = v;
         if (a.sell_col) a.sell_col[e] = c;

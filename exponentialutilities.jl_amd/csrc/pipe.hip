@@ -91,8 +91,13 @@ __device__ __forceinline__ double ld_shared_f64(const double *p) {   // value an
 __device__ unsigned long long g_pipe_trace[33][1024][12];
 __device__ unsigned g_pipe_hw[33][1024];   // HW_ID | XCC_ID << 16 of thread 0's wave
 #define PIPE_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 33 && blockIdx.x < 1024) g_pipe_trace[step][blockIdx.x][slot] = wall_clock64(); } while (0)
+// wave form: per tile of a workgroup {tile start, u_j computed (window landed), store acknowledged + flag up, neighbours' flags seen,
+// y~ stored (gather done), sums done}; every 8th workgroup (tools/wave_trace.py)
+__device__ unsigned long long g_wave_trace[33][128][6][6];
+#define WAVE_STAMP(step, tl, slot) do { if (threadIdx.x == 0 && (step) < 33 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 128 && (tl) < 6) g_wave_trace[step][blockIdx.x >> 3][tl][slot] = wall_clock64(); } while (0)
 #else
 #define PIPE_STAMP(step, slot) do { } while (0)
+#define WAVE_STAMP(step, tl, slot) do { } while (0)
 #endif
 template <class T>
 struct PipeSharedT {
@@ -290,9 +295,13 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     if (tile >= (WAVE ? ntiles : t1)) break;
     const int64_t r0 = tile * TR, i = r0 + N * (int64_t)tid;
     const bool act = i < nb;   // whole waves: nb is a multiple of the rows a wave owns
+    if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 0);
     // ---- operator slots of this lane's rows: issued now, consumed after the barrier ------------
     Pack<T> av[PS > 0 ? PS : 1];
-    int2 aci[PS > 0 ? PS : 1];
+    // SELL wave form: the column indices of up to 6 slots are fetched ahead of the flag wait even when the register budget has
+    // no room for their values (PS = 0): the gather behind the wait then needs one memory round trip, not two (index -> u_j[index])
+    constexpr int PSI = (WAVE && !DIA && PS < 6) ? 6 : (PS > 0 ? PS : 1);
+    int2 aci[PSI];
     int L = 0;
     const T *avp = nullptr;
     const int32_t *acp = nullptr;
@@ -324,6 +333,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
             aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
           }
+#pragma unroll
+        for (int sl = PS; sl < PSI; ++sl)
+          if (sl < L) aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
       }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
@@ -485,6 +497,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     if constexpr (WAVE) {
       // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
       // u_j of the tiles their diagonals reach into, so wait for those flags (bounded)
+      WAVE_STAMP(pa.step, tl, 1);
       if (act) st_tile<true, T>(Vw + (int64_t)jcol * a.ldv + i, u);
       if constexpr (DIA) {   // near diagonals (|offset| <= PIPE_WMAX) take u_j of this tile from LDS, like the halo form
 #pragma unroll
@@ -496,6 +509,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(pa.tile_flags + tile, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      WAVE_STAMP(pa.step, tl, 2);
       if (!pa.final) {
         if (tid < 64) {
           bool ok = true;
@@ -528,6 +542,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           }
         }
         __syncthreads();
+        WAVE_STAMP(pa.step, tl, 3);
         if (__builtin_amdgcn_readfirstlane(flag_s) != 0) return 3;
         if constexpr (DIA && !ST<T>::is_complex) {
           // PIPE_WMAX rows above and below the tile (their tiles' flags were part of the wait whenever a near diagonal exists)
@@ -561,7 +576,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             y.v[0] = fma(av[sl].v[0], ucol[aci[sl].x], y.v[0]);   // padding entries: value 0, column 0
             y.v[1] = fma(av[sl].v[1], ucol[aci[sl].y], y.v[1]);
           }
-        for (int sl = PS; sl < L; ++sl) {
+#pragma unroll
+        for (int sl = PS; sl < PSI; ++sl)          // indices in registers, values fetched together with the gather
+          if (sl < L) {
+            const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
+            y.v[0] = fma(v2.v[0], ucol[aci[sl].x], y.v[0]);
+            y.v[1] = fma(v2.v[1], ucol[aci[sl].y], y.v[1]);
+          }
+        for (int sl = PSI; sl < L; ++sl) {
           const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
           const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
           y.v[0] = fma(v2.v[0], ucol[ci.x], y.v[0]);
@@ -666,6 +688,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     }
     if (act && !pa.final) st_tile<LIVE, T>(ybuf + i, y);
     if (tl == 0) PIPE_STAMP(pa.step, 9);
+    if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 4);
     // ---- phase 3: this tile's products, summed across the wave at once -----------------------------------
     // The LSET values of a set (CH-1 window slots + the self term, NR reals each) are reduced in P parts of K values by
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
@@ -677,6 +700,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       tile_set(sidx, sidx < P ? y : u);
     }
     if constexpr (!WAVE) __syncthreads();   // us is rewritten by the next tile
+    if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 5);
   }
 
   PIPE_STAMP(pa.step, 1);
@@ -1415,6 +1439,21 @@ extern "C" void expv_mi_pipe_trace_dump(const char *path) {
       for (int st = 1; st < 33; ++st)
         for (int b = 0; b < 1024; ++b)
           if (h[((size_t)st * 1024 + b) * 12]) std::fprintf(g, "%d %d %u\n", st, b, hw[(size_t)st * 1024 + b]);
+      std::fclose(g);
+    }
+  }
+  {   // wave form: per-tile phases
+    std::vector<unsigned long long> wv((size_t)33 * 128 * 6 * 6);
+    (void)hipMemcpyFromSymbol(wv.data(), HIP_SYMBOL(g_wave_trace), wv.size() * 8);
+    const std::string p4 = std::string(path) + ".wave";
+    FILE *g = std::fopen(p4.c_str(), "w");
+    if (g) {
+      for (int st = 1; st < 33; ++st)
+        for (int b = 0; b < 128; ++b)
+          for (int tl = 0; tl < 6; ++tl) {
+            const unsigned long long *r = &wv[(((size_t)st * 128 + b) * 6 + tl) * 6];
+            if (r[0]) std::fprintf(g, "%d %d %d %llu %llu %llu %llu %llu %llu\n", st, b * 8, tl, r[0], r[1], r[2], r[3], r[4], r[5]);
+          }
       std::fclose(g);
     }
   }

@@ -349,10 +349,11 @@ const char *expv_mi_abi_layout(int kind);
  * and so they can be tested without a GPU.
  * exponential!(A, ExpMethodHigham2005Base()), in place  (exp_baseexp.jl:112-161) */
 /* Host only (no GPU needed): which storage forms expv_mi_op_create_csr/_csc would build for a 0-based CSR32 pattern and
- * therefore which factorisation path the operator takes.  out[0] SELL slices built (regular rows),
+ * therefore which factorisation path the operator takes.  out[0] SELL slices built,
  * out[1] max |col - row|, out[2] diagonals of the DIA form of the banded pipeline (0: none), out[3] diagonals of the
  * general DIA form (0: none), out[4] its largest |offset|, out[5] reach in rows of the SELL wave form (-1: n/a),
- * out[6] rows sorted and free of duplicates, out[7] reserved.  No reference counterpart (the reference stores CSC only). */
+ * out[6] rows sorted and free of duplicates, out[7] slot cut-off of the SELL form (0: regular rows, every slice keeps its longest
+ * row; > 0: irregular rows -- the entries of a row beyond the cut are applied from the CSR arrays by the overflow pass).  No reference counterpart (the reference stores CSC only). */
 int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int64_t out[8]);
 int expv_mi_host_expm(int dtype, int n, void *A, int lda);
 /* Z*(exp.(t*lambda).*Z[1,:]) of SymTridiagonal(d, e)  (krylov_phiv.jl:227-228); out: n complex */

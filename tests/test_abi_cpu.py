@@ -150,7 +150,9 @@ def test_host_pattern_info_selects_the_storage_forms(eu):
     ragged[0, :400] = 1.0                                                                  # one long row per slice-full of short ones
     ragged.setdiag(2.0)
     i = eu.host_pattern_info(ragged.tocsr())
-    assert i["path"].startswith("modular") or i["sell"]                                    # padding rule decides; never crashes
+    assert i["sell"] and 1 <= i["sell_cut"] <= 4 and "overflow" in i["path"]               # one 400-entry row: slots up to a small cut + overflow
+    assert i["pipeline_dia_diagonals"] == 0 and i["general_dia_diagonals"] == 0 and i["sell_wave_reach"] == -1
+    assert eu.host_pattern_info(c2)["sell_cut"] == 0 and eu.host_pattern_info(irr)["sell_cut"] == 0
     unsorted = sp.csr_matrix((np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1]), np.array([0, 2, 3])), shape=(2, 2))
     unsorted.has_sorted_indices = True                                                     # keep scipy from sorting them
     assert eu.host_pattern_info(unsorted)["rows_sorted_unique"] in (True, False)

@@ -447,8 +447,83 @@ def test_m_larger_than_n_breaks_down(eu):
     assert Ks.m == Ko.m <= n and Ks.wasbreakdown and Ko.wasbreakdown
 
 
+def powerlaw_matrix(n, seed, cplx=False, local=0, longest=None):
+    """irregular rows: Zipf-distributed lengths (mean ~5, a few rows with hundreds of entries), random columns (anywhere, or
+    within +-local of the row); test/gpu/gputests.jl:41-58 uses sprand -- this is the harder, skewed version of it"""
+    rng = np.random.default_rng(seed)
+    ln = np.minimum(rng.zipf(1.8, size=n), n // 2)
+    ln = np.maximum(1, (ln * (5.0 / ln.mean())).astype(np.int64))
+    ln = np.minimum(ln, n - 1)
+    if longest is not None:
+        ln[n // 3] = longest                                   # one row long enough for several overflow segments
+    rows = np.repeat(np.arange(n), ln)
+    cols = rng.integers(0, n, size=rows.size) if not local else np.clip(rows + rng.integers(-local, local + 1, size=rows.size), 0, n - 1)
+    vals = rng.standard_normal(rows.size) / np.sqrt(np.repeat(ln, ln))
+    if cplx:
+        vals = vals * (1 + 0.3j) + 0.1j * rng.standard_normal(rows.size) / np.sqrt(np.repeat(ln, ln))
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags([np.full(n, -0.5)], [0], format="csr")   # (a larger shift makes MGS itself lose orthogonality: y = A v ~ shift * v)
+    A.sum_duplicates()
+    A[7, :] = 0                                                # an empty row
+    A.eliminate_zeros()
+    return A.tocsr()
+
+
+@pytest.mark.parametrize("case", ["real", "complex", "real_local", "real_very_long_row", "real_csc_input"])
+def test_irregular_rows_sell_cut_plus_overflow(eu, case):
+    """Power-law row lengths: SELL slots up to a cut-off + the overflow pass (segments of the CSR arrays, 8 lanes per segment,
+    several segments for a very long row), on the two-kernel step (full Arnoldi, IOP, Lanczos is not applicable) and on the
+    modular launches (strict MGS), against the oracle; also through expv / phiv and mul!."""
+    n, m = 6000, 30
+    cplx = case == "complex"
+    A = powerlaw_matrix(n, 77, cplx=cplx, local=400 if case == "real_local" else 0, longest=1500 if case == "real_very_long_row" else None)
+    if case == "real_csc_input":
+        A = A.tocsc()
+    info = eu.host_pattern_info(A.tocsr(), np.complex128 if cplx else np.float64)
+    assert info["sell"] and info["sell_cut"] > 0 and "overflow" in info["path"], info
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    op = eu.MIOperator(A)
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    close(op @ x, A @ x, 1e-13, "mul! irregular rows %s" % case)
+    for ortho, iop in (("lowsync", 0), ("mgs", 0), ("lowsync", 3)):
+        Ks = eu.arnoldi(op, b, m=m, ishermitian=False, ortho=ortho, iop=iop)
+        Ko = ko.arnoldi(A, b, m=m, ishermitian=False, iop=iop)
+        assert Ks.m == Ko.m
+        close(Ks.getH(), Ko.getH(), TOL, "arnoldi H irregular rows %s %s iop=%d" % (case, ortho, iop), mat=True)
+        close(Ks.getV(), Ko.getV(), TOL, "arnoldi V irregular rows %s %s iop=%d (max abs)" % (case, ortho, iop), absolute=True)
+    w = eu.expv(0.8, op, b, m=m, ishermitian=False)
+    assert "two_kernel" in eu.expv.last_stats["path"], eu.expv.last_stats
+    close(w, ko.expv(0.8, A, b, m=m, ishermitian=False), TOL, "expv irregular rows %s" % case)
+    close(eu.phiv(0.5, op, b, 2, m=20), ko.phiv(0.5, A, b, 2, m=20), 1e-11, "phiv irregular rows %s" % case)
+    if not cplx:
+        # values-only refresh on the same pattern: the SELL slots AND the overflow entries follow
+        A2 = A.copy()
+        A2.data = A2.data * (1.0 + 0.1 * np.cos(np.arange(A2.nnz)))
+        op.update_values(A2)
+        close(eu.expv(0.8, op, b, m=m, ishermitian=False), ko.expv(0.8, A2.tocsr(), b, m=m, ishermitian=False), TOL,
+              "expv irregular rows %s after update_values" % case)
+
+
+def test_irregular_rows_kiops_and_timestep(eu):
+    """the augmented operator of kiops and the adaptive phiv_timestep on an irregular-row operator (two-kernel step + overflow pass)"""
+    n = 4000
+    A = powerlaw_matrix(n, 91, local=300) * 0.5
+    rng = np.random.default_rng(8)
+    u = rng.standard_normal((n, 3))
+    w, st = eu.kiops(0.7, A, u)
+    wo, so = ko.kiops(0.7, A, u)
+    assert tuple(st) == tuple(so)
+    close(w, wo, 1e-10, "kiops on an irregular-row operator")
+    B = rng.standard_normal((n, 3))
+    s1, s2 = {}, {}
+    U = eu.phiv_timestep(np.array([0.4, 1.0]), A, B, adaptive=True, tol=1e-8, stats=s1)
+    Uo = ko.phiv_timestep(np.array([0.4, 1.0]), A, B, adaptive=True, tol=1e-8, stats=s2)
+    assert (s1["num_timesteps"], s1["matvecs"], s1["m"]) == (s2["num_timesteps"], s2["matvecs"], s2["m"])
+    close(U, Uo, 1e-11, "phiv_timestep on an irregular-row operator")
+
+
 def test_irregular_rows_fall_back_to_csr_and_empty_rows(eu):
-    """A dense row makes SELL padding explode (kept as CSR, one row per lane); empty rows are legal."""
+    """A dense row makes SELL padding explode (SELL slots up to a cut-off + overflow pass); empty rows are legal."""
     rng = np.random.default_rng(21)
     n = 700
     A = sp.random(n, n, density=0.01, random_state=rng, format="lil")
