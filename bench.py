@@ -45,6 +45,31 @@ def c2_operator(n, sym=False, dtype=np.float64):
     return sp.diags(diags, C2_OFFSETS, shape=(n, n), format="csr", dtype=dtype)
 
 
+def general_sparse_operator(kind, n, seed=11):
+    """Non-banded test operators of the secondary lines (the reference's own GPU test uses sprand, test/gpu/gputests.jl:41-58):
+      "random"    regular rows: the diagonal + 4 entries in uniformly random columns (no locality at all: every gather of the
+                  operator apply is a cache miss in an 8 MB vector);
+      "local"     the same with the columns within +-2 % of the row (what a bandwidth-reducing ordering of a mesh gives);
+      "powerlaw"  irregular rows: Zipf-distributed lengths (median 2, mean ~6, longest several hundred), random columns."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    if kind in ("random", "local"):
+        rows = np.repeat(np.arange(n), 4)
+        cols = rng.integers(0, n, size=4 * n) if kind == "random" else np.clip(rows + rng.integers(-n // 50, n // 50 + 1, size=4 * n), 0, n - 1)
+        vals = rng.standard_normal(4 * n) * 0.3
+    elif kind == "powerlaw":
+        ln = np.minimum(rng.zipf(1.8, size=n), 2000)
+        ln = np.minimum(np.maximum(1, (ln * (5.0 / ln.mean())).astype(np.int64)), 4000)
+        rows = np.repeat(np.arange(n), ln)
+        cols = rng.integers(0, n, size=rows.size)
+        vals = rng.standard_normal(rows.size) / np.sqrt(np.repeat(ln, ln))
+    else:
+        raise ValueError(kind)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags([np.full(n, -0.5)], [0], format="csr")
+    A.sum_duplicates()
+    return A.tocsr()
+
+
 # ---------------------------------------------------------------- SURVEY.md §8d byte contracts --------------
 def a_bytes(n, nnz, s=8):
     """A_B = nnz (s + 4) + 4 (n + 1): CSR with 32-bit indices."""
@@ -426,6 +451,32 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["path"] = list(eu.expv.last_stats["path"])
     sec["grid_stencil_wave_form"] = e
     del opg, Ag
+    # (3c) general sparse operators: no band, no diagonals to exploit.  Regular rows with random columns and
+    # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
+    # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
+    import scipy.sparse.linalg as spl
+    for key, kind in (("general_sparse_random", "random"), ("general_sparse_local", "local"), ("irregular_sparse_powerlaw", "powerlaw")):
+        Ag = general_sparse_operator(kind, n)
+        t0 = time.perf_counter()
+        opx = eu.MIOperator(Ag, ctx)
+        t_set = time.perf_counter() - t0
+        fx = lambda: eu.expv(T_FINAL, opx, b, m=m, ishermitian=False, out=w)
+        fx()
+        env.sync()
+        pathx = list(eu.expv.last_stats["path"])
+        wx = w.cpu().numpy().copy()
+        tx = timed(fx, max(5, args.steps // 2), 1, env.sync)
+        truth = spl.expm_multiply(Ag * T_FINAL, b.cpu().numpy())
+        rl = np.diff(Ag.indptr)
+        e = entry("expv, %s rows / %s columns, n=%d nnz=%d m=%d" % ("irregular (Zipf)" if kind == "powerlaw" else "regular",
+                  "local (+-2 %% of the row)" if kind == "local" else "uniformly random", n, Ag.nnz, m), tx, m, alg_bytes_expv(n, Ag.nnz, m),
+                  path=pathx, setup_s=t_set, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
+                  storage=eu.host_pattern_info(Ag)["path"],
+                  verified_vs_scipy_expm_multiply=float(np.linalg.norm(wx - truth) / np.linalg.norm(truth)))
+        if e["verified_vs_scipy_expm_multiply"] > 1e-9:
+            raise SystemExit("%s: result differs from scipy's expm_multiply: %.3e" % (key, e["verified_vs_scipy_expm_multiply"]))
+        sec[key] = e
+        del opx, Ag
     # (4) BASELINE configs[3]: kiops, complex sparse, iop = 2 (the build's extension)
     Ac = (c2_operator(n) * (1 + 0.25j)).tocsc()
     opc = eu.MIOperator(Ac, ctx)
@@ -458,6 +509,42 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
                                "value": o5["value"], "unit": "matvecs/s", "ms_per_call": o5["ms_per_step"],
                                "alg_GBps": o5["roofline"]["achieved"], "frac": o5["roofline"]["frac"],
                                "verified_max_rel_err": o5["verified"]["max_rel_err"]}
+    # (6) BASELINE configs[2] on one GPU at a size that costs a few seconds: adaptive phiv_timestep, K = 4, dense fp64 operator
+    # generated on the device (n = 65 536: 34 GB); the step is operator applications (mul!), the kernel the library's dense GEMV
+    n3 = 65_536
+    try:
+        A3 = c3_rows(torch, env.device, n3, 0, n3)
+        op3 = eu.MIOperator(A3, ctx)                      # device-resident, column-major: no copy
+        g3 = torch.Generator(device=env.device)
+        g3.manual_seed(5)
+        B3 = torch.randn((5, n3), dtype=torch.float64, device=env.device, generator=g3).t()
+        st3 = {}
+        f3 = lambda: eu.phiv_timestep(1.0, op3, B3, adaptive=True, tol=1e-7, m=10, stats=st3)
+        f3()
+        env.sync()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        c0 = ctx.counters()
+        reps3 = 3
+        t3 = timed(f3, reps3, 0, env.sync)
+        c1 = ctx.counters()
+        pr3 = ctx.prof_get()
+        ctx.prof_enable(False)
+        apps = ((c1["op_applies"] - c0["op_applies"]) + (c1["krylov_steps"] - c0["krylov_steps"])) / reps3
+        mv = pr3.get("matvec", {"launches": 0, "total_ms": 0.0})
+        gemv_ms = mv["total_ms"] / max(mv["launches"], 1)
+        sec["c3_dense_phiv_timestep"] = {
+            "what": "BASELINE configs[2] at n=%d (%.1f GB, one GPU): phiv_timestep(1.0, A, B; adaptive, K=4, tol=1e-7, m0=10), dense fp64 A "
+                    "generated on the device; unit = operator applications (all mul! calls)" % (n3, 8e-9 * n3 * n3),
+            "value": apps / t3, "unit": "matvecs/s", "ms_per_call": 1e3 * t3, "applications_per_call": apps,
+            "stats": {k: st3.get(k) for k in ("num_timesteps", "matvecs", "m")},
+            "gemv_avg_ms": gemv_ms, "gemv_launches_profiled": mv["launches"],
+            "gemv_alg_GBps": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9) if gemv_ms > 0 else None,
+            "frac": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gemv_ms > 0 else None,
+            "whole_call_alg_GBps": 8.0 * n3 * n3 * apps / t3 / 1e9}
+        del op3, A3, B3
+    except torch.cuda.OutOfMemoryError as ex:      # (a smaller card: say so instead of dropping the line silently)
+        sec["c3_dense_phiv_timestep"] = {"error": "out of memory for the %d x %d operator: %s" % (n3, n3, str(ex)[:80])}
     return sec
 
 
