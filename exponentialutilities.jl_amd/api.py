@@ -199,6 +199,24 @@ def _ref_dtype(*dts):
     return np.dtype(np.float32 if (dt.kind == "f" and dt.itemsize <= 4) else np.float64)
 
 
+def _t_dtype(t):
+    """element type `t` contributes to promote_type(typeof(t), eltype(A), eltype(b)) (krylov_phiv.jl:142): a numpy scalar keeps
+    its own type (np.float64(1.0) with Float32 operands gives Float64, like a Julia Float64), a bare Python float / int /
+    complex is a literal and takes the operands' precision."""
+    if isinstance(t, np.generic):
+        return np.dtype(t.dtype) if t.dtype.kind in "fc" else np.dtype(np.float32)
+    return np.dtype(np.complex64) if isinstance(t, complex) and t.imag != 0.0 else np.dtype(np.float32)
+
+
+def _src_dtype(A):
+    """element type of an operator argument as the caller holds it (MIOperator remembers what it was built from)"""
+    if isinstance(A, MIOperator):
+        return np.dtype(A.src_dtype)
+    if hasattr(A, "indptr") or isinstance(A, np.ndarray):
+        return np.dtype(A.dtype)
+    return _np_dtype_of(A)
+
+
 def _round_to(x, dtype):
     """round a computed (fp64 / complex-fp64) result to the reference's result type when that is a 32-bit one"""
     dtype = np.dtype(dtype)
@@ -369,13 +387,19 @@ class MIOperator:
                 if M.ndim != 2 or M.shape[0] != M.shape[1]:
                     raise DimensionMismatch("operator must be square")
                 n = M.shape[0]
+                arg = None
                 if n >= 256 and not M.flags.f_contiguous:
                     # a row-major array would be transposed on the host first (numpy: 4 s at n = 8192): upload it as it lies
-                    # and lay it out column-major on the device (torch is the device-memory plumbing here)
-                    import torch
-                    Ad = torch.as_tensor(np.ascontiguousarray(M, dtype=dt), device="cuda:%d" % self.ctx.device)
-                    arg = _Arg(Ad, dt)
-                    del Ad
+                    # and lay it out column-major on the device (torch is the device-memory plumbing here).  torch is optional:
+                    # without a usable ROCm build the host transpose below does the same job, slower.
+                    try:
+                        import torch
+                        Ad = torch.as_tensor(np.ascontiguousarray(M, dtype=dt), device="cuda:%d" % self.ctx.device)
+                        arg = _Arg(Ad, dt)
+                        del Ad
+                    except (ImportError, RuntimeError, AssertionError):
+                        arg = None
+                if arg is not None:
                     _check(lib.expv_mi_op_create_dense(self.ctx._h, _code(dt), n, arg.ptr, arg.ld, L.DEVICE,
                                                        C.byref(h)), self.ctx._h)
                     self._keep = arg
@@ -460,13 +484,32 @@ def _torch_view(ptr, n, dt):
     return torch.as_tensor(s, device="cuda")
 
 
+_WEIGHTS = {}
+
+
 def _wrapsum(a):
-    """Wrap-around integer sum of an array's bytes (8 at a time): any in-place change of the contents changes it."""
+    """Order-SENSITIVE wrap-around checksum of an array's bytes, 8 at a time: sum (2 i + 1) x_i mod 2^64.  A plain
+    sum misses every in-place permutation of the contents (A.data[:] = A.data[::-1], two swapped entries); the index-weighted
+    sum changes whenever two different words trade places.  An F-ordered matrix is read through its transpose (a C-contiguous
+    view of the same memory: no copy)."""
+    a = np.asarray(a)
+    if a.ndim == 2 and a.flags.f_contiguous and not a.flags.c_contiguous:
+        a = a.T
     a = np.ascontiguousarray(a)
     raw = a.view(np.uint8).ravel()
     k = raw.size // 8 * 8
-    tot = int(np.add.reduce(raw[:k].view(np.uint64), dtype=np.uint64)) if k else 0
-    return (tot + int(np.add.reduce(raw[k:], dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
+    tail = int(np.add.reduce(raw[k:].astype(np.uint64) * np.arange(1, raw.size - k + 1, dtype=np.uint64), dtype=np.uint64)) if raw.size > k else 0
+    if not k:
+        return (0, tail)
+    words = raw[:k].view(np.uint64)
+    wts = _WEIGHTS.get(words.size)
+    if wts is None:
+        if len(_WEIGHTS) > 8:
+            _WEIGHTS.clear()
+        wts = _WEIGHTS[words.size] = np.arange(1, 2 * words.size, 2, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        weighted = int(np.dot(words, wts))            # (integer dot: one pass, no temporary; wraps mod 2^64)
+    return (words.size, (weighted + tail) & 0xFFFFFFFFFFFFFFFF)
 
 
 def _fingerprint(A):
@@ -700,7 +743,7 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
                                      C.byref(o), C.byref(st)), opT.ctx._h)
         wa.finish()
         if kw.get("out") is None:
-            w = _round_to(w, _ref_dtype(tdt if tc else np.float32, getattr(op, "src_dtype", op.dtype), bdt))
+            w = _round_to(w, _ref_dtype(_t_dtype(t), getattr(op, "src_dtype", op.dtype), bdt))
         expv.last_stats = {"m": st.m_used, "wasbreakdown": bool(st.wasbreakdown), "matvecs": st.matvecs, "beta": st.beta,
                            "path": [k for k, v in L.PATH_FLAGS.items() if st.path_flags & v]}
         return w
@@ -722,7 +765,7 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
                                                     float(tol), float(rtol), int(m), int(bool(ish))), Ks.ctx._h)
         wa.finish()
         expv.last_subspace = Ks
-        return w
+        return _round_to(w, _ref_dtype(_t_dtype(t), getattr(op, "src_dtype", op.dtype), bdt))     # same result type in every mode
     raise ValueError(f"Unknown Krylov iteration termination mode, {mode}")     # ArgumentError (:132)
 
 
@@ -752,7 +795,10 @@ def phiv(t, A, b, k=None, *, correct=False, errest=False, **kw):
     Ks = arnoldi(A, b, **kw)
     wdt = _work_dtype(_np_dtype_of(b), Ks.T, np.complex128 if _t_parts(t)[2] else np.float64)
     w = _empty_like(b, (b.shape[0], k + 1), wdt)
-    return phiv_(w, t, Ks, k, correct=correct, errest=errest)
+    res = phiv_(w, t, Ks, k, correct=correct, errest=errest)
+    # result type of the reference: promote_type(typeof(t), eltype(A), eltype(b)) -- Float32 operands give a Float32 result
+    rdt = _ref_dtype(_t_dtype(t), _src_dtype(A), _np_dtype_of(b))
+    return (_round_to(res[0], rdt), res[1]) if errest else _round_to(res, rdt)
 
 
 # ---------------------------------------------------------------------------------------------

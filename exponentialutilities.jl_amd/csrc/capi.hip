@@ -587,6 +587,8 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   for (auto &p : ctx->prof)
     for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ht_report();
+  for (Ctx **slot : ctx->children) *slot = nullptr;     // handles that outlive the context: only their destroy is legal from here on
+  ctx->children.clear();
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
   if (ctx->ws_kiops && ctx->ws_kiops_free) ctx->ws_kiops_free(ctx->ws_kiops);
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
@@ -736,6 +738,7 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
     if (colptr[n] - index_base > 0x7fffffffLL) fail(EXPV_MI_ARGUMENT_ERROR, "op_create_csc: nnz exceeds CSR32");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
+    op->device = ctx->device;
     op->dtype = dtype;
     std::vector<int32_t> rp, ci;
     if (dtype == EXPV_MI_C64) {
@@ -747,6 +750,7 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
       csc_to_csr<double>(n, colptr, rowval, reinterpret_cast<const double *>(nzval), index_base, rp, ci, va, &op->csc_pos);
       make_csr_op<double>(*op, n, rp, ci, va);
     }
+    ctx->adopt(&op->ctx);
     *out = op.release();
   });
 }
@@ -782,6 +786,7 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
     }
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
+    op->device = ctx->device;
     op->dtype = dtype;
     if (dtype == EXPV_MI_C64) {
       std::vector<cd> va(reinterpret_cast<const cd *>(vals), reinterpret_cast<const cd *>(vals) + nnz);
@@ -790,6 +795,7 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
       std::vector<double> va(reinterpret_cast<const double *>(vals), reinterpret_cast<const double *>(vals) + nnz);
       make_csr_op<double>(*op, n, rp, ci, va);
     }
+    ctx->adopt(&op->ctx);
     *out = op.release();
   });
 }
@@ -802,6 +808,7 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
     check_device_dtype(dtype, "op_create_dense");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
+    op->device = ctx->device;
     op->dtype = dtype;
     op->kind = OP_DENSE;
     op->n = n;
@@ -845,6 +852,7 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
       op->nnz = (int64_t)h[1];
       op->ishermitian = h[2] == 0 ? 1 : 0;
     }
+    ctx->adopt(&op->ctx);
     *out = op.release();
   });
 }
@@ -856,6 +864,7 @@ int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_
     check_device_dtype(dtype, "op_create_callback");
     std::unique_ptr<expv_mi_op_s> op(new expv_mi_op_s());
     op->ctx = ctx;
+    op->device = ctx->device;
     op->dtype = dtype;
     op->kind = OP_CALLBACK;
     op->n = n;
@@ -864,13 +873,15 @@ int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_
     op->opnorm_inf = NAN;
     op->fn = fn;
     op->user = user;
+    ctx->adopt(&op->ctx);
     *out = op.release();
   });
 }
 
 int expv_mi_op_destroy(expv_mi_op_t op) {
   if (op) {
-    (void)hipSetDevice(op->ctx->device);
+    (void)hipSetDevice(op->device);
+    if (op->ctx) op->ctx->release(&op->ctx);      // (nullptr: the context went first -- its back pointer is already cleared)
     delete op;
   }
   return EXPV_MI_OK;
@@ -947,22 +958,31 @@ int expv_mi_ks_create(expv_mi_ctx_t ctx, int dtype_T, int dtype_U, int64_t n, in
     }
     std::unique_ptr<expv_mi_ks_s> ks(new expv_mi_ks_s());
     ks_alloc(*ks, ctx, dtype_T, dtype_U, n, maxiter, augmented);
+    ks->device = ctx->device;
+    ctx->adopt(&ks->ctx);
     *out = ks.release();
   });
 }
 int expv_mi_ks_destroy(expv_mi_ks_t ks) {
   if (ks) {
     Ctx *ctx = ks->ctx;
-    (void)hipSetDevice(ctx->device);
+    (void)hipSetDevice(ks->device);
+    if (!ctx) {                  // the context was destroyed first: free the storage, touch nothing else
+      delete ks;
+      return EXPV_MI_OK;
+    }
+    if (ctx->ks_spare == ks) return EXPV_MI_OK;      // destroyed twice: it already is the context's spare
     if (ctx->opt.recycle) {      // keep the storage for the next create of the same shape (one per context)
       try {
         ks_recycle(*ks);
-        delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
-        ctx->ks_spare = ks;
+        expv_mi_ks_s *old = reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
+        if (old) { ctx->release(&old->ctx); delete old; }
+        ctx->ks_spare = ks;      // (stays adopted: the context clears / frees it)
         return EXPV_MI_OK;
       } catch (...) {
       }
     }
+    ctx->release(&ks->ctx);
     delete ks;
   }
   return EXPV_MI_OK;
@@ -1160,12 +1180,17 @@ int expv_mi_timestep_caches_create(expv_mi_ctx_t ctx, int dtype, int64_t n, int 
     c->P.alloc(esz * std::max<int64_t>(n, 1) * (p + 2));
     c->ks = new expv_mi_ks_s();
     ks_alloc(*c->ks, ctx, dtype, dtype, n, maxiter, 0);
+    c->device = c->ks->device = ctx->device;
+    ctx->adopt(&c->ctx);
+    ctx->adopt(&c->ks->ctx);
     *out = c.release();
   });
 }
 int expv_mi_timestep_caches_destroy(expv_mi_tscache_t c) {
   if (c) {
-    (void)hipSetDevice(c->ctx->device);
+    (void)hipSetDevice(c->device);
+    if (c->ctx) c->ctx->release(&c->ctx);
+    if (c->ks && c->ks->ctx) c->ks->ctx->release(&c->ks->ctx);
     delete c->ks;
     delete c;
   }

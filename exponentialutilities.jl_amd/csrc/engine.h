@@ -80,6 +80,15 @@ struct Ctx {
   void *ws_kiops = nullptr;   // cached KrylovSubspace + scratch of kiops (owned; see engine_drivers.hip)
   void (*ws_kiops_free)(void *) = nullptr;
   void *ks_spare = nullptr;   // storage of the last destroyed KrylovSubspace (expv_mi_ks_s *), handed to the next create of the same shape
+  // Handles that point back at this context (KrylovSubspace, operator, timestep caches).  A host language may destroy them in
+  // any order (Julia runs finalizers in arbitrary order at exit): expv_mi_ctx_destroy clears their back pointers, and their own
+  // destroy then frees the device memory without touching the context.
+  std::vector<Ctx **> children;
+  void adopt(Ctx **slot) { children.push_back(slot); }
+  void release(Ctx **slot) {
+    for (size_t i = 0; i < children.size(); ++i)
+      if (children[i] == slot) { children[i] = children.back(); children.pop_back(); return; }
+  }
   void *ws_ts = nullptr;      // cached work arrays + KrylovSubspace of a phiv_timestep! call without caches (owned; engine_drivers.hip)
   void (*ws_ts_free)(void *) = nullptr;
   void *ws_batch_pat = nullptr;   // cached DIA layout of the last batch's shared pattern (owned; engine_batch.hip)
@@ -155,7 +164,8 @@ struct ProfScope {  // brackets one launch with events when profiling is on
 enum OpKind { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2 };
 
 struct Op {
-  Ctx *ctx = nullptr;
+  Ctx *ctx = nullptr;       // (nullptr once the context has been destroyed: only op_destroy is legal then)
+  int device = 0;
   int kind = OP_CSR, dtype = EXPV_MI_F64;
   int64_t n = 0, nnz = 0;
   int ishermitian = 0;
@@ -205,7 +215,8 @@ struct expv_mi_op_s : expv_mi::Op {};
 namespace expv_mi {
 
 struct Ks {
-  Ctx *ctx = nullptr;
+  Ctx *ctx = nullptr;       // (nullptr once the context has been destroyed: only ks_destroy is legal then)
+  int device = 0;
   int dtypeT = EXPV_MI_F64, dtypeU = EXPV_MI_F64;
   int64_t n = 0;       // operator size (rows of V minus augmented)
   int maxiter = 30, augmented = 0;
@@ -262,6 +273,7 @@ namespace expv_mi {
 
 struct TsCache {
   Ctx *ctx = nullptr;
+  int device = 0;
   int dtype = EXPV_MI_F64;
   int64_t n = 0;
   int maxiter = 0, p = 0;

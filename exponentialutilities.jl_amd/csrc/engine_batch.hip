@@ -17,6 +17,8 @@
 #include <thread>
 #include <type_traits>
 
+#include <cstring>
+
 #include "engine.h"
 
 namespace expv_mi {
@@ -65,20 +67,19 @@ static DiaPattern dia_pattern(int64_t n, const int32_t *rp, const int32_t *ci, i
 
 // The pattern of a batch is the same call after call (an integrator's Jacobians): its DIA layout -- two passes over the
 // pattern and an nnz-long permutation, 17 ms at n = 1e6, 1.7 ms of a 15 ms call at config 5's n = 1e5 -- and the device
-// copy of the permutation are kept in the context and reused while (n, nnz, wrap-sums of rowptr and colind) are unchanged.
+// copy of the permutation are kept in the context and reused while the pattern (compared entry by entry) is unchanged.
 struct BatchPatternCache {
-  int64_t n = -1, nnz = -1;
-  uint64_t sum_rp = 0, sum_ci = 0;
+  // the pattern the cached layout was built from, kept whole: a checksum of the index arrays can collide (two patterns that
+  // exchange columns between positions of equal weight), and a stale layout would silently permute the wrong values
+  std::vector<int32_t> rowptr, colind;
   DiaPattern P;
   bool perm_uploaded = false;
+  bool matches(int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci) const {
+    return (int64_t)rowptr.size() == n + 1 && (int64_t)colind.size() == nnz &&
+           std::memcmp(rowptr.data(), rp, sizeof(int32_t) * (size_t)(n + 1)) == 0 &&
+           (nnz == 0 || std::memcmp(colind.data(), ci, sizeof(int32_t) * (size_t)nnz) == 0);
+  }
 };
-static uint64_t wrap_sum32(const int32_t *p, int64_t count) {
-  uint64_t a = 0, b = 0, c = 0, d = 0;
-  int64_t i = 0;
-  for (; i + 4 <= count; i += 4) { a += (uint32_t)p[i]; b += (uint32_t)p[i + 1] * 3u; c += (uint32_t)p[i + 2] * 5u; d += (uint32_t)p[i + 3] * 7u; }
-  for (; i < count; ++i) a += (uint32_t)p[i] * 11u;
-  return a + (b << 1) + (c << 2) + (d << 3) + (uint64_t)count;
-}
 
 // Banded pattern, fp64: every problem of a chunk advances by ONE k_pipe launch per Krylov step (problem index in
 // blockIdx.y) -- the single-pass step of pipe.hip, V of each problem read once per step, diagonals without column
@@ -335,10 +336,10 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
         ctx->ws_batch_pat = pc;
         ctx->ws_batch_pat_free = [](void *q) { delete reinterpret_cast<BatchPatternCache *>(q); };
       }
-      const uint64_t srp = wrap_sum32(rowptr_h, n + 1), sci = wrap_sum32(colind_h, nnz);
-      if (pc->n != n || pc->nnz != nnz || pc->sum_rp != srp || pc->sum_ci != sci) {
+      if (!pc->matches(n, nnz, rowptr_h, colind_h)) {      // exact comparison: the same O(nnz) read a checksum would cost
         pc->P = dia_pattern(n, rowptr_h, colind_h, nnz);
-        pc->n = n; pc->nnz = nnz; pc->sum_rp = srp; pc->sum_ci = sci;
+        pc->rowptr.assign(rowptr_h, rowptr_h + n + 1);
+        pc->colind.assign(colind_h, colind_h + nnz);
         pc->perm_uploaded = false;
       }
       if (pc->P.ndiag > 0) {

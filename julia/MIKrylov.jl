@@ -106,6 +106,9 @@ function Ctx(device::Integer = 0)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:expv_mi_ctx_create, lib), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, r), C_NULL)
     c = Ctx(r[])
+    # Julia runs finalizers in no particular order at exit: the library expects that -- expv_mi_ctx_destroy clears the back
+    # pointers of the operator / KrylovSubspace / cache handles that outlive it, and their own destroy then only frees their
+    # device memory (tests/test_gpu_configs.py: test_handles_may_outlive_their_context...; tests/c_harness does exactly this)
     finalizer(c -> ccall((:expv_mi_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), c)
     c
 end

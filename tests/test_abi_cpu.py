@@ -177,6 +177,25 @@ def test_operator_fingerprint_detects_in_place_changes(eu):
     D[2, 1] = -D[2, 1]
     assert api._fingerprint(D) != g0
     assert api._fingerprint(np.zeros((3, 3), dtype=complex)) != api._fingerprint(np.zeros((3, 3)))
+    # in-place PERMUTATIONS of the values leave a plain sum unchanged -- the checksum is order-sensitive
+    A = sp.diags([np.arange(1.0, 2000.0), np.arange(5.0, 2005.0), np.arange(2.0, 2001.0)], [-1, 0, 1], format="csr")
+    f0 = api._fingerprint(A)
+    A.data[:] = A.data[::-1].copy()
+    assert api._fingerprint(A) != f0
+    A.data[:] = A.data[::-1].copy()
+    assert api._fingerprint(A) == f0
+    A.data[[10, 20]] = A.data[[20, 10]]                      # two entries trade places
+    assert api._fingerprint(A) != f0
+    S = np.arange(16.0).reshape(4, 4)
+    S = S + S.T
+    S[0, 3] += 1.0
+    g0 = api._fingerprint(S)
+    S[:] = S.T.copy()                                         # in-place transpose of the values
+    assert api._fingerprint(S) != g0
+    F = np.asfortranarray(np.arange(12.0).reshape(3, 4))
+    h0 = api._fingerprint(F)                                  # F-ordered: checksummed through its transpose view, no copy
+    F[1, 2], F[2, 1] = F[2, 1], F[1, 2]
+    assert api._fingerprint(F) != h0
 
 
 def test_struct_layouts_match_the_library(eu):

@@ -430,6 +430,14 @@ def test_32bit_operands_follow_the_reference_result_type(eu, T):
     close(w.astype(np.complex128), truth, 2e-6, "expv with %s operands vs dense truth (fp32 rounding of inputs and result)" % np.dtype(T).name)
     w64 = eu.expv(0.5, A.astype(np.complex128 if np.dtype(T).kind == "c" else np.float64), b, m=30)
     assert w64.dtype.itemsize == 2 * np.dtype(T).itemsize
+    # promote_type(typeof(t), eltype(A), eltype(b)): a Float64 t (numpy scalar) with 32-bit operands gives the 64-bit type,
+    # a literal takes the operands' precision -- in every front end
+    assert eu.expv(np.float64(0.5), A, b, m=30).dtype.itemsize == 2 * np.dtype(T).itemsize
+    assert eu.phiv(0.5, A, b, 2, m=20).dtype == np.dtype(T)
+    assert eu.phiv(np.float64(0.5), A, b, 2, m=20).dtype.itemsize == 2 * np.dtype(T).itemsize
+    if np.dtype(T).kind == "f":
+        As = ((A + A.T) / 2).astype(T)
+        assert eu.expv(0.5, As, b, m=30, mode="error_estimate").dtype == np.dtype(T)
     with pytest.raises(eu.ExpvMIError) as ei:                      # the C ABI itself says so, instead of misreading the bytes
         import ctypes as C
         from exponentialutilities_jl_amd import _lib as L
@@ -892,3 +900,43 @@ def test_batch_pattern_cache_follows_a_changed_pattern(eu):
             Ap = P.copy()
             Ap.data = vals[p].copy()
             close(W[:, p], ko.expv(0.7, Ap, B[:, p], m=m, ishermitian=False), 1e-12, "batch call %d, column %d vs oracle" % (rnd, p))
+
+
+def test_handles_may_outlive_their_context_and_double_destroy_is_harmless(eu):
+    """a host language may run finalizers in any order.  Destroying the context first leaves KrylovSubspace / operator
+    / timestep-cache handles whose own destroy must free their memory without touching the dead context; destroying a
+    KrylovSubspace twice (it became the context's recycled spare) is a no-op."""
+    import ctypes as C
+    from exponentialutilities_jl_amd import _lib as L
+    lib = L.load()
+    n = 4096
+    A = c2_operator(n).tocsr()
+    for order in ("ctx_first", "ctx_last"):
+        ctx, ks, ks2, op, tsc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert lib.expv_mi_ctx_create(0, None, C.byref(ctx)) == 0
+        assert lib.expv_mi_ks_create(ctx, L.F64, L.F64, n, 10, 0, C.byref(ks)) == 0
+        assert lib.expv_mi_ks_create(ctx, L.F64, L.F64, n, 12, 0, C.byref(ks2)) == 0
+        ip, ix, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        assert lib.expv_mi_op_create_csr(ctx, L.F64, n, ip.ctypes.data, ix.ctypes.data, va.ctypes.data, 4, 0, C.byref(op)) == 0
+        assert lib.expv_mi_timestep_caches_create(ctx, L.F64, n, 10, 1, C.byref(tsc)) == 0
+        b = np.ones(n)
+        o = L.ArnoldiOpts()
+        lib.expv_mi_arnoldi_opts_default(C.byref(o))
+        o.m = 10
+        assert lib.expv_mi_arnoldi(ks, op, b.ctypes.data, L.HOST, C.byref(o)) == 0
+        if order == "ctx_first":
+            assert lib.expv_mi_ks_destroy(ks2) == 0          # becomes the context's spare ...
+            assert lib.expv_mi_ks_destroy(ks2) == 0          # ... and a second destroy of it changes nothing
+            assert lib.expv_mi_ctx_destroy(ctx) == 0         # frees the spare; ks / op / tsc are orphans now
+            assert lib.expv_mi_ks_destroy(ks) == 0
+            assert lib.expv_mi_op_destroy(op) == 0
+            assert lib.expv_mi_timestep_caches_destroy(tsc) == 0
+        else:
+            assert lib.expv_mi_timestep_caches_destroy(tsc) == 0
+            assert lib.expv_mi_op_destroy(op) == 0
+            assert lib.expv_mi_ks_destroy(ks) == 0
+            assert lib.expv_mi_ks_destroy(ks2) == 0
+            assert lib.expv_mi_ctx_destroy(ctx) == 0
+    # the library still works afterwards
+    w = eu.expv(0.3, A, np.ones(n), m=10)
+    close(w, ko.expv(0.3, A, np.ones(n), m=10), 1e-12, "expv after out-of-order handle destruction")
