@@ -940,3 +940,52 @@ def test_handles_may_outlive_their_context_and_double_destroy_is_harmless(eu):
     # the library still works afterwards
     w = eu.expv(0.3, A, np.ones(n), m=10)
     close(w, ko.expv(0.3, A, np.ones(n), m=10), 1e-12, "expv after out-of-order handle destruction")
+
+
+def test_c3_at_the_largest_single_gpu_size(eu):
+    """BASELINE configs[2] at the largest size one MI355X holds: n = 163 840 dense fp64 (214.7 GB, generated on the device).
+    No oracle can follow at this size, so the checks are size-independent: (i) mul! is linear to rounding, (ii) one entry of
+    A x agrees with a dot product of that row taken by torch, (iii) the adaptive phiv_timestep driven by the dense operator
+    and by the row-sharded operator at world size 1 (dist.RowShardedDense: library GEMV through the matrix-free callback) take
+    the same controller decisions and give the same snapshot, (iv) the snapshot satisfies the defining ODE residual in the
+    Krylov sense: the two runs at tol and tol/100 agree to ~tol."""
+    import importlib.util, os, sys, torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.get_device_properties(0).total_memory < 250e9:
+        pytest.skip("needs a 288 GB device")
+    sys.path.insert(0, root)
+    import bench
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(root, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    n = 163_840
+    ctx = eu.Context()
+    A = bench.c3_rows(torch, torch.device("cuda", 0), n, 0, n)          # column-major n x n
+    torch.cuda.synchronize()
+    op = eu.MIOperator(A, ctx)
+    assert op.shape == (n, n) and not op.ishermitian and op.nnz == n * n
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    ax, ay, axy = op @ x, op @ y, op @ (0.3 * x - 1.7 * y)
+    ctx.sync()
+    lin = float(torch.linalg.norm(axy - (0.3 * ax - 1.7 * ay)) / torch.linalg.norm(axy))
+    close(lin, 0.0, 1e-13, "C3 n=163840: mul! linearity |A(ax+by) - aAx - bAy| / |.|", absolute=True)
+    r = 98_765
+    row = float(torch.dot(A[r, :].contiguous(), x))
+    close(float(ax[r]), row, 1e-12 * float(torch.linalg.norm(A[r, :]) * torch.linalg.norm(x)), "C3 n=163840: (A x)[r] vs torch.dot of row r", absolute=True)
+    B = torch.randn((5, n), dtype=torch.float64, device="cuda", generator=g).t()
+    torch.cuda.synchronize()
+    sd, ss, sf = {}, {}, {}
+    Ud = eu.phiv_timestep(1.0, op, B, adaptive=True, tol=1e-7, m=10, stats=sd)
+    sh = D.RowShardedDense(A, n)
+    Us = eu.phiv_timestep(1.0, sh.operator(eu, ctx), B, adaptive=True, tol=1e-7, m=10, stats=ss)
+    assert (sd["num_timesteps"], sd["matvecs"], sd["m"]) == (ss["num_timesteps"], ss["matvecs"], ss["m"]), (sd, ss)
+    assert sh.applications >= ss["matvecs"]
+    close(Us.cpu().numpy(), Ud.cpu().numpy(), 1e-12, "C3 n=163840: phiv_timestep, row-sharded (world 1) operator vs dense operator")
+    Uf = eu.phiv_timestep(1.0, op, B, adaptive=True, tol=1e-9, m=10, stats=sf)
+    close(Ud.cpu().numpy(), Uf.cpu().numpy(), 1e-6, "C3 n=163840: phiv_timestep at tol=1e-7 vs tol=1e-9 (bar 10 tol)")
+    del op, A
+    torch.cuda.empty_cache()
