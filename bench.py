@@ -509,6 +509,27 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
                                "value": o5["value"], "unit": "matvecs/s", "ms_per_call": o5["ms_per_step"],
                                "alg_GBps": o5["roofline"]["achieved"], "frac": o5["roofline"]["frac"],
                                "verified_max_rel_err": o5["verified"]["max_rel_err"]}
+    # (5b) the integrator-facing calls on the headline operator (what OrdinaryDiffEq's exponential integrators call,
+    # krylov_phiv_adaptive.jl:57-114, :184-232): adaptive expv_timestep and adaptive phiv_timestep with K = 4 phi-functions;
+    # unit = operator applications (Krylov steps + the p applications of the W recurrence per sub-step)
+    Bk = torch.as_tensor(np.random.default_rng(5).standard_normal((5, n)), device=env.device).t()      # n x 5, column-major
+    for key, what, fn in (
+            ("expv_timestep_adaptive", "expv_timestep([0.5, 1.0], A, b; adaptive=true, tol=1e-6), C2 operator",
+             lambda st: eu.expv_timestep([0.5, 1.0], op, b, tol=1e-6, adaptive=True, stats=st)),
+            ("phiv_timestep_K4_sparse", "phiv_timestep([1.0], A, B; adaptive=true, tol=1e-8), K=4 (B is n x 5), C2 operator",
+             lambda st: eu.phiv_timestep([1.0], op, Bk, tol=1e-8, adaptive=True, stats=st))):
+        stx = {}
+        fn(stx)
+        env.sync()
+        c0 = ctx.counters()
+        reps = max(5, args.steps // 2)
+        tt = timed(lambda: fn(stx), reps, 1, env.sync)
+        c1 = ctx.counters()
+        ksteps = (c1["krylov_steps"] - c0["krylov_steps"]) / (reps + 1)
+        apps = ksteps + (c1["op_applies"] - c0["op_applies"]) / (reps + 1)
+        sec[key] = {"what": what, "value": apps / tt, "unit": "matvecs/s", "ms_per_call": 1e3 * tt, "krylov_steps_per_call": ksteps,
+                    "operator_applications_per_call": apps, "us_per_operator_application": 1e6 * tt / max(apps, 1),
+                    "stats": {k: stx.get(k) for k in ("num_timesteps", "matvecs", "m", "arnoldi_calls", "arnoldi_reused")}}
     # (6) BASELINE configs[2] on one GPU at a size that costs a few seconds: adaptive phiv_timestep, K = 4, dense fp64 operator
     # generated on the device (n = 65 536: 34 GB); the step is operator applications (mul!), the kernel the library's dense GEMV
     n3 = 65_536

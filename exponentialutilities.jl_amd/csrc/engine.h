@@ -312,6 +312,9 @@ void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int au
 void ks_resize(Ks &ks, int maxiter);
 void ks_materialize(Ks &ks);   // apply pending column scales (pipelined factorisation) so that V is orthonormal in HBM
 void op_apply_dev(Op &op, const void *x_dev, void *y_dev, const StepState *st, int step, bool count = true);
+// y = A x + sum_l coef[l] in[l] (real coefficients, l < nterms <= 6) in one pass when the operator has a stored sparse form;
+// returns false (nothing done) otherwise: the caller applies the operator and the linear combination separately
+bool op_apply_lincomb_dev(Op &op, const void *x_dev, void *y_dev, int nterms, const void *const *in, const double *coef);
 
 struct ArnoldiAug {  // augmented operator pieces (kiops)
   const void *B = nullptr;  // device, n x p, dtype T
@@ -328,8 +331,14 @@ int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o
 void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype);
 void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
                double *errest);
+// optional tail of combine_host_coef (one output column, device output): W = (scale * V c) * pscale + sum_l coef[l] in[l]
+struct LcSpec { int nterms = 0; const void *in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double coef[6] = {0, 0, 0, 0, 0, 0}; double pscale = 1.0; };
 void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
-                       void *W, int64_t ldw, int w_loc, int w_dtype);
+                       void *W, int64_t ldw, int w_loc, int w_dtype, const LcSpec *lc = nullptr);
+// host half of _phiv! (krylov_phiv.jl:620-653): the (m [+1]) x (k+1) coefficient matrix Ce (packed, real or interleaved complex,
+// *mext rows) and the error estimate; phiv_eval = phiv_coefficients + combine_host_coef
+void phiv_coefficients(Ks &ks, double t_re, double t_im, int k, int correct, std::vector<double> &Ce, int *mext, bool *is_cplx,
+                       double *errest);
 
 // max |x_i| (mode 0) / sum |x_i| (mode 1) of a DEVICE vector: partials on the device, finished on the host in index order
 double abs_reduce_dev(Ctx *ctx, int dtype, const void *x_dev, int64_t n, int mode);

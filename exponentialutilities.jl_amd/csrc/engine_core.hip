@@ -234,6 +234,32 @@ void op_apply_dev(Op &op, const void *x, void *y, const StepState *st, int step,
   else op_apply_T<double>(op, (const double *)x, (double *)y, st, step);
 }
 
+template <class T>
+static bool op_apply_lincomb_T(Op &op, const T *x, T *y, int nterms, const void *const *in, const double *coef) {
+  if (op.kind != OP_CSR || !op.sell_ok || nterms > 6) return false;
+  Ctx *c = op.ctx;
+  ++c->cnt_opapply;
+  dev::ApplyLcArgs<T> a{};
+  a.A = dev::SellView<T>{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+  if (op.gndiag > 0 && c->opt.dia) {       // banded and structured-grid operators: the diagonal form, no column indices
+    a.dia_val = op.gdia_ptr<T>(); a.dia_ld = op.gdia_ld; a.ndiag = op.gndiag; a.dia_off = op.gdia_off.as<int32_t>();
+  }
+  a.x = x; a.y = y; a.n = op.n; a.nterms = nterms;
+  for (int l = 0; l < nterms; ++l) { a.in[l] = reinterpret_cast<const T *>(in[l]); a.coef[l] = ST<T>::from_real(coef[l]); }
+  if (op.ovf_nseg > 0 && a.ndiag == 0) {
+    ProfScope ps(c, EXPV_MI_K_MATVEC);
+    dev::spmv_ovf<T>(c->stream, ovf_view<T>(op), x, nullptr, 0);
+    a.ovf_y = op.ovf_y.as<T>();
+  }
+  ProfScope ps(c, EXPV_MI_K_MATVEC);
+  dev::apply_lincomb<T>(c->stream, a);
+  return true;
+}
+bool op_apply_lincomb_dev(Op &op, const void *x, void *y, int nterms, const void *const *in, const double *coef) {
+  if (op.dtype == EXPV_MI_C64) return op_apply_lincomb_T<cplx>(op, (const cplx *)x, (cplx *)y, nterms, in, coef);
+  return op_apply_lincomb_T<double>(op, (const double *)x, (double *)y, nterms, in, coef);
+}
+
 // ------------------------------------------------------------------------------------------
 // arnoldi! / lanczos!
 // ------------------------------------------------------------------------------------------
@@ -1108,7 +1134,7 @@ int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o
 // combine: W = scale * V[:, 0:mcols] * C                       krylov_phiv.jl:229-244, :641
 // ------------------------------------------------------------------------------------------
 void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
-                       void *W, int64_t ldw, int w_loc, int w_dtype) {
+                       void *W, int64_t ldw, int w_loc, int w_dtype, const LcSpec *lc) {
   Ctx *c = ks.ctx;
   c->use();
   if (mcols < 0 || mcols > ks.maxiter + 1) fail(EXPV_MI_ASSERTION, "combine: more columns than the basis holds");
@@ -1145,6 +1171,8 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
       }
   }
   const bool by_value = (ncols == 1 && mcols <= dev::COEF_BY_VALUE_MAX && (w_loc == EXPV_MI_HOST || ldw >= rows || true));
+  if (lc && (!by_value || w_loc != EXPV_MI_DEVICE || (Cc != Tc)))
+    fail(EXPV_MI_ARGUMENT_ERROR, "combine with a linear-combination tail: one column, <= 64 coefficients, device output of the basis type");
   DevBuf cdev;
   if (!by_value) {
     cdev.alloc(cbuf.size() * sizeof(double) + 16);
@@ -1162,7 +1190,23 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   {
     ProfScope ps(c, EXPV_MI_K_COMBINE);
     const int mc = std::max(mcols, 0);
-    if (by_value) {
+    if (by_value && lc) {
+      if (!Cc) {
+        dev::CoefVec<double> cv;
+        for (int i = 0; i < mc; ++i) cv.c[i] = cbuf[i];
+        dev::LcTerms<double> lt{};
+        lt.nterms = lc->nterms; lt.pscale = lc->pscale;
+        for (int l = 0; l < lc->nterms; ++l) { lt.in[l] = reinterpret_cast<const double *>(lc->in[l]); lt.coef[l] = lc->coef[l]; }
+        dev::combine1_lc<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, lt, (double *)Wd);
+      } else {
+        dev::CoefVec<cplx> cv;
+        for (int i = 0; i < mc; ++i) cv.c[i] = make_cplx(cbuf[2 * i], cbuf[2 * i + 1]);
+        dev::LcTerms<cplx> lt{};
+        lt.nterms = lc->nterms; lt.pscale = lc->pscale;
+        for (int l = 0; l < lc->nterms; ++l) { lt.in[l] = reinterpret_cast<const cplx *>(lc->in[l]); lt.coef[l] = make_cplx(lc->coef[l], 0.0); }
+        dev::combine1_lc<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cv, scale, lt, (cplx *)Wd);
+      }
+    } else if (by_value) {
       if (!Cc) {
         dev::CoefVec<double> cv;
         for (int i = 0; i < mc; ++i) cv.c[i] = cbuf[i];
@@ -1251,16 +1295,15 @@ void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype
 // ------------------------------------------------------------------------------------------
 // _phiv!(w, t, Ks, k, cache, correct, expmethod)                 krylov_phiv.jl:620-653
 // ------------------------------------------------------------------------------------------
-void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
-               double *errest) {
+void phiv_coefficients(Ks &ks, double t_re, double t_im, int k, int correct, std::vector<double> &Ce_out, int *mext_out,
+                       bool *is_cplx, double *errest) {
   const int m = ks.m;
   const bool tc = (t_im != 0.0);
   if (k < 1) fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: k >= 1 required");
-  if ((tc || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
-    fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: w must be complex when t or the basis is complex");
   const cd t(t_re, t_im);
   const int hend_r = m, hend_c = m - 1 + (ks.augmented != 0 ? 1 : 0);   // H[end, end] of getH(Ks)
-  const cd hend = getH(ks, hend_r, hend_c);
+  // (H[m+1, m] may still be on its way -- a deferred closing pass, Ks::defer_tail_req: the small exponential below only needs
+  //  H[1:m, 1:m] and runs on the host meanwhile; ks_finish_tail() picks the entry up right after it)
   const bool cplx_small = tc || ks.dtypeU == EXPV_MI_C64;
   const int mext = m + (correct ? 1 : 0);
   double err = 0.0;
@@ -1271,13 +1314,16 @@ void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, in
     std::vector<cd> e(m, cd(0));
     if (m > 0) e[0] = cd(1);
     Mat<cd> C2 = dense::phiv_dense(Hc, e, k);
+    ks_finish_tail(ks);
+    const cd hend = getH(ks, hend_r, hend_c);
     Mat<cd> Ce(mext, k + 1);
     for (int q = 0; q <= k; ++q)
       for (int i = 0; i < m; ++i) Ce(i, q) = C2(i, q);
     if (correct)
       for (int i = 1; i <= k; ++i) Ce(m, i - 1) = hend * t * C2(m - 1, i);   // betah*C2[end,i+1] / beta
     err = std::abs(ks.beta * hend * t * C2(m - 1, k));
-    combine_host_coef(ks, mext, k + 1, Ce.data(), mext, EXPV_MI_C64, ks.beta, W, ldw, w_loc, w_dtype);
+    Ce_out.resize((size_t)2 * mext * (k + 1));
+    std::memcpy(Ce_out.data(), Ce.data(), sizeof(double) * Ce_out.size());
   } else {
     Mat<double> Hr(m, m);
     for (int j = 0; j < m; ++j)
@@ -1285,15 +1331,30 @@ void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, in
     std::vector<double> e(m, 0.0);
     if (m > 0) e[0] = 1.0;
     Mat<double> C2 = dense::phiv_dense(Hr, e, k);
+    ks_finish_tail(ks);
+    const cd hend = getH(ks, hend_r, hend_c);
     Mat<double> Ce(mext, k + 1);
     for (int q = 0; q <= k; ++q)
       for (int i = 0; i < m; ++i) Ce(i, q) = C2(i, q);
     if (correct)
       for (int i = 1; i <= k; ++i) Ce(m, i - 1) = hend.real() * t_re * C2(m - 1, i);
     err = std::fabs(ks.beta * hend.real() * t_re * C2(m - 1, k));
-    combine_host_coef(ks, mext, k + 1, Ce.data(), mext, EXPV_MI_F64, ks.beta, W, ldw, w_loc, w_dtype);
+    Ce_out.assign(Ce.data(), Ce.data() + (size_t)mext * (k + 1));
   }
+  *mext_out = mext;
+  *is_cplx = cplx_small;
   if (errest) *errest = err;
+}
+
+void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
+               double *errest) {
+  if ((t_im != 0.0 || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
+    fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: w must be complex when t or the basis is complex");
+  std::vector<double> Ce;
+  int mext = 0;
+  bool cplx_small = false;
+  phiv_coefficients(ks, t_re, t_im, k, correct, Ce, &mext, &cplx_small, errest);
+  combine_host_coef(ks, mext, k + 1, Ce.data(), mext, cplx_small ? EXPV_MI_C64 : EXPV_MI_F64, ks.beta, W, ldw, w_loc, w_dtype);
 }
 
 // ------------------------------------------------------------------------------------------

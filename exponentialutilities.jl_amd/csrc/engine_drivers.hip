@@ -183,12 +183,22 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
   while (t < tend) {
     if (t + tau > tend) tau = tend - t;
     // Part 1: w0..wp by recurrence (16)  (:353-362)
-    HIPCHECK(hipMemcpyAsync(W, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+    // (p == 0, expv_timestep!: W[:, 1] = u is only the starting vector of the factorisation, which has consumed it before Part 3
+    //  overwrites u -- everything is ordered on one stream -- so the factorisation reads u in place: no copy)
+    T *wlast = (p == 0) ? u : W + (size_t)p * n;
+    if (p > 0) HIPCHECK(hipMemcpyAsync(W, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
     for (int l = 1; l <= p - 1; ++l) coeffs[l] = coeffs[l - 1] * t / l;
     for (int j = 1; j <= p; ++j) {
       T *wj = W + (size_t)j * n;
-      op_apply_dev(op, W + (size_t)(j - 1) * n, wj, nullptr, 0);
       ++matvecs;
+      // w_j = A w_{j-1} + sum_l coeffs[l] B[:, j+l]: one pass over the operator when it has a stored sparse form (w_j is not
+      // written and read again in between), operator apply + linear combination otherwise (dense, matrix-free, > 6 terms)
+      const int nt = p - j + 1;
+      const void *tin[6];
+      double tcf[6];
+      for (int l = 0; l < nt && l < 6; ++l) { tin[l] = B + (size_t)(j + l) * ldb; tcf[l] = coeffs[l]; }
+      if (nt <= 6 && op_apply_lincomb_dev(op, W + (size_t)(j - 1) * n, wj, nt, tin, tcf)) continue;
+      op_apply_dev(op, W + (size_t)(j - 1) * n, wj, nullptr, 0);
       std::vector<const T *> in{wj};
       std::vector<double> cf{1.0};
       for (int l = 0; l <= p - j; ++l) {
@@ -201,7 +211,36 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
     ao.m = m;
     ao.iop = iop;
     ao.init = 0;
-    last_fact_matvecs = arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);
+    // Deferred closing pass (like kiops): once the absolute tolerance is known nothing needs H[m+1, m] before the error
+    // estimate, so arnoldi_run may return at the early mailbox flag and the host's small exponential (phiv_eval) runs while
+    // the device still produces v_{m+1} / H[m+1, m]; phiv_eval picks the entry up.  A happy breakdown found only by that
+    // closing pass (beta_m < tol) changes tau (:385): the evaluation is then repeated with the right tau.
+    auto factorise = [&]() {
+      ks->defer_tail_req = have_abstol;
+      struct Off { Ks *k; ~Off() { k->defer_tail_req = false; } } off{ks};
+      return arnoldi_run(*ks, op, wlast, ao, nullptr, false);
+    };
+    // _phiv!(P, tau, Ks, p + 1, ...) (:386, :418): of its n x (p+2) result the loop reads ONE column (P[:, end-1], Part 3) and the
+    // error estimate, which is a host scalar.  The host half (small exponential -> coefficient matrix Ce + estimate) therefore
+    // runs alone here, adaptation retries included; the device forms P[:, end-1] once per accepted sub-step / snapshot, in the
+    // same pass that applies Part 3's linear combination (u_update).  P stays what it is in the reference: scratch.
+    std::vector<double> Ce;
+    int mext = 0;
+    bool ce_cplx = false;
+    double ce_tau = 0.0;
+    auto coefficients = [&](double tt, double *eps) {
+      phiv_coefficients(*ks, tt, 0.0, p + 1, o.correct, Ce, &mext, &ce_cplx, eps);
+      ce_tau = tt;
+    };
+    auto evaluate = [&](double *eps) {
+      const bool pending = ks->tail.pending;
+      coefficients(tau, eps);
+      if (pending && ks->wasbreakdown && tau != tend - t) {
+        tau = tend - t;
+        coefficients(tau, eps);
+      }
+    };
+    last_fact_matvecs = factorise();
     matvecs += last_fact_matvecs;
     ++arn_calls;
     if (!have_abstol) {
@@ -217,7 +256,7 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
     }
     if (ks->wasbreakdown) tau = tend - t;
     double epsilon = 0.0;
-    phiv_eval(*ks, tau, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &epsilon);
+    evaluate(&epsilon);
     emit(o, fmt("t = %.17g, m = %d, tau = %.17g, error estimate = %.17g", t, m, tau, epsilon));
     if (o.adaptive) {
       double omega = (tend / tau) * (epsilon / abstol);
@@ -251,12 +290,12 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
           matvecs += last_fact_matvecs;
           ++arn_reused;
         } else {
-          last_fact_matvecs = arnoldi_run(*ks, op, W + (size_t)p * n, ao, nullptr, false);   // from scratch, like :417
+          last_fact_matvecs = factorise();   // from scratch, like :417
           matvecs += last_fact_matvecs;
         }
         ++arn_calls;
         double epsilon_new = 0.0;
-        phiv_eval(*ks, tau, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &epsilon_new);
+        coefficients(tau, &epsilon_new);   // (no wasbreakdown -> tau rule here: :417-418)
         epsilon_old = epsilon;
         epsilon = epsilon_new;
         omega = (tend / tau) * (epsilon / abstol);
@@ -264,8 +303,22 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
       }
     }
     // Part 3: u update (15)  (:425-431)
+    // dst = tt^p * (beta V Ce[:, p]) + sum_j coeffs[j] W[:, j]   with Ce evaluated at tt
     auto u_update = [&](T *dst, double tt) {
+      if (ce_tau != tt) { double dummy; coefficients(tt, &dummy); }      // (a snapshot at the end of the sub-step reuses Ce: same inputs)
       for (int l = 1; l <= p - 1; ++l) coeffs[l] = coeffs[l - 1] * tt / l;
+      const size_t esz = ce_cplx ? 2 : 1;
+      const double *col = Ce.data() + esz * (size_t)p * mext;          // column p of Ce = P[:, end-1]
+      if (p <= 6 && mext <= dev::COEF_BY_VALUE_MAX && (ce_cplx == (dt == EXPV_MI_C64))) {
+        LcSpec lc;
+        lc.nterms = p;
+        lc.pscale = std::pow(tt, p);
+        for (int j = 0; j <= p - 1; ++j) { lc.in[j] = W + (size_t)j * n; lc.coef[j] = coeffs[j]; }
+        combine_host_coef(*ks, mext, 1, col, mext, ce_cplx ? EXPV_MI_C64 : EXPV_MI_F64, ks->beta, dst, n, EXPV_MI_DEVICE, dt, &lc);
+        return;
+      }
+      // long windows / many terms: the column, then the linear combination
+      combine_host_coef(*ks, mext, 1, col, mext, ce_cplx ? EXPV_MI_C64 : EXPV_MI_F64, ks->beta, P + (size_t)p * n, n, EXPV_MI_DEVICE, dt);
       std::vector<const T *> in{P + (size_t)p * n};
       std::vector<double> cf{std::pow(tt, p)};
       for (int j = 0; j <= p - 1; ++j) {
@@ -277,8 +330,6 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
     u_update(u, tau);
     while (snapshot <= nts && t + tau >= ts[snapshot - 1]) {   // snapshots (:433-445)
       const double tau_snapshot = ts[snapshot - 1] - t;
-      double dummy;
-      phiv_eval(*ks, tau_snapshot, 0.0, p + 1, o.correct, P, n, EXPV_MI_DEVICE, dt, &dummy);
       u_update(Udev + (size_t)(snapshot - 1) * ldu, tau_snapshot);
       ++snapshot;
     }

@@ -132,6 +132,52 @@ void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y,
   hipLaunchKernelGGL(k_spmv_sell<T>, dim3((int)g), dim3(BLOCK), 0, s, n, A, x, y, st, step, ovf_y);
 }
 
+// ---- operator apply + linear combination in one pass (W recurrence of phiv_timestep!) -------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_apply_lincomb(ApplyLcArgs<T> a) {
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool aly = is_al16(a.y);
+  bool alin[6];
+#pragma unroll
+  for (int l = 0; l < 6; ++l) alin[l] = l < a.nterms && is_al16(a.in[l]);
+  const int64_t nsl = (a.n + SH - 1) / SH;
+  for (int64_t slice = (int64_t)blockIdx.x * (BLOCK / 64) + wave; slice < nsl; slice += (int64_t)gridDim.x * (BLOCK / 64)) {
+    const int64_t i = slice * SH + (int64_t)lane * N;
+    Pack<T> acc;
+    // the terms do not depend on the operator: in flight together with its slots
+    Pack<T> tv[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l)
+      if (l < a.nterms) tv[l] = ld_pack_user(a.in[l], i, a.n, alin[l]);
+    if (a.ndiag > 0) dia_rows<T>(a.dia_val, a.dia_ld, a.ndiag, a.dia_off, i, a.n, a.x, acc.v);
+    else {
+      sell_rows<T>(a.A, slice, lane, a.x, acc.v);
+      if (a.ovf_y) {
+        const Pack<T> o = *reinterpret_cast<const Pack<T> *>(a.ovf_y + i);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc.v[k] = ST<T>::add(acc.v[k], o.v[k]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l)
+      if (l < a.nterms) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) ST<T>::fma_(acc.v[k], a.coef[l], tv[l].v[k]);
+      }
+    st_pack_user(a.y, i, a.n, aly, acc);
+  }
+}
+template <class T>
+void apply_lincomb(hipStream_t s, const ApplyLcArgs<T> &a) {
+  constexpr int SH = 64 * Pack<T>::N;
+  int64_t g = ((a.n + SH - 1) / SH + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (g > MAX_GRID) g = MAX_GRID;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_apply_lincomb<T>, dim3((int)g), dim3(BLOCK), 0, s, a);
+}
+
 // ---- fused half-step A ----------------------------------------------------------------------
 template <class T, bool GRAM>
 __global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_fused_a(FusedAArgs<T> fa, int spw) {
@@ -550,6 +596,7 @@ void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *cs
 #define INSTF(T)                                                                                               \
   template void spmv_sell<T>(hipStream_t, int64_t, const SellView<T> &, const T *, T *, const StepState *, int, const T *); \
   template void fused_a<T>(hipStream_t, const FusedAArgs<T> &);                                                \
+  template void apply_lincomb<T>(hipStream_t, const ApplyLcArgs<T> &);                                         \
   template void fused_a2<T>(hipStream_t, const FusedAArgs<T> &, double, int);                                  \
   template void update2<T>(hipStream_t, const UpdateArgs<T> &, int, int);                                      \
   template void norm_final<T>(hipStream_t, const T *, int64_t, double *, double *, StepState *, T *, int, int,  \

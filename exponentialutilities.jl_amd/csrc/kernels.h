@@ -137,6 +137,20 @@ template <class T>
 void spmv_sell(hipStream_t s, int64_t n, const SellView<T> &A, const T *x, T *y, const StepState *st, int step,
                const T *ovf_y = nullptr);   // ovf_y: added to the SELL part (spmv_ovf ran on the same x before)
 
+// y = A x + sum_l coef[l] * in[l]  (l < nterms <= 6) in ONE pass: the W recurrence of phiv_timestep!
+// (krylov_phiv_adaptive.jl:353-362: mul!(w_j, A, w_{j-1}) followed by axpy!s of the columns of B) without writing and
+// re-reading w_j in between.  The operator is read through its diagonal form when it has one (no column indices), its SELL
+// slots otherwise (+ the overflow pass's ovf_y for irregular rows).
+template <class T>
+struct ApplyLcArgs {
+  SellView<T> A;
+  const T *dia_val; int64_t dia_ld; int ndiag; const int32_t *dia_off;
+  const T *ovf_y;
+  const T *x; T *y; int64_t n;
+  int nterms; const T *in[6]; T coef[6];
+};
+template <class T> void apply_lincomb(hipStream_t s, const ApplyLcArgs<T> &a);
+
 // fused Krylov half-step A: v_j = u / beta_{j-1};  y = A v_j;  projection sums of y (and the Gram row
 // of v_j) against the window of V -- one pass, one grid reduction (arnoldi.jl:185, :302, :306 fused)
 template <class T>
@@ -301,6 +315,12 @@ constexpr int COEF_BY_VALUE_MAX = 64;
 template <class TC> struct CoefVec { TC c[COEF_BY_VALUE_MAX]; };
 template <class TV, class TC>
 void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W);
+// the same with a tail of linear-combination terms:  W = ((scale * V c) * pscale) + sum_l coef[l] in[l]   (l < nterms <= 6)
+// -- Part 3 of phiv_timestep! (krylov_phiv_adaptive.jl:425-431: u = tau^p P[:, end-1] + sum_j c_j W[:, j]) in the pass that
+// forms the one column of P it reads, instead of a n x (p+2) product followed by a second pass
+template <class TC> struct LcTerms { int nterms; const TC *in[6]; TC coef[6]; double pscale; };
+template <class TV, class TC>
+void combine1_lc(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, const LcTerms<TC> &lt, TC *W);
 
 // out = sum_k coef[k] * in[k]   (k < nterms <= 8); out may alias in[0]
 template <class T>

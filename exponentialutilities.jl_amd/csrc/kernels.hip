@@ -733,6 +733,46 @@ void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const C
 }
 
 template <class TV, class TC>
+__global__ __launch_bounds__(BLOCK) void k_combine1_lc(int64_t n, const TV *__restrict__ V, int64_t ldv, int m, CoefVec<TC> cv,
+                                                       double scale, LcTerms<TC> lt, TC *__restrict__ W, int64_t rpb) {
+  constexpr int N = Pack<TV>::N;
+  const bool al = ((ldv * sizeof(TV)) % 16 == 0) && is_al16(V);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
+  for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += (int64_t)BLOCK * N) {
+    TC acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = ST<TC>::zero();
+    int c = 0;
+    for (; c + 8 <= m; c += 8) {
+      Pack<TV> vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[u] = ld_pack(V + (int64_t)(c + u) * ldv, i, n, al);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < N; ++k) mulacc<TV, TC>(acc[k], vv[u].v[k], cv.c[c + u]);
+    }
+    for (; c < m; ++c) {
+      const Pack<TV> vv = ld_pack(V + (int64_t)c * ldv, i, n, al);
+#pragma unroll
+      for (int k = 0; k < N; ++k) mulacc<TV, TC>(acc[k], vv.v[k], cv.c[c]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (i + k >= n) continue;
+      TC v = ST<TC>::mul_real(ST<TC>::mul_real(acc[k], scale), lt.pscale);    // lmul!(beta, .) then lmul!(tau^p, .)
+      for (int l = 0; l < lt.nterms; ++l) ST<TC>::fma_(v, lt.coef[l], lt.in[l][i + k]);    // axpy!s in the reference's order
+      W[i + k] = v;
+    }
+  }
+}
+template <class TV, class TC>
+void combine1_lc(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, const LcTerms<TC> &lt, TC *W) {
+  const RowPlan p = plan_rows(n, 64 * Pack<TV>::N, resident_blocks((const void *)k_combine1_lc<TV, TC>));
+  hipLaunchKernelGGL((k_combine1_lc<TV, TC>), dim3(p.nblocks), dim3(BLOCK), 0, s, n, V, ldv, m, cv, scale, lt, W, p.rows_per_block);
+}
+
+template <class TV, class TC>
 void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC *C, int ldc, int ncols, double scale,
              TC *W, int64_t ldw) {
   const int g = grid_for(n, BLOCK * Pack<TV>::N * 2);
@@ -810,6 +850,10 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void lincomb<T>(hipStream_t, const LincombArgs<T> &);
 INST(double)
 INST(cplx)
+template void combine1_lc<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<double> &, double,
+                                          const LcTerms<double> &, double *);
+template void combine1_lc<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefVec<cplx> &, double,
+                                      const LcTerms<cplx> &, cplx *);
 template void combine1<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<double> &,
                                        double, double *);
 template void combine1<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<cplx> &, double,
