@@ -125,6 +125,7 @@ PROTOTYPES = {
     "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),
     "expv_mi_host_expm": (_i, [_i, _i, _vp, _i]),
     "expv_mi_host_symtridiag_expcol": (_i, [_i, _pd, _pd, _d, _d, _pd]),
+    "expv_mi_host_symtridiag_exp_last": (_i, [_i, _pd, _pd, _d, _d, _pd]),
     "expv_mi_host_phiv_dense": (_i, [_i, _i, _i, _vp, _i, _vp, _vp]),
 }
 

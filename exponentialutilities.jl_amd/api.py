@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol", "host_pattern_info", "clear_operator_cache",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "clear_operator_cache",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -1087,6 +1087,17 @@ def host_phiv_dense(A, v, k):
     _check(L.load().expv_mi_host_phiv_dense(_HOST_CODES[dt], m, int(k), A.ctypes.data, max(m, 1), v.ctypes.data,
                                             w.ctypes.data))
     return w
+
+
+def host_symtridiag_exp_last(d, e, t):
+    """last entry of host_symtridiag_expcol, computed from the first and last eigenvector rows only (O(n^2))."""
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    e = np.ascontiguousarray(e, dtype=np.float64)
+    out = np.empty(1, dtype=np.complex128)
+    tr, ti, _ = _t_parts(t)
+    _check(L.load().expv_mi_host_symtridiag_exp_last(d.size, d.ctypes.data_as(L._pd), e.ctypes.data_as(L._pd), tr, ti,
+                                                     out.ctypes.data_as(L._pd)))
+    return complex(out[0])
 
 
 def host_symtridiag_expcol(d, e, t):

@@ -1265,6 +1265,15 @@ int expv_mi_host_symtridiag_expcol(int n, const double *d, const double *e, doub
     for (int i = 0; i < n; ++i) { out_c64[2 * i] = r[i].real(); out_c64[2 * i + 1] = r[i].imag(); }
   });
 }
+int expv_mi_host_symtridiag_exp_last(int n, const double *d, const double *e, double t_re, double t_im, double *out_c64) {
+  return guarded(nullptr, [&] {
+    if (n < 1) fail(EXPV_MI_ARGUMENT_ERROR, "symtridiag_exp_last: n >= 1 required");
+    std::vector<double> dv(d, d + n), ev(e, e + (n > 1 ? n - 1 : 0));
+    const cd r = dense::symtridiag_exp_last<cd>(dv, ev, cd(t_re, t_im));
+    out_c64[0] = r.real();
+    out_c64[1] = r.imag();
+  });
+}
 // phiv_dense!(w, A, v, k)  (phi.jl:84-115); w is m x (k+1), ldw = m
 int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, const void *v, void *w) {
   return guarded(nullptr, [&] {

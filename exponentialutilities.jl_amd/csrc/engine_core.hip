@@ -1442,9 +1442,16 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
     alpha.push_back(aj);
     betas.push_back(bj);
     std::vector<double> off(betas.begin(), betas.begin() + (j - 1));   // SymTridiagonal(alpha, beta) uses beta[1:j-1]
-    cv = dense::symtridiag_expcol<cd>(alpha, off, t);                  // expT!  (:58-68)
-    const double sigma = bj * ks.beta * std::abs(cv[j - 1]);           // Saad's Er2  (:197)
-    if (sigma < eps_stop) { ks.m = j; break; }
+    // expT! (:58-68) forms all of exp(t T_j) e_1 every step, but the test (:197) reads its LAST entry only: that entry comes from
+    // the first and last rows of the eigenvector matrix, O(j^2) per step instead of O(j^3) -- bit for bit the entry the full
+    // decomposition gives (dense::symtridiag_exp_last), so the stopping step cannot differ.  The whole vector is formed once,
+    // at the step that stops.
+    const cd last = dense::symtridiag_exp_last<cd>(alpha, off, t);
+    const double sigma = bj * ks.beta * std::abs(last);                // Saad's Er2  (:197)
+    if (sigma < eps_stop || j == m) {
+      cv = dense::symtridiag_expcol<cd>(alpha, off, t);
+      if (sigma < eps_stop) { ks.m = j; break; }
+    }
   }
   for (auto e : ev)
     if (e) (void)hipEventDestroy(e);

@@ -524,10 +524,20 @@ inline void expm_higham2005base(Mat<S> &A) {
 
 // ---- symmetric tridiagonal eigen-decomposition (implicit QL, EISPACK tql2 lineage) -----------
 // d[0..n) diagonal, e[0..n-1) off-diagonal; on return d = eigenvalues (ascending), Z = vectors.
+// ENDS_ONLY: accumulate only the FIRST and LAST row of Z (stored as rows 0 and 1 of a 2 x n matrix).  Every rotation acts on the
+// rows of Z independently, so these two rows come out bit for bit as in the full decomposition, at O(n) instead of O(n^2) per
+// sweep -- all that e_n' f(T) e_1 = sum_i Z[n,i] f(lambda_i) Z[1,i] needs (the per-step stopping test of the error-estimate
+// mode, krylov_phiv_error_estimate.jl:58-68, :197).
+template <bool ENDS_ONLY = false>
 inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat<double> &Z) {
   const int n = (int)d.size();
-  Z = Mat<double>(n, n);
-  for (int i = 0; i < n; ++i) Z(i, i) = 1.0;
+  const int zr = ENDS_ONLY ? 2 : n;
+  Z = Mat<double>(zr, n);
+  if (ENDS_ONLY) {
+    if (n > 0) { Z(0, 0) = 1.0; Z(1, n - 1) = 1.0; }
+  } else {
+    for (int i = 0; i < n; ++i) Z(i, i) = 1.0;
+  }
   if (n <= 1) return;
   std::vector<double> e(n, 0.0);
   for (int i = 0; i + 1 < n; ++i) e[i] = e_in[i];
@@ -557,7 +567,7 @@ inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat
           p = s * r;
           d[i + 1] = g + p;
           g = c * r - b;
-          for (int k = 0; k < n; ++k) {
+          for (int k = 0; k < zr; ++k) {
             f = Z(k, i + 1);
             Z(k, i + 1) = s * Z(k, i) + c * f;
             Z(k, i) = c * Z(k, i) - s * f;
@@ -576,7 +586,7 @@ inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat
     for (int j = i + 1; j < n; ++j) if (d[j] < d[k]) k = j;
     if (k != i) {
       std::swap(d[i], d[k]);
-      for (int r = 0; r < n; ++r) std::swap(Z(r, i), Z(r, k));
+      for (int r = 0; r < zr; ++r) std::swap(Z(r, i), Z(r, k));
     }
   }
 }
@@ -592,6 +602,19 @@ inline std::vector<St> symtridiag_expcol(const std::vector<double> &diag, const 
   for (int i = 0; i < n; ++i) wv[i] = std::exp(t * d[i]) * Z(0, i);
   for (int i = 0; i < n; ++i)
     for (int r = 0; r < n; ++r) out[r] += Z(r, i) * wv[i];
+  return out;
+}
+
+// last entry of symtridiag_expcol: e_n' exp(t T) e_1, from the first and last rows of Z only -- O(n^2) for the whole
+// decomposition instead of O(n^3), the same arithmetic on those rows and the same summation order, hence the same bits
+template <class St>
+inline St symtridiag_exp_last(const std::vector<double> &diag, const std::vector<double> &off, St t) {
+  std::vector<double> d = diag;
+  Mat<double> Z;
+  symtridiag_eig<true>(d, off, Z);
+  const int n = (int)d.size();
+  St out(0);
+  for (int i = 0; i < n; ++i) out += Z(n > 1 ? 1 : 0, i) * (std::exp(t * d[i]) * Z(0, i));
   return out;
 }
 

@@ -359,6 +359,11 @@ int expv_mi_host_expm(int dtype, int n, void *A, int lda);
 /* Z*(exp.(t*lambda).*Z[1,:]) of SymTridiagonal(d, e)  (krylov_phiv.jl:227-228); out: n complex */
 int expv_mi_host_symtridiag_expcol(int n, const double *d, const double *e, double t_re, double t_im,
                                    double *out_c64);
+/* Its last entry alone, e_n' exp(t T) e_1 -- what the per-step stopping test of the error-estimate mode reads
+ * (krylov_phiv_error_estimate.jl:197) -- from the first and last rows of the eigenvector matrix only: O(n^2) instead of O(n^3),
+ * bit for bit the entry the full product gives; out: one complex */
+int expv_mi_host_symtridiag_exp_last(int n, const double *d, const double *e, double t_re, double t_im,
+                                     double *out_c64);
 /* phiv_dense!(w, A, v, k)  (phi.jl:84-115); w is m x (k+1) packed */
 int expv_mi_host_phiv_dense(int dtype, int m, int k, const void *A, int lda, const void *v, void *w);
 

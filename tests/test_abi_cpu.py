@@ -105,6 +105,26 @@ def test_host_symtridiag_expcol(eu, t, n):
     assert np.abs(eu.host_symtridiag_expcol(d, e, t) - sl.expm(t * M)[:, 0]).max() < 1e-13
 
 
+@pytest.mark.parametrize("t", [0.7, -2.5, 0.3 - 1.1j, -1j])
+@pytest.mark.parametrize("n", [1, 2, 5, 30, 97])
+def test_host_symtridiag_exp_last_is_the_last_entry_bit_for_bit(eu, t, n):
+    """the per-step stopping test of the error-estimate mode reads e_j' exp(t T_j) e_1 only; it is computed from
+    the first and last eigenvector rows (O(j^2) per step) and must be EXACTLY the entry the full product gives, so that the
+    stopping step cannot move -- including on a Lanczos matrix with ghost eigenvalue clusters."""
+    rng = np.random.default_rng(n)
+    d = rng.standard_normal(n)
+    e = np.abs(rng.standard_normal(max(n - 1, 0))) + 0.1
+    if n > 10:                                  # clustered spectrum: several nearly equal diagonal entries, tiny couplings
+        d[3:8] = 5.0 + 1e-9 * rng.standard_normal(5)
+        e[3:7] = 1e-7
+    full = eu.host_symtridiag_expcol(d, e, t)
+    last = eu.host_symtridiag_exp_last(d, e, t)
+    assert last.real == full[-1].real and last.imag == full[-1].imag
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    truth = sl.expm(t * T)[-1, 0]
+    assert abs(last - truth) <= 1e-12 * max(1.0, abs(sl.expm(t * T)).max())
+
+
 @pytest.mark.parametrize("T", [float, complex])
 def test_host_phiv_dense(eu, T):
     rng = np.random.default_rng(11)
