@@ -49,13 +49,15 @@ def general_sparse_operator(kind, n, seed=11):
     """Non-banded test operators of the secondary lines (the reference's own GPU test uses sprand, test/gpu/gputests.jl:41-58):
       "random"    regular rows: the diagonal + 4 entries in uniformly random columns (no locality at all: every gather of the
                   operator apply is a cache miss in an 8 MB vector);
-      "local"     the same with the columns within +-2 % of the row (what a bandwidth-reducing ordering of a mesh gives);
+      "local"     the same with the columns within +-2 % of the row, "local_narrow" within +-0.2 % (what a bandwidth-reducing
+                  ordering of a 3-D / 2-D mesh of 1e6 nodes gives: bandwidth ~ n^(2/3) / n^(1/2));
       "powerlaw"  irregular rows: Zipf-distributed lengths (median 2, mean ~6, longest several hundred), random columns."""
     import scipy.sparse as sp
     rng = np.random.default_rng(seed)
-    if kind in ("random", "local"):
+    if kind in ("random", "local", "local_narrow"):
         rows = np.repeat(np.arange(n), 4)
-        cols = rng.integers(0, n, size=4 * n) if kind == "random" else np.clip(rows + rng.integers(-n // 50, n // 50 + 1, size=4 * n), 0, n - 1)
+        reach = n // 50 if kind == "local" else n // 500
+        cols = rng.integers(0, n, size=4 * n) if kind == "random" else np.clip(rows + rng.integers(-reach, reach + 1, size=4 * n), 0, n - 1)
         vals = rng.standard_normal(4 * n) * 0.3
     elif kind == "powerlaw":
         ln = np.minimum(rng.zipf(1.8, size=n), 2000)
@@ -455,7 +457,8 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
     import scipy.sparse.linalg as spl
-    for key, kind in (("general_sparse_random", "random"), ("general_sparse_local", "local"), ("irregular_sparse_powerlaw", "powerlaw")):
+    for key, kind in (("general_sparse_random", "random"), ("general_sparse_local", "local"), ("general_sparse_local_narrow", "local_narrow"),
+                      ("irregular_sparse_powerlaw", "powerlaw")):
         Ag = general_sparse_operator(kind, n)
         t0 = time.perf_counter()
         opx = eu.MIOperator(Ag, ctx)
@@ -469,7 +472,8 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         truth = spl.expm_multiply(Ag * T_FINAL, b.cpu().numpy())
         rl = np.diff(Ag.indptr)
         e = entry("expv, %s rows / %s columns, n=%d nnz=%d m=%d" % ("irregular (Zipf)" if kind == "powerlaw" else "regular",
-                  "local (+-2 %% of the row)" if kind == "local" else "uniformly random", n, Ag.nnz, m), tx, m, alg_bytes_expv(n, Ag.nnz, m),
+                  {"local": "local (+-2 %% of the row)", "local_narrow": "local (+-0.2 %% of the row)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
+                  tx, m, alg_bytes_expv(n, Ag.nnz, m),
                   path=pathx, setup_s=t_set, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
                   storage=eu.host_pattern_info(Ag)["path"],
                   verified_vs_scipy_expm_multiply=float(np.linalg.norm(wx - truth) / np.linalg.norm(truth)))
