@@ -453,6 +453,23 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["path"] = list(eu.expv.last_stats["path"])
     sec["grid_stencil_wave_form"] = e
     del opg, Ag
+    # (3b') the headline operator in Float32 (BlasFloat of the reference, ExponentialUtilities.jl:19): native 32-bit storage on
+    # the two-kernel step (4 rows per 16-byte pack, fp64 projection sums), priced against the s = 4 contract
+    A32 = c2_operator(n).astype(np.float32)
+    op32 = eu.MIOperator(A32, ctx)
+    b32 = b.to(torch.float32)
+    w32 = torch.empty(n, dtype=torch.float32, device=env.device)
+    f32 = lambda: eu.expv(T_FINAL, op32, b32, m=m, ishermitian=False, out=w32)
+    f32()
+    env.sync()
+    e = entry("expv, C2 operator in Float32 (native 32-bit storage, two-kernel step), n=%d m=%d; contract with s = 4" % (n, m),
+              timed(f32, args.steps, 2, env.sync), m, alg_bytes_expv(n, A32.nnz, m, s=4))
+    e["path"] = list(eu.expv.last_stats["path"])
+    eu.expv(T_FINAL, op, b, m=m, ishermitian=False, out=w)            # the fp64 result of the same problem
+    env.sync()
+    e["rel_diff_to_fp64_result"] = float(torch.linalg.norm(w32.double() - w) / torch.linalg.norm(w))
+    sec["c2_float32"] = e
+    del op32, A32
     # (3c) general sparse operators: no band, no diagonals to exploit.  Regular rows with random columns and
     # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.

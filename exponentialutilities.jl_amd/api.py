@@ -180,13 +180,25 @@ def _np_dtype_of(x):
         return x.dtype
     if _is_torch(x):
         import torch
-        return {torch.float64: np.dtype(np.float64), torch.complex128: np.dtype(np.complex128)}.get(
+        return {torch.float64: np.dtype(np.float64), torch.complex128: np.dtype(np.complex128),
+                torch.float32: np.dtype(np.float32), torch.complex64: np.dtype(np.complex64)}.get(
             x.dtype, np.dtype(np.float64) if not x.is_complex() else np.dtype(np.complex128))
     return np.asarray(x).dtype
 
 
 def _code(dt):
-    return L.C64 if np.issubdtype(np.dtype(dt), np.complexfloating) else L.F64
+    dt = np.dtype(dt)
+    if dt.kind == "c":
+        return L.C32 if dt.itemsize == 8 else L.C64
+    return L.F32 if (dt.kind == "f" and dt.itemsize == 4) else L.F64
+
+
+_TORCH_NAMES = {"float64": "float64", "complex128": "complex128", "float32": "float32", "complex64": "complex64"}
+
+
+def _torch_dtype(dt):
+    import torch
+    return getattr(torch, _TORCH_NAMES[np.dtype(dt).name])
 
 
 def _ref_dtype(*dts):
@@ -218,21 +230,40 @@ def _src_dtype(A):
 
 
 def _round_to(x, dtype):
-    """round a computed (fp64 / complex-fp64) result to the reference's result type when that is a 32-bit one"""
+    """a computed result in the reference's result type promote_type(typeof(t), eltype(A), eltype(b)): rounded when that is
+    narrower than the work type, widened when a Float64 t met 32-bit operands"""
     dtype = np.dtype(dtype)
-    if dtype.itemsize * (1 if dtype.kind == "f" else 1) >= (8 if dtype.kind == "f" else 16):
+    if _np_dtype_of(x) == dtype or isinstance(x, DeviceArray):
         return x
     if _is_torch(x):
-        import torch
-        return x.to(torch.complex64 if dtype.kind == "c" else torch.float32)
-    if isinstance(x, DeviceArray):
-        return x
+        return x.to(_torch_dtype(dtype))
     return np.asarray(x).astype(dtype)
 
 
 def _work_dtype(*dts):
-    return np.dtype(np.complex128) if any(np.issubdtype(np.dtype(d), np.complexfloating) for d in dts) \
-        else np.dtype(np.float64)
+    """element type the device computes in for operands of these types: the BlasFloat the reference would promote to
+    (ExponentialUtilities.jl:19) -- Float32 / ComplexF32 stay 32-bit (half the HBM traffic), everything else is fp64."""
+    dts = [np.dtype(d) for d in dts]
+    cplx = any(d.kind == "c" for d in dts)
+    is32 = all((d.kind == "f" and d.itemsize == 4) or (d.kind == "c" and d.itemsize == 8) for d in dts)
+    if is32:
+        return np.dtype(np.complex64 if cplx else np.float32)
+    return np.dtype(np.complex128 if cplx else np.float64)
+
+
+def _work64(*dts):
+    """the 64-bit work type (entry points whose reference method is Float64-only: kiops; the batched step)"""
+    return np.dtype(np.complex128 if any(np.dtype(d).kind == "c" for d in dts) else np.float64)
+
+
+def _complex_of(dt):
+    dt = np.dtype(dt)
+    return np.dtype(np.complex64) if dt.itemsize <= (8 if dt.kind == "c" else 4) else np.dtype(np.complex128)
+
+
+def _real_of(dt):
+    dt = np.dtype(dt)
+    return np.dtype(np.float32) if dt.itemsize <= (8 if dt.kind == "c" else 4) else np.dtype(np.float64)
 
 
 class _Arg:
@@ -250,7 +281,7 @@ class _Arg:
             self.keep = x
         elif _is_torch(x):
             import torch
-            want = torch.complex128 if self.dtype.kind == "c" else torch.float64
+            want = _torch_dtype(self.dtype)
             if not x.is_cuda:
                 raise TypeError("torch tensors must live on the GPU (or pass a numpy array)")
             if x.dtype != want:
@@ -304,7 +335,7 @@ def _empty_like(ref, shape, dtype):
         return DeviceArray(shape, dtype, ref.ctx)
     if _is_torch(ref):
         import torch
-        tdt = torch.complex128 if dtype.kind == "c" else torch.float64
+        tdt = _torch_dtype(dtype)
         if len(shape) == 1:
             return torch.empty(shape[0], dtype=tdt, device=ref.device)
         return torch.empty((shape[1], shape[0]), dtype=tdt, device=ref.device).t()   # column-major
@@ -410,7 +441,12 @@ class MIOperator:
         self._h = h
         self._finalizer = weakref.finalize(self, lib.expv_mi_op_destroy, h)
         try:            # element type the caller handed over (Float32 operands: see _ref_dtype)
-            self.src_dtype = _np_dtype_of(A) if A is not None else np.dtype(dtype or np.float64)
+            if A is None:
+                self.src_dtype = np.dtype(dtype or np.float64)
+            elif hasattr(A, "indptr") or isinstance(A, np.ndarray):
+                self.src_dtype = np.dtype(A.dtype)
+            else:
+                self.src_dtype = _np_dtype_of(A)
         except Exception:
             self.src_dtype = np.dtype(np.float64)
         n_, nnz, herm, opn, dtc = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
@@ -419,7 +455,7 @@ class MIOperator:
         self.nnz = int(nnz.value)
         self.ishermitian = bool(herm.value) if ishermitian is None else bool(ishermitian)
         self.opnorm_inf = float(opn.value)
-        self.dtype = np.dtype(np.complex128 if dtc.value == L.C64 else np.float64)
+        self.dtype = np.dtype({L.F64: np.float64, L.C64: np.complex128, L.F32: np.float32, L.C32: np.complex64}[dtc.value])
 
     def update_values(self, A):
         """New values on the same sparsity pattern (expv_mi_op_update_values): ``A`` is the matrix the operator was created
@@ -479,7 +515,7 @@ def _torch_view(ptr, n, dt):
         pass
 
     s = _Shim()
-    s.__cuda_array_interface__ = {"shape": (n,), "typestr": "<c16" if np.dtype(dt).kind == "c" else "<f8",
+    s.__cuda_array_interface__ = {"shape": (n,), "typestr": np.dtype(dt).str,
                                   "data": (int(ptr), False), "version": 3}
     return torch.as_tensor(s, device="cuda")
 
@@ -558,8 +594,10 @@ def _as_operator(A, want_dtype=None, ctx=None):
                 cache.pop(next(iter(cache)))
         else:
             op = ent[1]
-    if want_dtype is not None and np.dtype(want_dtype).kind == "c" and op.dtype.kind != "c":
-        op = op.astype(np.complex128)
+    if want_dtype is not None:
+        want = _work_dtype(want_dtype, op.dtype)      # conversions only go up (real -> complex, 32 -> 64 bit), never down
+        if want != op.dtype:
+            op = op.astype(want)
     return op
 
 
@@ -605,8 +643,7 @@ class KrylovSubspace:
         """Ks.H -- live view of the host matrix, (maxiter+1) x (maxiter + (augmented != 0))."""
         p, ld, nr, nc = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
         _check(L.load().expv_mi_ks_H(self._h, C.byref(p), C.byref(ld), C.byref(nr), C.byref(nc)))
-        k = 2 if self.U.kind == "c" else 1
-        buf = (C.c_double * (ld.value * nc.value * k)).from_address(p.value)
+        buf = (C.c_char * (ld.value * nc.value * self.U.itemsize)).from_address(p.value)
         a = np.frombuffer(buf, dtype=self.U).reshape((nc.value, ld.value)).T
         return a[: nr.value, :]
 
@@ -682,7 +719,7 @@ def arnoldi(A, b, *, m=None, ishermitian=None, **kw):
         m = min(30, op.shape[0])
     if ishermitian is None:
         ishermitian = op.ishermitian
-    U = np.dtype(np.float64) if ishermitian else T
+    U = _real_of(T) if ishermitian else T
     n = b.shape[0] if hasattr(b, "shape") else len(b)
     Ks = KrylovSubspace(T, U, n, m, 0, op.ctx)
     return arnoldi_(Ks, op, b, m=m, ishermitian=ishermitian, **kw)
@@ -702,7 +739,7 @@ def expv_(w, t, Ks):
     wdt = _np_dtype_of(w)
     if (tc or Ks.T.kind == "c") and wdt.kind != "c":
         raise TypeError("InexactError: w must be complex when t or the basis is complex")
-    wa = _Arg(w, _work_dtype(wdt), writable=True)
+    wa = _Arg(w, _complex_of(Ks.T) if wdt.kind == "c" else _real_of(Ks.T), writable=True)   # (the basis' precision; a numpy w of another one is filled through a copy)
     if wa.shape[0] != Ks.n + Ks.augmented:
         raise AssertionError("Dimension mismatch")
     _check(L.load().expv_mi_expv_ks(Ks._h, tr, ti, wa.ptr, wa.loc, _code(wa.dtype)), Ks.ctx._h)
@@ -714,10 +751,10 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
     """expv(t, A, b; mode = :happy_breakdown | :error_estimate, kwargs...)  (krylov_phiv.jl:125-160)."""
     if isinstance(A, KrylovSubspace):       # expv(t, Ks)  (:161-168)
         Ks = A
-        w = np.empty(Ks.n, dtype=_work_dtype(Ks.T, np.complex128 if _t_parts(t)[2] else np.float64), order="F")
+        w = np.empty(Ks.n, dtype=_complex_of(Ks.T) if _t_parts(t)[2] else Ks.T, order="F")
         return expv_(w, t, Ks)
     tr, ti, tc = _t_parts(t)
-    tdt = np.complex128 if tc else np.float64
+    tdt = np.complex64 if tc else np.float32        # (weak: t never widens the work type; the RESULT type follows _t_dtype(t))
     op = _as_operator(A, None)
     bdt = _np_dtype_of(b)
     n = b.shape[0]
@@ -758,7 +795,7 @@ def expv(t, A, b, *, mode="happy_breakdown", **kw):
         opT = _as_operator(op, T)
         if not ish:
             raise RuntimeError("Error estimation not yet available for non-Hermitian matrices.")
-        Ks = KrylovSubspace(T, np.float64, op.shape[0], m, 0, op.ctx)
+        Ks = KrylovSubspace(T, _real_of(T), op.shape[0], m, 0, op.ctx)
         w = _empty_like(b, (n,), T)
         ba, wa = _Arg(b, T), _Arg(w, T, writable=True)
         _check(L.load().expv_mi_expv_error_estimate(Ks._h, opT._h, tr, ti, ba.ptr, ba.loc, wa.ptr, wa.loc,
@@ -775,7 +812,7 @@ def phiv_(w, t, Ks, k, *, correct=False, errest=False):
     wdt = _np_dtype_of(w)
     if (tc or Ks.T.kind == "c") and wdt.kind != "c":
         raise TypeError("InexactError: w must be complex when t or the basis is complex")
-    wa = _Arg(w, _work_dtype(wdt), writable=True)
+    wa = _Arg(w, _complex_of(Ks.T) if wdt.kind == "c" else _real_of(Ks.T), writable=True)
     if len(wa.shape) != 2 or wa.shape[0] != Ks.n + Ks.augmented or wa.shape[1] != k + 1:
         raise AssertionError("Dimension mismatch")
     err = C.c_double(0.0)
@@ -789,11 +826,10 @@ def phiv(t, A, b, k=None, *, correct=False, errest=False, **kw):
     """phiv(t, A, b, k; correct, errest, kwargs...) and phiv(t, Ks, k; ...)  (krylov_phiv.jl:563-575)."""
     if isinstance(A, KrylovSubspace):
         Ks, kk = A, b
-        w = np.empty((Ks.n, kk + 1), dtype=_work_dtype(Ks.T, np.complex128 if _t_parts(t)[2] else np.float64),
-                     order="F")
+        w = np.empty((Ks.n, kk + 1), dtype=_complex_of(Ks.T) if _t_parts(t)[2] else Ks.T, order="F")
         return phiv_(w, t, Ks, kk, correct=correct, errest=errest)
     Ks = arnoldi(A, b, **kw)
-    wdt = _work_dtype(_np_dtype_of(b), Ks.T, np.complex128 if _t_parts(t)[2] else np.float64)
+    wdt = _complex_of(Ks.T) if _t_parts(t)[2] else Ks.T
     w = _empty_like(b, (b.shape[0], k + 1), wdt)
     res = phiv_(w, t, Ks, k, correct=correct, errest=errest)
     # result type of the reference: promote_type(typeof(t), eltype(A), eltype(b)) -- Float32 operands give a Float32 result
@@ -905,7 +941,7 @@ def kiops(tau_out, A, u, *, mmin=10, mmax=128, m=None, tol=1e-7, opnorm=None, io
     mathematical extension this build defines for complex operands (no reference behaviour exists)."""
     op = _as_operator(A, None)
     udt = _np_dtype_of(u)
-    T = _work_dtype(op.dtype, udt)
+    T = _work64(op.dtype, udt)       # the reference method is Float64-only (kiops.jl:89: w = zeros(n, numSteps))
     if T.kind == "c" and not allow_complex:
         raise TypeError("kiops: complex operands have no method in the reference (kiops.jl:89, arnoldi.jl:197)")
     op = _as_operator(op, T)
@@ -950,7 +986,7 @@ def expv_batch(ts, pattern, vals, B, *, m=None, tol=1e-7, iop=0, ishermitian=Fal
     n = P.shape[0]
     nnz = int(P.nnz)
     vdt, bdt = _np_dtype_of(vals), _np_dtype_of(B)
-    T = _work_dtype(vdt, bdt)
+    T = _work64(vdt, bdt)
     class _Raw:          # problem-major (nprob, nnz) values: row-major is the wanted layout here
         pass
     va = _Raw()

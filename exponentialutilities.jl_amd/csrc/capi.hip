@@ -62,12 +62,35 @@ void csc_to_csr(int64_t n, const int64_t *colptr, const int64_t *rowval, const V
     }
 }
 
+using dense::cf;
 inline double absd(double x) { return std::fabs(x); }
 inline double absd(const cd &x) { return std::abs(x); }
+inline double absd(float x) { return std::fabs((double)x); }
+inline double absd(const cf &x) { return std::hypot((double)x.real(), (double)x.imag()); }
 inline double conjd(double x) { return x; }
 inline cd conjd(const cd &x) { return std::conj(x); }
+inline float conjd(float x) { return x; }
+inline cf conjd(const cf &x) { return std::conj(x); }
 inline bool iszero(double x) { return x == 0.0; }
 inline bool iszero(const cd &x) { return x.real() == 0.0 && x.imag() == 0.0; }
+inline bool iszero(float x) { return x == 0.0f; }
+inline bool iszero(const cf &x) { return x.real() == 0.0f && x.imag() == 0.0f; }
+// host value type (what the caller's arrays hold) -> device element type with the same layout
+template <class V> struct DevOf;
+template <> struct DevOf<double> { using type = double; };
+template <> struct DevOf<cd> { using type = cplx; };
+template <> struct DevOf<float> { using type = float; };
+template <> struct DevOf<cf> { using type = cplx32; };
+// dtype code -> host value type, handed to a generic lambda (like dispatch_dtype for the device types)
+template <class F>
+inline auto dispatch_host_dtype(int dt, F &&f) {
+  switch (dt) {
+    case EXPV_MI_C64: return f(TypeTag<cd>{});
+    case EXPV_MI_F32: return f(TypeTag<float>{});
+    case EXPV_MI_C32: return f(TypeTag<cf>{});
+    default: return f(TypeTag<double>{});
+  }
+}
 
 // LinearAlgebra.ishermitian on CSR32 (explicit zeros ignored) and opnorm(A, Inf)
 template <class V>
@@ -418,7 +441,7 @@ static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long 
   dev::op_update_forms<T>(s, a);
   HIPCHECK(hipMemcpyAsync(out, op.upd_out.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
-  if (op.ndiag > 0 && !ST<T>::is_complex) {
+  if (op.ndiag > 0 && std::is_same<T, double>::value) {
     bool cst = true;
     for (int d = 0; d < op.ndiag; ++d) {
       cst = cst && out[2 + d] == 0;
@@ -457,8 +480,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("general DIA");
   {
     unsigned long long out[32];
-    if (std::is_same<V, cd>::value) op_fill_forms<cplx>(op, true, false, out);
-    else op_fill_forms<double>(op, true, false, out);
+    op_fill_forms<typename DevOf<V>::type>(op, true, false, out);
   }
   lap("device fill of the forms");
   if (op.sell_ok && P.tile_reach >= 0) {
@@ -484,9 +506,14 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
 
 // the device path computes in fp64 / complex-fp64 (include/expv_mi.h: expv_mi_dtype)
 void check_device_dtype(int dt, const char *who) {
-  if (dt == EXPV_MI_F32 || dt == EXPV_MI_C32)
-    fail(EXPV_MI_UNSUPPORTED, std::string(who) + ": the device path computes in fp64 / complex-fp64; promote 32-bit operands (the host mirrors do)");
-  if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": unknown dtype");
+  if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64 && dt != EXPV_MI_F32 && dt != EXPV_MI_C32)
+    fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": unknown dtype");
+}
+// entry points whose reference method exists for Float64 only (kiops, kiops.jl:89) or that the build offers for the 64-bit
+// element types only (the batched single-pass step)
+void check_64bit_dtype(int dt, const char *who) {
+  check_device_dtype(dt, who);
+  if (dtype_is_32bit(dt)) fail(EXPV_MI_UNSUPPORTED, std::string(who) + ": Float64 / ComplexF64 only");
 }
 
 const char *kKernelNames[EXPV_MI_K_COUNT] = {"firststep", "matvec", "dots",    "update", "scale", "combine",
@@ -741,15 +768,12 @@ int expv_mi_op_create_csc(expv_mi_ctx_t ctx, int dtype, int64_t n, const int64_t
     op->device = ctx->device;
     op->dtype = dtype;
     std::vector<int32_t> rp, ci;
-    if (dtype == EXPV_MI_C64) {
-      std::vector<cd> va;
-      csc_to_csr<cd>(n, colptr, rowval, reinterpret_cast<const cd *>(nzval), index_base, rp, ci, va, &op->csc_pos);
-      make_csr_op<cd>(*op, n, rp, ci, va);
-    } else {
-      std::vector<double> va;
-      csc_to_csr<double>(n, colptr, rowval, reinterpret_cast<const double *>(nzval), index_base, rp, ci, va, &op->csc_pos);
-      make_csr_op<double>(*op, n, rp, ci, va);
-    }
+    dispatch_host_dtype(dtype, [&](auto tag) {
+      using V = typename decltype(tag)::type;
+      std::vector<V> va;
+      csc_to_csr<V>(n, colptr, rowval, reinterpret_cast<const V *>(nzval), index_base, rp, ci, va, &op->csc_pos);
+      make_csr_op<V>(*op, n, rp, ci, va);
+    });
     ctx->adopt(&op->ctx);
     *out = op.release();
   });
@@ -788,13 +812,11 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
     op->ctx = ctx;
     op->device = ctx->device;
     op->dtype = dtype;
-    if (dtype == EXPV_MI_C64) {
-      std::vector<cd> va(reinterpret_cast<const cd *>(vals), reinterpret_cast<const cd *>(vals) + nnz);
-      make_csr_op<cd>(*op, n, rp, ci, va);
-    } else {
-      std::vector<double> va(reinterpret_cast<const double *>(vals), reinterpret_cast<const double *>(vals) + nnz);
-      make_csr_op<double>(*op, n, rp, ci, va);
-    }
+    dispatch_host_dtype(dtype, [&](auto tag) {
+      using V = typename decltype(tag)::type;
+      std::vector<V> va(reinterpret_cast<const V *>(vals), reinterpret_cast<const V *>(vals) + nnz);
+      make_csr_op<V>(*op, n, rp, ci, va);
+    });
     ctx->adopt(&op->ctx);
     *out = op.release();
   });
@@ -816,7 +838,8 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
     if (loc == EXPV_MI_HOST) {
       // (properties -- ishermitian, opnorm(A, Inf), count(!iszero, A) -- are taken from the uploaded copy below, by the kernels a
       //  device-resident matrix uses: the host loop over n^2 std::complex values took 4.6 s at n = 8192)
-      const int64_t ldd = (n + 1) / 2 * 2;  // even leading dimension keeps 16-B column alignment
+      const int64_t pk = 16 / (int64_t)esz;
+      const int64_t ldd = (n + pk - 1) / pk * pk;  // leading dimension in whole 16-byte packs: every column stays 16-B aligned
       op->dense.alloc((size_t)std::max<int64_t>(ldd * n, 1) * esz);
       if (n) HIPCHECK(hipMemcpy2DAsync(op->dense.p, ldd * esz, A, lda * esz, n * esz, n, hipMemcpyHostToDevice, ctx->stream));
       HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -841,10 +864,10 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
       // pass of two small kernels at create time (setup cost), the same answer wherever the matrix came from
       DevBuf scr(sizeof(double) * (size_t)split * (size_t)n), res(3 * sizeof(unsigned long long));
       HIPCHECK(hipMemsetAsync(res.p, 0, res.bytes, ctx->stream));
-      if (dtype == EXPV_MI_C64)
-        dev::dense_props<cplx>(ctx->stream, n, reinterpret_cast<const cplx *>(op->dense_ptr), op->lda, scr.as<double>(), split, res.as<unsigned long long>());
-      else
-        dev::dense_props<double>(ctx->stream, n, reinterpret_cast<const double *>(op->dense_ptr), op->lda, scr.as<double>(), split, res.as<unsigned long long>());
+      dispatch_dtype(dtype, [&](auto tag) {
+        using T = typename decltype(tag)::type;
+        dev::dense_props<T>(ctx->stream, n, reinterpret_cast<const T *>(op->dense_ptr), op->lda, scr.as<double>(), split, res.as<unsigned long long>());
+      });
       unsigned long long h[3] = {0, 0, 0};
       HIPCHECK(hipMemcpyAsync(h, res.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -905,8 +928,10 @@ int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc) {
     if (op->nnz > 0 && !vals) fail(EXPV_MI_ARGUMENT_ERROR, "op_update_values: null values");
     if (loc != EXPV_MI_HOST && loc != EXPV_MI_DEVICE) fail(EXPV_MI_ARGUMENT_ERROR, "op_update_values: bad location");
     if (op->nnz == 0) return;
-    if (op->dtype == EXPV_MI_C64) op_update_values_T<cplx, cd>(*op, vals, loc);
-    else op_update_values_T<double, double>(*op, vals, loc);
+    dispatch_host_dtype(op->dtype, [&](auto tag) {
+      using V = typename decltype(tag)::type;
+      op_update_values_T<typename DevOf<V>::type, V>(*op, vals, loc);
+    });
   });
 }
 
@@ -936,12 +961,11 @@ int expv_mi_gemv_block(expv_mi_ctx_t ctx, int dtype, int64_t nrows, int64_t ncol
     if (nsplit > 1 && !scratch) fail(EXPV_MI_ARGUMENT_ERROR, "gemv_block: nsplit > 1 needs scratch");
     ++ctx->cnt_opapply;
     ProfScope ps(ctx, EXPV_MI_K_MATVEC);
-    if (dtype == EXPV_MI_C64)
-      dev::gemv_dense<cplx>(ctx->stream, nrows, reinterpret_cast<const cplx *>(A), lda, reinterpret_cast<const cplx *>(x),
-                            reinterpret_cast<cplx *>(y), reinterpret_cast<cplx *>(scratch), nsplit, nullptr, 0, ncols);
-    else
-      dev::gemv_dense<double>(ctx->stream, nrows, reinterpret_cast<const double *>(A), lda, reinterpret_cast<const double *>(x),
-                              reinterpret_cast<double *>(y), reinterpret_cast<double *>(scratch), nsplit, nullptr, 0, ncols);
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = typename decltype(tag)::type;
+      dev::gemv_dense<T>(ctx->stream, nrows, reinterpret_cast<const T *>(A), lda, reinterpret_cast<const T *>(x), reinterpret_cast<T *>(y),
+                         reinterpret_cast<T *>(scratch), nsplit, nullptr, 0, ncols);
+    });
   });
 }
 
@@ -1125,7 +1149,7 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     // the internal subspace is private to this call: reuse it across calls of the same shape, and skip what
     // expv never reads (v_{m+1}, H[m+1, m])
     ht_mark(0);
-    const int dtU = herm ? EXPV_MI_F64 : op->dtype;
+    const int dtU = herm ? dtype_real_of(op->dtype) : op->dtype;
     expv_mi_ks_s *kp = reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
     if (!kp || kp->dtypeT != op->dtype || kp->dtypeU != dtU || kp->n != op->n || kp->maxiter != m || kp->augmented != 0) {
       delete kp;
@@ -1221,6 +1245,7 @@ int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int
                   int64_t ldu, int ncols_u, int u_loc, void *w, int64_t ldw, int w_loc, const expv_mi_kiops_opts *opts,
                   int64_t stats[5]) {
   return guarded(ctx, [&] {
+    check_64bit_dtype(op->dtype, "kiops (the reference method is Float64-only, kiops.jl:89)");
     expv_mi_kiops_opts o;
     if (opts) o = *opts; else expv_mi_kiops_opts_default(&o);
     int64_t st[5];
@@ -1291,6 +1316,7 @@ int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const
                        const void *vals, int64_t nnz_per_prob, int mat_loc, const double *t, const void *b, int64_t ldb,
                        int b_loc, void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used) {
   return guarded(ctx, [&] {
+    check_64bit_dtype(dtype, "expv_batch");
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     expv_batch_run(ctx, dtype, n, nprob, rowptr, colind, vals, nnz_per_prob, mat_loc, t, b, ldb, b_loc, w, ldw, w_loc, o,

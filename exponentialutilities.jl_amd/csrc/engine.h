@@ -31,7 +31,23 @@ struct Err {
                       std::string(#expr) + ": " + hipGetErrorString(e__));                               \
   } while (0)
 
-inline size_t dtype_size(int dt) { return dt == EXPV_MI_C64 ? 16 : 8; }
+inline size_t dtype_size(int dt) { return dt == EXPV_MI_C64 ? 16 : (dt == EXPV_MI_F32 ? 4 : 8); }   // F64 8, C64 16, F32 4, C32 8
+inline bool dtype_is_complex(int dt) { return dt == EXPV_MI_C64 || dt == EXPV_MI_C32; }
+inline bool dtype_is_32bit(int dt) { return dt == EXPV_MI_F32 || dt == EXPV_MI_C32; }
+inline int dtype_real_of(int dt) { return dtype_is_32bit(dt) ? EXPV_MI_F32 : EXPV_MI_F64; }
+inline int dtype_complex_of(int dt) { return dtype_is_32bit(dt) ? EXPV_MI_C32 : EXPV_MI_C64; }
+// the device element type of a dtype code, handed to a generic lambda: dispatch_dtype(dt, [&](auto tag) { using T = typename
+// decltype(tag)::type; ... })
+template <class T> struct TypeTag { using type = T; };
+template <class F>
+inline auto dispatch_dtype(int dt, F &&f) {
+  switch (dt) {
+    case EXPV_MI_C64: return f(TypeTag<cplx>{});
+    case EXPV_MI_F32: return f(TypeTag<float>{});
+    case EXPV_MI_C32: return f(TypeTag<cplx32>{});
+    default: return f(TypeTag<double>{});
+  }
+}
 
 // host-side phase timing (EXPV_MI_HOST_TIMING=1): wall time between consecutive marks, summed per mark id and
 // printed when the context is destroyed
@@ -284,26 +300,33 @@ struct TsCache {
 struct expv_mi_tscache_s : expv_mi::TsCache {};
 namespace expv_mi {
 
-// host H accessors (U-typed storage)
+// host H accessors (U-typed storage: Float64 / ComplexF64 / Float32 / ComplexF32, like the reference's Matrix{U})
 inline dense::cd getH(const Ks &ks, int i, int j) {
-  if (ks.dtypeU == EXPV_MI_C64) {
-    const double *p = reinterpret_cast<const double *>(ks.H.data()) + 2 * ((size_t)j * ks.ldh + i);
-    return dense::cd(p[0], p[1]);
+  const size_t e = (size_t)j * ks.ldh + i;
+  switch (ks.dtypeU) {
+    case EXPV_MI_C64: { const double *p = reinterpret_cast<const double *>(ks.H.data()) + 2 * e; return dense::cd(p[0], p[1]); }
+    case EXPV_MI_F32: return dense::cd((double)reinterpret_cast<const float *>(ks.H.data())[e], 0.0);
+    case EXPV_MI_C32: { const float *p = reinterpret_cast<const float *>(ks.H.data()) + 2 * e; return dense::cd((double)p[0], (double)p[1]); }
+    default: return dense::cd(reinterpret_cast<const double *>(ks.H.data())[e], 0.0);
   }
-  return dense::cd(reinterpret_cast<const double *>(ks.H.data())[(size_t)j * ks.ldh + i], 0.0);
 }
 inline void setH(Ks &ks, int i, int j, dense::cd v) {
-  if (ks.dtypeU == EXPV_MI_C64) {
-    double *p = reinterpret_cast<double *>(ks.H.data()) + 2 * ((size_t)j * ks.ldh + i);
-    p[0] = v.real();
-    p[1] = v.imag();
-  } else {
-    reinterpret_cast<double *>(ks.H.data())[(size_t)j * ks.ldh + i] = v.real();
+  const size_t e = (size_t)j * ks.ldh + i;
+  switch (ks.dtypeU) {
+    case EXPV_MI_C64: { double *p = reinterpret_cast<double *>(ks.H.data()) + 2 * e; p[0] = v.real(); p[1] = v.imag(); } break;
+    case EXPV_MI_F32: reinterpret_cast<float *>(ks.H.data())[e] = (float)v.real(); break;
+    case EXPV_MI_C32: { float *p = reinterpret_cast<float *>(ks.H.data()) + 2 * e; p[0] = (float)v.real(); p[1] = (float)v.imag(); } break;
+    default: reinterpret_cast<double *>(ks.H.data())[e] = v.real(); break;
   }
 }
 inline void setH_realpart(Ks &ks, int i, int j, double v) {  // realview(...) write, arnoldi.jl:418-421
-  if (ks.dtypeU == EXPV_MI_C64) reinterpret_cast<double *>(ks.H.data())[2 * ((size_t)j * ks.ldh + i)] = v;
-  else reinterpret_cast<double *>(ks.H.data())[(size_t)j * ks.ldh + i] = v;
+  const size_t e = (size_t)j * ks.ldh + i;
+  switch (ks.dtypeU) {
+    case EXPV_MI_C64: reinterpret_cast<double *>(ks.H.data())[2 * e] = v; break;
+    case EXPV_MI_F32: reinterpret_cast<float *>(ks.H.data())[e] = (float)v; break;
+    case EXPV_MI_C32: reinterpret_cast<float *>(ks.H.data())[2 * e] = (float)v; break;
+    default: reinterpret_cast<double *>(ks.H.data())[e] = v; break;
+  }
 }
 
 

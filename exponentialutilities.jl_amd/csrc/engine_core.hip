@@ -13,6 +13,8 @@
 #include <chrono>
 #include <cstdio>
 
+#include <type_traits>
+
 #include "engine.h"
 
 namespace expv_mi {
@@ -37,8 +39,10 @@ double abs_reduce_dev(Ctx *ctx, int dtype, const void *x, int64_t n, int mode) {
   if (n <= 0) return 0.0;
   ctx->use();
   DevBuf part(sizeof(double) * dev::MAX_GRID);
-  const int g = (dtype == EXPV_MI_C64) ? dev::abs_partial<cplx>(ctx->stream, (const cplx *)x, n, part.as<double>(), mode)
-                                       : dev::abs_partial<double>(ctx->stream, (const double *)x, n, part.as<double>(), mode);
+  const int g = dispatch_dtype(dtype, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    return dev::abs_partial<T>(ctx->stream, (const T *)x, n, part.as<double>(), mode);
+  });
   std::vector<double> h(g);
   HIPCHECK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * g, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -79,7 +83,7 @@ void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_d
 static void ks_alloc_aux(Ks &ks) {
   const size_t esz = dtype_size(ks.dtypeT);
   ks.ldhd = ks.maxiter + 2;
-  ks.Hdev.alloc((size_t)ks.ldhd * (ks.maxiter + 1) * esz);
+  ks.Hdev.alloc((size_t)ks.ldhd * (ks.maxiter + 1) * esz + 8);      // (+8: the mailbox copy moves whole 8-byte words)
   HIPCHECK(hipMemsetAsync(ks.Hdev.p, 0, ks.Hdev.bytes, ks.ctx->stream));
   ks.ldg = ks.maxiter + 1;
   ks.gram.alloc((size_t)ks.ldg * ks.ldg * esz);
@@ -97,12 +101,10 @@ static void ks_alloc_aux(Ks &ks) {
 
 void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int augmented) {
   if (n < 0 || maxiter < 1 || augmented < 0) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: bad n/maxiter/augmented");
-  for (int dt : {dtT, dtU}) {
-    if (dt == EXPV_MI_F32 || dt == EXPV_MI_C32)
-      fail(EXPV_MI_UNSUPPORTED, "KrylovSubspace: the device path computes in fp64 / complex-fp64; promote 32-bit operands");
-    if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: unknown dtype");
-  }
-  if (dtT == EXPV_MI_F64 && dtU == EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: U complex with T real");
+  for (int dt : {dtT, dtU})
+    if (dt != EXPV_MI_F64 && dt != EXPV_MI_C64 && dt != EXPV_MI_F32 && dt != EXPV_MI_C32) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: unknown dtype");
+  if (!dtype_is_complex(dtT) && dtype_is_complex(dtU)) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: U complex with T real");
+  if (dtype_is_32bit(dtT) != dtype_is_32bit(dtU)) fail(EXPV_MI_ARGUMENT_ERROR, "KrylovSubspace: T and U must have the same precision (U = T or real(T))");
   ctx->use();
   ks.ctx = ctx;
   ks.dtypeT = dtT;
@@ -188,8 +190,10 @@ void ks_materialize(Ks &ks) {
   if (!ks.scale_pending) return;
   ks.ctx->use();
   if (ks.scale_cols > 0) {
+    // (pending scales only come from the single-pass step, which runs on the 64-bit element types)
     if (ks.dtypeT == EXPV_MI_F64) dev::scale_columns<double>(ks.ctx->stream, ks.V.as<double>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
-    else dev::scale_columns<cplx>(ks.ctx->stream, ks.V.as<cplx>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+    else if (ks.dtypeT == EXPV_MI_C64) dev::scale_columns<cplx>(ks.ctx->stream, ks.V.as<cplx>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+    else fail(EXPV_MI_HIP_ERROR, "pending column scales on a 32-bit basis");
   }
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
   ks.scale_pending = false;
@@ -230,8 +234,10 @@ static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) 
 }
 void op_apply_dev(Op &op, const void *x, void *y, const StepState *st, int step, bool) {
   ++op.ctx->cnt_opapply;
-  if (op.dtype == EXPV_MI_C64) op_apply_T<cplx>(op, (const cplx *)x, (cplx *)y, st, step);
-  else op_apply_T<double>(op, (const double *)x, (double *)y, st, step);
+  dispatch_dtype(op.dtype, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    op_apply_T<T>(op, (const T *)x, (T *)y, st, step);
+  });
 }
 
 template <class T>
@@ -256,8 +262,10 @@ static bool op_apply_lincomb_T(Op &op, const T *x, T *y, int nterms, const void 
   return true;
 }
 bool op_apply_lincomb_dev(Op &op, const void *x, void *y, int nterms, const void *const *in, const double *coef) {
-  if (op.dtype == EXPV_MI_C64) return op_apply_lincomb_T<cplx>(op, (const cplx *)x, (cplx *)y, nterms, in, coef);
-  return op_apply_lincomb_T<double>(op, (const double *)x, (double *)y, nterms, in, coef);
+  return dispatch_dtype(op.dtype, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    return op_apply_lincomb_T<T>(op, (const T *)x, (T *)y, nterms, in, coef);
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -273,7 +281,7 @@ static void read_state(Ks &ks, StepState *out) {
 // layout in 8-byte words: [0, hwords) H as on the device, [hwords, hwords + maxiter + 2) column scales,
 // then 4 words of state and the `done` word.
 struct MailboxView { double *H, *scales, *state; unsigned long long *done; };
-static size_t mailbox_hwords(const Ks &ks) { return (dtype_size(ks.dtypeT) / 8) * (size_t)ks.ldhd * (ks.maxiter + 1); }
+static size_t mailbox_hwords(const Ks &ks) { return (dtype_size(ks.dtypeT) * (size_t)ks.ldhd * (ks.maxiter + 1) + 7) / 8; }   // 8-byte words
 static MailboxView mailbox_view(const Ks &ks, void *base) {
   double *m = reinterpret_cast<double *>(base);
   const size_t hw = mailbox_hwords(ks), sw = (size_t)ks.maxiter + 2;
@@ -292,7 +300,7 @@ static bool mailbox_arm(Ks &ks, int m) {
     std::memset(ks.mbox, 0, need);
   }
   const MailboxView v = mailbox_view(ks, ks.mbox);
-  std::memset(v.H, 0, dtype_size(ks.dtypeT) * (size_t)ks.ldhd * (m + 1));   // columns this call fills
+  std::memset(v.H, 0, std::min(sizeof(double) * mailbox_hwords(ks), dtype_size(ks.dtypeT) * (size_t)ks.ldhd * (m + 1) + 8));   // columns this call fills
   std::memset(v.state, 0, sizeof(double) * 4);
   ks.pipe_seq = (ks.pipe_seq + 1) & dev::PIPE_SEQ_MASK;   // (the step flags carry it in 20 bits: a wider value would never match)
   if (ks.pipe_seq == 0) ks.pipe_seq = 1;
@@ -356,6 +364,9 @@ void ht_report() {
 }
 template <class T>
 static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos);
+// the single-pass step (pipe.hip) exists for the 64-bit element types; Float32 / ComplexF32 run the two-kernel step and the
+// modular launches (4 / 2 rows per 16-byte pack, fp64 projection sums)
+template <class T> constexpr bool kPipeType = std::is_same<T, double>::value || std::is_same<T, cplx>::value;
 
 // One arnoldi! / lanczos! call.  The three step forms share the call's state; each lives in its own
 // member function:
@@ -390,7 +401,7 @@ struct ArnoldiCall {
 
   ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
       : ks(ks_), op(op_), b(b_), o(o_), aug(aug_), lanczos(lanczos_), c(ks_.ctx), s(ks_.ctx->stream), isaug(aug_ != nullptr),
-        real_coeff(ks_.dtypeT == EXPV_MI_C64 && ks_.dtypeU == EXPV_MI_F64), no_dia_env(!ks_.ctx->opt.dia),
+        real_coeff(dtype_is_complex(ks_.dtypeT) && !dtype_is_complex(ks_.dtypeU)), no_dia_env(!ks_.ctx->opt.dia),
         p(aug_ ? aug_->p : 0), tol(o_.tol), init(o_.init), fresh(o_.init == 0) {}
 
   int run() {
@@ -418,7 +429,10 @@ struct ArnoldiCall {
     jstart = lanczos ? 1 : init;     // lanczos!: loop is always 1:m (arnoldi.jl:480)
     if (jstart > m) return 0;
     reset_device_state();
-    if (use_pipe) steps_single_pass();
+    if (use_pipe) {
+      if constexpr (kPipeType<T>) steps_single_pass();
+      else fail(EXPV_MI_HIP_ERROR, "single-pass step chosen for a 32-bit element type");
+    }
     else if (use_fused && single_red) steps_two_kernel();
     else if (use_fused) steps_two_kernel_two_reductions();
     else steps_modular();
@@ -441,12 +455,12 @@ struct ArnoldiCall {
       const int iopw = lanczos ? 2 : (o.iop == 0 ? m : std::min(o.iop, m));
       const int wstep = std::min(m - 1, iopw);
       const bool have_dia = op.ndiag > 0 && !no_dia_env;
-      use_pipe = use_fused && single_red && !no_pipe && op.sell_cut == 0 && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
+      use_pipe = kPipeType<T> && use_fused && single_red && !no_pipe && op.sell_cut == 0 && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
                  (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
   }
-  if constexpr (!ST<T>::is_complex) {
+  if constexpr (std::is_same<T, double>::value) {
     // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
     // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
     const bool no_wave = !c->opt.wave;
@@ -848,7 +862,7 @@ struct ArnoldiCall {
     dev::finalize_last<T>(s, V, ks.ldv, rows, nullptr, st);
   } else if (mailbox_arm(ks, m)) {   // whole-call expv: H and the final state go to the host through the mailbox
     const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)(dtype_size(ks.dtypeT) / 8) * ks.ldhd * m, st, mv.H,
+    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)((dtype_size(ks.dtypeT) * (size_t)ks.ldhd * m + 7) / 8), st, mv.H,
                       mv.state, mv.done, ks.pipe_seq);
     mbox_generic = true;
   }
@@ -1126,24 +1140,66 @@ int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o
   int herm = o.ishermitian;
   if (herm < 0) herm = op.ishermitian;
   const bool lanczos = force_lanczos || herm != 0;
-  if (ks.dtypeT == EXPV_MI_C64) return arnoldi_T<cplx>(ks, op, (const cplx *)b_dev, o, aug, lanczos);
-  return arnoldi_T<double>(ks, op, (const double *)b_dev, o, aug, lanczos);
+  return dispatch_dtype(ks.dtypeT, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    return arnoldi_T<T>(ks, op, (const T *)b_dev, o, aug, lanczos);
+  });
 }
 
 // ------------------------------------------------------------------------------------------
 // combine: W = scale * V[:, 0:mcols] * C                       krylov_phiv.jl:229-244, :641
 // ------------------------------------------------------------------------------------------
+// coefficient k of a packed (real or interleaved complex) fp64 buffer in the kernels' coefficient type
+template <class TC> static inline TC coef_as(const std::vector<double> &cbuf, size_t k, bool cplx_buf);
+template <> inline double coef_as<double>(const std::vector<double> &b, size_t k, bool c) { return c ? b[2 * k] : b[k]; }
+template <> inline float coef_as<float>(const std::vector<double> &b, size_t k, bool c) { return (float)(c ? b[2 * k] : b[k]); }
+template <> inline cplx coef_as<cplx>(const std::vector<double> &b, size_t k, bool c) { return c ? make_cplx(b[2 * k], b[2 * k + 1]) : make_cplx(b[k], 0.0); }
+template <> inline cplx32 coef_as<cplx32>(const std::vector<double> &b, size_t k, bool c) {
+  return c ? make_cplx32((float)b[2 * k], (float)b[2 * k + 1]) : make_cplx32((float)b[k], 0.0f);
+}
+
+template <class TV, class TC>
+static void combine_launch(Ks &ks, Ctx *c, int mcols, int ncols, const std::vector<double> &cbuf, bool cplx_buf, double scale, void *Wd,
+                           int64_t ldwd, int64_t rows, bool by_value, const LcSpec *lc) {
+  const int mc = std::max(mcols, 0);
+  const TV *V = ks.V.as<TV>();
+  if (by_value) {
+    dev::CoefVec<TC> cv;
+    for (int i = 0; i < mc; ++i) cv.c[i] = coef_as<TC>(cbuf, (size_t)i, cplx_buf);
+    if (lc) {
+      if constexpr (std::is_same<TV, TC>::value) {
+        dev::LcTerms<TC> lt{};
+        lt.nterms = lc->nterms;
+        lt.pscale = lc->pscale;
+        for (int l = 0; l < lc->nterms; ++l) { lt.in[l] = reinterpret_cast<const TC *>(lc->in[l]); lt.coef[l] = ST<TC>::from_real(lc->coef[l]); }
+        dev::combine1_lc<TV, TC>(c->stream, rows, V, ks.ldv, mc, cv, scale, lt, (TC *)Wd);
+      }
+    } else {
+      dev::combine1<TV, TC>(c->stream, rows, V, ks.ldv, mc, cv, scale, (TC *)Wd);
+    }
+    return;
+  }
+  std::vector<TC> ch((size_t)mcols * ncols);
+  for (size_t k = 0; k < ch.size(); ++k) ch[k] = coef_as<TC>(cbuf, k, cplx_buf);
+  DevBuf cdev(ch.size() * sizeof(TC) + 16);
+  HIPCHECK(hipMemcpyAsync(cdev.p, ch.data(), ch.size() * sizeof(TC), hipMemcpyHostToDevice, c->stream));
+  dev::combine<TV, TC>(c->stream, rows, V, ks.ldv, mc, cdev.as<TC>(), mcols, ncols, scale, (TC *)Wd, ldwd);
+  HIPCHECK(hipStreamSynchronize(c->stream));      // (`ch` and `cdev` leave scope)
+}
+
 void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype, double scale,
                        void *W, int64_t ldw, int w_loc, int w_dtype, const LcSpec *lc) {
   Ctx *c = ks.ctx;
   c->use();
   if (mcols < 0 || mcols > ks.maxiter + 1) fail(EXPV_MI_ASSERTION, "combine: more columns than the basis holds");
-  const bool Tc = ks.dtypeT == EXPV_MI_C64;
-  const bool Cc = (coef_dtype == EXPV_MI_C64) || Tc || (w_dtype == EXPV_MI_C64);
-  if (Cc && w_dtype != EXPV_MI_C64) fail(EXPV_MI_ARGUMENT_ERROR, "InexactError: complex result into a real output");
+  const bool Tc = dtype_is_complex(ks.dtypeT);
+  const bool Cc = dtype_is_complex(coef_dtype) || Tc || dtype_is_complex(w_dtype);
+  if (Cc && !dtype_is_complex(w_dtype)) fail(EXPV_MI_ARGUMENT_ERROR, "InexactError: complex result into a real output");
+  if (dtype_is_32bit(ks.dtypeT) != dtype_is_32bit(w_dtype))
+    fail(EXPV_MI_ARGUMENT_ERROR, "combine: the output must have the precision of the basis (32-bit basis -> Float32 / ComplexF32 result)");
   const int64_t rows = ks.n;   // outputs cover the operator rows only (V[1:n, :] for augmented subspaces)
   const size_t wsz = dtype_size(w_dtype);
-  // coefficient matrix, packed, in the compute type
+  // coefficient matrix, packed, fp64 (the host's small exponentials are computed in fp64 for every element type)
   std::vector<double> cbuf((size_t)mcols * ncols * (Cc ? 2 : 1));
   for (int q = 0; q < ncols; ++q)
     for (int i = 0; i < mcols; ++i) {
@@ -1170,14 +1226,9 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
         else cbuf[(size_t)q * mcols + i] *= sc;
       }
   }
-  const bool by_value = (ncols == 1 && mcols <= dev::COEF_BY_VALUE_MAX && (w_loc == EXPV_MI_HOST || ldw >= rows || true));
+  const bool by_value = (ncols == 1 && mcols <= dev::COEF_BY_VALUE_MAX);
   if (lc && (!by_value || w_loc != EXPV_MI_DEVICE || (Cc != Tc)))
     fail(EXPV_MI_ARGUMENT_ERROR, "combine with a linear-combination tail: one column, <= 64 coefficients, device output of the basis type");
-  DevBuf cdev;
-  if (!by_value) {
-    cdev.alloc(cbuf.size() * sizeof(double) + 16);
-    HIPCHECK(hipMemcpyAsync(cdev.p, cbuf.data(), cbuf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  }
   DevBuf wtmp;
   void *Wd = W;
   int64_t ldwd = ldw;
@@ -1189,43 +1240,16 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   ht_mark(8);
   {
     ProfScope ps(c, EXPV_MI_K_COMBINE);
-    const int mc = std::max(mcols, 0);
-    if (by_value && lc) {
-      if (!Cc) {
-        dev::CoefVec<double> cv;
-        for (int i = 0; i < mc; ++i) cv.c[i] = cbuf[i];
-        dev::LcTerms<double> lt{};
-        lt.nterms = lc->nterms; lt.pscale = lc->pscale;
-        for (int l = 0; l < lc->nterms; ++l) { lt.in[l] = reinterpret_cast<const double *>(lc->in[l]); lt.coef[l] = lc->coef[l]; }
-        dev::combine1_lc<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, lt, (double *)Wd);
-      } else {
-        dev::CoefVec<cplx> cv;
-        for (int i = 0; i < mc; ++i) cv.c[i] = make_cplx(cbuf[2 * i], cbuf[2 * i + 1]);
-        dev::LcTerms<cplx> lt{};
-        lt.nterms = lc->nterms; lt.pscale = lc->pscale;
-        for (int l = 0; l < lc->nterms; ++l) { lt.in[l] = reinterpret_cast<const cplx *>(lc->in[l]); lt.coef[l] = make_cplx(lc->coef[l], 0.0); }
-        dev::combine1_lc<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cv, scale, lt, (cplx *)Wd);
-      }
-    } else if (by_value) {
-      if (!Cc) {
-        dev::CoefVec<double> cv;
-        for (int i = 0; i < mc; ++i) cv.c[i] = cbuf[i];
-        dev::combine1<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, (double *)Wd);
-      } else {
-        dev::CoefVec<cplx> cv;
-        for (int i = 0; i < mc; ++i) cv.c[i] = make_cplx(cbuf[2 * i], cbuf[2 * i + 1]);
-        if (!Tc) dev::combine1<double, cplx>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cv, scale, (cplx *)Wd);
-        else dev::combine1<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cv, scale, (cplx *)Wd);
-      }
-    } else if (!Cc)
-      dev::combine<double, double>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cdev.as<double>(), mcols, ncols,
-                                   scale, (double *)Wd, ldwd);
-    else if (!Tc)
-      dev::combine<double, cplx>(c->stream, rows, ks.V.as<double>(), ks.ldv, mc, cdev.as<cplx>(), mcols, ncols, scale,
-                                 (cplx *)Wd, ldwd);
-    else
-      dev::combine<cplx, cplx>(c->stream, rows, ks.V.as<cplx>(), ks.ldv, mc, cdev.as<cplx>(), mcols, ncols, scale,
-                               (cplx *)Wd, ldwd);
+    const bool w32 = dtype_is_32bit(w_dtype);
+    if (!w32) {
+      if (!Cc) combine_launch<double, double>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      else if (!Tc) combine_launch<double, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      else combine_launch<cplx, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+    } else {
+      if (!Cc) combine_launch<float, float>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      else if (!Tc) combine_launch<float, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      else combine_launch<cplx32, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+    }
   }
   if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
   else if (!c->async_out) HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1246,7 +1270,7 @@ static void zero_output(Ctx *c, void *W, int64_t ldw, int w_loc, int64_t rows, i
 void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype) {
   const int m = ks.m;
   const bool tc = (t_im != 0.0);
-  if ((tc || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
+  if ((tc || dtype_is_complex(ks.dtypeT)) && !dtype_is_complex(w_dtype))
     fail(EXPV_MI_ARGUMENT_ERROR, "expv!: w must be complex when t or the basis is complex");
   if (ks.beta == 0.0) {  // zero input: V was never initialised; the result is exactly zero (:206-213)
     zero_output(ks.ctx, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
@@ -1276,7 +1300,7 @@ void expv_eval(Ks &ks, double t_re, double t_im, void *w, int w_loc, int w_dtype
     }
     return;
   }
-  const bool cplx_small = tc || ks.dtypeU == EXPV_MI_C64;
+  const bool cplx_small = tc || dtype_is_complex(ks.dtypeU);
   if (cplx_small) {  // lmul!(t, Hcopy); exponential!(Hcopy, ExpMethodHigham2005Base())  (:231-232)
     for (auto &v : Hc.a) v *= t;
     dense::expm_higham2005base(Hc);
@@ -1304,7 +1328,7 @@ void phiv_coefficients(Ks &ks, double t_re, double t_im, int k, int correct, std
   const int hend_r = m, hend_c = m - 1 + (ks.augmented != 0 ? 1 : 0);   // H[end, end] of getH(Ks)
   // (H[m+1, m] may still be on its way -- a deferred closing pass, Ks::defer_tail_req: the small exponential below only needs
   //  H[1:m, 1:m] and runs on the host meanwhile; ks_finish_tail() picks the entry up right after it)
-  const bool cplx_small = tc || ks.dtypeU == EXPV_MI_C64;
+  const bool cplx_small = tc || dtype_is_complex(ks.dtypeU);
   const int mext = m + (correct ? 1 : 0);
   double err = 0.0;
   if (cplx_small) {
@@ -1348,7 +1372,7 @@ void phiv_coefficients(Ks &ks, double t_re, double t_im, int k, int correct, std
 
 void phiv_eval(Ks &ks, double t_re, double t_im, int k, int correct, void *W, int64_t ldw, int w_loc, int w_dtype,
                double *errest) {
-  if ((t_im != 0.0 || ks.dtypeT == EXPV_MI_C64) && w_dtype != EXPV_MI_C64)
+  if ((t_im != 0.0 || dtype_is_complex(ks.dtypeT)) && !dtype_is_complex(w_dtype))
     fail(EXPV_MI_ARGUMENT_ERROR, "phiv!: w must be complex when t or the basis is complex");
   std::vector<double> Ce;
   int mext = 0;
@@ -1382,7 +1406,8 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
   StepState h;
   read_state<T>(ks, &h);
   ks.beta = std::sqrt(h.sumsq);
-  const int w_dtype = EXPV_MI_C64 * ((ks.dtypeT == EXPV_MI_C64) || t.imag() != 0.0);
+  const bool w_cplx = dtype_is_complex(ks.dtypeT) || t.imag() != 0.0;
+  const int w_dtype = w_cplx ? dtype_complex_of(ks.dtypeT) : dtype_real_of(ks.dtypeT);
   if (ks.beta == 0.0) {
     ks.m = 0;
     zero_output(c, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
@@ -1456,12 +1481,12 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
   for (auto e : ev)
     if (e) (void)hipEventDestroy(e);
   const int mm = ks.m;
-  if (t.imag() == 0.0 && ks.dtypeT == EXPV_MI_F64) {
+  if (!w_cplx) {
     std::vector<double> cr(mm);
     for (int i = 0; i < mm; ++i) cr[i] = cv[i].real();
-    combine_host_coef(ks, mm, 1, cr.data(), mm, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, EXPV_MI_F64);
+    combine_host_coef(ks, mm, 1, cr.data(), mm, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);
   } else {
-    combine_host_coef(ks, mm, 1, cv.data(), mm, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, EXPV_MI_C64);
+    combine_host_coef(ks, mm, 1, cv.data(), mm, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, w_dtype);
   }
 }
 
@@ -1469,12 +1494,14 @@ void expv_error_estimate_run(Ks &ks, Op &op, double t_re, double t_im, const voi
                              double atol, double rtol, int m, int ishermitian) {
   int herm = ishermitian < 0 ? op.ishermitian : ishermitian;
   if (!herm) fail(EXPV_MI_UNSUPPORTED, "Error estimation not yet available for non-Hermitian matrices.");
-  if (ks.dtypeU != EXPV_MI_F64)
+  if (dtype_is_complex(ks.dtypeU))
     fail(EXPV_MI_UNSUPPORTED, "Subspace exponential caches not yet available for non-Hermitian matrices.");
   DevBuf tmp;
   const void *bd = stage_in(ks.ctx, b, b_loc, (size_t)ks.n * dtype_size(ks.dtypeT), tmp);
-  if (ks.dtypeT == EXPV_MI_C64) error_estimate_T<cplx>(ks, op, cd(t_re, t_im), (const cplx *)bd, w, w_loc, atol, rtol, m);
-  else error_estimate_T<double>(ks, op, cd(t_re, t_im), (const double *)bd, w, w_loc, atol, rtol, m);
+  dispatch_dtype(ks.dtypeT, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    error_estimate_T<T>(ks, op, cd(t_re, t_im), (const T *)bd, w, w_loc, atol, rtol, m);
+  });
 }
 
 }  // namespace expv_mi

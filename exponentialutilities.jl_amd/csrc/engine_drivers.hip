@@ -309,7 +309,7 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
       for (int l = 1; l <= p - 1; ++l) coeffs[l] = coeffs[l - 1] * tt / l;
       const size_t esz = ce_cplx ? 2 : 1;
       const double *col = Ce.data() + esz * (size_t)p * mext;          // column p of Ce = P[:, end-1]
-      if (p <= 6 && mext <= dev::COEF_BY_VALUE_MAX && (ce_cplx == (dt == EXPV_MI_C64))) {
+      if (p <= 6 && mext <= dev::COEF_BY_VALUE_MAX && (ce_cplx == dtype_is_complex(dt))) {
         LcSpec lc;
         lc.nterms = p;
         lc.pscale = std::pow(tt, p);
@@ -366,10 +366,10 @@ void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int
     Ud = utmp.p;
     ldud = n;
   }
-  if (op.dtype == EXPV_MI_C64)
-    phiv_timestep_T<cplx>(ctx, op, nts, ts, (const cplx *)Bd, ldbd, ncoef, (cplx *)Ud, ldud, o, cache, stats);
-  else
-    phiv_timestep_T<double>(ctx, op, nts, ts, (const double *)Bd, ldbd, ncoef, (double *)Ud, ldud, o, cache, stats);
+  dispatch_dtype(op.dtype, [&](auto tag) {
+    using T = typename decltype(tag)::type;
+    phiv_timestep_T<T>(ctx, op, nts, ts, (const T *)Bd, ldbd, ncoef, (T *)Ud, ldud, o, cache, stats);
+  });
   if (u_loc == EXPV_MI_HOST) copy_out_2d(ctx, U, EXPV_MI_HOST, ldu, Ud, ldud, n, nts, esz);
 }
 

@@ -27,6 +27,20 @@ __device__ __forceinline__ void load_cols<double>(const int32_t *p, int32_t *c) 
 }
 template <>
 __device__ __forceinline__ void load_cols<cplx>(const int32_t *p, int32_t *c) { c[0] = *p; }
+template <>
+__device__ __forceinline__ void load_cols<float>(const int32_t *p, int32_t *c) {      // 4 rows per lane
+  const int4 v = *reinterpret_cast<const int4 *>(p);
+  c[0] = v.x;
+  c[1] = v.y;
+  c[2] = v.z;
+  c[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_cols<cplx32>(const int32_t *p, int32_t *c) {
+  const int2 v = *reinterpret_cast<const int2 *>(p);
+  c[0] = v.x;
+  c[1] = v.y;
+}
 
 // y-rows of one slice for this lane from the DIA form: acc[k] = sum_d val[d][r] * x[r + off[d]]  (ascending offsets =
 // ascending columns: the order of the CSR/SELL row; absent entries are explicit zeros)
@@ -199,12 +213,13 @@ __global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_fused_a(FusedAArgs<T> fa,
   const bool alu = is_al16(fa.u);
 
   for (int cb = 0; cb < a.nd; cb += CH) {
-    T accd[CH], accg[GRAM ? CH : 1];
+    using AT = typename ST<T>::acc_t;        // fp64 sums for the 32-bit element types
+    AT accd[CH], accg[GRAM ? CH : 1];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) accd[c] = ST<T>::zero();
+    for (int c = 0; c < CH; ++c) accd[c] = ST<AT>::zero();
     if (GRAM) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
+      for (int c = 0; c < CH; ++c) accg[c] = ST<AT>::zero();
     }
     const int64_t s0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * spw;
     const int64_t s1 = (s0 + spw < fa.A.nslices) ? s0 + spw : fa.A.nslices;
@@ -315,12 +330,13 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(fa.ybuf) && is_al16(u);
   double nrm = 0.0;
   for (int cb = 0; cb < a.nd; cb += CH) {
-    T accd[CH], accg[GRAM ? CH : 1];
+    using AT = typename ST<T>::acc_t;        // fp64 sums for the 32-bit element types
+    AT accd[CH], accg[GRAM ? CH : 1];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) accd[c] = ST<T>::zero();
+    for (int c = 0; c < CH; ++c) accd[c] = ST<AT>::zero();
     if (GRAM) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
+      for (int c = 0; c < CH; ++c) accg[c] = ST<AT>::zero();
     }
     // augmented operator: the slices run over n_op + p rows; the last ones may lie beyond the operator's own
     const int p_aug = fa.aug_p;
@@ -607,6 +623,8 @@ void permute_values(hipStream_t s, T *sell_val, int64_t sell_stride, const T *cs
   template void finalize_last<T>(hipStream_t, T *, int64_t, int64_t, const T *, const StepState *, int64_t, int);
 INSTF(double)
 INSTF(cplx)
+INSTF(float)
+INSTF(cplx32)
 
 }  // namespace dev
 }  // namespace expv_mi

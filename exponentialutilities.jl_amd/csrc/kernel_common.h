@@ -312,11 +312,15 @@ template <> __device__ __forceinline__ void acc_to_vals<cplx>(const cplx &a, dou
 template <class T> __device__ __forceinline__ T vals_to_T(const double *v);
 template <> __device__ __forceinline__ double vals_to_T<double>(const double *v) { return v[0]; }
 template <> __device__ __forceinline__ cplx vals_to_T<cplx>(const double *v) { return make_cplx(v[0], v[1]); }
+template <> __device__ __forceinline__ float vals_to_T<float>(const double *v) { return (float)v[0]; }
+template <> __device__ __forceinline__ cplx32 vals_to_T<cplx32>(const double *v) { return make_cplx32((float)v[0], (float)v[1]); }
 template <class T> __device__ __forceinline__ T shfl_T(T v, int src);
 template <> __device__ __forceinline__ double shfl_T<double>(double v, int src) { return __shfl(v, src, 64); }
 template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) {
   return make_cplx(__shfl(v.re, src, 64), __shfl(v.im, src, 64));
 }
+template <> __device__ __forceinline__ float shfl_T<float>(float v, int src) { return __shfl(v, src, 64); }
+template <> __device__ __forceinline__ cplx32 shfl_T<cplx32>(cplx32 v, int src) { return make_cplx32(__shfl(v.re, src, 64), __shfl(v.im, src, 64)); }
 
 // minimum waves/SIMD requested for the projection kernels (= workgroups/CU at 256 threads): 3 keeps
 // them spill-free at <= 168 VGPRs; the balanced row partition makes the grid exactly one resident round
@@ -325,12 +329,13 @@ template <> __device__ __forceinline__ cplx shfl_T<cplx>(cplx v, int src) {
 #endif
 template <class T> struct DotChunk { static constexpr int CH = 16; };
 template <> struct DotChunk<cplx> { static constexpr int CH = 8; };
+template <> struct DotChunk<cplx32> { static constexpr int CH = 8; };
 
 // Accumulate one row pack into the chunk's projection sums; columns cb..cb+CH-1 of the window.
 template <class T, bool GRAM, int CH = DotChunk<T>::CH>
 __device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t n, int c0, int dir, int nd,
                                                 int cb, int64_t i, bool al, const Pack<T> &yv, const Pack<T> &xv,
-                                                T *accd, T *accg) {
+                                                typename ST<T>::acc_t *accd, typename ST<T>::acc_t *accg) {
   constexpr int N = Pack<T>::N;
   constexpr int LB = 8;   // loads in flight per lane: 8 x 16 B; keeps the kernel at <= 128 VGPRs (4 workgroups/CU)
 #ifndef DOTS_PTR_STEP
@@ -369,7 +374,7 @@ __device__ __forceinline__ void dots_accumulate(const T *V, int64_t ldv, int64_t
 
 // workgroup reduction of a chunk's accumulators and publication of the per-workgroup partials
 template <class T, bool GRAM, int CH = DotChunk<T>::CH>
-__device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg, int cb, int nd, double *part,
+__device__ __forceinline__ void dots_publish_chunk(const typename ST<T>::acc_t *accd, const typename ST<T>::acc_t *accg, int cb, int nd, double *part,
                                                    double (*red_s)[CH * ST<T>::nreal * (GRAM ? 2 : 1)]) {
   constexpr int NR = ST<T>::nreal;
   constexpr int NSETS = GRAM ? 2 : 1;
@@ -379,14 +384,14 @@ __device__ __forceinline__ void dots_publish_chunk(const T *accd, const T *accg,
   {
     double a[K1];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc_to_vals<T>(accd[c], &a[c * NR]);
+    for (int c = 0; c < CH; ++c) acc_to_vals<typename ST<T>::acc_t>(accd[c], &a[c * NR]);
     wave_reduce_multi<K1>(a);
     if (K1 >= 64 || (lane & ((64 / K1) - 1)) == 0) red_s[wave][wave_multi_index<K1>(lane)] = a[0];
   }
   if (GRAM) {
     double a[K1];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc_to_vals<T>(accg[c], &a[c * NR]);
+    for (int c = 0; c < CH; ++c) acc_to_vals<typename ST<T>::acc_t>(accg[c], &a[c * NR]);
     wave_reduce_multi<K1>(a);
     if (K1 >= 64 || (lane & ((64 / K1) - 1)) == 0) red_s[wave][K1 + wave_multi_index<K1>(lane)] = a[0];
   }
@@ -442,6 +447,9 @@ __device__ __forceinline__ double readlane_f64(double v, int k) {
 template <class T> __device__ __forceinline__ T readlane_T(T v, int k);
 template <> __device__ __forceinline__ double readlane_T<double>(double v, int k) { return readlane_f64(v, k); }
 template <> __device__ __forceinline__ cplx readlane_T<cplx>(cplx v, int k) { return make_cplx(readlane_f64(v.re, k), readlane_f64(v.im, k)); }
+__device__ __forceinline__ float readlane_f32(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+template <> __device__ __forceinline__ float readlane_T<float>(float v, int k) { return readlane_f32(v, k); }
+template <> __device__ __forceinline__ cplx32 readlane_T<cplx32>(cplx32 v, int k) { return make_cplx32(readlane_f32(v.re, k), readlane_f32(v.im, k)); }
 
 // MAXND: longest window of the caller (rows of the triangular solve); <= 32 keeps a lane's row of the Gram triangle in registers
 template <class T, bool SHARED = false, int MAXND = LOWSYNC_MAX>

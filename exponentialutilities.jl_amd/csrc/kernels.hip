@@ -22,6 +22,8 @@
 #include <map>
 #include <mutex>
 
+#include <type_traits>
+
 #include "kernel_common.h"
 
 namespace expv_mi {
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(BLOCK) void k_abs_partial(const T *__restrict__ x, 
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     const T v = x[i];
     double a;
-    if constexpr (ST<T>::is_complex) a = hypot(v.re, v.im);
-    else a = fabs(v);
+    if constexpr (ST<T>::is_complex) a = hypot((double)v.re, (double)v.im);
+    else a = fabs((double)v);
     if (mode == 0) acc = (a > acc || a != a) ? a : acc;      // NaN propagates like maximum(abs, x)
     else acc += a;
   }
@@ -163,6 +165,8 @@ int abs_partial(hipStream_t s, const T *x, int64_t n, double *part, int mode) {
 }
 template int abs_partial<double>(hipStream_t, const double *, int64_t, double *, int);
 template int abs_partial<cplx>(hipStream_t, const cplx *, int64_t, double *, int);
+template int abs_partial<float>(hipStream_t, const float *, int64_t, double *, int);
+template int abs_partial<cplx32>(hipStream_t, const cplx32 *, int64_t, double *, int);
 
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_scale_copy(T *__restrict__ dst, const T *__restrict__ src, int64_t n,
@@ -271,6 +275,12 @@ __device__ __forceinline__ double group8_sum<double>(double v) {
 }
 template <>
 __device__ __forceinline__ cplx group8_sum<cplx>(cplx v) { return make_cplx(group8_sum<double>(v.re), group8_sum<double>(v.im)); }
+template <>
+__device__ __forceinline__ float group8_sum<float>(float v) { return (float)group8_sum<double>((double)v); }      // (the 8 partial sums are added in fp64)
+template <>
+__device__ __forceinline__ cplx32 group8_sum<cplx32>(cplx32 v) {
+  return make_cplx32((float)group8_sum<double>((double)v.re), (float)group8_sum<double>((double)v.im));
+}
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_spmv_ovf(OvfView<T> o, const T *__restrict__ x, const StepState *st, int step,
                                                     int64_t x_stride) {
@@ -492,6 +502,8 @@ void dense_props(hipStream_t s, int64_t n, const T *A, int64_t lda, double *scra
 }
 template void dense_props<double>(hipStream_t, int64_t, const double *, int64_t, double *, int, unsigned long long *);
 template void dense_props<cplx>(hipStream_t, int64_t, const cplx *, int64_t, double *, int, unsigned long long *);
+template void dense_props<float>(hipStream_t, int64_t, const float *, int64_t, double *, int, unsigned long long *);
+template void dense_props<cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, double *, int, unsigned long long *);
 
 // K8: augmented operator [A B; 0 K] of kiops (arnoldi.jl:195-202): the A*x part is already in y[0:n)
 template <class T>
@@ -535,12 +547,13 @@ __global__ __launch_bounds__(BLOCK, DOTS_WAVES) void k_dots(DotsArgs<T> a, int s
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(a.y) && (!GRAM || is_al16(a.x));
   const int64_t tile = (int64_t)BLOCK * N;
   for (int cb = 0; cb < a.nd; cb += CH) {
-    T accd[CH], accg[GRAM ? CH : 1];
+    using AT = typename ST<T>::acc_t;        // fp64 sums for the 32-bit element types
+    AT accd[CH], accg[GRAM ? CH : 1];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) accd[c] = ST<T>::zero();
+    for (int c = 0; c < CH; ++c) accd[c] = ST<AT>::zero();
     if (GRAM) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) accg[c] = ST<T>::zero();
+      for (int c = 0; c < CH; ++c) accg[c] = ST<AT>::zero();
     }
     const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < a.n) ? r0 + rpb : a.n;
     for (int64_t i = r0 + (int64_t)threadIdx.x * N; i < r1; i += tile) {
@@ -642,6 +655,15 @@ __device__ __forceinline__ void mulacc<double, cplx>(cplx &acc, double v, cplx c
 }
 template <>
 __device__ __forceinline__ void mulacc<cplx, cplx>(cplx &acc, cplx v, cplx c) { ST<cplx>::fma_(acc, v, c); }
+template <>
+__device__ __forceinline__ void mulacc<float, float>(float &acc, float v, float c) { acc = fmaf(v, c, acc); }
+template <>
+__device__ __forceinline__ void mulacc<float, cplx32>(cplx32 &acc, float v, cplx32 c) {
+  acc.re = fmaf(v, c.re, acc.re);
+  acc.im = fmaf(v, c.im, acc.im);
+}
+template <>
+__device__ __forceinline__ void mulacc<cplx32, cplx32>(cplx32 &acc, cplx32 v, cplx32 c) { ST<cplx32>::fma_(acc, v, c); }
 
 template <class TV, class TC, int NC>
 __global__ __launch_bounds__(BLOCK) void k_combine(int64_t n, const TV *__restrict__ V, int64_t ldv, int m,
@@ -850,6 +872,18 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void lincomb<T>(hipStream_t, const LincombArgs<T> &);
 INST(double)
 INST(cplx)
+INST(float)
+INST(cplx32)
+template void combine1_lc<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<float> &, double,
+                                        const LcTerms<float> &, float *);
+template void combine1_lc<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double,
+                                          const LcTerms<cplx32> &, cplx32 *);
+template void combine1<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<float> &, double, float *);
+template void combine1<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
+template void combine1<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
+template void combine<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const float *, int, int, double, float *, int64_t);
+template void combine<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const cplx32 *, int, int, double, cplx32 *, int64_t);
+template void combine<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const cplx32 *, int, int, double, cplx32 *, int64_t);
 template void combine1_lc<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<double> &, double,
                                           const LcTerms<double> &, double *);
 template void combine1_lc<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefVec<cplx> &, double,
@@ -945,6 +979,14 @@ __device__ __forceinline__ bool upd_eq_conj(double a, double b) { return a == b;
 __device__ __forceinline__ bool upd_eq_conj(cplx a, cplx b) { return a.re == b.re && a.im == -b.im; }
 __device__ __forceinline__ unsigned long long upd_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ unsigned long long upd_bits(cplx v) { return (unsigned long long)__double_as_longlong(v.re); }
+__device__ __forceinline__ double upd_abs(float v) { return fabs((double)v); }
+__device__ __forceinline__ double upd_abs(cplx32 v) { return hypot((double)v.re, (double)v.im); }
+__device__ __forceinline__ bool upd_is_zero(float v) { return v == 0.0f; }
+__device__ __forceinline__ bool upd_is_zero(cplx32 v) { return v.re == 0.0f && v.im == 0.0f; }
+__device__ __forceinline__ bool upd_eq_conj(float a, float b) { return a == b; }
+__device__ __forceinline__ bool upd_eq_conj(cplx32 a, cplx32 b) { return a.re == b.re && a.im == -b.im; }
+__device__ __forceinline__ unsigned long long upd_bits(float v) { return (unsigned long long)(unsigned)__float_as_int(v); }
+__device__ __forceinline__ unsigned long long upd_bits(cplx32 v) { return (unsigned long long)(unsigned)__float_as_int(v.re); }
 // one thread per row: the row's entries go to their SELL slots and diagonal slots (absent entries keep the zeros they were
 // built with: the pattern does not change), the row's absolute sum feeds opnorm(A, Inf), and every non-zero entry (r, c)
 // looks for its conjugate partner in row c
@@ -1023,13 +1065,17 @@ template <class T>
 void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a) {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_op_update_forms<T>, dim3((unsigned)((a.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
-  if (a.dia && a.nd > 0 && a.nd <= 8 && !ST<T>::is_complex)
+  if (a.dia && a.nd > 0 && a.nd <= 8 && std::is_same<T, double>::value)      // (constant-coefficient option of the fp64 banded step)
     hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd), dim3(BLOCK), 0, s, a.dia, a.dia_ld, a.dia_off, a.n, a.out);
 }
 template void op_scatter_values<double>(hipStream_t, double *, const double *, const int32_t *, int64_t);
 template void op_scatter_values<cplx>(hipStream_t, cplx *, const cplx *, const int32_t *, int64_t);
 template void op_update_forms<double>(hipStream_t, const OpUpdateArgs<double> &);
 template void op_update_forms<cplx>(hipStream_t, const OpUpdateArgs<cplx> &);
+template void op_scatter_values<float>(hipStream_t, float *, const float *, const int32_t *, int64_t);
+template void op_scatter_values<cplx32>(hipStream_t, cplx32 *, const cplx32 *, const int32_t *, int64_t);
+template void op_update_forms<float>(hipStream_t, const OpUpdateArgs<float> &);
+template void op_update_forms<cplx32>(hipStream_t, const OpUpdateArgs<cplx32> &);
 
 }  // namespace dev
 }  // namespace expv_mi

@@ -44,10 +44,12 @@ typedef enum {
   EXPV_MI_BOUNDS = 8              /* BoundsError (kiops.jl:303 with several output times)    */
 } expv_mi_status;
 
-/* F64 / C64: every entry point.  F32 / C32: the HOST small-dense functions (expv_mi_host_expm, expv_mi_host_phiv_dense:
- * exponential!(A, ExpMethodHigham2005Base()) for every BlasFloat, test/basictests.jl:952-974).  The device path computes in
- * fp64 / complex-fp64: entry points that take device data answer EXPV_MI_UNSUPPORTED for F32 / C32, and the host mirrors
- * promote 32-bit operands on upload and round the result back to the reference's promote_type. */
+/* Element types = the reference's BlasFloat (ExponentialUtilities.jl:19).  F64 / C64: every entry point, every step form.
+ * F32 / C32: operators, KrylovSubspace (T and U of one precision), arnoldi! / lanczos!, expv! / phiv! / combine, expv,
+ * the error-estimate mode, phiv_timestep!, mul!, and the host small-dense functions -- computed natively on 32-bit storage
+ * (4 / 2 rows per 16-byte pack: half the HBM traffic), with the projection sums accumulated in fp64 and the host's small
+ * exponentials in fp64; they run the two-kernel step and the modular launches (the single-pass step is 64-bit only).
+ * expv_mi_kiops (reference method Float64-only, kiops.jl:89) and expv_mi_expv_batch answer EXPV_MI_UNSUPPORTED for F32 / C32. */
 typedef enum { EXPV_MI_F64 = 0, EXPV_MI_C64 = 1, EXPV_MI_F32 = 2, EXPV_MI_C32 = 3 } expv_mi_dtype;
 typedef enum { EXPV_MI_HOST = 0, EXPV_MI_DEVICE = 1 } expv_mi_loc;
 

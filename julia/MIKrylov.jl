@@ -29,11 +29,15 @@ import ExponentialUtilities: KrylovSubspace, arnoldi, arnoldi!, lanczos!, expv, 
                              _phiv_timestep_caches, get_subspace_cache, getV, getH
 
 const lib = get(ENV, "EXPV_MI_LIB", joinpath(@__DIR__, "..", "exponentialutilities.jl_amd", "libexpv_mi.so"))
-const F64, C64 = Cint(0), Cint(1)
+const F64, C64, F32, C32 = Cint(0), Cint(1), Cint(2), Cint(3)
 const HOST, DEVICE = Cint(0), Cint(1)
-const MIScalar = Union{Float64, ComplexF64}
+# every BlasFloat (ExponentialUtilities.jl:19): the 32-bit types run natively on 32-bit storage (two-kernel step, fp64 projection
+# sums); kiops is Float64-only like the reference method and answers Unsupported for them
+const MIScalar = Union{Float64, ComplexF64, Float32, ComplexF32}
 dtype(::Type{Float64}) = F64
 dtype(::Type{ComplexF64}) = C64
+dtype(::Type{Float32}) = F32
+dtype(::Type{ComplexF32}) = C32
 
 # ---- option / result structs: field order and types of include/expv_mi.h (verified by check_abi) ----------------
 struct ArnoldiOpts

@@ -438,12 +438,76 @@ def test_32bit_operands_follow_the_reference_result_type(eu, T):
     if np.dtype(T).kind == "f":
         As = ((A + A.T) / 2).astype(T)
         assert eu.expv(0.5, As, b, m=30, mode="error_estimate").dtype == np.dtype(T)
-    with pytest.raises(eu.ExpvMIError) as ei:                      # the C ABI itself says so, instead of misreading the bytes
-        import ctypes as C
-        from exponentialutilities_jl_amd import _lib as L
-        h = C.c_void_p()
-        L.check(L.load().expv_mi_ks_create(eu.default_context()._h, L.F32, L.F32, 10, 5, 0, C.byref(h)), eu.default_context()._h)
-    assert ei.value.kind == "Unsupported"
+    assert "two_kernel" in eu.expv.last_stats["path"] or "modular" in eu.expv.last_stats["path"]
+
+
+@pytest.mark.parametrize("T", [np.float32, np.complex64])
+@pytest.mark.parametrize("kind", ["sparse_banded", "sparse_irregular", "dense"])
+def test_native_32bit_krylov_path(eu, T, kind):
+    """Float32 / ComplexF32 natively on the device (ExponentialUtilities.jl:19 BlasFloat,
+    test/basictests.jl:952-974): 32-bit storage (4 / 2 rows per 16-byte pack), fp64 projection sums, the two-kernel step and the
+    modular launches.  Against the fp64 oracle on the same (fp32-representable) inputs at fp32 bars: H and V of arnoldi!, expv,
+    phiv, mul!, strict MGS and low-sync, Lanczos on a Hermitian operator, the error-estimate mode and phiv_timestep!."""
+    from tests.test_gpu_parity import powerlaw_matrix
+    cplx = np.dtype(T).kind == "c"
+    rng = np.random.default_rng(41)
+    n, m = 3000, 20
+    if kind == "sparse_banded":
+        A = (c2_operator(n) * (1 + (0.25j if cplx else 0))).astype(T).tocsr()
+    elif kind == "sparse_irregular":
+        A = powerlaw_matrix(n, 5, cplx=cplx).astype(T).tocsr()
+    else:
+        n = 700
+        A = (-0.5 * np.eye(n) + (rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)) / np.sqrt(n)).astype(T)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    A64 = A.astype(np.complex128 if cplx else np.float64)
+    b64 = b.astype(np.complex128 if cplx else np.float64)
+    op = eu.MIOperator(A)
+    assert op.dtype == np.dtype(T)
+    x = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    y = op @ x
+    assert np.asarray(y).dtype == np.dtype(T)
+    close(np.asarray(y).astype(A64.dtype), A64 @ x.astype(A64.dtype), 5e-6, "mul! %s %s (fp32 bar)" % (np.dtype(T).name, kind))
+    for ortho in ("lowsync", "mgs"):
+        Ks = eu.arnoldi(op, b, m=m, ishermitian=False, ortho=ortho)
+        Ko = ko.arnoldi(A64, b64, m=m, ishermitian=False)
+        assert Ks.T == np.dtype(T) and Ks.m == Ko.m and Ks.getH().dtype == np.dtype(T)
+        close(Ks.getH().astype(A64.dtype), Ko.getH(), 2e-5, "arnoldi H %s %s %s (fp32 bar)" % (np.dtype(T).name, kind, ortho), mat=True)
+        close(Ks.getV().astype(A64.dtype), Ko.getV(), 2e-5, "arnoldi V %s %s %s (max abs, fp32 bar)" % (np.dtype(T).name, kind, ortho), absolute=True)
+    w = eu.expv(0.7, op, b, m=m, ishermitian=False)
+    assert np.asarray(w).dtype == np.dtype(T)
+    close(np.asarray(w).astype(A64.dtype), ko.expv(0.7, A64, b64, m=m, ishermitian=False), 1e-5, "expv %s %s (fp32 bar)" % (np.dtype(T).name, kind))
+    W = eu.phiv(0.5, op, b, 2, m=m)
+    assert np.asarray(W).dtype == np.dtype(T)
+    close(np.asarray(W).astype(A64.dtype), ko.phiv(0.5, A64, b64, 2, m=m), 2e-5, "phiv %s %s (fp32 bar)" % (np.dtype(T).name, kind))
+    # complex time on 32-bit operands: ComplexF32 result
+    wc = eu.expv(0.3 - 0.4j, op, b, m=m, ishermitian=False)
+    assert np.asarray(wc).dtype == np.dtype(np.complex64)
+    close(np.asarray(wc).astype(np.complex128), ko.expv(0.3 - 0.4j, A64, b64, m=m, ishermitian=False), 1e-5,
+          "expv complex t %s %s (fp32 bar)" % (np.dtype(T).name, kind))
+    if kind != "sparse_irregular":
+        # Hermitian operator: lanczos!, U = Float32, and the error-estimate mode
+        Ah = ((A64 + A64.conj().T) * 0.5)
+        Ah = Ah.astype(T) if kind == "dense" else Ah.astype(T).tocsr()
+        Ah64 = Ah.astype(A64.dtype)
+        Kh = eu.arnoldi(Ah, b, m=m)
+        assert Kh.U == np.dtype(np.float32) and Kh.getH().dtype == np.dtype(np.float32)
+        Kho = ko.arnoldi(Ah64, b64, m=m)
+        close(Kh.getH().astype(np.float64), np.real(Kho.getH()), 2e-5, "lanczos H %s %s (fp32 bar)" % (np.dtype(T).name, kind), mat=True)
+        we = eu.expv(0.7, Ah, b, m=m, mode="error_estimate", rtol=1e-4)
+        assert np.asarray(we).dtype == np.dtype(T)
+        truth = sl.expm(0.7 * (Ah64.toarray() if hasattr(Ah64, "toarray") else Ah64)) @ b64
+        close(np.asarray(we).astype(A64.dtype), truth, 5e-4, "expv error_estimate %s %s (rtol 1e-4)" % (np.dtype(T).name, kind))
+    # phiv_timestep!, adaptive
+    B = (rng.standard_normal((n, 3)) + (1j * rng.standard_normal((n, 3)) if cplx else 0)).astype(T)
+    U = eu.phiv_timestep(np.array([0.4, 1.0]), op, B, adaptive=True, tol=1e-5)
+    assert np.asarray(U).dtype == np.dtype(T)
+    Uo = ko.phiv_timestep(np.array([0.4, 1.0]), A64, B.astype(A64.dtype), adaptive=True, tol=1e-5)
+    close(np.asarray(U).astype(A64.dtype), Uo, 2e-4, "phiv_timestep %s %s (tol 1e-5, fp32 bar)" % (np.dtype(T).name, kind))
+    # the 64-bit-only entry points say so through the C ABI; the Python mirrors promote (kiops: Float64 reference method)
+    if not cplx:
+        wk, st = eu.kiops(0.5, A, B)
+        assert np.asarray(wk).dtype == np.float64
 
 
 def test_context_options_select_the_step_form(eu):
