@@ -631,6 +631,18 @@ def test_banded_operator_forms(eu, case):
     close(w, wo, max(TOL, 10 * loss), "banded form %s: w" % case)
     close(Ks.getV(), Ko.getV(), max(TOL, 100 * loss), "banded form %s: V (max abs)" % case, absolute=True)
     close(eu.expv(0.5, A, b, m=m, ishermitian=herm), wo, max(TOL, 10 * loss), "banded form %s: whole-call w" % case)
+    # FIXED bars next to the scaled ones: the Arnoldi relation A V_m = V_{m+1} H holds to rounding for ANY correct
+    # orthogonalisation, whatever orthogonality the basis has lost -- residual relative to |A| |V| at 1e-13 for the device basis
+    # (the oracle's own residual is printed beside it), and beta / the first column at 1e-14
+    Vd, Hd = Ks.getV(), Ks.H[: m + 1, :m]
+    Ad = A.toarray() if hasattr(A, "toarray") else np.asarray(A)
+    scale = float(np.linalg.norm(Ad, 2))
+    res_d = float(np.max(np.abs(Ad @ Vd[:, :m] - Vd @ Hd)) / scale)
+    res_o = float(np.max(np.abs(Ad @ Vo[:, :m] - Vo @ Ko.H[: m + 1, :m])) / scale)
+    print("[parity] %-90s Arnoldi relation residual: device %.3e, oracle %.3e" % ("banded forms: " + case, res_d, res_o))
+    close(res_d, 0.0, 1e-13, "banded form %s: |A V_m - V_{m+1} H| / |A| (fixed bar)" % case, absolute=True)
+    close(Ks.beta, Ko.beta, 1e-14 * Ko.beta, "banded form %s: beta (fixed bar)" % case, absolute=True)
+    close(Vd[:, 0], Vo[:, 0], 1e-14, "banded form %s: v_1 (max abs, fixed bar)" % case, absolute=True)
 
 
 def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
