@@ -190,10 +190,10 @@ void ks_materialize(Ks &ks) {
   if (!ks.scale_pending) return;
   ks.ctx->use();
   if (ks.scale_cols > 0) {
-    // (pending scales only come from the single-pass step, which runs on the 64-bit element types)
-    if (ks.dtypeT == EXPV_MI_F64) dev::scale_columns<double>(ks.ctx->stream, ks.V.as<double>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
-    else if (ks.dtypeT == EXPV_MI_C64) dev::scale_columns<cplx>(ks.ctx->stream, ks.V.as<cplx>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
-    else fail(EXPV_MI_HIP_ERROR, "pending column scales on a 32-bit basis");
+    dispatch_dtype(ks.dtypeT, [&](auto tag) {
+      using T = typename decltype(tag)::type;
+      dev::scale_columns<T>(ks.ctx->stream, ks.V.as<T>(), ks.ldv, ks.rows(), ks.colscale.as<double>(), ks.scale_cols);
+    });
   }
   HIPCHECK(hipStreamSynchronize(ks.ctx->stream));
   ks.scale_pending = false;
@@ -364,9 +364,8 @@ void ht_report() {
 }
 template <class T>
 static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos);
-// the single-pass step (pipe.hip) exists for the 64-bit element types; Float32 / ComplexF32 run the two-kernel step and the
-// modular launches (4 / 2 rows per 16-byte pack, fp64 projection sums)
-template <class T> constexpr bool kPipeType = std::is_same<T, double>::value || std::is_same<T, cplx>::value;
+// the single-pass step (pipe.hip): fp64 in every form, the other element types on the diagonal (DIA) halo form
+template <class T> constexpr bool kPipeType = true;      // (every element type: the 32-bit ones on the diagonal halo form)
 
 // One arnoldi! / lanczos! call.  The three step forms share the call's state; each lives in its own
 // member function:
@@ -457,7 +456,8 @@ struct ArnoldiCall {
       const bool have_dia = op.ndiag > 0 && !no_dia_env;
       use_pipe = kPipeType<T> && use_fused && single_red && !no_pipe && op.sell_cut == 0 && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
-                 (have_dia || (!ST<T>::is_complex && !isaug)) &&          // complex / augmented operators: DIA form only
+                 (have_dia || (std::is_same<T, double>::value && !isaug)) &&          // everything but plain fp64: DIA form only
+                 (!isaug || !dtype_is_32bit(ks.dtypeT)) &&
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
   }
   if constexpr (std::is_same<T, double>::value) {
@@ -658,7 +658,7 @@ struct ArnoldiCall {
   // (pipe.hip).  Shape: fp64 banded DIA operator, fresh call, full window, everything else as in the overlapped form.
   bool resident_done = false;
   ks.pipe_resident_used = false;
-  if constexpr (!ST<T>::is_complex) {
+  if constexpr (std::is_same<T, double>::value) {
     if (live && c->opt.resident && fresh && !use_wave && !isaug && !lanczos && op.ndiag > 0 && !no_dia_env && iop >= m &&
         m + (closing ? 1 : 0) <= dev::PIPE_CH && (ks.skip_tail || closing) && ks.mbox_armed) {
       dev::ResArgs ra{};
@@ -693,7 +693,7 @@ struct ArnoldiCall {
       pa.cont = cont ? 1 : 0;
       pa.cont_inv = cont ? ks.colscale_host[j - 1] : 1.0;
       pa.A = A;
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (std::is_same<T, double>::value) {
         if (use_wave) {
           if (op.gndiag > 0 && !no_dia_env) {
             pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
@@ -765,18 +765,18 @@ struct ArnoldiCall {
         // The gate keeps step j from being dispatched before step j-1 is completely resident.  Two grids that together have
         // no more workgroups than the device has CUs are resident together whatever the order: no gate, half the launches
         // (a small problem is bound by the host's launch rate: profiles/r02_trace_small_n.txt)
-        const int64_t tile_rows = (ST<T>::is_complex ? 1 : 2) * (int64_t)dev::BLOCK;   // pipe.hip: 16-byte packs, one per thread
+        const int64_t tile_rows = (int64_t)(16 / sizeof(T)) * (int64_t)dev::BLOCK;   // pipe.hip: 16-byte packs, one per thread
         const int64_t live_tiles = (rows + tile_rows - 1) / tile_rows;
         const bool gate = use_wave || 2 * live_tiles > dev::device_cus();
         if (j > jstart && gate) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-        if constexpr (!ST<T>::is_complex) {
+        if constexpr (std::is_same<T, double>::value) {
           prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
         } else {
           prev_grid = dev::pipe_step_live(sj, pa);
         }
         if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
       } else if (use_wave) {
-        if constexpr (!ST<T>::is_complex) {
+        if constexpr (std::is_same<T, double>::value) {
           ProfScope ps1(c, EXPV_MI_K_FUSED_A);
           if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
         }

@@ -156,7 +156,21 @@ template <> __device__ __forceinline__ double consume_T<double>(const double *p)
 template <> __device__ __forceinline__ cplx consume_T<cplx>(const cplx *p) {
   return make_cplx(consume_f64(&p->re), consume_f64(&p->im));
 }
+__device__ __forceinline__ float consume_f32(const float *p) {
+  const unsigned u = __hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __int_as_float((int)u);
+}
+__device__ __forceinline__ void publish_f32(float *p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned *>(p), (unsigned)__float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <> __device__ __forceinline__ float consume_T<float>(const float *p) { return consume_f32(p); }
+template <> __device__ __forceinline__ cplx32 consume_T<cplx32>(const cplx32 *p) { return make_cplx32(consume_f32(&p->re), consume_f32(&p->im)); }
 template <class T> __device__ __forceinline__ void publish_T(T *p, T v);
+template <> __device__ __forceinline__ void publish_T<float>(float *p, float v) { publish_f32(p, v); }
+template <> __device__ __forceinline__ void publish_T<cplx32>(cplx32 *p, cplx32 v) {
+  publish_f32(&p->re, v.re);
+  publish_f32(&p->im, v.im);
+}
 template <> __device__ __forceinline__ void publish_T<double>(double *p, double v) { publish_f64(p, v); }
 template <> __device__ __forceinline__ void publish_T<cplx>(cplx *p, cplx v) {
   publish_f64(&p->re, v.re);

