@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK) void k_op_dia_const(const T *__restrict__ di
   if (rhi <= rlo) { if (threadIdx.x == 0) out[2 + d] = 1ull; return; }
   const T c0 = dia[(int64_t)d * ld + rlo];
   bool diff = false;
-  for (int64_t r = rlo + threadIdx.x; r < rhi; r += BLOCK) {
+  for (int64_t r = rlo + (int64_t)blockIdx.y * BLOCK + threadIdx.x; r < rhi; r += (int64_t)gridDim.y * BLOCK) {   // (one block per diagonal took 1.2 ms at n = 1e6)
     const T v = dia[(int64_t)d * ld + r];
     diff = diff || upd_bits(v) != upd_bits(c0) || !upd_eq_conj(v, v) || !upd_eq_conj(c0, c0);
   }
@@ -1066,7 +1066,8 @@ void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a) {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_op_update_forms<T>, dim3((unsigned)((a.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
   if (a.dia && a.nd > 0 && a.nd <= 8 && std::is_same<T, double>::value)      // (constant-coefficient option of the fp64 banded step)
-    hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd), dim3(BLOCK), 0, s, a.dia, a.dia_ld, a.dia_off, a.n, a.out);
+    hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd, (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, a.n / (4 * BLOCK)))), dim3(BLOCK), 0, s, a.dia,
+                       a.dia_ld, a.dia_off, a.n, a.out);
 }
 template void op_scatter_values<double>(hipStream_t, double *, const double *, const int32_t *, int64_t);
 template void op_scatter_values<cplx>(hipStream_t, cplx *, const cplx *, const int32_t *, int64_t);
