@@ -530,9 +530,16 @@ __device__ __forceinline__ void projection_epilogue(const DotsArgs<T> &a, const 
     T sv = (lane < nd) ? vals_to_T<T>(vals_s + lane * NR) : ST<T>::zero();
     const int rowbase = lane * (lane - 1) / 2;
     if constexpr (MAXND <= 32) {
+      // row `lane` of the strict lower triangle, zeros elsewhere: the loads are unconditional (index clamped into the packed
+      // triangle, the value selected afterwards) -- a conditional load costs an exec-mask branch per entry (0.8 us for a
+      // 31-column window when one wave per SIMD runs it, profiles/r03_ab_variants.txt item 11)
       T grow[MAXND - 1];
+      const int rb_c = (lane < MAXND) ? rowbase : 0;
 #pragma unroll
-      for (int k = 0; k < MAXND - 1; ++k) grow[k] = (k < lane && lane < nd) ? gs_s[rowbase + k] : ST<T>::zero();
+      for (int k = 0; k < MAXND - 1; ++k) {
+        const T g = gs_s[(k < lane) ? rb_c + k : 0];
+        grow[k] = (k < lane && lane < nd) ? g : ST<T>::zero();
+      }
 #pragma unroll
       for (int k = 0; k < MAXND - 1; ++k) {
         if (k < nd - 1) {   // (wave-uniform; no early exit: the unrolled loop keeps grow[] in registers)
