@@ -453,8 +453,22 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["path"] = list(eu.expv.last_stats["path"])
     sec["grid_stencil_wave_form"] = e
     del opg, Ag
+    # (3b'') the 3-D counterpart: 7-point stencil on a k x k x k grid (offsets +-1, +-k, +-k^2, k = 100): the diagonals reach 20
+    # tiles either way
+    k3 = int(round(n ** (1.0 / 3.0)))
+    n3d = k3 ** 3
+    if n3d == n:
+        Ag3 = sp.diags([0.2, 0.3, 1.1, -2.0, 0.7, -0.1, 0.15], [-k3 * k3, -k3, -1, 0, 1, k3, k3 * k3], shape=(n, n), format="csc")
+        opg3 = eu.MIOperator(Ag3, ctx)
+        grid3 = lambda: eu.expv(T_FINAL, opg3, b, m=m, ishermitian=False, out=w)
+        grid3()
+        e = entry("expv, 7-point grid stencil offsets (+-1, +-%d, +-%d) (wave form of the single-pass step), n=%d m=%d" % (k3, k3 * k3, n, m),
+                  timed(grid3, args.steps, 2, env.sync), m, alg_bytes_expv(n, Ag3.nnz, m))
+        e["path"] = list(eu.expv.last_stats["path"])
+        sec["grid3d_stencil_wave_form"] = e
+        del opg3, Ag3
     # (3b') the headline operator in Float32 (BlasFloat of the reference, ExponentialUtilities.jl:19): native 32-bit storage on
-    # the two-kernel step (4 rows per 16-byte pack, fp64 projection sums), priced against the s = 4 contract
+    # the single-pass step (4 rows per 16-byte pack, fp64 projection sums), priced against the s = 4 contract
     A32 = c2_operator(n).astype(np.float32)
     op32 = eu.MIOperator(A32, ctx)
     b32 = b.to(torch.float32)
@@ -462,7 +476,7 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     f32 = lambda: eu.expv(T_FINAL, op32, b32, m=m, ishermitian=False, out=w32)
     f32()
     env.sync()
-    e = entry("expv, C2 operator in Float32 (native 32-bit storage, two-kernel step), n=%d m=%d; contract with s = 4" % (n, m),
+    e = entry("expv, C2 operator in Float32 (native 32-bit storage, single-pass step), n=%d m=%d; contract with s = 4" % (n, m),
               timed(f32, args.steps, 2, env.sync), m, alg_bytes_expv(n, A32.nnz, m, s=4))
     e["path"] = list(eu.expv.last_stats["path"])
     eu.expv(T_FINAL, op, b, m=m, ishermitian=False, out=w)            # the fp64 result of the same problem

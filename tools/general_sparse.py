@@ -1,5 +1,5 @@
 """expv on general (non-banded) sparse operators: which step form runs, per-kernel time, fraction of the SURVEY 8d contract.
-    python tools/general_sparse.py [kind ...]     kinds: c2 rand5 band5 rand5sorted powerlaw"""
+    python tools/general_sparse.py [kind ...]     kinds: c2 rand5 band5[_REACH] grid grid3 powerlaw c2f32"""
 import json
 import sys
 import time
@@ -38,6 +38,14 @@ def make(kind, n, seed=11):
         d = [0.3 + 0.05 * rng.random(n - k), 1.2 + 0.05 * rng.random(n - 1), -2.0 + 0.05 * rng.random(n), 0.8 + 0.05 * rng.random(n - 1),
              -0.1 + 0.05 * rng.random(n - k)]
         return sp.diags(d, [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+    if kind == "grid3":                     # 3-D 7-point stencil on a k x k x k grid, variable coefficients: general DIA form
+        k = int(round(n ** (1.0 / 3.0)))
+        nn = k * k * k
+        offs = [-k * k, -k, -1, 0, 1, k, k * k]
+        base = [0.2, 0.3, 1.1, -2.0, 0.7, -0.1, 0.15]
+        d = [c + 0.05 * rng.random(nn - abs(o)) for c, o in zip(base, offs)]
+        A = sp.diags(d, offs, shape=(nn, nn), format="csr")
+        return sp.block_diag([A, -0.5 * sp.identity(n - nn, format="csr")], format="csr") if n > nn else A
     if kind == "powerlaw":                  # irregular rows: lengths ~ Zipf, mean ~5, max capped
         ln = np.minimum(rng.zipf(1.8, size=n), 2000)
         ln = np.maximum(1, (ln * (5.0 / ln.mean())).astype(np.int64))
