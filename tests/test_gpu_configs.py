@@ -1101,6 +1101,7 @@ def test_two_processes_sharing_the_device_get_correct_results():
     redone.  Every result must equal the one-launch-after-the-other result bit for bit, or to 1e-12 when the call was redone in
     another step form (tools/stress_shared_device.py; VERDICT r2, design / robustness)."""
     import json
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
