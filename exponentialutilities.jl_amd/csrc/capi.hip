@@ -358,7 +358,7 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) 
       HIPCHECK(hipMemcpyAsync(op.ovf_multi.p, multi.data(), sizeof(int32_t) * multi.size(), hipMemcpyHostToDevice, c->stream));
       op.ovf_part.alloc(sizeof(V) * (size_t)npart);
     }
-    op.ovf_y.alloc(sizeof(V) * (size_t)((n + 127) / 128 * 128));
+    op.ovf_y.alloc(sizeof(V) * (size_t)((n + 255) / 256 * 256));      // (whole waves of 16-byte packs for every element type)
     HIPCHECK(hipMemsetAsync(op.ovf_y.p, 0, op.ovf_y.bytes, c->stream));     // rows without overflow stay zero for good
   }
   HIPCHECK(hipStreamSynchronize(c->stream));      // (`off`, `seg`, `multi` leave scope)

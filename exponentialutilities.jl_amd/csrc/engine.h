@@ -34,6 +34,8 @@ struct Err {
 inline size_t dtype_size(int dt) { return dt == EXPV_MI_C64 ? 16 : (dt == EXPV_MI_F32 ? 4 : 8); }   // F64 8, C64 16, F32 4, C32 8
 inline bool dtype_is_complex(int dt) { return dt == EXPV_MI_C64 || dt == EXPV_MI_C32; }
 inline bool dtype_is_32bit(int dt) { return dt == EXPV_MI_F32 || dt == EXPV_MI_C32; }
+// rows a library-owned vector is padded to: one wave of 16-byte packs (Float32: 4 rows per lane; everything else <= 2)
+inline int64_t dtype_row_pad(int dt) { return dt == EXPV_MI_F32 ? 256 : 128; }
 inline int dtype_real_of(int dt) { return dtype_is_32bit(dt) ? EXPV_MI_F32 : EXPV_MI_F64; }
 inline int dtype_complex_of(int dt) { return dtype_is_32bit(dt) ? EXPV_MI_C32 : EXPV_MI_C64; }
 // the device element type of a dtype code, handed to a generic lambda: dispatch_dtype(dt, [&](auto tag) { using T = typename

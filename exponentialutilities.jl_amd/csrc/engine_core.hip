@@ -114,7 +114,9 @@ void ks_alloc(Ks &ks, Ctx *ctx, int dtT, int dtU, int64_t n, int maxiter, int au
   ks.augmented = augmented;
   ks.beta = 0.0;
   ks.wasbreakdown = false;
-  ks.ldv = round_up(ks.rows() > 0 ? ks.rows() : 1, 128);
+  // padded to whole waves of 16-byte row packs (64 lanes x 2 rows fp64 / 4 rows Float32): a kernel may move any pack that starts
+  // inside the padded column, and the rows beyond n hold zeros
+  ks.ldv = round_up(ks.rows() > 0 ? ks.rows() : 1, dtype_row_pad(dtT));
   const size_t esz = dtype_size(dtT);
   ks.V.alloc((size_t)ks.ldv * (maxiter + 1) * esz);
   HIPCHECK(hipMemsetAsync(ks.V.p, 0, ks.V.bytes, ctx->stream));  // padding rows must stay zero

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_last(T *V, int64_t ldv, int6
   for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
     Pack<T> p = ld_pack(u, i, n, al);
 #pragma unroll
-    for (int k = 0; k < N; ++k) p.v[k] = ST<T>::div_real(p.v[k], beta);
+    for (int k = 0; k < N; ++k) p.v[k] = (i + k < n) ? ST<T>::div_real(p.v[k], beta) : ST<T>::zero();      // (padding rows stay zero when beta is 0)
     st_pack(dst, i, n, al, p);
   }
 }

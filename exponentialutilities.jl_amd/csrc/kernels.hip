@@ -195,8 +195,10 @@ __global__ __launch_bounds__(BLOCK) void k_scale_by_state(T *__restrict__ y, int
   const bool al = is_al16(y);
   for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < n; i += (int64_t)gridDim.x * BLOCK * N) {
     Pack<T> p = ld_pack(y, i, n, al);
+    // (the padding rows of a library vector stay ZERO: on an exact breakdown beta is 0 and 0 / 0 would plant NaNs there that the
+    //  whole-pack sums of every later factorisation on this subspace pick up; the rows < n get the reference's NaN / Inf)
 #pragma unroll
-    for (int k = 0; k < N; ++k) p.v[k] = ST<T>::div_real(p.v[k], beta);
+    for (int k = 0; k < N; ++k) p.v[k] = (i + k < n) ? ST<T>::div_real(p.v[k], beta) : ST<T>::zero();
     st_pack(y, i, n, al, p);
   }
 }

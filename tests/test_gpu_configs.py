@@ -1111,3 +1111,34 @@ def test_two_processes_sharing_the_device_get_correct_results():
     assert p.returncode == 0 and len(rows) == 2, p.stdout + p.stderr
     for r in rows:
         assert r["mismatches"] == 0 and r["calls"] > 50 and r["worst_rel"] <= 1e-12, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [128, 384, 1408])
+def test_float32_columns_are_padded_to_whole_waves(eu, n):
+    """Float32 moves 4 rows per lane, a wave 256: a basis column padded to 128 rows let the two-kernel step read the NEXT column
+    through the tail of a wave whenever ceil(n / 128) is odd -- invisible on a fresh subspace (zeros), wrong (beta^2 off by the
+    squared norm of the stale neighbour) from the second factorisation on.  Found by tools/fuzz_parity.py (seed 2026, case 2391:
+    adaptive expv_timestep never terminated on the garbage error estimates).  Repeated factorisations on one subspace, growing
+    and shrinking m, nine diagonals (two-kernel step), Lanczos and Arnoldi, then the adaptive time stepper."""
+    rng = np.random.default_rng(7)
+    offs = [-5, -4, -3, -2, 0, 2, 3, 4, 5]
+    d = [rng.standard_normal(n - abs(o)) * 0.1 for o in offs]
+    A = sp.diags(d, offs, shape=(n, n), format="csr")
+    A = (((A + A.T) * 0.5) - 0.5 * sp.identity(n)).tocsr().astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    for herm in (True, False):
+        Ks = eu.KrylovSubspace(np.float32, None, n, 5)
+        for m in (5, 7, 5, 7, 3):
+            eu.arnoldi_(Ks, A, b, m=m, ishermitian=herm)
+            Ko = ko.arnoldi(A64, b64, m=m, ishermitian=herm)
+            assert abs(Ks.beta - Ko.beta) <= 1e-5 * Ko.beta
+            close(np.asarray(Ks.getH()).astype(np.float64), np.real(Ko.getH()), 2e-5,
+                  "Float32 n=%d reused subspace, m=%d hermitian=%s: H (fp32 bar)" % (n, m, herm), mat=True)
+    ts = np.array([0.66, 0.93])
+    st = {}
+    U = eu.expv_timestep(ts.copy(), A, b, tol=1e-5, m=5, adaptive=True, stats=st)
+    Uo = ko.expv_timestep(ts.copy(), A64, b64, tol=1e-5, m=5, adaptive=True)
+    close(np.asarray(U).astype(np.float64), Uo, 2e-4, "Float32 n=%d adaptive expv_timestep after reuse (fp32 bar)" % n)
+    assert st["num_timesteps"] <= 4

@@ -791,3 +791,29 @@ def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
     close(w, eu.expv_(np.empty(n), 0.4, Km), TOL, "SELL wave form n=%d: w vs strict MGS" % n)
     if n <= 100_000:
         close(w, ko.expv(0.4, A, b, m=m, ishermitian=False), TOL, "SELL wave form n=%d: w vs oracle" % n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float32, np.float64, np.complex64])
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+def test_exact_breakdown_leaves_no_nan_for_the_next_factorisation(eu, T, kind):
+    """An EXACT happy breakdown (beta = 0) makes v_{m+1} = y / beta NaN, in the reference too (arnoldi.jl:306, :399: the division
+    comes before the test).  The padding rows of that column must stay zero (0 / 0 is NaN as well) and the stale NaN column must
+    not reach the next factorisation on the same subspace.  Found by tools/fuzz_parity.py (seed 11, case 2496: n = 1, Float32)."""
+    A = np.array([[-0.55]], dtype=T)
+    Ah = np.array([[-0.7]], dtype=T)
+    b = np.array([0.36], dtype=T)
+    if kind == "csr":
+        A, Ah = sp.csr_matrix(A), sp.csr_matrix(Ah)
+    for ortho in ("mgs", "lowsync"):
+        Ks = eu.KrylovSubspace(T, None, 1, 31)
+        eu.arnoldi_(Ks, Ah, b, m=31, ishermitian=True, ortho=ortho)
+        assert Ks.m == 1 and Ks.wasbreakdown
+        eu.arnoldi_(Ks, A, b, m=31, iop=7, ishermitian=False, ortho=ortho)
+        H = np.asarray(Ks.getH())
+        assert Ks.m <= 2 and Ks.wasbreakdown and np.isfinite(H[:Ks.m, :Ks.m]).all(), (Ks.m, H[:3, :3])
+        w = eu.expv(0.7, Ah, b, m=31, ishermitian=True, ortho=ortho)
+        w2 = eu.expv(0.7, A, b, m=31, ishermitian=False, ortho=ortho)
+        tol = 1e-6 if np.dtype(T).itemsize <= 8 and np.dtype(T) != np.float64 else 1e-14
+        close(np.asarray(w).astype(np.complex128), np.exp(0.7 * -0.7) * 0.36, tol, "n=1 %s %s %s after an exact breakdown: expv (Lanczos)" % (np.dtype(T).name, kind, ortho))
+        close(np.asarray(w2).astype(np.complex128), np.exp(0.7 * -0.55) * 0.36, tol, "n=1 %s %s %s after an exact breakdown: expv (Arnoldi)" % (np.dtype(T).name, kind, ortho))

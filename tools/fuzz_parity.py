@@ -1,0 +1,208 @@
+"""Randomised parity hunt against the oracle: random sizes, element types, operator structures, calls and options.
+Every case is derived from (seed, index), printed on failure and reproducible with  python tools/fuzz_parity.py 0 SEED INDEX.
+    python tools/fuzz_parity.py SECONDS [SEED]
+Test infrastructure (imports the oracle); not part of the product or of the measured path."""
+import json
+import sys
+import time
+import traceback
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, ".")
+import expv_mi_loader
+from oracle import krylov_oracle as ko
+
+eu = expv_mi_loader.load()
+
+
+def make_operator(rng, n, cplx):
+    kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense"])
+    def vals(shape, scale):
+        v = rng.standard_normal(shape) * scale
+        return v + 1j * rng.standard_normal(shape) * scale if cplx else v
+    if kind in ("banded", "symmetric_banded"):
+        w = int(rng.integers(0, min(9, n)))
+        offs = sorted(set([0] + [int(o) for o in rng.integers(-w, w + 1, size=int(rng.integers(1, 9)))]))
+        if kind == "symmetric_banded":
+            offs = sorted(set(offs + [-o for o in offs]))
+        d = [vals(n - abs(o), 0.3 / np.sqrt(len(offs))) if rng.random() < 0.7 else np.full(n - abs(o), vals((), 0.3)) for o in offs]
+        A = sp.diags(d, offs, shape=(n, n), format="csr")
+        if kind == "symmetric_banded":
+            A = ((A + A.conj().T) * 0.5).tocsr()
+        A = A - 0.5 * sp.identity(n, format="csr")
+    elif kind == "wide_diagonals":
+        nd = int(rng.integers(2, 7))
+        offs = sorted(set([0] + [int(o) for o in rng.integers(-(n - 1), n, size=nd)]))
+        d = [vals(n - abs(o), 0.3 / np.sqrt(len(offs))) for o in offs]
+        A = sp.diags(d, offs, shape=(n, n), format="csr") - 0.5 * sp.identity(n, format="csr")
+    elif kind in ("regular_rows", "irregular_rows"):
+        if kind == "regular_rows":
+            ln = np.full(n, int(rng.integers(1, 7)))
+        else:
+            ln = np.minimum(rng.zipf(1.7, size=n), max(1, n // 2))
+        rows = np.repeat(np.arange(n), ln)
+        cols = rng.integers(0, n, size=rows.size)
+        v = vals(rows.size, 0.3) / np.sqrt(np.repeat(ln, ln))
+        A = (sp.coo_matrix((v, (rows, cols)), shape=(n, n)).tocsr() - 0.5 * sp.identity(n, format="csr")).tocsr()
+        A.sum_duplicates()
+    else:
+        n = min(n, 400)
+        A = vals((n, n), 1.0 / np.sqrt(n)) - 0.5 * np.eye(n)
+        if kind == "hermitian_dense":
+            A = (A + A.conj().T) * 0.5
+    return kind, n, A
+
+
+def one_case(seed, index, verbose=False):
+    rng = np.random.default_rng([seed, index])
+    T = np.dtype(rng.choice(["float64", "float64", "complex128", "float32", "complex64"]))
+    cplx = T.kind == "c"
+    T64 = np.dtype(np.complex128 if cplx else np.float64)
+    single = T.itemsize == (8 if cplx else 4)
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 127, 128, 129, 511, 512, 513, 1000, 1537, 2500, 4099]))
+    kind, n, A64 = make_operator(rng, n, cplx)
+    A = A64.astype(T)
+    A64 = A.astype(T64)               # the oracle sees exactly the values the device has
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    b64 = b.astype(T64)
+    m = int(rng.integers(1, 41))
+    iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
+    herm = kind in ("symmetric_banded", "hermitian_dense") and bool(rng.integers(0, 2))
+    call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate"])
+    ortho = str(rng.choice(["lowsync", "mgs"]))
+    desc = {"seed": seed, "index": index, "T": T.name, "n": n, "operator": kind, "m": m, "iop": iop, "hermitian": herm, "call": str(call), "ortho": ortho}
+    if verbose:
+        print(desc, flush=True)
+    tol = 3e-4 if single else 1e-10
+    kw = dict(m=m, iop=iop, ishermitian=herm)
+    as64 = lambda x: np.asarray(x).astype(T64 if np.asarray(x).dtype.kind == "c" or cplx else np.float64)
+    def rel(a, r):
+        a, r = np.asarray(a), np.asarray(r)
+        if not np.isfinite(a).all():
+            return float("inf")
+        return float(np.linalg.norm(a.astype(np.complex128) - r) / max(np.linalg.norm(r), 1e-300))
+    err, extra = 0.0, {}
+    if call == "expv":
+        w = eu.expv(0.7, A, b, ortho=ortho, **kw)
+        err = rel(w, ko.expv(0.7, A64, b64, **kw))
+    elif call == "expv_complex_t":
+        w = eu.expv(0.3 - 0.4j, A, b, **kw)
+        err = rel(w, ko.expv(0.3 - 0.4j, A64, b64, **kw))
+    elif call == "arnoldi":
+        Ks = eu.arnoldi(A, b, ortho=ortho, **kw)
+        Ko = ko.arnoldi(A64, b64, **kw)
+        extra = {"m_dev": int(Ks.m), "m_ref": int(Ko.m)}
+        md = int(Ks.m)
+        brk = md < min(m, n) or md == n      # happy breakdown: column md + 1 of V and H[md + 1, md] are rounding noise
+        Hsub = np.abs(np.diag(np.asarray(Ko.getH()), -1))
+        near_tol = Ks.m != Ko.m and min(Ks.m, Ko.m) - 1 < len(Hsub) and Hsub[min(Ks.m, Ko.m) - 1] < 1e-5
+        if not single and Ks.m != Ko.m and not near_tol:      # (a residual within 100x of the breakdown tolerance may fall either side of it)
+            err = float("inf")
+        elif Ks.m != Ko.m and not np.isfinite(np.asarray(Ks.getH())).all():
+            err = float("inf")
+            extra["H_not_finite"] = True
+        else:
+            # (1) the Arnoldi relation  A V_k = V_{k+1} H_k  on the columns that are defined
+            Hd = np.asarray(Ks.getH()).astype(np.complex128)
+            Vd = np.asarray(Ks.getV()).astype(np.complex128)
+            kc = md - 1 if brk else md
+            if Ks.m != Ko.m:
+                kc = min(kc, int(Ko.m) - 1)
+            eps = 1.2e-7 if single else 2.2e-16
+            if kc >= 1:
+                AV = A64 @ Vd[:, :kc]
+                R = AV - Vd[:, :kc + 1] @ Hd[:kc + 1, :kc]
+                nA = np.linalg.norm(A64.toarray() if sp.issparse(A64) else A64)
+                err = float(np.linalg.norm(R) / max(nA, 1e-300)) / (200 * eps) * tol       # bar: 200 eps ||A||_F
+            # (2) H against the oracle where the oracle itself kept its basis orthogonal (else both are rounding-dominated)
+            if Ks.m == Ko.m and kc >= 1:
+                Vo = Ko.getV()[:, :kc]
+                loss = float(np.max(np.abs(Vo.conj().T @ Vo - np.eye(kc))))
+                extra["oracle_orthogonality_loss"] = loss
+                if loss < 1e-12 and not (iop and not herm) and not single:      # (fp32: rounding is amplified by ||A|| / H[j+1, j] per column; the relation above is the check)
+                    Ho = np.asarray(Ko.getH())[:kc, :kc]
+                    eh = float(np.max(np.abs(Hd[:kc, :kc] - Ho)) / max(float(np.max(np.abs(Ho))), 1e-300))
+                    extra["H_err"] = eh
+                    err = max(err, eh * (tol / (3e-4 if single else 1e-9)))
+    elif call == "phiv":
+        k = int(rng.integers(1, 5))
+        W = eu.phiv(0.5, A, b, k, m=m, iop=iop)
+        err = rel(W, ko.phiv(0.5, A64, b64, k, m=m, iop=iop))
+    elif call in ("expv_timestep", "phiv_timestep"):
+        ts = np.sort(rng.uniform(0.1, 1.5, size=int(rng.integers(1, 4))))
+        tolk = 1e-5 if single else float(rng.choice([1e-6, 1e-8]))
+        mm = max(2, min(m, 30))
+        if call == "expv_timestep":
+            U = eu.expv_timestep(ts, A, b, tol=tolk, m=mm, iop=iop, adaptive=True)
+            Uo = ko.expv_timestep(ts, A64, b64, tol=tolk, m=mm, iop=iop, adaptive=True)
+        else:
+            p = int(rng.integers(1, 5))
+            B = (rng.standard_normal((n, p + 1)) + (1j * rng.standard_normal((n, p + 1)) if cplx else 0)).astype(T)
+            U = eu.phiv_timestep(ts, A, B, tol=tolk, m=mm, iop=iop, adaptive=True)
+            Uo = ko.phiv_timestep(ts, A64, B.astype(T64), tol=tolk, m=mm, iop=iop, adaptive=True)
+        err = rel(U, Uo)
+        tol = max(tol, 50 * tolk) if single else 1e-9
+    elif call == "kiops":
+        if cplx or single:
+            return desc, 0.0, tol, {"skipped": "kiops is Float64 in the reference"}
+        w, st = eu.kiops(1.0, A, b, tol=1e-8, iop=max(iop, 2))
+        wo, so = ko.kiops(1.0, A64, b64, tol=1e-8, iop=max(iop, 2))
+        err = rel(w, wo)
+        tol = 1e-9
+    else:
+        if not herm:
+            return desc, 0.0, tol, {"skipped": "error estimate needs a Hermitian operator here"}
+        w = eu.expv(0.7, A, b, m=max(m, 3), mode="error_estimate", rtol=1e-6 if not single else 1e-4)
+        wo = ko.expv(0.7, A64, b64, m=max(m, 3), mode="error_estimate", rtol=1e-6 if not single else 1e-4)
+        err = rel(w, wo)
+        tol = 1e-9 if not single else 5e-4
+    return desc, err, tol, extra
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    if len(sys.argv) > 3:
+        desc, err, tol, extra = one_case(seed, int(sys.argv[3]), verbose=True)
+        print(json.dumps({**desc, "err": err, "tol": tol, **extra}))
+        return
+    t0 = time.time()
+    index = int(sys.argv[3]) if False else 0
+    fails = 0
+    worst = {}
+    import signal
+
+    def on_alarm(sig, frm):
+        raise TimeoutError("case took more than 120 s")
+    signal.signal(signal.SIGALRM, on_alarm)
+    start = int(__import__("os").environ.get("FUZZ_START", "0"))
+    index = start
+    while time.time() - t0 < seconds:
+        signal.alarm(120)
+        if __import__("os").environ.get("FUZZ_VERBOSE"):
+            print("case", index, round(time.time() - t0, 1), flush=True)
+        try:
+            desc, err, tol, extra = one_case(seed, index)
+            key = (desc["call"], "32" if desc["T"] in ("float32", "complex64") else "64")
+            if "skipped" not in extra:
+                worst[key] = max(worst.get(key, 0.0), err if np.isfinite(err) else 1e300)
+            if not err <= tol:
+                fails += 1
+                print("FAIL", json.dumps({**desc, "err": err, "tol": tol, **extra}), flush=True)
+        except Exception as e:
+            fails += 1
+            print("EXCEPTION", json.dumps({"seed": seed, "index": index}), repr(e), flush=True)
+            traceback.print_exc(limit=3)
+        index += 1
+    signal.alarm(0)
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)      # (a hang while the interpreter tears down is reported, not waited for)
+    print(json.dumps({"cases": index - start, "failures": fails, "seconds": round(time.time() - t0, 1),
+                      "worst_by_call": {"%s/%s" % k: v for k, v in sorted(worst.items())}}), flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
