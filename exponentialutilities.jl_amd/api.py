@@ -747,7 +747,7 @@ def expv_(w, t, Ks):
     return w
 
 
-def expv(t, A, b, *, mode="happy_breakdown", **kw):
+def expv(t, A, b=None, *, mode="happy_breakdown", **kw):
     """expv(t, A, b; mode = :happy_breakdown | :error_estimate, kwargs...)  (krylov_phiv.jl:125-160)."""
     if isinstance(A, KrylovSubspace):       # expv(t, Ks)  (:161-168)
         Ks = A

@@ -9,6 +9,7 @@ import traceback
 
 import numpy as np
 import scipy.sparse as sp
+import scipy.sparse.linalg  # noqa: F401  (sp.linalg.norm)
 
 sys.path.insert(0, ".")
 import expv_mi_loader
@@ -41,7 +42,7 @@ def make_operator(rng, n, cplx):
         if kind == "regular_rows":
             ln = np.full(n, int(rng.integers(1, 7)))
         else:
-            ln = np.minimum(rng.zipf(1.7, size=n), max(1, n // 2))
+            ln = np.minimum(rng.zipf(1.7, size=n), max(1, min(n // 2, 3000)))
         rows = np.repeat(np.arange(n), ln)
         cols = rng.integers(0, n, size=rows.size)
         v = vals(rows.size, 0.3) / np.sqrt(np.repeat(ln, ln))
@@ -62,6 +63,8 @@ def one_case(seed, index, verbose=False):
     T64 = np.dtype(np.complex128 if cplx else np.float64)
     single = T.itemsize == (8 if cplx else 4)
     n = int(rng.choice([1, 2, 3, 5, 17, 64, 127, 128, 129, 511, 512, 513, 1000, 1537, 2500, 4099]))
+    if rng.random() < float(__import__('os').environ.get('FUZZ_LARGE', '0.04')):            # grids of many workgroups: wave form, several tiles per workgroup, overlapped launches
+        n = int(rng.choice([20000, 65537, 150001, 300000]))
     kind, n, A64 = make_operator(rng, n, cplx)
     A = A64.astype(T)
     A64 = A.astype(T64)               # the oracle sees exactly the values the device has
@@ -70,8 +73,11 @@ def one_case(seed, index, verbose=False):
     m = int(rng.integers(1, 41))
     iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
     herm = kind in ("symmetric_banded", "hermitian_dense") and bool(rng.integers(0, 2))
-    call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate"])
+    call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate",
+                       "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct"])
     ortho = str(rng.choice(["lowsync", "mgs"]))
+    if n > 5000 and call not in ("expv", "arnoldi", "expv_complex_t", "phiv", "subspace_reuse", "update_values"):
+        call = "expv"                 # (large cases: the calls whose oracle stays cheap)
     desc = {"seed": seed, "index": index, "T": T.name, "n": n, "operator": kind, "m": m, "iop": iop, "hermitian": herm, "call": str(call), "ortho": ortho}
     if verbose:
         print(desc, flush=True)
@@ -114,7 +120,7 @@ def one_case(seed, index, verbose=False):
             if kc >= 1:
                 AV = A64 @ Vd[:, :kc]
                 R = AV - Vd[:, :kc + 1] @ Hd[:kc + 1, :kc]
-                nA = np.linalg.norm(A64.toarray() if sp.issparse(A64) else A64)
+                nA = float(sp.linalg.norm(A64)) if sp.issparse(A64) else float(np.linalg.norm(A64))
                 err = float(np.linalg.norm(R) / max(nA, 1e-300)) / (200 * eps) * tol       # bar: 200 eps ||A||_F
             # (2) H against the oracle where the oracle itself kept its basis orthogonal (else both are rounding-dominated)
             if Ks.m == Ko.m and kc >= 1:
@@ -151,6 +157,73 @@ def one_case(seed, index, verbose=False):
         wo, so = ko.kiops(1.0, A64, b64, tol=1e-8, iop=max(iop, 2))
         err = rel(w, wo)
         tol = 1e-9
+    elif call == "subspace_reuse":
+        # one KrylovSubspace through several factorisations: growing / shrinking m, other starting vectors, Lanczos <-> Arnoldi
+        Ks = eu.KrylovSubspace(T, None, n, max(1, m // 2))
+        for rep in range(int(rng.integers(2, 5))):
+            mm = int(rng.integers(1, m + 1))
+            hh = herm and bool(rng.integers(0, 2))
+            bb = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+            eu.arnoldi_(Ks, A, bb, m=mm, iop=iop, ishermitian=hh, ortho=ortho)
+            w = eu.expv(0.6, Ks)
+            err = max(err, rel(w, ko.expv(0.6, A64, bb.astype(T64), m=mm, iop=iop, ishermitian=hh)))
+    elif call == "continuation":
+        # arnoldi!(Ks, A, b; m = m1) then arnoldi!(...; m = m2, init = Ks.m)  (arnoldi.jl:345-377) against one run to m2
+        if herm:
+            return desc, 0.0, tol, {"skipped": "continuation is exercised on the Arnoldi path"}
+        m2 = max(2, m)
+        m1 = int(rng.integers(1, m2))
+        Ks = eu.KrylovSubspace(T, None, n, m2)
+        eu.arnoldi_(Ks, A, b, m=m1, iop=iop, ishermitian=False, ortho=ortho)
+        if Ks.wasbreakdown:
+            return desc, 0.0, tol, {"skipped": "breakdown before the continuation point"}
+        eu.arnoldi_(Ks, A, b, m=m2, iop=iop, ishermitian=False, ortho=ortho, init=m1)
+        w = eu.expv(0.6, Ks)
+        err = rel(w, ko.expv(0.6, A64, b64, m=m2, iop=iop, ishermitian=False))
+        extra = {"m1": m1, "m2": m2}
+        tol = max(tol, 1e-9)
+    elif call == "update_values":
+        if not sp.issparse(A):
+            return desc, 0.0, tol, {"skipped": "value updates are for sparse operators"}
+        op = eu.MIOperator(A.copy())
+        w0 = eu.expv(0.7, op, b, **kw)
+        A2 = A.copy()
+        A2.data = (A2.data * (1 + 0.1 * rng.standard_normal(A2.nnz))).astype(T)
+        op.update_values(A2)
+        w = eu.expv(0.7, op, b, **kw)
+        err = max(rel(w0, ko.expv(0.7, A64, b64, **kw)), rel(w, ko.expv(0.7, A2.astype(T64), b64, **kw)))
+    elif call == "matrix_free":
+        import torch
+        if single or n > 5000:
+            return desc, 0.0, tol, {"skipped": "matrix-free case kept to 64-bit, small n"}
+        Ad = torch.as_tensor(A64.toarray() if sp.issparse(A64) else A64, device="cuda")
+        op = eu.MIOperator(None, matvec=lambda x: Ad @ x, shape=(n, n), dtype=T, ishermitian=herm)
+        w = eu.expv(0.7, op, b, **kw)
+        err = rel(w, ko.expv(0.7, A64, b64, **kw))
+    elif call == "batch":
+        if single or not sp.issparse(A) or n > 5000 or herm:
+            return desc, 0.0, tol, {"skipped": "batch: 64-bit sparse operators"}
+        nprob = int(rng.integers(1, 6))
+        P = A.tocsr()
+        P.sort_indices()
+        vals = np.stack([P.data * (1 + 0.05 * rng.standard_normal(P.nnz)) for _ in range(nprob)]).astype(T)
+        Bm = np.asfortranarray((rng.standard_normal((n, nprob)) + (1j * rng.standard_normal((n, nprob)) if cplx else 0)).astype(T))
+        mb = min(m, 30)
+        W = np.asarray(eu.expv_batch(0.7, P, vals, Bm, m=mb, iop=iop))
+        for q in range(nprob):
+            Aq = P.copy()
+            Aq.data = vals[q].copy()
+            err = max(err, rel(W[:, q], ko.expv(0.7, Aq.astype(T64), Bm[:, q].astype(T64), m=mb, iop=iop, ishermitian=False)))
+    elif call == "phiv_correct":
+        k = int(rng.integers(1, 4))
+        Ko = ko.arnoldi(A64, b64, m=m, iop=iop)
+        if Ko.wasbreakdown or Ko.m < m:
+            return desc, 0.0, tol, {"skipped": "the correction uses v_{m+1} and H[m+1, m]: rounding noise (or NaN) after a happy breakdown"}
+        W, e1 = eu.phiv(0.5, A, b, k, m=m, iop=iop, correct=True, errest=True)
+        Wo, e2 = ko.phiv(0.5, A64, b64, k, m=m, iop=iop, correct=True, errest=True)
+        err = rel(W, Wo)
+        if np.isfinite(e2) and e2 > 1e-300 and not single:
+            err = max(err, abs(e1 - e2) / max(abs(e2), 1e-30) * 1e-4)      # the estimate itself to 1e-6 relative
     else:
         if not herm:
             return desc, 0.0, tol, {"skipped": "error estimate needs a Hermitian operator here"}
