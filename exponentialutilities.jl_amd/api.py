@@ -224,7 +224,7 @@ def _src_dtype(A):
     """element type of an operator argument as the caller holds it (MIOperator remembers what it was built from)"""
     if isinstance(A, MIOperator):
         return np.dtype(A.src_dtype)
-    if hasattr(A, "indptr") or isinstance(A, np.ndarray):
+    if hasattr(A, "indptr") or hasattr(A, "tocsr") or isinstance(A, np.ndarray):      # (any scipy sparse format)
         return np.dtype(A.dtype)
     return _np_dtype_of(A)
 
@@ -379,7 +379,9 @@ class MIOperator:
             self._cb = L.MATVEC_FN(_cb)
             _check(lib.expv_mi_op_create_callback(self.ctx._h, _code(dt), n, self._cb, None,
                                                   int(bool(ishermitian)), 0, C.byref(h)), self.ctx._h)
-        elif hasattr(A, "tocsc") and hasattr(A, "indptr"):
+        elif hasattr(A, "tocsc") and (hasattr(A, "indptr") or hasattr(A, "tocsr")):
+            if not hasattr(A, "indptr"):
+                A = A.tocsr()
             dt = _work_dtype(A.dtype if dtype is None else dtype)
             n = A.shape[0]
             if A.shape[0] != A.shape[1]:
@@ -564,6 +566,8 @@ def _as_operator(A, want_dtype=None, ctx=None):
     Host matrices (scipy sparse / ndarray) passed directly are uploaded on first use and the upload is reused ONLY while
     (same object, same context, same content fingerprint) -- an in-place ``A.data[:] = ...`` / ``A *= dt`` between calls
     re-uploads, like the reference reading A at call time.  Device tensors are wrapped without a copy every time."""
+    if hasattr(A, "tocsr") and not hasattr(A, "indptr"):      # COO / DIA / LIL / ... : any scipy sparse matrix is an AbstractMatrix
+        A = A.tocsr()
     if isinstance(A, MIOperator):
         op = A
     elif _is_torch(A):

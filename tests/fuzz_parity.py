@@ -1,6 +1,6 @@
 """Randomised parity hunt against the oracle: random sizes, element types, operator structures, calls and options.
-Every case is derived from (seed, index), printed on failure and reproducible with  python tools/fuzz_parity.py 0 SEED INDEX.
-    python tools/fuzz_parity.py SECONDS [SEED]
+Every case is derived from (seed, index), printed on failure and reproducible with  python tests/fuzz_parity.py 0 SEED INDEX.
+    python tests/fuzz_parity.py SECONDS [SEED]
 Test infrastructure (imports the oracle); not part of the product or of the measured path."""
 import json
 import sys
@@ -11,7 +11,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg  # noqa: F401  (sp.linalg.norm)
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import expv_mi_loader
 from oracle import krylov_oracle as ko
 
@@ -56,6 +56,10 @@ def make_operator(rng, n, cplx):
     return kind, n, A
 
 
+def _np(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+
 def one_case(seed, index, verbose=False):
     rng = np.random.default_rng([seed, index])
     T = np.dtype(rng.choice(["float64", "float64", "complex128", "float32", "complex64"]))
@@ -83,6 +87,24 @@ def one_case(seed, index, verbose=False):
         print(desc, flush=True)
     tol = 3e-4 if single else 1e-10
     kw = dict(m=m, iop=iop, ishermitian=herm)
+    # how the caller hands the operands over (the values stay the same): CSC / CSR / COO, C- or Fortran-ordered dense, a strided view of b,
+    # device-resident b
+    pres = str(rng.choice(["plain", "plain", "csc", "coo", "fortran", "strided_b", "device_b"]))
+    desc["presentation"] = pres
+    Ain, bin_ = A, b
+    if pres == "csc" and sp.issparse(A):
+        Ain = A.tocsc()
+    elif pres == "coo" and sp.issparse(A):
+        Ain = A.tocoo()
+    elif pres == "fortran" and not sp.issparse(A):
+        Ain = np.asfortranarray(A)
+    elif pres == "strided_b":
+        big = np.zeros(2 * n, dtype=T)
+        big[::2] = b
+        bin_ = big[::2]
+    elif pres == "device_b":
+        import torch
+        bin_ = torch.as_tensor(b, device="cuda")
     as64 = lambda x: np.asarray(x).astype(T64 if np.asarray(x).dtype.kind == "c" or cplx else np.float64)
     def rel(a, r):
         a, r = np.asarray(a), np.asarray(r)
@@ -91,11 +113,11 @@ def one_case(seed, index, verbose=False):
         return float(np.linalg.norm(a.astype(np.complex128) - r) / max(np.linalg.norm(r), 1e-300))
     err, extra = 0.0, {}
     if call == "expv":
-        w = eu.expv(0.7, A, b, ortho=ortho, **kw)
-        err = rel(w, ko.expv(0.7, A64, b64, **kw))
+        w = eu.expv(0.7, Ain, bin_, ortho=ortho, **kw)
+        err = rel(_np(w), ko.expv(0.7, A64, b64, **kw))
     elif call == "expv_complex_t":
-        w = eu.expv(0.3 - 0.4j, A, b, **kw)
-        err = rel(w, ko.expv(0.3 - 0.4j, A64, b64, **kw))
+        w = eu.expv(0.3 - 0.4j, Ain, bin_, **kw)
+        err = rel(_np(w), ko.expv(0.3 - 0.4j, A64, b64, **kw))
     elif call == "arnoldi":
         Ks = eu.arnoldi(A, b, ortho=ortho, **kw)
         Ko = ko.arnoldi(A64, b64, **kw)
@@ -134,28 +156,53 @@ def one_case(seed, index, verbose=False):
                     err = max(err, eh * (tol / (3e-4 if single else 1e-9)))
     elif call == "phiv":
         k = int(rng.integers(1, 5))
-        W = eu.phiv(0.5, A, b, k, m=m, iop=iop)
-        err = rel(W, ko.phiv(0.5, A64, b64, k, m=m, iop=iop))
+        W = eu.phiv(0.5, Ain, bin_, k, m=m, iop=iop)
+        err = rel(_np(W), ko.phiv(0.5, A64, b64, k, m=m, iop=iop))
     elif call in ("expv_timestep", "phiv_timestep"):
         ts = np.sort(rng.uniform(0.1, 1.5, size=int(rng.integers(1, 4))))
         tolk = 1e-5 if single else float(rng.choice([1e-6, 1e-8]))
         mm = max(2, min(m, 30))
+        # (correct = true adds beta H[m+1, m] (...) v_{m+1}: 0 x NaN in the reference whenever the Krylov space is exhausted exactly)
+        tk = dict(tol=tolk, m=mm, iop=iop, adaptive=bool(rng.integers(0, 4)), correct=bool(rng.integers(0, 2)) and n > 8)
+        if not tk["adaptive"]:
+            tk["tau"] = float(rng.choice([0.05, 0.2]))
+            tk["m"] = max(mm, 12)
         if call == "expv_timestep":
-            U = eu.expv_timestep(ts, A, b, tol=tolk, m=mm, iop=iop, adaptive=True)
-            Uo = ko.expv_timestep(ts, A64, b64, tol=tolk, m=mm, iop=iop, adaptive=True)
+            U = eu.expv_timestep(ts.copy(), Ain, b, **tk)
+            Uo = ko.expv_timestep(ts.copy(), A64, b64, **tk)
         else:
             p = int(rng.integers(1, 5))
             B = (rng.standard_normal((n, p + 1)) + (1j * rng.standard_normal((n, p + 1)) if cplx else 0)).astype(T)
-            U = eu.phiv_timestep(ts, A, B, tol=tolk, m=mm, iop=iop, adaptive=True)
-            Uo = ko.phiv_timestep(ts, A64, B.astype(T64), tol=tolk, m=mm, iop=iop, adaptive=True)
+            U = eu.phiv_timestep(ts.copy(), Ain, B, **tk)
+            Uo = ko.phiv_timestep(ts.copy(), A64, B.astype(T64), **tk)
+        extra = {"timestep": {k: v for k, v in tk.items()}}
+        if not tk["adaptive"]:
+            tol = max(tol, 1e-6)       # (fixed steps: no controller equalises the two runs; the truncation error itself is ~1e-8)
         err = rel(U, Uo)
+        if not np.isfinite(np.asarray(Uo)).all():
+            return desc, 0.0, tol, {"skipped": "the reference result itself is not finite"}
         tol = max(tol, 50 * tolk) if single else 1e-9
     elif call == "kiops":
         if cplx or single:
             return desc, 0.0, tol, {"skipped": "kiops is Float64 in the reference"}
-        w, st = eu.kiops(1.0, A, b, tol=1e-8, iop=max(iop, 2))
-        wo, so = ko.kiops(1.0, A64, b64, tol=1e-8, iop=max(iop, 2))
+        tau = [1.0, np.array([0.4, 1.0]), np.array([[0.3, 0.7, 1.1]])][int(rng.integers(0, 3))]
+        kk = dict(tol=float(rng.choice([1e-6, 1e-8])), iop=max(iop, 2), task1=bool(rng.integers(0, 2)), mmin=int(rng.choice([4, 10])),
+                  mmax=int(rng.choice([30, 128])), m=int(rng.choice([5, 10, 25])))
+        # (the reference's own error behaviour -- kiops.jl:303 BoundsError, checkdims on a 2-D tau_out -- is part of the parity)
+        errs = []
+        res = []
+        for f in (lambda: eu.kiops(tau, Ain, b, **kk), lambda: ko.kiops(tau, A64, b64, **kk)):
+            try:
+                res.append(f())
+                errs.append(None)
+            except (IndexError, ValueError, AssertionError) as e:
+                res.append(None)
+                errs.append(type(e).__name__)
+        if errs[0] or errs[1]:
+            return desc, (0.0 if errs[0] and errs[1] else float("inf")), tol, {"raised_dev": errs[0], "raised_ref": errs[1], "skipped": "both raise"}
+        (w, st), (wo, so) = res
         err = rel(w, wo)
+        extra = {"kiops": {k: (v if not isinstance(v, np.ndarray) else v.tolist()) for k, v in kk.items()}}
         tol = 1e-9
     elif call == "subspace_reuse":
         # one KrylovSubspace through several factorisations: growing / shrinking m, other starting vectors, Lanczos <-> Arnoldi

@@ -1118,7 +1118,7 @@ def test_two_processes_sharing_the_device_get_correct_results():
 def test_float32_columns_are_padded_to_whole_waves(eu, n):
     """Float32 moves 4 rows per lane, a wave 256: a basis column padded to 128 rows let the two-kernel step read the NEXT column
     through the tail of a wave whenever ceil(n / 128) is odd -- invisible on a fresh subspace (zeros), wrong (beta^2 off by the
-    squared norm of the stale neighbour) from the second factorisation on.  Found by tools/fuzz_parity.py (seed 2026, case 2391:
+    squared norm of the stale neighbour) from the second factorisation on.  Found by tests/fuzz_parity.py (seed 2026, case 2391:
     adaptive expv_timestep never terminated on the garbage error estimates).  Repeated factorisations on one subspace, growing
     and shrinking m, nine diagonals (two-kernel step), Lanczos and Arnoldi, then the adaptive time stepper."""
     rng = np.random.default_rng(7)

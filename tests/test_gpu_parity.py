@@ -799,7 +799,7 @@ def test_irregular_banded_operator_wave_form_on_sell_slots(eu, n, m, band):
 def test_exact_breakdown_leaves_no_nan_for_the_next_factorisation(eu, T, kind):
     """An EXACT happy breakdown (beta = 0) makes v_{m+1} = y / beta NaN, in the reference too (arnoldi.jl:306, :399: the division
     comes before the test).  The padding rows of that column must stay zero (0 / 0 is NaN as well) and the stale NaN column must
-    not reach the next factorisation on the same subspace.  Found by tools/fuzz_parity.py (seed 11, case 2496: n = 1, Float32)."""
+    not reach the next factorisation on the same subspace.  Found by tests/fuzz_parity.py (seed 11, case 2496: n = 1, Float32)."""
     A = np.array([[-0.55]], dtype=T)
     Ah = np.array([[-0.7]], dtype=T)
     b = np.array([0.36], dtype=T)
@@ -817,3 +817,20 @@ def test_exact_breakdown_leaves_no_nan_for_the_next_factorisation(eu, T, kind):
         tol = 1e-6 if np.dtype(T).itemsize <= 8 and np.dtype(T) != np.float64 else 1e-14
         close(np.asarray(w).astype(np.complex128), np.exp(0.7 * -0.7) * 0.36, tol, "n=1 %s %s %s after an exact breakdown: expv (Lanczos)" % (np.dtype(T).name, kind, ortho))
         close(np.asarray(w2).astype(np.complex128), np.exp(0.7 * -0.55) * 0.36, tol, "n=1 %s %s %s after an exact breakdown: expv (Arnoldi)" % (np.dtype(T).name, kind, ortho))
+
+
+@pytest.mark.gpu
+def test_randomised_parity_hunt_short():
+    """Ten seconds of tests/fuzz_parity.py with a fixed seed (~600 random cases over element types, sizes, operator structures, calls
+    and options against the oracle): no failure, no exception.  profiles/r03_fuzz_parity.txt has the long runs and what they found."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_LARGE="0.02")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "10", "20260928"], cwd=root, capture_output=True, text=True,
+                       timeout=600, env=env)
+    last = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(last)
+    assert p.returncode == 0 and r["failures"] == 0 and r["cases"] > 100, p.stdout[-3000:] + p.stderr[-2000:]
