@@ -263,14 +263,25 @@ static void phiv_timestep_T(Ctx *ctx, Op &op, int nts, double *ts, const T *B, i
       double epsilon_old = epsilon, tau_old = tau, q = m / 4.0, kappa = 2.0;
       int m_old = m;
       const double maxtau = tend - t;
+      int proposals = 0;
       while (omega > delta) {  // inner loop of Algorithm 3
+        // The reference's loop has no bound (:390-423): with an error estimate that cannot fall (a NaN-free but meaningless
+        // estimate, tol below what the arithmetic resolves) it never returns, and here that would be a host thread feeding a
+        // GPU for ever.  A thousand rejected proposals for ONE sub-step is far beyond anything the controller does when it works.
+        if (++proposals > 1000)
+          fail(EXPV_MI_ARGUMENT_ERROR, "phiv_timestep!: the step-size controller did not reach the tolerance in 1000 proposals for one "
+                                       "sub-step (tol below the resolution of the element type?)");
         // _phiv_timestep_adapt (:455-481)
         if (tau_old > tau) q = std::log(tau / tau_old) / std::log(epsilon / epsilon_old) - 1;
         double tau_new = tau * std::pow(gamma / omega, 1.0 / (q + 1));
         tau_new = std::min(std::min(std::max(tau_new, tau / 5), 2 * tau), maxtau);
         if (m_old < m) kappa = std::pow(epsilon / epsilon_old, 1.0 / (m_old - m));
-        int m_new = m + (int)std::ceil(std::log(omega / gamma) / std::log(kappa));
-        m_new = std::min(std::max(std::max(m_new, (3 * m) / 4), 1), (int)std::ceil(4.0 * m / 3.0));
+        // m + ceil(Int, log(omega / gamma) / log(kappa))  (:470): a non-finite quotient (kappa == 1: the estimate did not move with
+        // m, e.g. an exhausted Krylov space) is Julia's InexactError; a huge finite one is clamped below like any other
+        const double dm = std::ceil(std::log(omega / gamma) / std::log(kappa));
+        if (!std::isfinite(dm)) fail(EXPV_MI_ARGUMENT_ERROR, "phiv_timestep!: InexactError in ceil(Int, ...) (krylov_phiv_adaptive.jl:470)");
+        const double m_lo = std::max((double)std::max((3 * m) / 4, 1), std::min((double)m + dm, 1e9));
+        int m_new = (int)std::min(m_lo, std::ceil(4.0 * m / 3.0));
         emit(o, fmt("  - Proposed new m: %d, new tau: %.17g", m_new, tau_new));
         const double Hn = hnorm1(*ks);
         const double cost_tau = estimate_flops(m, tau_new, n, p, NA, iop, Hn, maxtau);
@@ -573,6 +584,8 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
       ireject = 0;
     } else {
       ++ireject;
+      if (ireject > 1000)      // (the reference has no bound, kiops.jl:170-281; see phiv_timestep_T)
+        fail(EXPV_MI_ARGUMENT_ERROR, "kiops: 1000 rejected steps in a row (tol below the resolution of the arithmetic?)");
       setH(ks, 0, j, cd(0.0, 0.0));
     }
     oldtau = tau;

@@ -627,13 +627,19 @@ def _estimate_flops(m, tau, n, p, NA, iop, Hnorm, maxtau):
 def _timestep_adapt(m, tau, epsilon, m_old, tau_old, epsilon_old, q, kappa, gamma, omega,
                     maxtau, n, p, NA, iop, Hnorm, verbose, out):
     """krylov_phiv_adaptive.jl:455-481 (Algorithm 4)."""
-    if tau_old > tau:
-        q = math.log(tau / tau_old) / math.log(epsilon / epsilon_old) - 1
-    tau_new = tau * (gamma / omega) ** (1 / (q + 1))
-    tau_new = min(max(tau_new, tau / 5), 2 * tau, maxtau)
-    if m_old < m:
-        kappa = (epsilon / epsilon_old) ** (1 / (m_old - m))
-    m_new = m + math.ceil(math.log(omega / gamma) / math.log(kappa))
+    # Julia's Float64 arithmetic: x / 0.0 is +-Inf or NaN (no exception), ceil(Int, x) of a non-finite x is an InexactError
+    f = np.float64
+    with np.errstate(all="ignore"):
+        if tau_old > tau:
+            q = float(np.log(f(tau) / f(tau_old)) / np.log(f(epsilon) / f(epsilon_old)) - 1)
+        tau_new = float(f(tau) * (f(gamma) / f(omega)) ** (f(1) / (f(q) + 1)))
+        tau_new = min(max(tau_new, tau / 5), 2 * tau, maxtau)
+        if m_old < m:
+            kappa = float((f(epsilon) / f(epsilon_old)) ** (f(1) / f(m_old - m)))
+        dm = float(np.ceil(np.log(f(omega) / f(gamma)) / np.log(f(kappa))))
+    if not math.isfinite(dm):
+        raise ValueError("InexactError: ceil(Int64, %r)  (krylov_phiv_adaptive.jl:470)" % dm)
+    m_new = m + int(dm)
     m_new = min(max(m_new, (3 * m) // 4, 1), int(math.ceil(4 * m / 3)))
     if verbose:
         out(f"  - Proposed new m: {m_new}, new tau: {tau_new}")

@@ -1142,3 +1142,31 @@ def test_float32_columns_are_padded_to_whole_waves(eu, n):
     Uo = ko.expv_timestep(ts.copy(), A64, b64, tol=1e-5, m=5, adaptive=True)
     close(np.asarray(U).astype(np.float64), Uo, 2e-4, "Float32 n=%d adaptive expv_timestep after reuse (fp32 bar)" % n)
     assert st["num_timesteps"] <= 4
+
+
+@pytest.mark.gpu
+def test_adaptive_controller_errors_like_the_reference_and_never_spins(eu):
+    """krylov_phiv_adaptive.jl:470 takes ceil(Int, log(omega / gamma) / log(kappa)): when the error estimate does not move with m
+    (an exhausted Krylov space: n = 5, m = 30) kappa is 1 and Julia throws InexactError.  The device driver used to carry on with
+    an undefined integer and reject proposals for ever (found by tests/fuzz_parity.py, seed 81 case 3518); it now raises the same
+    error, the oracle does too, and any sub-step is bounded by 1000 proposals."""
+    rng = np.random.default_rng([81, 3518, 1])
+    n = 5
+    A0 = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)
+    A = 35.0 * ((A0 + A0.conj().T) * 0.5 - 0.5 * np.eye(n))
+    B = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    ts = np.array([0.128, 0.148, 0.551])
+    kw = dict(tol=1e-8, m=30, iop=7, adaptive=True)
+    outcome = []
+    for f in (lambda: eu.phiv_timestep(ts.copy(), A, B, **kw), lambda: ko.phiv_timestep(ts.copy(), A, B, **kw)):
+        try:
+            outcome.append(np.asarray(f()))
+        except (ValueError, RuntimeError) as e:
+            assert "InexactError" in str(e) or "did not reach the tolerance" in str(e), e
+            outcome.append(None)
+    assert (outcome[0] is None) == (outcome[1] is None), "device and oracle must fail (or succeed) together"
+    if outcome[0] is not None:
+        close(outcome[0], outcome[1], 1e-9, "phiv_timestep on an exhausted Krylov space")
+    # and the engine is still usable afterwards
+    b = rng.standard_normal(n) + 0j
+    close(np.asarray(eu.expv(0.1, A, b, m=5)), ko.expv(0.1, A, b, m=5), 1e-10, "expv after a controller error")
