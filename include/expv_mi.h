@@ -197,7 +197,7 @@ int expv_mi_ks_H(expv_mi_ks_t ks, void **H, int *ldh, int *nrows, int *ncols);
 /* copy columns [col0, col0+ncols) of Ks.V to / from the host (ld of the host array = ldh_host) */
 int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64_t ld_dst);
 int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, int64_t ld_src);
-int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv);
+int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv);   /* ldv: rows padded to whole waves of 16-byte packs (128; 256 for F32), padding = 0 */
 
 /* arnoldi!(Ks, A, b; tol, m, ishermitian, iop, init)  (arnoldi.jl:345-377);
  * ishermitian != 0 runs lanczos! (arnoldi.jl:456-490).  ishermitian < 0 = ask the operator. */
@@ -290,7 +290,10 @@ int expv_mi_timestep_caches_create(expv_mi_ctx_t ctx, int dtype, int64_t n, int 
                                    expv_mi_tscache_t *cache);
 int expv_mi_timestep_caches_destroy(expv_mi_tscache_t cache);
 /* phiv_timestep!(U, ts, A, B; ...)  (krylov_phiv_adaptive.jl:260-453).  B is n x (p+1); U is n x nts;
- * ts (host) is sorted in place like the reference (:297).  expv_timestep! is the p = 0 case. */
+ * ts (host) is sorted in place like the reference (:297).  expv_timestep! is the p = 0 case.
+ * Errors of the adaptive controller: EXPV_MI_ARGUMENT_ERROR "InexactError" where Julia's ceil(Int, ...) of :470 throws (the
+ * error estimate did not move with m, e.g. an exhausted Krylov space), and -- where the reference would loop for ever --
+ * after 1000 rejected proposals for one sub-step (kiops: 1000 rejected steps in a row). */
 int expv_mi_phiv_timestep(expv_mi_ctx_t ctx, expv_mi_op_t op, int nts, double *ts, const void *B,
                           int64_t ldb, int ncoef, int b_loc, void *U, int64_t ldu, int u_loc,
                           const expv_mi_timestep_opts *opts, expv_mi_tscache_t caches,

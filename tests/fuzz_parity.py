@@ -56,6 +56,15 @@ def make_operator(rng, n, cplx):
     return kind, n, A
 
 
+_ACTX = []
+
+
+def _async_ctx():
+    if not _ACTX:
+        _ACTX.append(eu.Context(async_outputs=True))
+    return _ACTX[0]
+
+
 def _np(x):
     return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
 
@@ -71,7 +80,9 @@ def one_case(seed, index, verbose=False):
         n = int(rng.choice([20000, 65537, 150001, 300000]))
     kind, n, A64 = make_operator(rng, n, cplx)
     if rng.random() < 0.25:           # other magnitudes of the operator: scaling / squaring counts, Pade degrees, slow or no convergence
-        A64 = A64 * float(rng.choice([1e-3, 0.1, 10.0, 40.0]))
+        # (32-bit: |tau A| of 20-80 with a truncated orthogonalisation amplifies fp32 rounding by ~|A| / H[j+1, j] per step -- the
+        #  fp64 oracle is no yardstick there, seed 102 cases 189 / 2268 -- so the large factors are for the 64-bit types)
+        A64 = A64 * float(rng.choice([1e-3, 0.1, 10.0, 40.0] if T.itemsize == (16 if cplx else 8) else [1e-3, 0.1, 2.0]))
     A = A64.astype(T)
     A64 = A.astype(T64)               # the oracle sees exactly the values the device has
     b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
@@ -85,7 +96,7 @@ def one_case(seed, index, verbose=False):
     iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
     herm = kind in ("symmetric_banded", "hermitian_dense") and bool(rng.integers(0, 2))
     call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate",
-                       "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct"])
+                       "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct", "async_device", "caches"])
     ortho = str(rng.choice(["lowsync", "mgs"]))
     if n > 5000 and call not in ("expv", "arnoldi", "expv_complex_t", "phiv", "subspace_reuse", "update_values"):
         call = "expv"                 # (large cases: the calls whose oracle stays cheap)
@@ -297,6 +308,50 @@ def one_case(seed, index, verbose=False):
             Aq = P.copy()
             Aq.data = vals[q].copy()
             err = max(err, rel(W[:, q], ko.expv(0.7, Aq.astype(T64), Bm[:, q].astype(T64), m=mb, iop=iop, ishermitian=False)))
+    elif call == "async_device":
+        # the mode the headline runs in: a context with stream-ordered outputs, operands and results resident on the device,
+        # several calls in flight before one synchronisation
+        import torch
+        if n > 200000:
+            return desc, 0.0, tol, {"skipped": "size"}
+        ctx = _async_ctx()
+        op = eu.MIOperator(A, ctx)
+        tdt = {"float32": torch.float32, "float64": torch.float64, "complex64": torch.complex64, "complex128": torch.complex128}[T.name]
+        nb = int(rng.integers(1, 4))
+        bs = [(rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T) for _ in range(nb)]
+        bd = [torch.as_tensor(x, device="cuda") for x in bs]
+        outs = [torch.empty(n, dtype=tdt, device="cuda") for _ in range(nb)]
+        for x, o in zip(bd, outs):
+            eu.expv(0.7, op, x, out=o, ortho=ortho, **kw)
+        ctx.sync()
+        for x, o in zip(bs, outs):
+            err = max(err, rel(o.cpu().numpy(), ko.expv(0.7, A64, x.astype(T64), **kw)))
+    elif call == "caches":
+        # phiv_timestep! through _phiv_timestep_caches, reused over calls with other p and a larger m (krylov_phiv_adaptive.jl:502-511)
+        if n > 5000:
+            return desc, 0.0, tol, {"skipped": "size"}
+        mm = max(2, min(m, 20))
+        nrep = int(rng.integers(2, 4))
+        pmax = 3
+        caches = eu.timestep_caches(b, mm + 3 * nrep, pmax)       # (the reference asserts the cache dimensions: sized for the largest call)
+        for rep in range(nrep):
+            p = pmax if rep == 0 else int(rng.integers(0, pmax + 1))
+            B = (rng.standard_normal((n, p + 1)) + (1j * rng.standard_normal((n, p + 1)) if cplx else 0)).astype(T)
+            ts = rng.uniform(0.1, 1.2, size=int(rng.integers(1, 4)))       # (unsorted: sorted in place like the reference)
+            tolk = 1e-5 if single else 1e-7
+            mrep = mm + 3 * rep
+            U = np.empty((n, len(ts)), dtype=T, order="F")
+            try:
+                eu.phiv_timestep_(U, ts.copy(), A, B if p else B[:, 0], tol=tolk, m=mrep, iop=iop, adaptive=True, caches=caches)
+                Uo = ko.phiv_timestep(ts.copy(), A64, (B if p else B[:, 0]).astype(T64), tol=tolk, m=mrep, iop=iop, adaptive=True)
+            except (ValueError, RuntimeError) as e:
+                if "InexactError" not in str(e):
+                    raise
+                continue              # (the controller's own error: compared in the expv_timestep / phiv_timestep cases)
+            if not np.isfinite(np.asarray(Uo)).all():
+                continue
+            err = max(err, rel(U, Uo))
+        tol = 50 * 1e-5 if single else 1e-9
     elif call == "phiv_correct":
         k = int(rng.integers(1, 4))
         Ko = ko.arnoldi(A64, b64, m=m, iop=iop)
@@ -305,8 +360,8 @@ def one_case(seed, index, verbose=False):
         W, e1 = eu.phiv(0.5, A, b, k, m=m, iop=iop, correct=True, errest=True)
         Wo, e2 = ko.phiv(0.5, A64, b64, k, m=m, iop=iop, correct=True, errest=True)
         err = rel(W, Wo)
-        if np.isfinite(e2) and e2 > 1e-300 and not single:
-            err = max(err, abs(e1 - e2) / max(abs(e2), 1e-30) * 1e-4)      # the estimate itself to 1e-6 relative
+        if np.isfinite(e2) and e2 > 1e-10 * max(float(np.linalg.norm(Wo)), 1e-300) and not single:
+            err = max(err, abs(e1 - e2) / abs(e2) * 1e-4)      # the estimate itself to 1e-6 relative (where it is more than rounding noise)
     else:
         if not herm:
             return desc, 0.0, tol, {"skipped": "error estimate needs a Hermitian operator here"}
