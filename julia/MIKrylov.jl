@@ -146,6 +146,8 @@ function check(code::Integer, h)
     code == 0 && return nothing
     msg = unsafe_string(ccall((:expv_mi_last_error, lib), Cstring, (Ptr{Cvoid},), h))
     code == 1 && throw(DimensionMismatch(msg))
+    # (where the reference's `ceil(Int, x)` meets a non-finite x -- kiops.jl:210, krylov_phiv_adaptive.jl:470 -- it throws InexactError)
+    code == 2 && occursin("InexactError", msg) && throw(InexactError(:ceil, Int, NaN))
     code == 2 && throw(ArgumentError(msg))
     code == 3 && throw(AssertionError(msg))
     code == 4 && throw(LinearAlgebra.SingularException(0))
