@@ -77,7 +77,12 @@ static double estimate_flops(int m, double tau, int64_t n, int p, int64_t NA, in
   const double MH = 44.0 / 3.0 + 2.0 * std::ceil(std::max(0.0, std::log2(Hnorm / 5.37)));
   const double flops_phiv = std::nearbyint(MH * std::pow((double)(m + p), 3));
   const double onestep = flops_W + flops_u + flops_matvec + flops_vecvec + flops_phiv;
-  return onestep * std::ceil(maxtau / tau);
+  const double nsteps = std::ceil(maxtau / tau);
+  // round(Int, ...) (:497) and Int(ceil(maxtau / tau)) (:500) throw InexactError for a non-finite or out-of-range argument
+  // (tau driven to 0 by the controller, a non-finite ||H||)
+  if (!(std::fabs(flops_phiv) < 9.2e18) || !(std::fabs(nsteps) < 9.2e18))
+    fail(EXPV_MI_ARGUMENT_ERROR, "phiv_timestep!: InexactError in the flops estimate (krylov_phiv_adaptive.jl:497-500)");
+  return onestep * nsteps;
 }
 
 // opnorm(getH(Ks), 1)  (:372, :408)

@@ -621,7 +621,11 @@ def _estimate_flops(m, tau, n, p, NA, iop, Hnorm, maxtau):
     MH = 44 / 3 + 2 * math.ceil(max(0.0, math.log2(Hnorm / 5.37)))
     flops_phiv = round(MH * (m + p) ** 3)
     onestep = flops_W + flops_u + flops_matvec + flops_vecvec + flops_phiv
-    return onestep * int(math.ceil(maxtau / tau))
+    with np.errstate(all="ignore"):
+        nsteps = float(np.ceil(np.float64(maxtau) / np.float64(tau)))
+    if not (abs(nsteps) < 9.2e18) or not (abs(float(flops_phiv)) < 9.2e18):
+        raise ValueError("InexactError: Int(%r)  (krylov_phiv_adaptive.jl:497-500)" % nsteps)
+    return onestep * int(nsteps)
 
 
 def _timestep_adapt(m, tau, epsilon, m_old, tau_old, epsilon_old, q, kappa, gamma, omega,
