@@ -126,7 +126,7 @@ def one_case(seed, index, verbose=False):
     kw = dict(m=m, iop=iop, ishermitian=herm)
     # how the caller hands the operands over (the values stay the same): CSC / CSR / COO, C- or Fortran-ordered dense, a strided view of b,
     # device-resident b
-    pres = str(rng.choice(["plain", "plain", "csc", "coo", "fortran", "strided_b", "device_b"]))
+    pres = str(rng.choice(["plain", "plain", "csc", "coo", "fortran", "strided_b", "device_b", "device_dense"]))
     desc["presentation"] = pres
     Ain, bin_ = A, b
     if pres == "csc" and sp.issparse(A):
@@ -142,6 +142,10 @@ def one_case(seed, index, verbose=False):
     elif pres == "device_b":
         import torch
         bin_ = torch.as_tensor(b, device="cuda")
+    elif pres == "device_dense" and not sp.issparse(A):
+        import torch                  # a device-resident dense operator, row-major (torch's default) or column-major
+        Ad = torch.as_tensor(A, device="cuda")
+        Ain = Ad if rng.random() < 0.5 else Ad.t().contiguous().t()
     as64 = lambda x: np.asarray(x).astype(T64 if np.asarray(x).dtype.kind == "c" or cplx else np.float64)
     def rel(a, r):
         a, r = np.asarray(a), np.asarray(r)
