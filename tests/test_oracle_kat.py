@@ -245,3 +245,21 @@ def test_kiops_quirks():
         ko.kiops(np.array([[0.5, 1.0]]), A, u)
     with pytest.raises(TypeError):                      # complex has no method in the reference
         ko.kiops(1.0, A.astype(complex), u)
+
+
+def test_controller_arithmetic_follows_julia_not_python():
+    """krylov_phiv_adaptive.jl:455-501 in Float64: x / 0.0 is +-Inf or NaN (no exception) and only `ceil(Int, x)` / `Int(x)` of a
+    non-finite x throws (InexactError).  Python's float division raises ZeroDivisionError instead, which would make the oracle fail
+    where the reference carries on (q = -Inf -> tau unchanged) and fail DIFFERENTLY where it throws."""
+    import pytest
+    from oracle import krylov_oracle as ko
+    # equal estimates at two step sizes: log(eps / eps_old) = 0 -> q = +-Inf -> (gamma / omega)^0 = 1: tau_new = tau, no exception
+    m_new, tau_new, q, kappa = ko._timestep_adapt(10, 0.5, 1e-3, 10, 1.0, 1e-3, 2.5, 2.0, 0.8, 5.0, 1.0, 100, 1, 500, 0, 3.0, False, None)
+    assert tau_new == pytest.approx(0.5) or tau_new == pytest.approx(0.1) or tau_new == pytest.approx(1.0)
+    assert np.isinf(q) or np.isnan(q)
+    # the estimate did not move with m: kappa = 1 -> ceil(Int, x / 0) -> InexactError
+    with pytest.raises(ValueError, match="InexactError"):
+        ko._timestep_adapt(12, 0.5, 1e-3, 10, 0.5, 1e-3, 2.5, 2.0, 0.8, 5.0, 1.0, 100, 1, 500, 0, 3.0, False, None)
+    # tau driven to zero: Int(ceil(maxtau / tau)) -> InexactError
+    with pytest.raises(ValueError, match="InexactError"):
+        ko._estimate_flops(10, 0.0, 100, 1, 500, 0, 3.0, 1.0)
