@@ -430,7 +430,30 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     lan = lambda: eu.expv(T_FINAL, ops, b, m=m, ishermitian=True, out=w)
     sec["lanczos"] = entry("expv, symmetric 5-diagonal operator (Lanczos, window 2), n=%d m=%d" % (n, m),
                            timed(lan, args.steps, 2, env.sync), m, alg_bytes_expv_window(n, As.nnz, m, 2))
+    # (3') the same symmetric operator through expv(...; mode = :error_estimate) (krylov_phiv_error_estimate.jl): Lanczos with the
+    # a-posteriori stopping test after every step; unit = the Lanczos steps it took
+    est = {}
+    ee = lambda: eu.expv(T_FINAL, ops, b, m=m, mode="error_estimate", rtol=1e-8)
+    ee()
+    env.sync()
+    tee = timed(ee, max(5, args.steps // 2), 1, env.sync)
+    msteps = int(eu.expv.last_subspace.m)
+    sec["error_estimate_mode"] = {"what": "expv(t, A, b; mode=:error_estimate, rtol=1e-8), symmetric 5-diagonal operator, n=%d, m <= %d" % (n, m),
+                                  "value": msteps / tee, "unit": "matvecs/s", "ms_per_call": 1e3 * tee, "lanczos_steps": msteps}
     del ops, As
+    # (3'') small systems (the size most exponential integrators run at): a Krylov step costs what its chain of dependent round trips
+    # costs, whatever n: ms per expv and us per step
+    small = {}
+    for ns in (20_000, 100_000, 200_000):
+        o_s = eu.MIOperator(c2_operator(ns), ctx)
+        b_s, w_s = b[:ns].clone(), w[:ns].clone()
+        f_s = lambda: eu.expv(T_FINAL, o_s, b_s, m=m, ishermitian=False, out=w_s)
+        f_s()
+        env.sync()
+        t_s = timed(f_s, max(20, args.steps), 3, env.sync)
+        small["n=%d" % ns] = {"ms_per_expv": 1e3 * t_s, "us_per_krylov_step": 1e6 * t_s / m, "matvecs_per_s": m / t_s}
+        del o_s
+    sec["small_systems"] = {"what": "expv, C2 operator at small n, m=%d: bound by the per-step reduction chain, not by bandwidth" % m, **small}
     # (3a) the headline operator with the "stencil" option: its diagonals are constant, so they can be passed as five scalars and
     # NOT streamed (40 MB less per step).  Reported separately: the headline measures the general path, which streams them.
     ctx.set_option("stencil", 1)

@@ -78,6 +78,7 @@ struct Options {
   int stencil = 0;         // constant-coefficient banded operators: pass the diagonals as scalars, do not stream them (EXPV_MI_STENCIL=1 -> 1)
   int nontemporal = -1;    // non-temporal loads in the single-pass step: -1 by footprint, 0 never, 1 always  (EXPV_MI_NONTEMPORAL=0|1)
   int recycle = 1;         // a destroyed KrylovSubspace's storage is kept (one per context) for the next create of the same shape (EXPV_MI_NO_RECYCLE=1 -> 0)
+  int ee_blocked = 1;      // error-estimate mode: blocks of Lanczos steps through the ordinary factorisation          (EXPV_MI_EE_STEPWISE=1 -> 0)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();
@@ -261,6 +262,7 @@ struct Ks {
   DevBuf hcoef2, colscale;          // pipelined path: second coefficient buffer, per-column scales s_c
   DevBuf flags;                      // ... the step flags of its overlapped form (arrival counters: behind `state`)
   DevBuf tflags;                     // ... the per-tile flags of its wave form
+  bool lanczos_continue = false;   // lanczos!(...; init) as a true continuation (internal: the reference's loop restarts at 1)
   uint32_t pipe_seq = 0;
   bool pipe_resident_used = false;   // the last factorisation ran as one resident kernel
   bool pipe_serial = false, pipe_live_used = false;   // overlapped form switched off after an expired wait ...

@@ -321,6 +321,7 @@ Options Options::from_env() {
   if (flag("EXPV_MI_NO_MAILBOX")) o.mailbox = 0;
   if (flag("EXPV_MI_RESIDENT")) o.resident = 1;
   if (flag("EXPV_MI_NO_RECYCLE")) o.recycle = 0;
+  if (flag("EXPV_MI_EE_STEPWISE")) o.ee_blocked = 0;
   if (flag("EXPV_MI_STENCIL")) o.stencil = 1;
   if (const char *e = std::getenv("EXPV_MI_NONTEMPORAL")) o.nontemporal = std::atoi(e) ? 1 : 0;
   if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
@@ -338,6 +339,7 @@ int *Options::find(const char *name) {
   if (n == "mailbox") return &mailbox;
   if (n == "resident") return &resident;
   if (n == "recycle") return &recycle;
+  if (n == "ee_blocked") return &ee_blocked;
   if (n == "stencil") return &stencil;
   if (n == "nontemporal") return &nontemporal;
   if (n == "pipeline_serial") return &pipeline_serial;
@@ -427,7 +429,9 @@ struct ArnoldiCall {
     if (ks.beta == 0.0) return 0;
     iop = o.iop;
     if (iop == 0) iop = m;
-    jstart = lanczos ? 1 : init;     // lanczos!: loop is always 1:m (arnoldi.jl:480)
+    // lanczos!: the loop is always 1:m (arnoldi.jl:480) -- `init` restarts it; the library's own block-wise use (error-estimate
+    // mode) asks for a true continuation through Ks::lanczos_continue
+    jstart = (lanczos && !ks.lanczos_continue) ? 1 : init;
     if (jstart > m) return 0;
     reset_device_state();
     if (use_pipe) {
@@ -1399,6 +1403,67 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
   else ks.m = m;
   if (op.n != ks.n || ks.augmented != 0) fail(EXPV_MI_DIMENSION_MISMATCH, "expv!: operator / subspace size mismatch");
   if (op.dtype != ks.dtypeT) fail(EXPV_MI_ARGUMENT_ERROR, "operator dtype must equal the subspace dtype T");
+  if (c->opt.ee_blocked) {
+    // Blocks of Lanczos steps through the ordinary factorisation (arnoldi_run: single-pass / overlapped step where the operator
+    // allows it, continuation `init` between blocks), the stopping test of every step of a block evaluated on the host once the
+    // block is there.  The step-by-step form below costs 5 launches + an event per step (59 us per step at n = 1e6); a block
+    // costs its ~20 us per step + one hand-over, and at most a block's length of steps is computed in vain (Ks.m = the step
+    // that satisfies the test, exactly as if the loop had stopped there).  Same recurrence, same test (:174-200).
+    expv_mi_arnoldi_opts ao;
+    expv_mi_arnoldi_opts_default(&ao);
+    ao.tol = -1.0;                 // (this loop has no happy-breakdown exit in the reference: sigma -> 0 ends it)
+    ao.ishermitian = 1;
+    ao.iop = 0;
+    std::vector<double> alpha, betas;
+    std::vector<cd> cv;
+    int done = 0, jstop = 0;
+    double eps_stop = 0.0;
+    const bool w_cplx = dtype_is_complex(ks.dtypeT) || t.imag() != 0.0;
+    const int w_dtype = w_cplx ? dtype_complex_of(ks.dtypeT) : dtype_real_of(ks.dtypeT);
+    while (done < m && jstop == 0) {
+      const int target = std::min(m, done + (done == 0 ? 10 : 6));
+      ao.m = target;
+      ao.init = done ? done + 1 : 0;       // the next step to take: v_{done+1} and H[done+1, done] are there (closing pass of the last block)
+      {
+        ks.lanczos_continue = true;
+        struct Off { Ks &k; ~Off() { k.lanczos_continue = false; } } off{ks};
+        arnoldi_run(ks, op, b, ao, nullptr, true);
+      }
+      if (done == 0) {
+        if (ks.beta == 0.0) {          // zero starting vector (:166)
+          ks.m = 0;
+          zero_output(c, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
+          return;
+        }
+        eps_stop = atol + rtol * ks.beta;
+      }
+      for (int j = done + 1; j <= target; ++j) {
+        const double aj = getH(ks, j - 1, j - 1).real(), bj = getH(ks, j, j - 1).real();
+        alpha.push_back(aj);
+        betas.push_back(bj);
+        std::vector<double> off(betas.begin(), betas.begin() + (j - 1));
+        const cd last = dense::symtridiag_exp_last<cd>(alpha, off, t);
+        const double sigma = bj * ks.beta * std::abs(last);                // Saad's Er2  (:197)
+        if (sigma < eps_stop || j == m) {
+          cv = dense::symtridiag_expcol<cd>(alpha, off, t);
+          if (sigma < eps_stop) jstop = j;
+          if (jstop || j == m) break;
+        }
+      }
+      done = target;
+    }
+    const int mm = jstop ? jstop : m;
+    ks.m = mm;
+    ks.wasbreakdown = false;
+    if (!w_cplx) {
+      std::vector<double> cr(mm);
+      for (int i = 0; i < mm; ++i) cr[i] = cv[i].real();
+      combine_host_coef(ks, mm, 1, cr.data(), mm, EXPV_MI_F64, ks.beta, w, ks.n, w_loc, w_dtype);
+    } else {
+      combine_host_coef(ks, mm, 1, cv.data(), mm, EXPV_MI_C64, ks.beta, w, ks.n, w_loc, w_dtype);
+    }
+    return;
+  }
   T *V = ks.V.as<T>();
   StepState *st = ks.state.as<StepState>();
   StepState z;
@@ -1415,9 +1480,9 @@ static void error_estimate_T(Ks &ks, Op &op, cd t, const T *b, void *w, int w_lo
     zero_output(c, w, ks.n, w_loc, ks.n, 1, dtype_size(w_dtype));
     return;
   }
+  const double eps_stop = atol + rtol * ks.beta;
   dev::scale_copy<T>(s, V, b, ks.n, ks.beta, 1);   // @. V[:, 1] = b / Ks.beta
   ks.gram_rows = 0;
-  const double eps_stop = atol + rtol * ks.beta;
   HIPCHECK(hipMemsetAsync(ks.Hdev.p, 0, ks.Hdev.bytes, s));
   T *Hd = ks.Hdev.as<T>();
   std::vector<double> alpha, betas;

@@ -1170,3 +1170,48 @@ def test_adaptive_controller_errors_like_the_reference_and_never_spins(eu):
     # and the engine is still usable afterwards
     b = rng.standard_normal(n) + 0j
     close(np.asarray(eu.expv(0.1, A, b, m=5)), ko.expv(0.1, A, b, m=5), 1e-10, "expv after a controller error")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.complex128, np.float32])
+@pytest.mark.parametrize("kind", ["banded", "irregular", "dense"])
+def test_error_estimate_mode_blocks_equal_the_step_by_step_form(eu, T, kind):
+    """mode = :error_estimate (krylov_phiv_error_estimate.jl:149-207) runs its Lanczos steps in blocks through the ordinary
+    factorisation (10, then 6 at a time, a true Lanczos continuation between blocks) and tests every step of a block on the host;
+    the step-by-step form (context option ee_blocked = 0: 5 launches + an event per step) is the same recurrence one step at a
+    time.  Same stopping step, same result, for stopping steps inside the first block, across block boundaries and at m."""
+    from tests.test_gpu_parity import powerlaw_matrix
+    cplx = np.dtype(T).kind == "c"
+    single = np.dtype(T).itemsize == (8 if cplx else 4)
+    rng = np.random.default_rng(17)
+    n = 3000
+    if kind == "banded":
+        A = c2_operator(n, sym=True).astype(T)
+    elif kind == "irregular":
+        P = powerlaw_matrix(n, 5, cplx=cplx)
+        A = ((P + P.conj().T) * 0.5).tocsr().astype(T)
+    else:
+        n = 600
+        M = (rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)) / np.sqrt(n)
+        A = ((M + M.conj().T) * 0.5 - 0.5 * np.eye(n)).astype(T)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    A64 = A.astype(np.complex128 if cplx else np.float64)
+    b64 = b.astype(A64.dtype)
+    seen = set()
+    for m, rtol in ((30, 1e-2), (30, 1e-6), (30, 1e-10 if not single else 1e-5), (30, 1e-14), (7, 1e-14), (16, 1e-14), (17, 1e-14)):
+        res = {}
+        for blocked in (1, 0):
+            ctx.set_option("ee_blocked", blocked)
+            w = eu.expv(0.9, op, b, m=m, mode="error_estimate", rtol=rtol)
+            res[blocked] = (int(eu.expv.last_subspace.m), np.asarray(w).astype(A64.dtype), np.asarray(eu.expv.last_subspace.getH()).astype(np.float64))
+        assert res[1][0] == res[0][0], (m, rtol, res[1][0], res[0][0])
+        seen.add(res[1][0])
+        bar = 2e-5 if single else 1e-12
+        close(res[1][1], res[0][1], bar, "error-estimate mode %s %s m=%d rtol=%g (stops at %d): blocks vs step by step" % (np.dtype(T).name, kind, m, rtol, res[1][0]))
+        for kd in (0, -1):         # alpha and beta (what the mode defines; the super-diagonal is lanczos!'s own copy, arnoldi.jl:488)
+            close(np.diag(res[1][2], kd), np.diag(res[0][2], kd), bar, "... H of the subspace, diagonal %d" % kd, mat=True)
+        wo = ko.expv(0.9, A64, b64, m=m, mode="error_estimate", rtol=rtol)
+        close(res[1][1], wo, 3e-4 if single else 1e-10, "... against the oracle")
+    assert len(seen) >= 3, seen           # (the cases really stop at different steps)
