@@ -94,10 +94,12 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *   "recycle" 1         expv_mi_ks_destroy keeps the storage of the subspace (one per context) and the next expv_mi_ks_create of
  *                       the same shape takes it over, reset to the freshly built state: the create-use-destroy pattern of the
  *                       convenience methods costs no hipMalloc / hipFree.  0: destroy frees at once
+ *   "ee_blocked" 1      error-estimate mode: blocks of Lanczos steps through the ordinary factorisation, every step of a block
+ *                       tested on the host when the block is there; 0: one step at a time (same stopping step, same result)
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
- * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE (read once, at creation) -- nothing reads the environment later.
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE, _EE_STEPWISE (read once, at creation) -- nothing reads the environment later.
  * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
 int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
 int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
