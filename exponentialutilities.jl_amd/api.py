@@ -1110,7 +1110,8 @@ def host_pattern_info(A, dtype=np.float64):
         info["path"] = "two-kernel step, SELL slots up to the cut + overflow pass (irregular rows)"
     elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) == np.float64 and info["bandwidth"] <= 8):
         info["path"] = "pipeline, halo form"
-    elif np.dtype(dtype) == np.float64 and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0):
+    elif (np.dtype(dtype) == np.float64 and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0)) or \
+            (np.dtype(dtype) == np.float32 and info["general_dia_diagonals"]):
         info["path"] = "pipeline, wave form (when the reach is small against the resident grid), else two-kernel step"
     else:
         info["path"] = "two-kernel step"

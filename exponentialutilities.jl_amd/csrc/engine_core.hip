@@ -466,17 +466,19 @@ struct ArnoldiCall {
                  (!isaug || !dtype_is_32bit(ks.dtypeT)) &&
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
   }
-  if constexpr (std::is_same<T, double>::value) {
+  if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
     // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
-    // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip)
+    // form), as long as the diagonals reach over few tiles compared with the resident grid (pipe.hip); fp64 also on SELL
+    // slots with local columns.  Float32: the general diagonal form (tiles of 1024 rows)
     const bool no_wave = !c->opt.wave;
-    const int64_t ntiles_w = (ks.n + 511) / 512;
+    const int64_t trw = (int64_t)(16 / sizeof(T)) * dev::BLOCK;
+    const int64_t ntiles_w = (ks.n + trw - 1) / trw;
     if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
     const bool wave_dia = op.gndiag > 0 && !no_dia_env;
-    const bool wave_sell = !wave_dia && op.tile_reach >= 0;
+    const bool wave_sell = std::is_same<T, double>::value && !wave_dia && op.tile_reach >= 0;
     const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
     if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
-        m <= dev::PIPE_CH && !real_coeff && fresh && (ntiles_w <= 400 || (reach_rows / 512 + 2) * 4 <= 400)) {
+        m <= dev::PIPE_CH && !real_coeff && fresh && (ntiles_w <= 400 || (reach_rows / trw + 2) * 4 <= 400)) {
       use_pipe = true;
       use_wave = true;
       wave_reach = reach_rows;
@@ -699,7 +701,7 @@ struct ArnoldiCall {
       pa.cont = cont ? 1 : 0;
       pa.cont_inv = cont ? ks.colscale_host[j - 1] : 1.0;
       pa.A = A;
-      if constexpr (std::is_same<T, double>::value) {
+      if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
         if (use_wave) {
           if (op.gndiag > 0 && !no_dia_env) {
             pa.dia_val = op.gdia_ptr<T>(); pa.dia_ld = op.gdia_ld; pa.ndiag = op.gndiag;
@@ -775,14 +777,14 @@ struct ArnoldiCall {
         const int64_t live_tiles = (rows + tile_rows - 1) / tile_rows;
         const bool gate = use_wave || 2 * live_tiles > dev::device_cus();
         if (j > jstart && gate) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
-        if constexpr (std::is_same<T, double>::value) {
+        if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
           prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
         } else {
           prev_grid = dev::pipe_step_live(sj, pa);
         }
         if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
       } else if (use_wave) {
-        if constexpr (std::is_same<T, double>::value) {
+        if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
           ProfScope ps1(c, EXPV_MI_K_FUSED_A);
           if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
         }
@@ -799,8 +801,8 @@ struct ArnoldiCall {
   ks.pipe_live_used = live;
   if (use_wave && !live && ks.skip_tail && ks.mbox_armed) {   // H, scales and the final state to the host through the mailbox
     const MailboxView mv = mailbox_view(ks, ks.mbox_dev);
-    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)ks.ldhd * m, st, mv.H, mv.state, mv.done, ks.pipe_seq,
-                      ks.colscale.as<double>(), m, mv.scales);
+    dev::mailbox_fill(s, reinterpret_cast<const double *>(Hd), (int64_t)((dtype_size(ks.dtypeT) * (size_t)ks.ldhd * m + 7) / 8), st, mv.H,
+                      mv.state, mv.done, ks.pipe_seq, ks.colscale.as<double>(), m, mv.scales);      // (H in whole 8-byte words of ANY element type)
     mbox_generic = true;
   }
   ht_mark(2);

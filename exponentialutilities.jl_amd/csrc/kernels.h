@@ -293,6 +293,8 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx32> &pa, int nbatch = 1, int b
 // wave form; returns false (nothing launched) when the diagonals reach too far for the resident grid
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // operator form: pa.ndiag > 0 ? DIA : SELL
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
+bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off);      // Float32: general diagonal form only
+int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa);
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa);

@@ -204,7 +204,8 @@ __device__ __forceinline__ double pack_prod(const Pack<cplx32> &v, const Pack<cp
 template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
   static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
-  constexpr bool IS_F64 = std::is_same<T, double>::value;      // SELL slots, wave form, constant diagonals: fp64 only
+  constexpr bool IS_F64 = std::is_same<T, double>::value;      // SELL slots, constant diagonals: fp64 only
+  constexpr bool IS_F32 = std::is_same<T, float>::value;       // (the wave form on general diagonals also runs in Float32)
   constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64), 1 (complex-fp64), 4 (fp32), 2 (complex-fp32)
   constexpr int NR = ST<T>::nreal;
   constexpr int TR = N * BLOCK;               // rows per tile
@@ -214,7 +215,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
   static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
-  static_assert(!WAVE || IS_F64, "the wave form is fp64 only");
+  static_assert(!WAVE || IS_F64 || (DIA && IS_F32), "the wave form: fp64, or Float32 on the general diagonal form");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
   static_assert(DIA || IS_F64, "every element type but fp64 uses the DIA form");
   T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
@@ -565,7 +566,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         __syncthreads();
         WAVE_STAMP(pa.step, tl, 3);
         if (__builtin_amdgcn_readfirstlane(flag_s) != 0) return 3;
-        if constexpr (DIA && IS_F64) {
+        if constexpr (DIA && (IS_F64 || IS_F32)) {
           // PIPE_WMAX rows above and below the tile (their tiles' flags were part of the wait whenever a near diagonal exists)
           if (tid < 2 * PIPE_WMAX) {
             const int64_t hr = (tid < PIPE_WMAX) ? r0 - PIPE_WMAX + tid : r0 + TR + (tid - PIPE_WMAX);
@@ -614,29 +615,29 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
       }
     } else if constexpr (WAVE) {
-      if constexpr (IS_F64) {
+      if constexpr (IS_F64 || IS_F32) {
       if (act) {   // diagonals with arbitrary offsets: u_j straight from its column in memory
         const T *ucol = a.V + (int64_t)jcol * a.ldv;
         auto term = [&](const Pack<T> &v2, int sl) {
           const int off = pa.gdia_off[sl];
-          double x0, x1;
+          T x[N];
           if (off >= -PIPE_WMAX && off <= PIPE_WMAX) {      // near: LDS (tile + PIPE_WMAX rows either side; rows outside the matrix hold 0)
             const int o = PIPE_WMAX + N * tid + off;
-            x0 = us[o];
-            x1 = us[o + 1];
+#pragma unroll
+            for (int e = 0; e < N; ++e) x[e] = us[o + e];
           } else {
             const int64_t c0 = i + off;
-            if ((off & 1) == 0 && c0 >= 0 && c0 + 1 < a.n) {   // even offset: the pair is one aligned 16-byte load
+            if ((off & (N - 1)) == 0 && c0 >= 0 && c0 + N <= a.n) {   // offset a multiple of the pack: one aligned 16-byte load
               const Pack<T> xx = *reinterpret_cast<const Pack<T> *>(ucol + c0);
-              x0 = xx.v[0];
-              x1 = xx.v[1];
+#pragma unroll
+              for (int e = 0; e < N; ++e) x[e] = xx.v[e];
             } else {
-              x0 = (c0 >= 0 && c0 < a.n) ? ucol[c0] : 0.0;
-              x1 = (c0 + 1 >= 0 && c0 + 1 < a.n) ? ucol[c0 + 1] : 0.0;
+#pragma unroll
+              for (int e = 0; e < N; ++e) x[e] = (c0 + e >= 0 && c0 + e < a.n) ? ucol[c0 + e] : ST<T>::zero();
             }
           }
-          y.v[0] = fma(v2.v[0], x0, y.v[0]);
-          y.v[1] = fma(v2.v[1], x1, y.v[1]);
+#pragma unroll
+          for (int e = 0; e < N; ++e) y.v[e] = fma(v2.v[e], x[e], y.v[e]);
         };
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
@@ -839,10 +840,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgsT<T> pa, in
 // waits for the tiles its diagonals reach into; tiles are dealt round-robin to the resident workgroups so those
 // neighbours are being worked on at the same time (pipe_step_wave checks that the reach is small against the grid, which
 // makes the wait graph acyclic: the first half of a tile never waits).  V is read once per step, as in the banded form.
-template <int CH, int WAVES, int PS, bool DIA>
-__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_wave(const PipeArgs pa, int tiles_per_block) {
-  __shared__ PipeSharedT<double> sh;
-  (void)pipe_pass<double, CH, PS, false, DIA, true>(pa, tiles_per_block, sh);
+template <class T, int CH, int WAVES, int PS, bool DIA>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_wave(const PipeArgsT<T> pa, int tiles_per_block) {
+  __shared__ PipeSharedT<T> sh;
+  (void)pipe_pass<T, CH, PS, false, DIA, true>(pa, tiles_per_block, sh);
 }
 
 // ---- overlapped form: the kernel of step j+1 runs while step j finishes ------------------------------
@@ -1331,26 +1332,36 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx32> &pa, int nbatch, int batch
   else pipe_launch<cplx32, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
 }
 
-template <int CH, int WAVES, int PS, bool DIA>
-static bool pipe_wave_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
-  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_wave<CH, WAVES, PS, DIA>);
+template <class T, int CH, int WAVES, int PS, bool DIA>
+static bool pipe_wave_launch(hipStream_t s, const PipeArgsT<T> &pa, int64_t max_abs_off) {
+  const int64_t tr = pipe_tile_rows<T>();
+  const int64_t ntiles = (pa.d.n + tr - 1) / tr;
+  const int maxb = resident_blocks((const void *)k_pipe_wave<T, CH, WAVES, PS, DIA>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  const int64_t reach = max_abs_off / (2 * BLOCK) + 2;       // tiles a tile may wait for, on each side
+  const int64_t reach = max_abs_off / tr + 2;                // tiles a tile may wait for, on each side
   if (tpb > 1 && reach * 4 > nb) return false;               // too far for the round-robin deal: not acyclic for sure
-  hipLaunchKernelGGL((k_pipe_wave<CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_wave<T, CH, WAVES, PS, DIA>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return true;
 }
 bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
   const int v = pipe_variant(pa.und);
 #define PIPE_WCASE(i, ch, waves, ps)                                                     \
-  if (v == i) return pa.ndiag > 0 ? pipe_wave_launch<ch, waves, ps, true>(s, pa, max_abs_off) \
-                                  : pipe_wave_launch<ch, waves, ps, false>(s, pa, max_abs_off);
+  if (v == i) return pa.ndiag > 0 ? pipe_wave_launch<double, ch, waves, ps, true>(s, pa, max_abs_off) \
+                                  : pipe_wave_launch<double, ch, waves, ps, false>(s, pa, max_abs_off);
   PIPE_WCASE(0, 8, 4, 6) PIPE_WCASE(1, 16, 3, 6) PIPE_WCASE(2, 24, 3, 0) PIPE_WCASE(3, 32, 2, 5)
 #undef PIPE_WCASE
   return false;
+}
+bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off) {      // Float32: general diagonals only
+  if (pa.ndiag <= 0) return false;
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_wave_launch<float, 8, 4, 6, true>(s, pa, max_abs_off);
+    case 1: return pipe_wave_launch<float, 16, 3, 6, true>(s, pa, max_abs_off);
+    case 2: return pipe_wave_launch<float, 24, 3, 0, true>(s, pa, max_abs_off);
+    default: return pipe_wave_launch<float, 32, 2, 5, true>(s, pa, max_abs_off);
+  }
 }
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
@@ -1369,26 +1380,36 @@ static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
   hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
-template <int CH, int WAVES, int PS, bool DIA>
-static int pipe_wave_live_launch(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
-  const int64_t ntiles = (pa.d.n + 2 * BLOCK - 1) / (2 * BLOCK);
-  const int maxb = resident_blocks((const void *)k_pipe_live<double, CH, WAVES, PS, DIA, true>);
+template <class T, int CH, int WAVES, int PS, bool DIA>
+static int pipe_wave_live_launch(hipStream_t s, const PipeArgsT<T> &pa, int64_t max_abs_off) {
+  const int64_t tr = pipe_tile_rows<T>();
+  const int64_t ntiles = (pa.d.n + tr - 1) / tr;
+  const int maxb = resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, DIA, true>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  const int64_t reach = max_abs_off / (2 * BLOCK) + 2;
+  const int64_t reach = max_abs_off / tr + 2;
   if (tpb > 1 && reach * 4 > nb) return 0;
-  hipLaunchKernelGGL((k_pipe_live<double, CH, WAVES, PS, DIA, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {   // workgroups launched, 0: refused
   const int v = pipe_variant(pa.und);
 #define PIPE_WCASE(i, ch, waves, ps)                                                          \
-  if (v == i) return pa.ndiag > 0 ? pipe_wave_live_launch<ch, waves, ps, true>(s, pa, max_abs_off) \
-                                  : pipe_wave_live_launch<ch, waves, ps, false>(s, pa, max_abs_off);
+  if (v == i) return pa.ndiag > 0 ? pipe_wave_live_launch<double, ch, waves, ps, true>(s, pa, max_abs_off) \
+                                  : pipe_wave_live_launch<double, ch, waves, ps, false>(s, pa, max_abs_off);
   PIPE_WCASE(0, 8, 4, 6) PIPE_WCASE(1, 16, 3, 6) PIPE_WCASE(2, 24, 3, 0) PIPE_WCASE(3, 32, 2, 5)
 #undef PIPE_WCASE
   return 0;
+}
+int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off) {
+  if (pa.ndiag <= 0) return 0;
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_wave_live_launch<float, 8, 4, 6, true>(s, pa, max_abs_off);
+    case 1: return pipe_wave_live_launch<float, 16, 3, 6, true>(s, pa, max_abs_off);
+    case 2: return pipe_wave_live_launch<float, 24, 3, 0, true>(s, pa, max_abs_off);
+    default: return pipe_wave_live_launch<float, 32, 2, 5, true>(s, pa, max_abs_off);
+  }
 }
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);

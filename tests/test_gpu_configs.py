@@ -1215,3 +1215,45 @@ def test_error_estimate_mode_blocks_equal_the_step_by_step_form(eu, T, kind):
         wo = ko.expv(0.9, A64, b64, m=m, mode="error_estimate", rtol=rtol)
         close(res[1][1], wo, 3e-4 if single else 1e-10, "... against the oracle")
     assert len(seen) >= 3, seen           # (the cases really stop at different steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["grid2d", "grid3d", "near_and_far"])
+def test_float32_wave_form_on_general_diagonals(eu, shape):
+    """Float32 operators made of a few diagonals with arbitrary offsets (structured-grid stencils) run the wave form of the single-pass
+    step like their fp64 counterparts (tiles of 1024 rows, u_j gathered from its column in memory, offsets that are a multiple of
+    the 4-row pack as one 16-byte load): path, H / w against the fp64 oracle at fp32 bars, overlapped = one launch after the other
+    bit for bit, IOP window, sizes that are not a multiple of the tile."""
+    rng = np.random.default_rng(23)
+    if shape == "grid2d":
+        k = 150
+        n = k * k + 37
+        offs = [-k, -1, 0, 1, k]
+    elif shape == "grid3d":
+        k = 28
+        n = k ** 3
+        offs = [-k * k, -k, -1, 0, 1, k, k * k]
+    else:
+        n = 40_000
+        offs = [-9000, -8, -3, 0, 2, 4096, 12001]
+    d = [(0.1 + 0.05 * rng.random(n - abs(o))) * (1 if o else -6.0) for o in offs]
+    A = sp.diags(d, offs, shape=(n, n), format="csr").astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    for m, iop in ((20, 0), (31, 0), (25, 4)):
+        ctx.set_pipeline_overlap(True)
+        w = np.asarray(eu.expv(0.4, op, b, m=m, iop=iop, ishermitian=False)).copy()
+        path = list(eu.expv.last_stats["path"])
+        assert "pipeline" in path and "wave" in path, path
+        ctx.set_pipeline_overlap(False)
+        w2 = np.asarray(eu.expv(0.4, op, b, m=m, iop=iop, ishermitian=False)).copy()
+        assert np.array_equal(w, w2), "overlapped and serial wave forms differ"
+        assert w.dtype == np.float32
+        close(w.astype(np.float64), ko.expv(0.4, A64, b64, m=m, iop=iop, ishermitian=False), 1e-5, "Float32 wave form %s m=%d iop=%d: expv (fp32 bar)" % (shape, m, iop))
+    ctx.set_pipeline_overlap(True)
+    # (H of a few steps: on this diagonally dominant operator fp32 rounding grows ~2.3x per column against an fp64 run)
+    Ks = eu.arnoldi(op, b, m=6, ishermitian=False)
+    Ko = ko.arnoldi(A64, b64, m=6, ishermitian=False)
+    close(np.asarray(Ks.getH()).astype(np.float64), Ko.getH(), 2e-5, "Float32 wave form %s: H of 6 steps incl. H[7, 6] (fp32 bar)" % shape, mat=True)

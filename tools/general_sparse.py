@@ -38,6 +38,8 @@ def make(kind, n, seed=11):
         d = [0.3 + 0.05 * rng.random(n - k), 1.2 + 0.05 * rng.random(n - 1), -2.0 + 0.05 * rng.random(n), 0.8 + 0.05 * rng.random(n - 1),
              -0.1 + 0.05 * rng.random(n - k)]
         return sp.diags(d, [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+    if kind == "gridf32":                   # the 2-D stencil in Float32: wave form on 1024-row tiles
+        return make("grid", n, seed).astype(np.float32)
     if kind == "grid3":                     # 3-D 7-point stencil on a k x k x k grid, variable coefficients: general DIA form
         k = int(round(n ** (1.0 / 3.0)))
         nn = k * k * k
