@@ -395,6 +395,14 @@ def timed(fn, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps
 
 
+def timed_median(fn, steps, warmup, sync, batches=3):
+    """Secondary entries with a few short calls: the median of `batches` timings of `steps` calls each -- one multi-millisecond
+    stall of the host (a deferred free of an earlier entry's buffers, the OS) would otherwise BE the entry.  The headline keeps
+    the contract's plain form (exactly K steps, one bracket)."""
+    ts = sorted(timed(fn, steps, warmup if i == 0 else 0, sync) for i in range(batches))
+    return ts[len(ts) // 2]
+
+
 def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     torch, ctx = env.torch, env.ctx
     sec = {}
@@ -436,7 +444,7 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     ee = lambda: eu.expv(T_FINAL, ops, b, m=m, mode="error_estimate", rtol=1e-8)
     ee()
     env.sync()
-    tee = timed(ee, max(5, args.steps // 2), 1, env.sync)
+    tee = timed_median(ee, max(5, args.steps // 2), 1, env.sync)
     msteps = int(eu.expv.last_subspace.m)
     sec["error_estimate_mode"] = {"what": "expv(t, A, b; mode=:error_estimate, rtol=1e-8), symmetric 5-diagonal operator, n=%d, m <= %d" % (n, m),
                                   "value": msteps / tee, "unit": "matvecs/s", "ms_per_call": 1e3 * tee, "lanczos_steps": msteps}
@@ -450,7 +458,7 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         f_s = lambda: eu.expv(T_FINAL, o_s, b_s, m=m, ishermitian=False, out=w_s)
         f_s()
         env.sync()
-        t_s = timed(f_s, max(20, args.steps), 3, env.sync)
+        t_s = timed_median(f_s, max(20, args.steps), 3, env.sync)
         small["n=%d" % ns] = {"ms_per_expv": 1e3 * t_s, "us_per_krylov_step": 1e6 * t_s / m, "matvecs_per_s": m / t_s}
         del o_s
     sec["small_systems"] = {"what": "expv, C2 operator at small n, m=%d: bound by the per-step reduction chain, not by bandwidth" % m, **small}
@@ -581,7 +589,7 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         env.sync()
         c0 = ctx.counters()
         reps = max(5, args.steps // 2)
-        tt = timed(lambda: fn(stx), reps, 1, env.sync)
+        tt = timed_median(lambda: fn(stx), reps, 1, env.sync)
         c1 = ctx.counters()
         ksteps = (c1["krylov_steps"] - c0["krylov_steps"]) / (reps + 1)
         apps = ksteps + (c1["op_applies"] - c0["op_applies"]) / (reps + 1)
