@@ -515,6 +515,18 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["rel_diff_to_fp64_result"] = float(torch.linalg.norm(w32.double() - w) / torch.linalg.norm(w))
     sec["c2_float32"] = e
     del op32, A32
+    # (3b''') the 2-D grid stencil in Float32: wave form on tiles of 1024 rows
+    kg = int(round(np.sqrt(n)))
+    Ag32 = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-kg, -1, 0, 1, kg], shape=(n, n), format="csc").astype(np.float32)
+    opg32 = eu.MIOperator(Ag32, ctx)
+    g32 = lambda: eu.expv(T_FINAL, opg32, b32, m=m, ishermitian=False, out=w32)
+    g32()
+    env.sync()
+    e = entry("expv, 5-point grid stencil offsets (-%d,-1,0,1,%d) in Float32 (wave form), n=%d m=%d; contract with s = 4" % (kg, kg, n, m),
+              timed(g32, args.steps, 2, env.sync), m, alg_bytes_expv(n, Ag32.nnz, m, s=4))
+    e["path"] = list(eu.expv.last_stats["path"])
+    sec["grid_stencil_float32"] = e
+    del opg32, Ag32
     # (3c) general sparse operators: no band, no diagonals to exploit.  Regular rows with random columns and
     # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
