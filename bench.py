@@ -428,6 +428,12 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     whole = lambda: eu.expv(T_FINAL, op, b, m=m, ishermitian=False, out=w)
     sec["sync_outputs"] = entry("expv(t,A,b), device result complete when the call returns (C-ABI default)",
                                 timed(whole, args.steps, 2, env.sync), m, b_alg)
+    # phiv(t, A, b, 4) = arnoldi! + phiv! with five output columns: the call of the non-adaptive exponential Runge-Kutta integrators
+    ph4 = lambda: eu.phiv(T_FINAL, op, b, 4, m=m, ishermitian=False)
+    ph4()
+    env.sync()
+    sec["phiv_k4"] = entry("phiv(t, A, b, 4): arnoldi! + phiv!, five output columns, results complete on return",
+                           timed(ph4, args.steps, 2, env.sync), m, b_alg + 8 * n * 4)
     sec["split_api_sync_outputs"] = entry("arnoldi! + expv!, results complete on return",
                                           timed(split, args.steps, 2, env.sync), m, b_alg)
     ctx.set_async_outputs(True)

@@ -1187,6 +1187,13 @@ static void combine_launch(Ks &ks, Ctx *c, int mcols, int ncols, const std::vect
     }
     return;
   }
+  if (ncols >= 2 && ncols <= dev::COEF_MAT_COLS && mc >= 1 && (size_t)mc * ncols <= (size_t)dev::COEF_MAT_MAX) {
+    // phiv! with a few columns: the coefficient matrix travels in the kernel arguments, ONE pass over the basis, nothing to wait for
+    dev::CoefMat<TC> cm;
+    for (size_t k = 0; k < (size_t)mc * ncols; ++k) cm.c[k] = coef_as<TC>(cbuf, k, cplx_buf);
+    dev::combine_v<TV, TC>(c->stream, rows, V, ks.ldv, mc, cm, ncols, scale, (TC *)Wd, ldwd);
+    return;
+  }
   std::vector<TC> ch((size_t)mcols * ncols);
   for (size_t k = 0; k < ch.size(); ++k) ch[k] = coef_as<TC>(cbuf, k, cplx_buf);
   DevBuf cdev(ch.size() * sizeof(TC) + 16);

@@ -319,6 +319,11 @@ void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC
 
 constexpr int COEF_BY_VALUE_MAX = 64;
 template <class TC> struct CoefVec { TC c[COEF_BY_VALUE_MAX]; };
+// a small coefficient matrix by value, column-major m x ncols with m * ncols <= COEF_MAT_MAX (complex fp64: 3 KB of kernel arguments)
+constexpr int COEF_MAT_MAX = 192, COEF_MAT_COLS = 6;
+template <class TC> struct CoefMat { TC c[COEF_MAT_MAX]; };
+template <class TV, class TC>
+void combine_v(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefMat<TC> &cm, int ncols, double scale, TC *W, int64_t ldw);
 template <class TV, class TC>
 void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W);
 // the same with a tail of linear-combination terms:  W = ((scale * V c) * pscale) + sum_l coef[l] in[l]   (l < nterms <= 6)

@@ -668,14 +668,33 @@ template <>
 __device__ __forceinline__ void mulacc<cplx32, cplx32>(cplx32 &acc, cplx32 v, cplx32 c) { ST<cplx32>::fma_(acc, v, c); }
 
 template <class TV, class TC, int NC>
+__device__ __forceinline__ void combine_body(int64_t n, const TV *__restrict__ V, int64_t ldv, int m, const TC *cs, double scale,
+                                             TC *__restrict__ W, int64_t ldw);
+template <class TV, class TC, int NC>
 __global__ __launch_bounds__(BLOCK) void k_combine(int64_t n, const TV *__restrict__ V, int64_t ldv, int m,
                                                    const TC *__restrict__ C, int ldc, double scale, TC *__restrict__ W,
                                                    int64_t ldw) {
-  constexpr int N = Pack<TV>::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TC *cs = reinterpret_cast<TC *>(smem);  // [m][NC]
   for (int e = threadIdx.x; e < m * NC; e += BLOCK) cs[e] = C[(e / NC) + (int64_t)(e % NC) * ldc];
   __syncthreads();
+  combine_body<TV, TC, NC>(n, V, ldv, m, cs, scale, W, ldw);
+}
+// the same with the (small) coefficient matrix BY VALUE in the kernel arguments, column-major m x NC: no device buffer, no H2D
+// copy and no synchronisation between the host's small exponential and the launch (phiv!: w = beta V phi_k(tH) e_1, k + 1 columns)
+template <class TV, class TC, int NC>
+__global__ __launch_bounds__(BLOCK) void k_combine_v(int64_t n, const TV *__restrict__ V, int64_t ldv, int m, CoefMat<TC> cm,
+                                                     double scale, TC *__restrict__ W, int64_t ldw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TC *cs = reinterpret_cast<TC *>(smem);  // [m][NC]
+  for (int e = threadIdx.x; e < m * NC; e += BLOCK) cs[e] = cm.c[(e / NC) + (e % NC) * m];
+  __syncthreads();
+  combine_body<TV, TC, NC>(n, V, ldv, m, cs, scale, W, ldw);
+}
+template <class TV, class TC, int NC>
+__device__ __forceinline__ void combine_body(int64_t n, const TV *__restrict__ V, int64_t ldv, int m, const TC *cs, double scale,
+                                             TC *__restrict__ W, int64_t ldw) {
+  constexpr int N = Pack<TV>::N;
   const bool al = ((ldv * sizeof(TV)) % 16 == 0) && is_al16(V);
   const int64_t tile = (int64_t)BLOCK * N;
   for (int64_t base = (int64_t)blockIdx.x * tile; base < n; base += (int64_t)gridDim.x * tile) {
@@ -687,12 +706,12 @@ __global__ __launch_bounds__(BLOCK) void k_combine(int64_t n, const TV *__restri
 #pragma unroll
       for (int q = 0; q < NC; ++q) acc[k][q] = ST<TC>::zero();
     int c = 0;
-    for (; c + 4 <= m; c += 4) {
-      Pack<TV> vv[4];
+    for (; c + 8 <= m; c += 8) {       // eight basis columns in flight per lane (four left the kernel at 3 TB/s)
+      Pack<TV> vv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vv[u] = ld_pack(V + (int64_t)(c + u) * ldv, i, n, al);
+      for (int u = 0; u < 8; ++u) vv[u] = ld_pack(V + (int64_t)(c + u) * ldv, i, n, al);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
           const TC cq = cs[(c + u) * NC + q];
@@ -797,16 +816,31 @@ void combine1_lc(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, cons
 }
 
 template <class TV, class TC>
+void combine_v(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefMat<TC> &cm, int ncols, double scale, TC *W, int64_t ldw) {
+  const int g = grid_for(n, BLOCK * Pack<TV>::N * 2);
+  const size_t sh = (size_t)m * ncols * sizeof(TC);
+  switch (ncols) {
+    case 6: hipLaunchKernelGGL((k_combine_v<TV, TC, 6>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, cm, scale, W, ldw); break;
+    case 5: hipLaunchKernelGGL((k_combine_v<TV, TC, 5>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, cm, scale, W, ldw); break;
+    case 4: hipLaunchKernelGGL((k_combine_v<TV, TC, 4>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, cm, scale, W, ldw); break;
+    case 3: hipLaunchKernelGGL((k_combine_v<TV, TC, 3>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, cm, scale, W, ldw); break;
+    default: hipLaunchKernelGGL((k_combine_v<TV, TC, 2>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, cm, scale, W, ldw); break;
+  }
+}
+
+template <class TV, class TC>
 void combine(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const TC *C, int ldc, int ncols, double scale,
              TC *W, int64_t ldw) {
   const int g = grid_for(n, BLOCK * Pack<TV>::N * 2);
   int q0 = 0;
-  while (q0 < ncols) {  // at most 4 output columns per pass keeps the accumulators in registers
-    const int nc = (ncols - q0 >= 4) ? 4 : (ncols - q0);
+  while (q0 < ncols) {  // at most 6 output columns per pass over the basis (phiv with k <= 5: ONE pass; the accumulators stay in registers)
+    const int nc = (ncols - q0 >= 6) ? 6 : (ncols - q0);
     const size_t sh = (size_t)m * nc * sizeof(TC);
     const TC *Cq = C + (int64_t)q0 * ldc;
     TC *Wq = W + (int64_t)q0 * ldw;
     switch (nc) {
+      case 6: hipLaunchKernelGGL((k_combine<TV, TC, 6>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, Cq, ldc, scale, Wq, ldw); break;
+      case 5: hipLaunchKernelGGL((k_combine<TV, TC, 5>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, Cq, ldc, scale, Wq, ldw); break;
       case 4: hipLaunchKernelGGL((k_combine<TV, TC, 4>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, Cq, ldc, scale, Wq, ldw); break;
       case 3: hipLaunchKernelGGL((k_combine<TV, TC, 3>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, Cq, ldc, scale, Wq, ldw); break;
       case 2: hipLaunchKernelGGL((k_combine<TV, TC, 2>), dim3(g), dim3(BLOCK), sh, s, n, V, ldv, m, Cq, ldc, scale, Wq, ldw); break;
@@ -883,6 +917,12 @@ template void combine1_lc<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, 
 template void combine1<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<float> &, double, float *);
 template void combine1<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
 template void combine1<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
+template void combine_v<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefMat<float> &, int, double, float *, int64_t);
+template void combine_v<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefMat<cplx32> &, int, double, cplx32 *, int64_t);
+template void combine_v<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefMat<cplx32> &, int, double, cplx32 *, int64_t);
+template void combine_v<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefMat<double> &, int, double, double *, int64_t);
+template void combine_v<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const CoefMat<cplx> &, int, double, cplx *, int64_t);
+template void combine_v<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefMat<cplx> &, int, double, cplx *, int64_t);
 template void combine<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const float *, int, int, double, float *, int64_t);
 template void combine<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const cplx32 *, int, int, double, cplx32 *, int64_t);
 template void combine<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const cplx32 *, int, int, double, cplx32 *, int64_t);
