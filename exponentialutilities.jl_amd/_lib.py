@@ -123,6 +123,7 @@ PROTOTYPES = {
     "expv_mi_abi_sizeof": (C.c_size_t, [_i]),
     "expv_mi_abi_layout": (C.c_char_p, [_i]),
     "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),
+    "expv_mi_host_wrapsum": (_i, [_vp, C.c_uint64, _vp]),
     "expv_mi_host_expm": (_i, [_i, _i, _vp, _i]),
     "expv_mi_host_symtridiag_expcol": (_i, [_i, _pd, _pd, _d, _d, _pd]),
     "expv_mi_host_symtridiag_exp_last": (_i, [_i, _pd, _pd, _d, _d, _pd]),

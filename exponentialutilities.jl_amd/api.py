@@ -534,6 +534,10 @@ def _wrapsum(a):
     if a.ndim == 2 and a.flags.f_contiguous and not a.flags.c_contiguous:
         a = a.T
     a = np.ascontiguousarray(a)
+    if a.nbytes >= 1 << 16:             # one threaded pass in the library (the same sum; numpy's integer dot below: 3 ms per 64 MB)
+        out = (C.c_uint64 * 2)()
+        _check(L.load().expv_mi_host_wrapsum(a.ctypes.data, a.nbytes, out))
+        return (int(out[0]), int(out[1]))
     raw = a.view(np.uint8).ravel()
     k = raw.size // 8 * 8
     tail = int(np.add.reduce(raw[k:].astype(np.uint64) * np.arange(1, raw.size - k + 1, dtype=np.uint64), dtype=np.uint64)) if raw.size > k else 0

@@ -317,3 +317,25 @@ def test_host_expm_across_blasfloat_types(eu, T, tol, scale):
         assert w.dtype == np.dtype(T)
         w64 = eu.host_phiv_dense(A.astype(np.complex128), v.astype(np.complex128), 2)
         assert np.linalg.norm(w.astype(np.complex128) - w64) / np.linalg.norm(w64) < 10 * tol
+
+
+def test_library_wrapsum_equals_the_numpy_definition(eu):
+    """expv_mi_host_wrapsum (threaded, in the library) is the same order-sensitive checksum as the numpy form it replaces in the
+    content fingerprint: sum (2 i + 1) x_i mod 2^64 over the whole 8-byte words + the weighted tail bytes -- sizes around the
+    thread-split thresholds, unaligned starts, tails of 0..7 bytes."""
+    import ctypes as C
+    from exponentialutilities_jl_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    for nbytes in (0, 1, 7, 8, 9, 4096 + 3, (1 << 21) + 5, 3 * (1 << 21) + 8, 40_000_013):
+        base = rng.integers(0, 256, size=nbytes + 16, dtype=np.uint8)
+        for shift in (0, 3):
+            a = base[shift:shift + nbytes]
+            out = (C.c_uint64 * 2)()
+            assert lib.expv_mi_host_wrapsum(a.ctypes.data if nbytes else None, nbytes, out) == 0
+            k = nbytes // 8 * 8
+            words = a[:k].copy().view(np.uint64)
+            with np.errstate(over="ignore"):
+                ref = int(np.dot(words, np.arange(1, 2 * words.size, 2, dtype=np.uint64))) if words.size else 0
+                ref += int(np.add.reduce(a[k:].astype(np.uint64) * np.arange(1, nbytes - k + 1, dtype=np.uint64), dtype=np.uint64)) if nbytes > k else 0
+            assert (int(out[0]), int(out[1])) == (words.size, ref & 0xFFFFFFFFFFFFFFFF), (nbytes, shift)
