@@ -622,6 +622,8 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   if (ctx->ws_ts && ctx->ws_ts_free) ctx->ws_ts_free(ctx->ws_ts);
   if (ctx->ws_batch_pat && ctx->ws_batch_pat_free) ctx->ws_batch_pat_free(ctx->ws_batch_pat);
   if (ctx->ws_batch && ctx->ws_batch_free) ctx->ws_batch_free(ctx->ws_batch);
+  for (auto &sp : ctx->stage_spares) (void)hipFree(sp.p);
+  ctx->stage_spares.clear();
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

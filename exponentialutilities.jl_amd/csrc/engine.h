@@ -127,6 +127,32 @@ struct Ctx {
     HIPCHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }
   void use() const { HIPCHECK(hipSetDevice(device)); }
+  // Staging buffers of an API call that takes host operands / returns host results (DevBuf::take_from): kept by the context
+  // between calls instead of hipMalloc + hipFree (a device synchronisation) per call.  Everything that touches such a buffer is
+  // ordered on `stream` (the second stream of the overlapped form is joined back before a call returns), so the next call's copy
+  // into a re-used buffer cannot overtake a kernel that still reads it.
+  struct Spare { void *p; size_t bytes; };
+  std::vector<Spare> stage_spares;
+  void *stage_take(size_t need, size_t *got) {
+    *got = 0;
+    if (need == 0) return nullptr;
+    for (size_t i = 0; i < stage_spares.size(); ++i)
+      if (stage_spares[i].bytes >= need && stage_spares[i].bytes <= 4 * need + ((size_t)1 << 20)) {
+        void *q = stage_spares[i].p;
+        *got = stage_spares[i].bytes;
+        stage_spares[i] = stage_spares.back();
+        stage_spares.pop_back();
+        return q;
+      }
+    void *q = nullptr;
+    HIPCHECK(hipMalloc(&q, need));
+    *got = need;
+    return q;
+  }
+  void stage_give(void *p, size_t bytes) {
+    if (stage_spares.size() < 4 && bytes <= ((size_t)1 << 30)) { stage_spares.push_back(Spare{p, bytes}); return; }
+    (void)hipFree(p);
+  }
 };
 }  // namespace expv_mi
 struct expv_mi_ctx_s : expv_mi::Ctx {};
@@ -136,13 +162,14 @@ namespace expv_mi {
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  Ctx *home = nullptr;      // a staging buffer taken from a context's spares goes back there (take_from)
   DevBuf() {}
   explicit DevBuf(size_t b) { alloc(b); }
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), home(o.home) { o.p = nullptr; o.bytes = 0; o.home = nullptr; }
   DevBuf &operator=(DevBuf &&o) noexcept {
-    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; home = o.home; o.p = nullptr; o.bytes = 0; o.home = nullptr; }
     return *this;
   }
   void alloc(size_t b) {
@@ -150,10 +177,19 @@ struct DevBuf {
     bytes = b;
     if (b) HIPCHECK(hipMalloc(&p, b));
   }
+  void take_from(Ctx *c, size_t b) {      // at least b bytes, from the context's spare staging buffers when one fits
+    release();
+    p = c->stage_take(b, &bytes);
+    home = p ? c : nullptr;
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (home) home->stage_give(p, bytes);
+      else (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
+    home = nullptr;
   }
   ~DevBuf() { release(); }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }

@@ -29,7 +29,7 @@ static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 // ------------------------------------------------------------------------------------------
 const void *stage_in(Ctx *ctx, const void *p, int loc, size_t bytes, DevBuf &tmp) {
   if (loc == EXPV_MI_DEVICE || bytes == 0) return p;
-  tmp.alloc(bytes);
+  tmp.take_from(ctx, bytes);
   HIPCHECK(hipMemcpyAsync(tmp.p, p, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return tmp.p;
@@ -60,7 +60,7 @@ const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t 
     *ld_out = ld;
     return p;
   }
-  tmp.alloc((size_t)rows * cols * esz);
+  tmp.take_from(ctx, (size_t)rows * cols * esz);
   if (rows > 0 && cols > 0) {
     HIPCHECK(hipMemcpy2DAsync(tmp.p, rows * esz, p, ld * esz, rows * esz, cols, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -1248,7 +1248,7 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   void *Wd = W;
   int64_t ldwd = ldw;
   if (w_loc == EXPV_MI_HOST) {
-    wtmp.alloc((size_t)rows * ncols * wsz + 16);
+    wtmp.take_from(c, (size_t)rows * ncols * wsz + 16);
     Wd = wtmp.p;
     ldwd = rows;
   }
