@@ -585,6 +585,23 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
               tk, steps_per_call, kb, stats=list(st_box["st"]), krylov_steps_per_call=steps_per_call)
     e["unit"] = "Krylov steps/s"
     sec["c4_kiops_complex"] = e
+    # (4') the method the reference itself defines: kiops on REAL Float64 operands (kiops.jl:89), the headline operator
+    st_r = {}
+
+    def kior():
+        st_r["st"] = eu.kiops(1.0, op, b, ishermitian=False, opnorm=4.4)[1]
+    kior()
+    env.sync()
+    c0 = ctx.counters()
+    tkr = timed(kior, args.steps, 1, env.sync)
+    c1 = ctx.counters()
+    spc = (c1["krylov_steps"] - c0["krylov_steps"]) / (args.steps + 1)
+    acc_r, exps_r = st_r["st"][0], st_r["st"][3]
+    j_acc_r = (spc - (exps_r - acc_r)) / max(acc_r, 1)
+    e = entry("kiops(1.0, A, u) on the REAL C2 operator (the reference's own method), n=%d, iop=2, tol=1e-7" % n, tkr, spc,
+              alg_bytes_kiops(n, nnz, spc, acc_r, j_acc_r, s=8), stats=list(st_r["st"]), krylov_steps_per_call=spc)
+    e["unit"] = "Krylov steps/s"
+    sec["kiops_real"] = e
     del opc, Ac, uc
     # (5) BASELINE configs[4] on ONE GPU: its 1/8 share of the 1024 problems
     a5 = argparse.Namespace(nprob=128, steps=max(2, args.steps // 5), warmup=1)
