@@ -1257,3 +1257,36 @@ def test_float32_wave_form_on_general_diagonals(eu, shape):
     Ks = eu.arnoldi(op, b, m=6, ishermitian=False)
     Ko = ko.arnoldi(A64, b64, m=6, ishermitian=False)
     close(np.asarray(Ks.getH()).astype(np.float64), Ko.getH(), 2e-5, "Float32 wave form %s: H of 6 steps incl. H[7, 6] (fp32 bar)" % shape, mat=True)
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """`python bench.py` (short): ONE JSON line with the keys the driver reads -- metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the dominant
+    kernel (bound, achieved, peak, unit, frac, traffic) and a `cpu_baseline` object (value, unit, cores, kind, sample); value
+    consistent with ms_per_step, fraction below 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-secondary"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f64" and d["unit"] == "matvecs/s"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 30 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.3 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
