@@ -185,10 +185,12 @@ class Env:
         if str(self.device).startswith("cuda"):
             idx = self.torch.device(self.device).index or 0
             pr = self.torch.cuda.get_device_properties(idx)
-            ident = getattr(pr, "uuid", None)
-            if ident is None:
-                ident = "pci-%s:%s.%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", idx))
-            mine = "%s/%s" % (socket.gethostname(), ident)
+            # uuid AND the PCI address: a driver that reports the same (or an all-zero) uuid for every GPU must not make N
+            # properly bound ranks look like one device; two ranks on ONE device still agree in both and are refused
+            pci = "pci-%s:%s.%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+            if pci == "pci-?:?.?":
+                pci = "hip-%d" % idx        # (no PCI fields in this torch: the HIP ordinal of the device the rank is bound to)
+            mine = "%s/%s/%s" % (socket.gethostname(), getattr(pr, "uuid", "no-uuid"), pci)
         else:
             mine = "%s/pid%d" % (socket.gethostname(), os.getpid())
         if self.world == 1:
