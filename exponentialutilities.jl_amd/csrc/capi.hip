@@ -701,8 +701,12 @@ const char *expv_mi_last_error(expv_mi_ctx_t ctx) { return ctx ? ctx->last_error
 int expv_mi_malloc(expv_mi_ctx_t ctx, size_t bytes, void **dptr) {
   return guarded(ctx, [&] { ctx->use(); HIPCHECK(hipMalloc(dptr, bytes ? bytes : 1)); });
 }
-int expv_mi_free(expv_mi_ctx_t ctx, void *dptr) {
-  return guarded(ctx, [&] { ctx->use(); if (dptr) HIPCHECK(hipFree(dptr)); });
+// The context argument is NOT dereferenced: the finalizer of a host-language array may run after the context's own (Julia runs
+// finalizers in no particular order at exit, MIKrylov.jl; Python collects a cycle of an array and its context in any order), and
+// hipFree finds the allocation's device by itself.  A failure is reported through the thread's last-error string
+// (expv_mi_last_error(NULL)).
+int expv_mi_free(expv_mi_ctx_t, void *dptr) {
+  return guarded(nullptr, [&] { if (dptr) HIPCHECK(hipFree(dptr)); });
 }
 int expv_mi_memcpy_h2d(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes) {
   return guarded(ctx, [&] {

@@ -126,6 +126,8 @@ const char *expv_mi_version(void);
 
 /* raw device memory for host languages without a GPU array type (the Julia shim's MIVector) */
 int expv_mi_malloc(expv_mi_ctx_t ctx, size_t bytes, void **dptr);
+/* expv_mi_free never dereferences `ctx` (it may already be destroyed -- finalizers run in any order -- or NULL); errors go to
+ * expv_mi_last_error(NULL) */
 int expv_mi_free(expv_mi_ctx_t ctx, void *dptr);
 int expv_mi_memcpy_h2d(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes);
 int expv_mi_memcpy_d2h(expv_mi_ctx_t ctx, void *dst, const void *src, size_t bytes);

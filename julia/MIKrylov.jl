@@ -113,7 +113,7 @@ function Ctx(device::Integer = 0)
     # Julia runs finalizers in no particular order at exit: the library expects that -- expv_mi_ctx_destroy clears the back
     # pointers of the operator / KrylovSubspace / cache handles that outlive it, and their own destroy then only frees their
     # device memory (tests/test_gpu_configs.py: test_handles_may_outlive_their_context...; tests/c_harness does exactly this)
-    finalizer(c -> ccall((:expv_mi_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h), c)
+    finalizer(c -> (ccall((:expv_mi_ctx_destroy, lib), Cint, (Ptr{Cvoid},), c.h); c.h = C_NULL), c)
     c
 end
 const CTX = Ref{Ctx}()
@@ -172,7 +172,9 @@ function MIArray{T}(::UndefInitializer, dims::Vararg{Int, N}) where {T <: MIScal
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:expv_mi_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx().h, max(prod(dims), 1) * sizeof(T), r), ctx().h)
     a = MIArray{T, N}(r[], dims, true)
-    finalizer(a -> a.owned && ccall((:expv_mi_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx().h, a.ptr), a)
+    # (never ctx() here: a finalizer must not create a context, and the context's own finalizer may have run already --
+    #  expv_mi_free does not dereference the handle it is given)
+    finalizer(a -> a.owned && ccall((:expv_mi_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), isassigned(CTX) ? CTX[].h : C_NULL, a.ptr), a)
     a
 end
 MIArray{T, N}(::UndefInitializer, dims::Vararg{Int, N}) where {T, N} = MIArray{T}(undef, dims...)      # VType(undef, rows, cols), arnoldi.jl:68

@@ -339,3 +339,20 @@ def test_library_wrapsum_equals_the_numpy_definition(eu):
                 ref = int(np.dot(words, np.arange(1, 2 * words.size, 2, dtype=np.uint64))) if words.size else 0
                 ref += int(np.add.reduce(a[k:].astype(np.uint64) * np.arange(1, nbytes - k + 1, dtype=np.uint64), dtype=np.uint64)) if nbytes > k else 0
             assert (int(out[0]), int(out[1])) == (words.size, ref & 0xFFFFFFFFFFFFFFFF), (nbytes, shift)
+
+
+def test_free_never_dereferences_the_context_handle(eu):
+    """expv_mi_free(ctx, p): the finalizer of a host-language array may run after its context's (Julia at exit, a Python cycle):
+    the context handle is not read -- a dangling (here: nonsense) handle with nothing to free returns OK instead of crashing."""
+    import ctypes as C
+    lib = eu._lib.load() if hasattr(eu, "_lib") else None
+    if lib is None:
+        import sys
+        lib = sys.modules[eu.__name__ + "._lib"].load()
+    assert lib.expv_mi_free(C.c_void_p(0x10), C.c_void_p(None)) == 0
+    assert lib.expv_mi_free(C.c_void_p(None), C.c_void_p(None)) == 0
+    # and the Julia shim's array finalizer neither creates a context nor needs a live one
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "MIKrylov.jl")).read()
+    line = [ln for ln in src.splitlines() if ":expv_mi_free" in ln and "finalizer" in ln]
+    assert len(line) == 1 and "ctx()" not in line[0] and "isassigned(CTX)" in line[0]

@@ -988,6 +988,8 @@ def test_handles_may_outlive_their_context_and_double_destroy_is_harmless(eu):
         lib.expv_mi_arnoldi_opts_default(C.byref(o))
         o.m = 10
         assert lib.expv_mi_arnoldi(ks, op, b.ctypes.data, L.HOST, C.byref(o)) == 0
+        raw = C.c_void_p()
+        assert lib.expv_mi_malloc(ctx, 1 << 20, C.byref(raw)) == 0      # (a host-language array: the Julia shim's MIVector)
         if order == "ctx_first":
             assert lib.expv_mi_ks_destroy(ks2) == 0          # becomes the context's spare ...
             assert lib.expv_mi_ks_destroy(ks2) == 0          # ... and a second destroy of it changes nothing
@@ -995,7 +997,9 @@ def test_handles_may_outlive_their_context_and_double_destroy_is_harmless(eu):
             assert lib.expv_mi_ks_destroy(ks) == 0
             assert lib.expv_mi_op_destroy(op) == 0
             assert lib.expv_mi_timestep_caches_destroy(tsc) == 0
+            assert lib.expv_mi_free(ctx, raw) == 0           # the array's finalizer after the context's: the dead handle is not read
         else:
+            assert lib.expv_mi_free(ctx, raw) == 0
             assert lib.expv_mi_timestep_caches_destroy(tsc) == 0
             assert lib.expv_mi_op_destroy(op) == 0
             assert lib.expv_mi_ks_destroy(ks) == 0
