@@ -6,6 +6,9 @@
 # these methods.
 #
 # STATUS: source only.  The build image has no Julia, so this file has never been executed; what IS checked here:
+#   * method signatures were checked by hand against the reference's for dispatch ambiguities (a method that is more specific in
+#     one argument and less in another is a MethodError at the first call): expv! is split into `t::Real` / `t::Complex` like
+#     krylov_phiv.jl:200-203, :252-255 for that reason,
 #   * every `ccall` below names an exported symbol with the argument order of include/expv_mi.h
 #     (tests/test_abi_cpu.py::test_julia_shim_calls_match_the_header),
 #   * the option structs restated below have the library's field order and types
@@ -168,6 +171,8 @@ const MIVecOrMat{T} = Union{MIVector{T}, MIMatrix{T}}
 Base.size(a::MIArray) = a.dims
 Base.IndexStyle(::Type{<:MIArray}) = IndexLinear()
 Base.getindex(a::MIArray, i...) = error("MIArray lives in HBM: copy it to the host with Array(a) first")
+Base.show(io::IO, a::MIArray{T}) where {T} = print(io, join(a.dims, "x"), " MIArray{", T, "} in HBM @", a.ptr)      # (the generic show would index)
+Base.show(io::IO, ::MIME"text/plain", a::MIArray) = show(io, a)
 function MIArray{T}(::UndefInitializer, dims::Vararg{Int, N}) where {T <: MIScalar, N}
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:expv_mi_malloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), ctx().h, max(prod(dims), 1) * sizeof(T), r), ctx().h)
@@ -229,6 +234,7 @@ function update_values!(op::MIOperator{T}, A::SparseMatrixCSC{T, Int64}) where {
     op.opnorm_inf = on[]
     op
 end
+MIOperator(A::SparseMatrixCSC{T}) where {T <: MIScalar} = MIOperator(SparseMatrixCSC{T, Int64}(A))      # (other index types: converted once)
 function MIOperator(A::Matrix{T}) where {T <: MIScalar}
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:expv_mi_op_create_dense, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{T}, Int64, Cint, Ref{Ptr{Cvoid}}),
@@ -368,11 +374,16 @@ end
 
 # expv!(w, t, Ks; cache, expmethod)                                                           (src/krylov_phiv.jl:200-280)
 # (the m x m exponential runs on the host inside the library: north_star; `cache` / `expmethod` are accepted and unused)
-function expv!(w::MIVector{Tw}, t::Number, Ks::MIKs{T, U}; cache = nothing, expmethod = nothing) where {Tw, T, U}
+# Two methods with the reference's own split of `t` (krylov_phiv.jl:200-203 `t::Real`, :252-255 `t::Complex` with a complex w): one
+# method on `t::Number` would be MORE specific than the reference's in w and Ks and LESS specific in t -- ambiguous for every call.
+function _expv_ks!(w::MIVector{Tw}, t::Number, Ks) where {Tw}
     check(ccall((:expv_mi_expv_ks, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cvoid}, Cint, Cint),
                 handle(Ks), real(t), imag(t), w.ptr, DEVICE, dtype(Tw)), ctx().h)
     w
 end
+expv!(w::MIVector{Tw}, t::Real, Ks::MIKs{T, U}; cache = nothing, expmethod = nothing) where {Tw, T, U} = _expv_ks!(w, t, Ks)
+expv!(w::MIVector{Complex{Tw}}, t::Complex{Tt}, Ks::MIKs{T, U}; cache = nothing, expmethod = nothing) where {Tw, Tt, T, U} =
+    _expv_ks!(w, t, Ks)
 # expv(t, A, b; kwargs...) in ONE library call (workspace reuse, no v_{m+1})                   (src/krylov_phiv.jl:135-144)
 function ExponentialUtilities._expv_hb(t::Tt, A::MIOperator{T}, b::MIVector{T}; expmethod = nothing, cache = nothing,
                                        m = min(30, size(A, 1)), tol = 1.0e-7, iop = 0,
@@ -383,6 +394,20 @@ function ExponentialUtilities._expv_hb(t::Tt, A::MIOperator{T}, b::MIVector{T}; 
                 (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint, Ref{ArnoldiOpts}, Ref{ExpvStats}),
                 ctx().h, A.h, real(t), imag(t), b.ptr, DEVICE, w.ptr, DEVICE, dtype(eltype(w)), opts(m, tol, iop, 0, ishermitian), st), ctx().h)
     w
+end
+# expv(t, A, b; mode = :error_estimate, ...)                                                  (src/krylov_phiv.jl:145-160)
+# The reference's _expv_ee builds a HOST KrylovSubspace{T, U}(n, m), which cannot hold device vectors: the subspace is created on
+# the device instead.  T = promote_type(typeof(t), eltype(A), eltype(b)) as there: a complex t (the Schroedinger case, -im) on a
+# real operator needs the operator and b in the complex type -- MIOperator(ComplexF64.(A)) -- which the reference's generic mul!
+# does implicitly.
+function ExponentialUtilities._expv_ee(t::Tt, A::MIOperator{T}, b::MIVector{T}; m = min(30, size(A, 1)), tol = 1.0e-7, rtol = √(tol),
+                                       ishermitian::Bool = LinearAlgebra.ishermitian(A), expmethod = nothing) where {Tt, T}
+    Tp = promote_type(Tt, T)
+    Tp == T || throw(ArgumentError("expv(...; mode = :error_estimate) with a $(Tt) time works in $(Tp): build the operator and b " *
+                                   "in that type (MIOperator($(Tp).(A)), MIArray($(Tp).(b)))"))
+    Ks = mi_subspace(T, ishermitian ? real(T) : T, length(b), m)
+    w = similar(b, T, (length(b),))
+    expv!(w, t, A, b, Ks, get_subspace_cache(Ks); atol = tol, rtol = rtol, ishermitian = ishermitian)
 end
 # phiv!(w, t, Ks, k; cache, correct, errest, expmethod) / _phiv!                              (src/krylov_phiv.jl:607-653)
 function _phiv!(w::MIMatrix{Tw}, t::Number, Ks::MIKs{T, U}, k::Integer, cache, correct, expmethod) where {Tw, T, U}
