@@ -356,3 +356,17 @@ def test_free_never_dereferences_the_context_handle(eu):
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "MIKrylov.jl")).read()
     line = [ln for ln in src.splitlines() if ":expv_mi_free" in ln and "finalizer" in ln]
     assert len(line) == 1 and "ctx()" not in line[0] and "isassigned(CTX)" in line[0]
+
+
+def test_julia_shim_expv_methods_do_not_collide_with_the_reference():
+    """The reference defines expv!(w::AbstractVector, t::Real, Ks) and expv!(w::AbstractVector{<:Complex}, t::Complex, Ks)
+    (krylov_phiv.jl:200-203, :252-255).  A shim method expv!(w::MIVector, t::Number, Ks::MIKs) is more specific in w and Ks and
+    less specific in t: Julia reports that as ambiguous at the first call.  The shim must keep the reference's split, and
+    expv(t, A, b; mode = :error_estimate) must not reach the reference's _expv_ee (it builds a host KrylovSubspace)."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "MIKrylov.jl")).read()
+    three_arg = [ln for ln in src.splitlines() if re.match(r"\s*(function\s+)?expv!\(w::MIVector\{[^}]*\}(\{[^}]*\})?,\s*t::", ln) and "Ks::MIKs" in ln and "A::" not in ln]
+    kinds = sorted(re.search(r"t::(\w+)", ln).group(1) for ln in three_arg)
+    assert kinds == ["Complex", "Real"], three_arg
+    assert "ExponentialUtilities._expv_ee(t::Tt, A::MIOperator{T}, b::MIVector{T}" in src
