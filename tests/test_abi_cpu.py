@@ -366,7 +366,7 @@ def test_julia_shim_expv_methods_do_not_collide_with_the_reference():
     import os
     import re
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "MIKrylov.jl")).read()
-    three_arg = [ln for ln in src.splitlines() if re.match(r"\s*(function\s+)?expv!\(w::MIVector\{[^}]*\}(\{[^}]*\})?,\s*t::", ln) and "Ks::MIKs" in ln and "A::" not in ln]
+    three_arg = [ln for ln in src.splitlines() if re.match(r"\s*(function\s+)?expv!\(w::MIVector\{", ln) and "Ks::MIKs" in ln and "A::" not in ln]
     kinds = sorted(re.search(r"t::(\w+)", ln).group(1) for ln in three_arg)
     assert kinds == ["Complex", "Real"], three_arg
     assert "ExponentialUtilities._expv_ee(t::Tt, A::MIOperator{T}, b::MIVector{T}" in src
