@@ -563,14 +563,22 @@ inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat
           s = f / r;
           c = g / r;
           g = d[i + 1] - p;
-          r = (d[i] - g) * s + 2.0 * c * b;
+          // (fused forms written out, the unfused sum pinned: the two instantiations of this function must round alike, see below)
+          r = std::fma(2.0 * c, b, (d[i] - g) * s);
           p = s * r;
-          d[i + 1] = g + p;
-          g = c * r - b;
+          {
+#pragma clang fp contract(off)
+            d[i + 1] = g + p;
+          }
+          g = std::fma(c, r, -b);
+          // The fused forms are written out: the first/last-rows-only instantiation must round exactly like the full one
+          // (the stopping test of the error-estimate mode reads the same entry from either), which must not depend on how the
+          // compiler contracts a*b + c*d in two different loop shapes (it differed at -O1: profiles/r03_sanitizers.txt).
           for (int k = 0; k < zr; ++k) {
             f = Z(k, i + 1);
-            Z(k, i + 1) = s * Z(k, i) + c * f;
-            Z(k, i) = c * Z(k, i) - s * f;
+            const double zk = Z(k, i);
+            Z(k, i + 1) = std::fma(c, f, s * zk);
+            Z(k, i) = std::fma(c, zk, -(s * f));
           }
         }
         if (r == 0.0 && i >= l) continue;
@@ -592,6 +600,13 @@ inline void symtridiag_eig(std::vector<double> &d, std::vector<double> e_in, Mat
 }
 
 // expHe = Z * (exp.(t*lambda) .* Z[1,:])   (krylov_phiv.jl:227-228 real t, :272-273 complex t)
+// acc += z * w with the fused form written out (real z; w real or complex): the full product and its single entry below must
+// round alike whatever the optimiser does with a*b + c in a vectorised loop and in a scalar one
+inline void fma_acc(double &acc, double z, double w) { acc = std::fma(z, w, acc); }
+inline void fma_acc(std::complex<double> &acc, double z, const std::complex<double> &w) {
+  acc = std::complex<double>(std::fma(z, w.real(), acc.real()), std::fma(z, w.imag(), acc.imag()));
+}
+
 template <class St>
 inline std::vector<St> symtridiag_expcol(const std::vector<double> &diag, const std::vector<double> &off, St t) {
   std::vector<double> d = diag;
@@ -601,7 +616,7 @@ inline std::vector<St> symtridiag_expcol(const std::vector<double> &diag, const 
   std::vector<St> wv(n), out(n, St(0));
   for (int i = 0; i < n; ++i) wv[i] = std::exp(t * d[i]) * Z(0, i);
   for (int i = 0; i < n; ++i)
-    for (int r = 0; r < n; ++r) out[r] += Z(r, i) * wv[i];
+    for (int r = 0; r < n; ++r) fma_acc(out[r], Z(r, i), wv[i]);
   return out;
 }
 
@@ -614,7 +629,7 @@ inline St symtridiag_exp_last(const std::vector<double> &diag, const std::vector
   symtridiag_eig<true>(d, off, Z);
   const int n = (int)d.size();
   St out(0);
-  for (int i = 0; i < n; ++i) out += Z(n > 1 ? 1 : 0, i) * (std::exp(t * d[i]) * Z(0, i));
+  for (int i = 0; i < n; ++i) fma_acc(out, Z(n > 1 ? 1 : 0, i), St(std::exp(t * d[i]) * Z(0, i)));
   return out;
 }
 
