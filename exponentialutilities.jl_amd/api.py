@@ -217,7 +217,9 @@ def _t_dtype(t):
     complex is a literal and takes the operands' precision."""
     if isinstance(t, np.generic):
         return np.dtype(t.dtype) if t.dtype.kind in "fc" else np.dtype(np.float32)
-    return np.dtype(np.complex64) if isinstance(t, complex) and t.imag != 0.0 else np.dtype(np.float32)
+    # (any Python complex is a Complex in the reference's promote_type, whatever its imaginary part: expv(1 + 0im, A, b) is a
+    #  complex vector there -- consistent with _t_parts, which routes every complex t through the complex evaluation)
+    return np.dtype(np.complex64) if isinstance(t, complex) else np.dtype(np.float32)
 
 
 def _src_dtype(A):
@@ -522,36 +524,18 @@ def _torch_view(ptr, n, dt):
     return torch.as_tensor(s, device="cuda")
 
 
-_WEIGHTS = {}
-
-
 def _wrapsum(a):
-    """Order-SENSITIVE wrap-around checksum of an array's bytes, 8 at a time: sum (2 i + 1) x_i mod 2^64.  A plain
-    sum misses every in-place permutation of the contents (A.data[:] = A.data[::-1], two swapped entries); the index-weighted
-    sum changes whenever two different words trade places.  An F-ordered matrix is read through its transpose (a C-contiguous
-    view of the same memory: no copy)."""
+    """Content hash of an array's bytes (expv_mi_host_wrapsum): sum_i mix64(x_i ^ (i + 1) g) mod 2^64 over the 8-byte words, every
+    word combined with its position and then put through a non-linear mixer -- any in-place permutation of the contents
+    (A.data[:] = A.data[::-1], two swapped entries, also of mantissa-free values like the 1 / -2 of a stencil, at any distance)
+    changes it.  An F-ordered matrix is read through its transpose (a C-contiguous view of the same memory: no copy)."""
     a = np.asarray(a)
     if a.ndim == 2 and a.flags.f_contiguous and not a.flags.c_contiguous:
         a = a.T
     a = np.ascontiguousarray(a)
-    if a.nbytes >= 1 << 16:             # one threaded pass in the library (the same sum; numpy's integer dot below: 3 ms per 64 MB)
-        out = (C.c_uint64 * 2)()
-        _check(L.load().expv_mi_host_wrapsum(a.ctypes.data, a.nbytes, out))
-        return (int(out[0]), int(out[1]))
-    raw = a.view(np.uint8).ravel()
-    k = raw.size // 8 * 8
-    tail = int(np.add.reduce(raw[k:].astype(np.uint64) * np.arange(1, raw.size - k + 1, dtype=np.uint64), dtype=np.uint64)) if raw.size > k else 0
-    if not k:
-        return (0, tail)
-    words = raw[:k].view(np.uint64)
-    wts = _WEIGHTS.get(words.size)
-    if wts is None:
-        if len(_WEIGHTS) > 8:
-            _WEIGHTS.clear()
-        wts = _WEIGHTS[words.size] = np.arange(1, 2 * words.size, 2, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        weighted = int(np.dot(words, wts))            # (integer dot: one pass, no temporary; wraps mod 2^64)
-    return (words.size, (weighted + tail) & 0xFFFFFFFFFFFFFFFF)
+    out = (C.c_uint64 * 2)()
+    _check(L.load().expv_mi_host_wrapsum(a.ctypes.data if a.nbytes else None, a.nbytes, out))
+    return (int(out[0]), int(out[1]))
 
 
 def _fingerprint(A):

@@ -245,6 +245,12 @@ static SellPlan plan_sell(int64_t n, const int32_t *rp, int64_t nnz, int SH) {
     }
     S.padded += (int64_t)std::min(L, bestL) * SH;
   }
+  // no cut pays off (e.g. many slices with half their rows empty: heavy padding, but no row beyond any useful cut): this is a
+  // REGULAR-row pattern -- a "cut" without overflow entries would only switch the diagonal, wave and single-pass forms off
+  if (S.cut >= maxlen || S.ovf_entries == 0) {
+    S.cut = 0;
+    S.ovf_entries = S.ovf_rows = S.ovf_segments = S.ovf_multi_rows = 0;
+  }
   return S;
 }
 
@@ -614,8 +620,7 @@ int expv_mi_ctx_destroy(expv_mi_ctx_t ctx) {
   for (auto &p : ctx->prof)
     for (auto &ev : p.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ht_report();
-  for (Ctx **slot : ctx->children) *slot = nullptr;     // handles that outlive the context: only their destroy is legal from here on
-  ctx->children.clear();
+  ctx->orphan_children();     // handles that outlive the context: only their destroy is legal from here on
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ws_ks);
   if (ctx->ws_kiops && ctx->ws_kiops_free) ctx->ws_kiops_free(ctx->ws_kiops);
   delete reinterpret_cast<expv_mi_ks_s *>(ctx->ks_spare);
@@ -1260,11 +1265,19 @@ int expv_mi_kiops(expv_mi_ctx_t ctx, expv_mi_op_t op, const double *tau_out, int
   });
 }
 
-// Order-sensitive wrap-around checksum of a host buffer, 8 bytes at a time: sum_i (2 i + 1) x_i  mod 2^64 over the whole 8-byte
-// words (+ the tail bytes weighted 1, 2, ...).  What the host mirrors use to decide whether an uploaded copy of a caller's matrix may
-// be reused (the reference reads A at call time): one pass at memory bandwidth over several threads instead of an interpreter-level
-// integer dot product (3.2 ms per call for the 64 MB of a 5e6-entry CSR matrix).  Sums mod 2^64 are associative: the split over
-// threads does not change the value.
+// Content hash of a host buffer, 8 bytes at a time: sum_i mix64(x_i ^ salt_i)  mod 2^64 over the whole 8-byte words (+ the tail
+// bytes packed into one more word), with mix64 the two-round multiply / xor-shift finaliser and salt_i = (i + 1) * golden ratio.
+// What the host mirrors use to decide whether an uploaded copy of a caller's matrix may be reused (the reference reads A at call
+// time).  Round 3 used the LINEAR form sum_i (2 i + 1) x_i: floats whose mantissa is all zeros (1.0, 2.0, -2.0, 0.5: exactly what
+// constant-coefficient stencils are made of) differ by multiples of 2^52, so two of them trading places at a distance of 2048 k
+// words left that sum unchanged.  Here every word goes through a bijective non-linear mixer AFTER being combined with its
+// position, so a permutation of the contents changes the sum unless two 64-bit mixed values collide.  A sum mod 2^64 is
+// associative: the split over threads does not change the value.
+static inline uint64_t mix64(uint64_t h) {
+  h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+  return h;
+}
+static constexpr uint64_t kHashSalt = 0x9e3779b97f4a7c15ull;
 int expv_mi_host_wrapsum(const void *buf, uint64_t nbytes, uint64_t out[2]) {
   return guarded(nullptr, [&] {
     if ((!buf && nbytes) || !out) fail(EXPV_MI_ARGUMENT_ERROR, "wrapsum: bad arguments");
@@ -1274,29 +1287,39 @@ int expv_mi_host_wrapsum(const void *buf, uint64_t nbytes, uint64_t out[2]) {
     const uint64_t per_thread_min = 1u << 18;      // 2 MB: below that a thread costs more than it reads
     const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(hw, 16u), nwords / per_thread_min));
     std::vector<uint64_t> part(nt, 0);
-    auto work = [&](unsigned t) {
+    auto work = [&part, bytes, nwords, nt](unsigned t) {
       const uint64_t w0 = nwords * t / nt, w1 = nwords * (t + 1) / nt;
       uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
       uint64_t i = w0;
-      for (; i + 4 <= w1; i += 4) {          // (unaligned buffers: memcpy loads)
+      for (; i + 4 <= w1; i += 4) {          // four independent chains (unaligned buffers: memcpy loads)
         uint64_t x0, x1, x2, x3;
         std::memcpy(&x0, bytes + 8 * i, 8); std::memcpy(&x1, bytes + 8 * i + 8, 8);
         std::memcpy(&x2, bytes + 8 * i + 16, 8); std::memcpy(&x3, bytes + 8 * i + 24, 8);
-        acc0 += (2 * i + 1) * x0; acc1 += (2 * i + 3) * x1; acc2 += (2 * i + 5) * x2; acc3 += (2 * i + 7) * x3;
+        acc0 += mix64(x0 ^ ((i + 1) * kHashSalt)); acc1 += mix64(x1 ^ ((i + 2) * kHashSalt));
+        acc2 += mix64(x2 ^ ((i + 3) * kHashSalt)); acc3 += mix64(x3 ^ ((i + 4) * kHashSalt));
       }
-      for (; i < w1; ++i) { uint64_t x; std::memcpy(&x, bytes + 8 * i, 8); acc0 += (2 * i + 1) * x; }
+      for (; i < w1; ++i) { uint64_t x; std::memcpy(&x, bytes + 8 * i, 8); acc0 += mix64(x ^ ((i + 1) * kHashSalt)); }
       part[t] = acc0 + acc1 + acc2 + acc3;
     };
-    if (nt == 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
-      work(0);
-      for (auto &x : th) x.join();
+    // the workers beyond the first run on their own threads; a thread that cannot be started (thread limit of the process) has
+    // its share done inline, and every started thread is joined before anything unwinds past `part`
+    std::vector<std::thread> th;
+    std::vector<unsigned> inline_shares;
+    if (nt > 1) th.reserve(nt - 1);
+    for (unsigned t = 1; t < nt; ++t) {
+      try { th.emplace_back(work, t); }
+      catch (...) { inline_shares.push_back(t); }
     }
+    work(0);
+    for (unsigned t : inline_shares) work(t);
+    for (auto &x : th) x.join();
     uint64_t sum = 0;
     for (unsigned t = 0; t < nt; ++t) sum += part[t];
-    for (uint64_t k = nwords * 8, j = 1; k < nbytes; ++k, ++j) sum += j * (uint64_t)bytes[k];
+    if (nwords * 8 < nbytes) {              // 1..7 tail bytes: one more (zero-extended) word, salted with its length as well
+      uint64_t x = 0;
+      std::memcpy(&x, bytes + 8 * nwords, (size_t)(nbytes - 8 * nwords));
+      sum += mix64(x ^ ((nwords + 1) * kHashSalt) ^ ((nbytes - 8 * nwords) << 56));
+    }
     out[0] = nwords;
     out[1] = sum;
   });

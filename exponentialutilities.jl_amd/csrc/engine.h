@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -102,11 +103,24 @@ struct Ctx {
   // Handles that point back at this context (KrylovSubspace, operator, timestep caches).  A host language may destroy them in
   // any order (Julia runs finalizers in arbitrary order at exit): expv_mi_ctx_destroy clears their back pointers, and their own
   // destroy then frees the device memory without touching the context.
+  // The destroys are what a host language's finalizers call (Julia GC thread, Python weakref.finalize) and may run while the
+  // owning thread is inside a create on the same context: the list has its own lock (everything else of a context belongs to
+  // one thread at a time).
   std::vector<Ctx **> children;
-  void adopt(Ctx **slot) { children.push_back(slot); }
+  std::mutex children_mu;
+  void adopt(Ctx **slot) {
+    std::lock_guard<std::mutex> g(children_mu);
+    children.push_back(slot);
+  }
   void release(Ctx **slot) {
+    std::lock_guard<std::mutex> g(children_mu);
     for (size_t i = 0; i < children.size(); ++i)
       if (children[i] == slot) { children[i] = children.back(); children.pop_back(); return; }
+  }
+  void orphan_children() {                 // expv_mi_ctx_destroy: handles that outlive the context keep only their own destroy
+    std::lock_guard<std::mutex> g(children_mu);
+    for (Ctx **slot : children) *slot = nullptr;
+    children.clear();
   }
   void *ws_ts = nullptr;      // cached work arrays + KrylovSubspace of a phiv_timestep! call without caches (owned; engine_drivers.hip)
   void (*ws_ts_free)(void *) = nullptr;

@@ -110,7 +110,7 @@ class RowShardedDense:
         if self.on_gpu:
             # column splits like expv_mi_op_create_dense picks them: >= 1024 workgroups for a block with few row tiles
             nloc = self.hi - self.lo
-            rows_per_block = 256 * (1 if rows.is_complex() else 2)
+            rows_per_block = 256 * (16 // rows.element_size())     # a lane moves one 16-byte pack: 1 / 2 / 4 rows (capi.hip: op_create_dense)
             gx = max(1, -(-nloc // rows_per_block))
             self._nsplit = 1 if nloc < 64 else min(64, max(1, -(-1024 // gx)))
             self._scratch = torch.empty(max(1, self._nsplit * nloc), dtype=rows.dtype, device=rows.device) if self._nsplit > 1 else None
@@ -130,7 +130,9 @@ class RowShardedDense:
             return
         if self._ctx is None:
             raise RuntimeError("RowShardedDense: call operator(eu, ctx) first (the local GEMV runs on the library's stream)")
-        code = 1 if self.rows.is_complex() else 0
+        code = _DTYPE_CODE[self.rows.dtype]                        # EXPV_MI_F64 / C64 / F32 / C32: the block's own element type
+        if x.dtype != self.rows.dtype:
+            raise TypeError("RowShardedDense: x is %s, the row block %s" % (x.dtype, self.rows.dtype))
         if not x.is_contiguous():
             x = x.contiguous()
         rc = self._lib.expv_mi_gemv_block(self._ctx._h, code, nloc, self.n, self.rows.data_ptr(), self.rows.stride(1) if self.n > 1 else max(nloc, 1),
@@ -164,6 +166,20 @@ class RowShardedDense:
             self._lib = eu._lib.load()
         return eu.MIOperator(None, ctx, dtype=_np_dtype(self.rows.dtype), ishermitian=ishermitian, matvec=self.matvec,
                              shape=(self.n, self.n))
+
+
+class _DtypeCodes(dict):
+    """torch dtype -> the library's element-type code (include/expv_mi.h: EXPV_MI_F64 = 0, C64 = 1, F32 = 2, C32 = 3)"""
+
+    def __missing__(self, key):
+        import torch
+        self.update({torch.float64: 0, torch.complex128: 1, torch.float32: 2, torch.complex64: 3})
+        if key not in self:
+            raise TypeError("RowShardedDense: unsupported element type %s" % (key,))
+        return self[key]
+
+
+_DTYPE_CODE = _DtypeCodes()
 
 
 def _np_dtype(torch_dtype):

@@ -364,8 +364,10 @@ const char *expv_mi_abi_layout(int kind);
  * out[6] rows sorted and free of duplicates, out[7] slot cut-off of the SELL form (0: regular rows, every slice keeps its longest
  * row; > 0: irregular rows -- the entries of a row beyond the cut are applied from the CSR arrays by the overflow pass).  No reference counterpart (the reference stores CSC only). */
 int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int64_t out[8]);
-/* Order-sensitive wrap-around checksum of a host buffer: out = {whole 8-byte words, sum_i (2 i + 1) x_i mod 2^64 (+ tail bytes
- * weighted 1, 2, ...)}, threaded.  For host mirrors that keep an uploaded copy of a caller's matrix and must notice in-place
+/* Content hash of a host buffer: out = {whole 8-byte words, sum_i mix64(x_i ^ (i + 1) g) mod 2^64 (+ the tail bytes as one more
+ * word)}, mix64 = the two-round multiply / xor-shift finaliser, g = 0x9e3779b97f4a7c15; threaded.  Position-salted AND non-linear:
+ * a permutation of the contents changes it (the linear index-weighted sum of round 3 did not, for mantissa-free values at
+ * distances of 2048 k words).  For host mirrors that keep an uploaded copy of a caller's matrix and must notice in-place
  * changes (the reference reads A at call time, krylov_phiv.jl / arnoldi.jl mul!); no counterpart in the reference. */
 int expv_mi_host_wrapsum(const void *buf, uint64_t nbytes, uint64_t out[2]);
 int expv_mi_host_expm(int dtype, int n, void *A, int lda);

@@ -173,6 +173,12 @@ def test_host_pattern_info_selects_the_storage_forms(eu):
     assert i["sell"] and 1 <= i["sell_cut"] <= 4 and "overflow" in i["path"]               # one 400-entry row: slots up to a small cut + overflow
     assert i["pipeline_dia_diagonals"] == 0 and i["general_dia_diagonals"] == 0 and i["sell_wave_reach"] == -1
     assert eu.host_pattern_info(c2)["sell_cut"] == 0 and eu.host_pattern_info(irr)["sell_cut"] == 0
+    # heavy padding but no useful cut (every slice: half its rows empty, the others all alike) is a REGULAR-row
+    # pattern -- no overflow, the diagonal forms stay available
+    half = sp.diags([np.where(np.arange(n) % 2 == 0, 1.0, 0.0)], [0], shape=(n, n), format="csr")
+    half.eliminate_zeros()
+    i = eu.host_pattern_info(half)
+    assert i["sell"] and i["sell_cut"] == 0 and "overflow" not in i["path"]
     unsorted = sp.csr_matrix((np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1]), np.array([0, 2, 3])), shape=(2, 2))
     unsorted.has_sorted_indices = True                                                     # keep scipy from sorting them
     assert eu.host_pattern_info(unsorted)["rows_sorted_unique"] in (True, False)
@@ -319,10 +325,34 @@ def test_host_expm_across_blasfloat_types(eu, T, tol, scale):
         assert np.linalg.norm(w.astype(np.complex128) - w64) / np.linalg.norm(w64) < 10 * tol
 
 
+def _np_content_hash(a):
+    """The definition of expv_mi_host_wrapsum restated in numpy (test infrastructure): sum_i mix64(x_i ^ (i + 1) g) mod 2^64."""
+    M = 0xFFFFFFFFFFFFFFFF
+    a = np.ascontiguousarray(a).view(np.uint8).ravel()
+    nbytes = a.size
+    k = nbytes // 8 * 8
+    g = np.uint64(0x9e3779b97f4a7c15)
+
+    def mix(h):
+        h = h ^ (h >> np.uint64(33)); h = h * np.uint64(0xff51afd7ed558ccd)
+        h = h ^ (h >> np.uint64(33)); h = h * np.uint64(0xc4ceb9fe1a85ec53)
+        return h ^ (h >> np.uint64(33))
+    total = 0
+    with np.errstate(over="ignore"):
+        if k:
+            words = a[:k].copy().view(np.uint64)
+            salt = np.arange(1, words.size + 1, dtype=np.uint64) * g
+            total = int(np.add.reduce(mix(words ^ salt), dtype=np.uint64))
+        if nbytes > k:
+            x = int.from_bytes(bytes(a[k:]), "little")
+            salt = ((k // 8 + 1) * 0x9e3779b97f4a7c15) & M
+            total += int(mix(np.array([x ^ salt ^ ((nbytes - k) << 56)], dtype=np.uint64))[0])
+    return (k // 8, total & M)
+
+
 def test_library_wrapsum_equals_the_numpy_definition(eu):
-    """expv_mi_host_wrapsum (threaded, in the library) is the same order-sensitive checksum as the numpy form it replaces in the
-    content fingerprint: sum (2 i + 1) x_i mod 2^64 over the whole 8-byte words + the weighted tail bytes -- sizes around the
-    thread-split thresholds, unaligned starts, tails of 0..7 bytes."""
+    """expv_mi_host_wrapsum (threaded, in the library) against its definition restated in numpy: sizes around the thread-split
+    thresholds, unaligned starts, tails of 0..7 bytes."""
     import ctypes as C
     from exponentialutilities_jl_amd import _lib as L
     lib = L.load()
@@ -333,12 +363,49 @@ def test_library_wrapsum_equals_the_numpy_definition(eu):
             a = base[shift:shift + nbytes]
             out = (C.c_uint64 * 2)()
             assert lib.expv_mi_host_wrapsum(a.ctypes.data if nbytes else None, nbytes, out) == 0
-            k = nbytes // 8 * 8
-            words = a[:k].copy().view(np.uint64)
-            with np.errstate(over="ignore"):
-                ref = int(np.dot(words, np.arange(1, 2 * words.size, 2, dtype=np.uint64))) if words.size else 0
-                ref += int(np.add.reduce(a[k:].astype(np.uint64) * np.arange(1, nbytes - k + 1, dtype=np.uint64), dtype=np.uint64)) if nbytes > k else 0
-            assert (int(out[0]), int(out[1])) == (words.size, ref & 0xFFFFFFFFFFFFFFFF), (nbytes, shift)
+            assert (int(out[0]), int(out[1])) == _np_content_hash(a), (nbytes, shift)
+
+
+def test_content_hash_sees_permutations_of_mantissa_free_values(eu):
+    """the linear index-weighted sum of round 3 collided on exactly the values stencils are made of -- 1.0 and 2.0
+    trading places at a distance of 2048 k words, a reversed {-2, 1} stencil, permutations of equal-exponent values.  The
+    position-salted mixing hash sees all of them, through the fingerprint the Python mirror uses."""
+    import scipy.sparse as sp
+    from exponentialutilities_jl_amd import api
+    a = np.ones(5000)
+    a[2048] = 2.0
+    b = a.copy()
+    b[0], b[2048] = b[2048], b[0]
+    assert api._wrapsum(a) != api._wrapsum(b)                 # (round 3: both (5000, 8939645260330434560))
+    for k in (1, 2, 3, 7, 16):
+        big = np.ones(2048 * k + 10)
+        big[5] = 2.0
+        sw = big.copy()
+        sw[5], sw[5 + 2048 * k] = sw[5 + 2048 * k], sw[5]
+        assert api._wrapsum(big) != api._wrapsum(sw), k
+    n = 300_000                                               # large enough for the threaded path (> 2 MB of values)
+    A = sp.diags([1.0, -2.0, 1.0], [-2, 0, 1], shape=(n, n), format="csr")      # (the symmetric 1, -2, 1 is its own reverse)
+    f0 = api._fingerprint(A)
+    assert not np.array_equal(A.data, A.data[::-1])
+    A.data[:] = A.data[::-1].copy()                           # reversed in place: only 1.0 / -2.0 trade places
+    assert api._fingerprint(A) != f0
+    A.data[:] = A.data[::-1].copy()
+    assert api._fingerprint(A) == f0
+    rng = np.random.default_rng(11)
+    vals = np.ldexp(1.0 + rng.integers(0, 8, size=70000) / 8.0, 3)      # equal exponent, three mantissa bits
+    h0 = api._wrapsum(vals)
+    seen = {h0}
+    for _ in range(20):
+        i, j = rng.integers(0, vals.size, size=2)
+        if vals[i] == vals[j]:
+            continue
+        w = vals.copy()
+        w[i], w[j] = w[j], w[i]
+        h = api._wrapsum(w)
+        assert h not in seen
+        seen.add(h)
+    assert api._wrapsum(np.zeros(100)) != api._wrapsum(np.zeros(101))
+    assert api._wrapsum(np.zeros(3, dtype=np.uint8)) != api._wrapsum(np.zeros(5, dtype=np.uint8))
 
 
 def test_free_never_dereferences_the_context_handle(eu):

@@ -439,6 +439,15 @@ def test_32bit_operands_follow_the_reference_result_type(eu, T):
         As = ((A + A.T) / 2).astype(T)
         assert eu.expv(0.5, As, b, m=30, mode="error_estimate").dtype == np.dtype(T)
     assert eu.expv.last_stats["path"]                              # (dense: modular launches; sparse banded: the single-pass step)
+    # a Python complex t is a Complex in promote_type whatever its imaginary part -- expv(1 + 0im, A, b) is complex
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        wc = eu.expv(0.5 + 0j, A, b, m=30)
+        pc = eu.phiv(0.5 + 0j, A, b, 1, m=20)
+    assert wc.dtype == np.dtype(np.complex64) and pc.dtype == np.dtype(np.complex64)
+    close(wc.astype(np.complex128), truth, 2e-6, "expv with t = 0.5 + 0j and %s operands: complex result" % np.dtype(T).name)
+    assert eu.expv(0.5 + 0j, A.astype(np.float64 if np.dtype(T).kind == "f" else np.complex128), b.astype(np.float64 if np.dtype(T).kind == "f" else np.complex128), m=30).dtype == np.dtype(np.complex128)
 
 
 @pytest.mark.parametrize("T", [np.float32, np.complex64])
@@ -668,6 +677,41 @@ def test_row_sharded_dense_operator_on_the_device(eu):
     assert (st["num_timesteps"], st["matvecs"], st["m"]) == (sd["num_timesteps"], sd["matvecs"], sd["m"]), (st, sd)
     assert sh.applications >= st["matvecs"]
     close(U, Ud, 1e-12, "phiv_timestep through the row-sharded operator vs the dense operator (n=%d)" % n)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex64, np.complex128])
+def test_row_sharded_dense_operator_passes_its_own_element_type(eu, dtype):
+    """RowShardedDense handed every block to expv_mi_gemv_block as fp64 / complex-fp64; a Float32 /
+    ComplexF32 block (which operator() creates natively in that type) was read as 8 / 16-byte elements.  mul! and expv through the
+    sharded operator (world size 1) against numpy / the dense operator of the same type, at a size that takes the column-split
+    form."""
+    import importlib.util, os, torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mi_dist", os.path.join(root, "exponentialutilities.jl_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    n = 1300
+    rng = np.random.default_rng(17)
+    A = (rng.standard_normal((n, n)) / np.sqrt(n)).astype(dtype)
+    x = rng.standard_normal(n).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        A = (A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)).astype(dtype)
+        x = (x + 1j * rng.standard_normal(n)).astype(dtype)
+    ctx = eu.Context()
+    sh = D.RowShardedDense(D.RowShardedDense.column_major(torch.as_tensor(np.ascontiguousarray(A), device="cuda")), n)
+    assert sh._nsplit > 1
+    op = sh.operator(eu, ctx)
+    assert op.dtype == np.dtype(dtype)
+    tol = 2e-5 if np.dtype(dtype).itemsize <= 8 else 1e-13
+    y = np.asarray(op.matvec(x))
+    close(y, A.astype(np.complex128 if np.dtype(dtype).kind == "c" else np.float64) @ x, tol, "row-sharded mul! %s vs numpy" % np.dtype(dtype).name)
+    w = np.asarray(eu.expv(0.7, op, x, m=12))
+    wd = np.asarray(eu.expv(0.7, eu.MIOperator(A, ctx), x, m=12))
+    assert w.dtype == wd.dtype
+    close(w, wd, tol, "expv through the row-sharded %s operator vs the dense operator" % np.dtype(dtype).name)
+    with pytest.raises(TypeError):
+        sh._local_gemv(torch.zeros(n, dtype=torch.float64 if dtype != np.float64 else torch.float32, device="cuda")
+                       if dtype != np.complex128 else torch.zeros(n, dtype=torch.float64, device="cuda"))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
