@@ -159,6 +159,10 @@ class Env:
     def __init__(self, torch, dist, world, rank, device, ctx, standin=None):
         self.torch, self.dist, self.world, self.rank, self.device, self.ctx = torch, dist, world, rank, device, ctx
         self.standin = standin          # name of the stand-in solver module (CPU plumbing tests only), or None
+        # collectives run whenever a process group exists -- also at world size 1 under a launcher (torch.distributed.run
+        # --nproc-per-node 1): the RCCL code path then executes for real on a one-GPU box
+        self.coll = bool(dist is not None and dist.is_available() and dist.is_initialized())
+        self.backend = dist.get_backend() if self.coll else None
 
     def sync(self):
         if str(self.device).startswith("cuda"):
@@ -168,12 +172,12 @@ class Env:
 
     def barrier(self):
         self.sync()
-        if self.world > 1:
+        if self.coll:
             self.dist.barrier()
 
     def ranks_seen(self):
         """all-reduce of ones: how many ranks really took part in the job."""
-        if self.world == 1:
+        if not self.coll:
             return 1
         t = self.torch.ones(1, dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -193,7 +197,7 @@ class Env:
             mine = "%s/%s/%s" % (socket.gethostname(), getattr(pr, "uuid", "no-uuid"), pci)
         else:
             mine = "%s/pid%d" % (socket.gethostname(), os.getpid())
-        if self.world == 1:
+        if not self.coll:
             return [mine]
         out = [None] * self.world
         self.dist.all_gather_object(out, mine)
@@ -209,7 +213,7 @@ class Env:
 
     def per_rank(self, x):
         """every rank's value of a scalar, in rank order."""
-        if self.world == 1:
+        if not self.coll:
             return [float(x)]
         mine = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
         out = self.torch.empty(self.world, dtype=self.torch.float64, device=self.device)
@@ -256,7 +260,7 @@ def run_c3(args, eu, env, emit=True):
     n = args.n3 if args.n3 > 0 else (200_000 if world > 1 else 163_840)
     lo, hi = D.shard_range(n, world, rank)
     rows = c3_rows(torch, env.device, n, lo, hi)
-    sh = D.RowShardedDense(rows, n)
+    sh = D.RowShardedDense(rows, n, collective_at_world_1=env.coll)
     op = sh.operator(eu, env.ctx)
     g = torch.Generator(device=env.device)
     g.manual_seed(5)
@@ -268,7 +272,7 @@ def run_c3(args, eu, env, emit=True):
     for _ in range(max(1, args.warmup)):
         u = step()
     env.barrier()
-    a0 = sh.applications
+    a0, c0 = sh.applications, sh.collectives
     t0 = time.perf_counter()
     for _ in range(args.steps):
         u = step()
@@ -280,7 +284,7 @@ def run_c3(args, eu, env, emit=True):
     # every rank holds the full result of the replicated iteration: they must agree to the last bit
     chk = torch.stack([u.abs().sum(), (u * torch.arange(n, device=env.device, dtype=torch.float64)).sum()])
     lo_chk, hi_chk = chk.clone(), chk.clone()
-    if world > 1:
+    if env.coll:
         env.dist.all_reduce(lo_chk, op=env.dist.ReduceOp.MIN)
         env.dist.all_reduce(hi_chk, op=env.dist.ReduceOp.MAX)
     same = bool(torch.equal(lo_chk, hi_chk))
@@ -294,6 +298,7 @@ def run_c3(args, eu, env, emit=True):
                                   "rows sharded over %d GPU(s)" % (n, 8e-9 * n * n, world), "n": n, "K": 4},
            "stats": {k: st.get(k) for k in ("num_timesteps", "matvecs", "m")}, "applications_per_call": apps / args.steps,
            "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "process_group": env.backend, "collectives_per_call": (sh.collectives - c0) / args.steps,
            "verified": {"replicas_bitwise_equal": same},
            "roofline": {"bound": "hbm", "achieved": gbps_per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps_per_gpu / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "k_gemv_dense on the rank's column-major row block (expv_mi_gemv_block) + all_gather of n*8 B",
@@ -328,7 +333,7 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
 
     def step():
         local["W"] = eu.expv_batch(T_FINAL, A0, vals, B, m=m, ctx=env.ctx)
-        return D.gather_columns(local["W"], nprob) if world > 1 else local["W"]
+        return D.gather_columns(local["W"], nprob) if env.coll else local["W"]
 
     for _ in range(args.warmup):
         step()
@@ -341,7 +346,7 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
     units, elapsed = D.aggregate_throughput((hi - lo) * m * args.steps, elapsed_local, device=env.device)
     # ---- the final gather alone (untimed extra): the one collective of the path, n x nprob fp64 over all ranks ----
     gather_ms = None
-    if world > 1:
+    if env.coll:
         env.barrier()
         tg = time.perf_counter()
         for _ in range(args.steps):
@@ -368,8 +373,9 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True):
            "config": {"workload": "BASELINE configs[4]: %d independent expv, n=%d, 5-diagonal, m=%d, sharded over %d "
                                   "GPU(s), final gather" % (nprob, n, m, world), "nprob": nprob, "n": n, "m": m},
            "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": [1e3 * v / args.steps for v in env.per_rank(elapsed_local)],
+           "process_group": env.backend,
            "gather": {"ms": gather_ms, "bytes_total": 8.0 * n * nprob,
-                      "what": "the final all_gather of the n x nprob result alone (inside ms_per_step too); null at one rank"},
+                      "what": "the final all_gather of the n x nprob result alone (inside ms_per_step too); null without a process group"},
            "verified": {"columns_per_rank": 2, "columns_rank0": cols, "max_rel_err": worst_all, "bar": 1e-12,
                         "how": "gathered W[:, p] vs expv(t, A_p, b_p) recomputed on the checking rank"},
            "roofline": {"bound": "hbm", "achieved": per_gpu_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -740,7 +746,7 @@ def launch_ranks(ngpus, argv):
     envv = dict(os.environ)
     envv.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
     envv.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=envv)
+    return subprocess.call(cmd, env=envv)      # (EXPV_MI_BENCH_STANDIN_OK, when a test set it, is inherited)
 
 
 def main(argv=None):
@@ -775,15 +781,20 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
 
+    launched = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run (the driver's N > 1 form)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d: one rank per GPU is the contract" % (args.gpus, world))
     if args.standin:
+        # the stand-in swaps the product for a CPU solver: only the gloo plumbing tests may do that, and they say so in the
+        # environment as well -- a stray flag on a command line cannot put stand-in output into a bench line
+        if os.environ.get("EXPV_MI_BENCH_STANDIN_OK") != "tests-only":
+            raise SystemExit("--standin is test plumbing (tests/test_dist_gloo.py); refusing to run it as a benchmark")
         import importlib
         eu = importlib.import_module(args.standin).StandIn
-        if world > 1:
+        if launched:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
         env = Env(torch, dist, world, rank, "cpu", None, standin=args.standin)
@@ -793,7 +804,7 @@ def main(argv=None):
         if local_rank >= torch.cuda.device_count():
             raise SystemExit("rank %d wants GPU %d, the node shows %d" % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
-        if world > 1:
+        if launched:      # one rank per GPU over RCCL -- also a single rank under a launcher (the collectives then run at world size 1)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         import expv_mi_loader
@@ -809,7 +820,7 @@ def main(argv=None):
         else:
             run_c2(args, eu, env)
     finally:
-        if world > 1 and dist.is_initialized():
+        if dist.is_available() and dist.is_initialized():
             dist.destroy_process_group()
 
 
@@ -939,12 +950,27 @@ def run_c2(args, eu, env):
                    "n": n, "m": m, "nnz": int(nnz), "ortho": args.ortho, "setup_s": t_setup,
                    "entry": "arnoldi!+expv!" if args.split_api else "expv(t,A,b)", "path": path,
                    "outputs": "complete on return" if args.sync_outputs else "stream-ordered"},
-        "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": per_rank_ms,
+        "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": per_rank_ms, "process_group": env.backend,
         "counters": ctx.counters() if ctx is not None else None,
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_secondary and n == N_ROWS and not args.split_api and ctx is not None:
-        out["secondary"] = secondary_block(args, eu, env, op, b, w, n, nnz, m)
+        sec = secondary_block(args, eu, env, op, b, w, n, nnz, m)
+        # the driver's record keeps the head of this line: the figures the verdicts ask about are repeated up front, in
+        # `config` (the full entries follow in `secondary`)
+        sa = sec.get("split_api_sync_outputs", {})
+        out["config"]["split_api_sync_outputs"] = {"value": sa.get("value"), "frac": sa.get("frac"), "ms_per_call": sa.get("ms_per_call"),
+                                                   "what": "arnoldi!(Ks,A,b) + expv!(w,t,Ks), results complete on return (the Julia shim's path)"}
+        summ = {}
+        for k_, e_ in sec.items():
+            if isinstance(e_, dict) and e_.get("frac") is not None:
+                summ[k_] = round(float(e_["frac"]), 3)
+        sm = sec.get("small_systems", {})
+        for k_, e_ in sm.items():
+            if isinstance(e_, dict) and "us_per_krylov_step" in e_:
+                summ["small_systems." + k_ + ".us_per_step"] = round(float(e_["us_per_krylov_step"]), 2)
+        out["config"]["secondary_fracs"] = summ
+        out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline and ctx is not None:
         eu.expv(T_FINAL, op, b, m=m, ishermitian=False, ortho=args.ortho, out=w)
         env.sync()

@@ -50,7 +50,7 @@ class TimestepOpts(C.Structure):
 
 class TimestepStats(C.Structure):
     _fields_ = [("num_timesteps", C.c_int32), ("matvecs", C.c_int32), ("m_final", C.c_int32),
-                ("arnoldi_calls", C.c_int32), ("arnoldi_reused", C.c_int32), ("reserved", C.c_int32)]
+                ("arnoldi_calls", C.c_int32), ("arnoldi_reused", C.c_int32), ("stalled_steps", C.c_int32)]
 
 
 class KiopsOpts(C.Structure):

@@ -881,7 +881,11 @@ def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0
     o.ortho = {"auto": 0, "mgs": 1, "lowsync": 2}[ortho] if isinstance(ortho, str) else int(ortho)
     o.NA = int(NA)
     o.no_basis_reuse = int(not reuse_basis)
-    sink = out if out is not None else print
+    if verbose:
+        sink = out if out is not None else print
+    else:      # not verbose: the only line the library sends is its slow-progress notice (stats["stalled_steps"]) -- a warning
+        import warnings
+        sink = lambda line: warnings.warn(line, RuntimeWarning, stacklevel=3)
     cb = L.PRINT_FN(lambda line, user: sink(line.decode()))
     o.print = cb
     st = L.TimestepStats()
@@ -893,7 +897,7 @@ def phiv_timestep_(U, ts, A, B, *, tau=0.0, m=None, tol=1e-7, opnorm=None, iop=0
         ts[...] = ts_arr
     if stats is not None:
         stats.update(num_timesteps=st.num_timesteps, matvecs=st.matvecs, m=st.m_final, arnoldi_calls=st.arnoldi_calls,
-                     arnoldi_reused=st.arnoldi_reused)
+                     arnoldi_reused=st.arnoldi_reused, stalled_steps=st.stalled_steps)
     return U
 
 

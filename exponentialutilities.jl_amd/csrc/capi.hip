@@ -1434,7 +1434,7 @@ const char *expv_mi_abi_layout(int kind) {
                                            std::string(EXPV_MI_F(expv_mi_timestep_opts, print, "ptr")), std::string(EXPV_MI_F(expv_mi_timestep_opts, print_user, "ptr"))});
     out[EXPV_MI_ABI_TIMESTEP_STATS] = join({std::string(EXPV_MI_F(expv_mi_timestep_stats, num_timesteps, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, matvecs, "i32")),
                                             std::string(EXPV_MI_F(expv_mi_timestep_stats, m_final, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, arnoldi_calls, "i32")),
-                                            std::string(EXPV_MI_F(expv_mi_timestep_stats, arnoldi_reused, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, reserved, "i32"))});
+                                            std::string(EXPV_MI_F(expv_mi_timestep_stats, arnoldi_reused, "i32")), std::string(EXPV_MI_F(expv_mi_timestep_stats, stalled_steps, "i32"))});
     out[EXPV_MI_ABI_KIOPS_OPTS] = join({std::string(EXPV_MI_F(expv_mi_kiops_opts, mmin, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, mmax, "i32")),
                                         std::string(EXPV_MI_F(expv_mi_kiops_opts, m, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, iop, "i32")),
                                         std::string(EXPV_MI_F(expv_mi_kiops_opts, ishermitian, "i32")), std::string(EXPV_MI_F(expv_mi_kiops_opts, task1, "i32")),

@@ -83,7 +83,7 @@ class RowShardedDense:
     other communication, and every rank ends with the full result.  `operator(eu, ctx)` wraps it as the library's matrix-free
     operator (expv_mi_op_create_callback).  A CPU tensor (the gloo tests of the collective plumbing) takes torch.mv."""
 
-    def __init__(self, rows, n, group=None, stage_through_host=False):
+    def __init__(self, rows, n, group=None, stage_through_host=False, collective_at_world_1=False):
         import torch
         import torch.distributed as dist
         self.rows = rows
@@ -105,6 +105,10 @@ class RowShardedDense:
         self._send = torch.zeros(self.width, dtype=rows.dtype, device=rows.device)
         self._recv = torch.empty(self.world * self.width, dtype=rows.dtype, device=rows.device)
         self.applications = 0
+        self.collectives = 0
+        # a single rank needs no exchange; with this flag it runs the all-gather anyway (a one-rank RCCL group on a one-GPU box
+        # executes the same collective code as N ranks do)
+        self.always_collective = bool(collective_at_world_1) and self.dist is not None
         self._ctx = None
         self._lib = None
         if self.on_gpu:
@@ -146,8 +150,9 @@ class RowShardedDense:
         import torch
         self.applications += 1
         self._local_gemv(x)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return self._send[: self.hi - self.lo]
+        self.collectives += 1
         if self.stage:
             send, recv = self._send.cpu(), torch.empty(self.world * self.width, dtype=self._send.dtype)
             self.dist.all_gather_into_tensor(recv, send, group=self.group)

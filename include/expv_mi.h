@@ -276,7 +276,8 @@ typedef struct {
                              bit-identical results, the saved factorisations are counted in stats.arnoldi_reused */
   int32_t reserved;
   int64_t NA;          /* 0: nnz of the operator                                    */
-  expv_mi_print_fn print;
+  expv_mi_print_fn print; /* verbose lines go here (stdout when NULL); the slow-progress notice (stats.stalled_steps) goes
+                             here whenever it is set, verbose or not                                                          */
   void *print_user;
 } expv_mi_timestep_opts;
 typedef struct {
@@ -286,7 +287,9 @@ typedef struct {
   int32_t arnoldi_calls;  /* factorisations the reference performs for this call (control-flow parity)             */
   int32_t arnoldi_reused; /* ... of which this many were NOT recomputed (tau-only retries reuse the basis);
                              `matvecs` keeps counting what the reference performs                                   */
-  int32_t reserved;
+  int32_t stalled_steps;  /* 0, or -- when it reached 10^4 -- the longest run of accepted sub-steps over which the step never
+                             grew: the reference's controller keeps a tiny seed step for the whole interval
+                             (krylov_phiv_adaptive.jl:391-417); the same is reported once per decade through `print`          */
 } expv_mi_timestep_stats;
 void expv_mi_timestep_opts_default(expv_mi_timestep_opts *o);
 /* _phiv_timestep_caches(u_prototype, maxiter, p)  (krylov_phiv_adaptive.jl:502-511) */

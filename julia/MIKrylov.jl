@@ -85,7 +85,7 @@ struct TimestepStats
     m_final::Cint
     arnoldi_calls::Cint
     arnoldi_reused::Cint
-    reserved::Cint
+    stalled_steps::Cint
 end
 struct KiopsOpts
     mmin::Cint
@@ -467,6 +467,11 @@ end
 const PRINTLN = Ref{Ptr{Cvoid}}(C_NULL)
 _println_cb(line::Cstring, ::Ptr{Cvoid}) = (println(unsafe_string(line)); nothing)
 println_ptr() = (PRINTLN[] == C_NULL && (PRINTLN[] = @cfunction(_println_cb, Cvoid, (Cstring, Ptr{Cvoid}))); PRINTLN[])
+# the library's slow-progress notice (>= 10^4 accepted sub-steps without step growth: the reference's controller keeps a tiny seed
+# step, krylov_phiv_adaptive.jl:391-417) reaches the user as a warning even without `verbose`
+const WARNLN = Ref{Ptr{Cvoid}}(C_NULL)
+_warn_cb(line::Cstring, ::Ptr{Cvoid}) = (@warn unsafe_string(line); nothing)
+warn_ptr() = (WARNLN[] == C_NULL && (WARNLN[] = @cfunction(_warn_cb, Cvoid, (Cstring, Ptr{Cvoid}))); WARNLN[])
 
 # phiv_timestep!(U, ts, A, B; ...)  -- the whole controller runs in the library                 (:260-453)
 function phiv_timestep!(U::MIVecOrMat{T}, ts::AbstractVector{tType}, A::MIOperator{T}, B::MIVecOrMat{T};
@@ -482,7 +487,7 @@ function phiv_timestep!(U::MIVecOrMat{T}, ts::AbstractVector{tType}, A::MIOperat
         has_opn, opn = 1, Float64(opnorm isa Number ? opnorm : opnorm(A, Inf))  # a number or a function (:276-281)
     end
     o = Ref(TimestepOpts(tau, tol, delta, gamma, opn, has_opn, m, iop, correct, adaptive, ishermitian, verbose, 0, 0, 0, NA,
-                         verbose ? println_ptr() : C_NULL, C_NULL))
+                         verbose ? println_ptr() : warn_ptr(), C_NULL))
     st = Ref(TimestepStats(0, 0, 0, 0, 0, 0))
     check(ccall((:expv_mi_phiv_timestep, lib), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cvoid}, Int64, Cint, Cint, Ptr{Cvoid}, Int64, Cint,

@@ -234,6 +234,7 @@ def _run_bench(extra, env_extra=None):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env["EXPV_MI_BENCH_STANDIN_OK"] = "tests-only"               # bench.py refuses --standin without it
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--standin",
                         "tests.standin_eu"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -257,6 +258,13 @@ def test_bench_gpus_2_launches_two_ranks_by_itself(cfg):
         assert out["verified"]["replicas_bitwise_equal"] is True and out["config"]["n"] == 101
     if cfg[1] == "c2":
         assert out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_bench_refuses_the_standin_outside_the_tests():
+    """--standin swaps the product for an oracle-backed CPU solver inside the bench harness; a flag alone must not be
+    enough to put its output into a bench line."""
+    r, out, lines = _run_bench(["--gpus", "1", "--config", "c2", "--n", "300"], env_extra={"EXPV_MI_BENCH_STANDIN_OK": ""})
+    assert r.returncode != 0 and not lines and "refusing" in (r.stderr + r.stdout)
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

@@ -1338,3 +1338,87 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+
+
+def _bench_under_launcher(extra, timeout=900):
+    """bench.py as the driver launches it for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- with N = 1: backend nccl (= RCCL), a real process group, real
+    collectives on the device, at world size 1 (the test box has one GPU)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1"] + extra,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_c5_under_the_launcher_runs_the_rccl_gather_at_world_size_1():
+    """the RCCL code path (not gloo) has executed -- `bench.py --config c5 --gpus 1` as a subprocess under
+    torch.distributed.run, backend nccl: process-group init, the all-reduce / all-gather of the rank checks, and THE collective of
+    the path, all_gather_into_tensor of the result block on the device; the gathered matrix is then verified column by column
+    against the single-problem entry point like at any world size."""
+    d = _bench_under_launcher(["--config", "c5", "--nprob", "12", "--steps", "2", "--warmup", "1"])
+    assert d["process_group"] == "nccl" and d["n_gpus"] == 1 and d["ranks_seen"] == 1 and len(d["devices"]) == 1
+    assert d["gather"]["ms"] is not None and d["gather"]["ms"] > 0          # the final gather ran, alone, and was timed
+    assert d["verified"]["max_rel_err"] <= 1e-12
+    assert d["value"] > 0 and d["config"]["nprob"] == 12
+
+
+@pytest.mark.gpu
+def test_c3_under_the_launcher_runs_the_rccl_all_gather_per_application():
+    """... and `--config c3 --gpus 1` the same way: the row-sharded dense operator performs its ONE all_gather_into_tensor per
+    operator application over RCCL from inside the library's matrix-free callback (on the library's stream), at world size 1."""
+    d = _bench_under_launcher(["--config", "c3", "--n3", "4096", "--steps", "2", "--warmup", "1"])
+    assert d["process_group"] == "nccl" and d["ranks_seen"] == 1
+    assert d["collectives_per_call"] >= d["applications_per_call"] > 0
+    assert d["verified"]["replicas_bitwise_equal"] is True and d["config"]["n"] == 4096
+
+
+@pytest.mark.gpu
+def test_c2_under_the_launcher_at_world_size_1():
+    """The headline config through the driver's N > 1 launch form at N = 1: barrier and per-rank gathers over RCCL around the timed
+    region."""
+    d = _bench_under_launcher(["--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-serial-pass"])
+    assert d["process_group"] == "nccl" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["per_rank_ms_per_step"]) == 1
+
+
+@pytest.mark.gpu
+def test_slow_progress_of_the_reference_controller_is_reported_not_changed(eu):
+    """the reference's adaptive controller never lengthens a step that meets the tolerance
+    (krylov_phiv_adaptive.jl:391-417), so a tiny seed step is kept for the whole interval.  The library reproduces that (same
+    number of sub-steps as tend / tau) and says so: one notice per decade through the print callback -- a RuntimeWarning in the
+    Python mirror, also without `verbose` -- and stats["stalled_steps"]."""
+    import warnings
+    n = 256
+    A = c2_operator(n).tocsc()
+    b = np.random.default_rng(2).standard_normal(n)
+    st = {}
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        u = eu.expv_timestep(0.0125, A, b, tau=1e-6, adaptive=True, tol=1e-6, m=5, stats=st)
+    assert st["num_timesteps"] >= 12_500 and st["stalled_steps"] >= 10_000, st
+    msgs = [str(w.message) for w in rec if "without step growth" in str(w.message)]
+    assert len(msgs) == 1 and "krylov_phiv_adaptive.jl:391-417" in msgs[0], msgs
+    close(u, sl.expm(0.0125 * A.toarray()) @ b, 1e-9, "expv_timestep over 12 500 kept seed steps vs dense truth")
+    st2 = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                  # an ordinary run: no notice, field zero
+        eu.expv_timestep(1.0, A, b, adaptive=True, tol=1e-6, stats=st2)
+    assert st2["stalled_steps"] == 0 and st2["num_timesteps"] < 100

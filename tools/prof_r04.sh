@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-4 profiling passes (run on the GPU box; writes under gpurun_out/).
+#  1. headline command in the DEFAULT (overlapped) mode: rocprofv3 kernel trace + stats -> tools/step_cadence.py reproduces
+#     roofline.frac from the trace (end-to-end cadence of consecutive k_pipe_live launches)
+#  2. the same in serial mode (per-launch durations)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+CMD="python bench.py --no-cpu-baseline --no-secondary --no-serial-pass --steps 8 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_default -o t -- $CMD > gpurun_out/r4_default.log 2>&1
+python tools/step_cadence.py gpurun_out/r4_default --skip 3 > gpurun_out/r04_step_cadence.txt 2>&1
+tail -12 gpurun_out/r04_step_cadence.txt
+EXPV_MI_PIPE_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4_serial -o t -- $CMD > gpurun_out/r4_serial.log 2>&1
+find gpurun_out -name "*.db" -delete
+ls gpurun_out/r4_default/*/ | head
