@@ -1,0 +1,163 @@
+// reorder.h -- host side of the bandwidth-reducing row/column ordering of an unstructured sparse operator.
+//
+// The reference applies the operator with whatever ordering the caller's SparseMatrixCSC has (mul!, /root/reference/src/
+// arnoldi.jl:185); its own GPU test matrix is sprand (/root/reference/test/gpu/gputests.jl:41-48).  The Krylov quantities the
+// caller sees -- H, beta, and through V the results w -- do not depend on a symmetric permutation P of the unknowns:
+// arnoldi(P A P', P b) has the same H and the basis P V.  So an operator whose natural ordering leaves it on the two-kernel step
+// (fused.hip: the basis read twice per step, every gather a cache miss) may be stored as P A P' when that puts it on the single-pass
+// step (pipe.hip: halo or wave form): vectors are permuted once on entry and once on exit (capi.hip), the basis stays permuted.
+//
+// P is reverse Cuthill-McKee on the pattern of A + A' (George & Liu pseudo-peripheral start per connected component, neighbours
+// by ascending degree).  Host only, O(nnz log d): part of operator creation (setup cost, reported by the bench).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace expv_mi {
+namespace reorder {
+
+// perm[i] = the row of A that becomes row i of P A P'
+inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci) {
+  std::vector<int32_t> perm((size_t)n);
+  if (n <= 0) return perm;
+  // --- symmetric adjacency without self loops: count, fill, sort + unique per node ---
+  std::vector<int64_t> ap((size_t)n + 1, 0);
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const int32_t c = ci[k];
+      if (c == r) continue;
+      ++ap[r + 1];
+      ++ap[c + 1];
+    }
+  for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
+  std::vector<int32_t> adj((size_t)ap[n]);
+  {
+    std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
+    for (int64_t r = 0; r < n; ++r)
+      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+        const int32_t c = ci[k];
+        if (c == r) continue;
+        adj[(size_t)fill[r]++] = c;
+        adj[(size_t)fill[c]++] = (int32_t)r;
+      }
+  }
+  std::vector<int32_t> deg((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t *b = adj.data() + ap[i], *e = adj.data() + ap[i + 1];
+    std::sort(b, e);
+    deg[i] = (int32_t)(std::unique(b, e) - b);      // (entries beyond deg[i] of the node's range are unused)
+  }
+  // neighbours by ascending degree (ties: ascending index): the Cuthill-McKee visiting order, fixed once
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t *b = adj.data() + ap[i];
+    std::sort(b, b + deg[i], [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
+  }
+  // nodes by ascending degree: candidates for the start of each component
+  std::vector<int32_t> bydeg((size_t)n);
+  std::iota(bydeg.begin(), bydeg.end(), 0);
+  std::stable_sort(bydeg.begin(), bydeg.end(), [&](int32_t x, int32_t y) { return deg[x] < deg[y]; });
+
+  std::vector<int32_t> stamp((size_t)n, 0), queue((size_t)n);
+  std::vector<char> placed((size_t)n, 0);
+  int32_t cur_stamp = 0;
+  // breadth-first level structure rooted at s inside the not-yet-placed part; returns (eccentricity, last-level node of least degree)
+  auto bfs_far = [&](int32_t s, int32_t *far, int64_t *width) {
+    ++cur_stamp;
+    int64_t head = 0, tail = 0, level_end = 1;
+    int32_t ecc = 0;
+    queue[(size_t)tail++] = s;
+    stamp[s] = cur_stamp;
+    int64_t level_begin = 0;
+    *width = 1;
+    while (head < tail) {
+      const int32_t u = queue[(size_t)head++];
+      for (int32_t k = 0; k < deg[u]; ++k) {
+        const int32_t v = adj[(size_t)ap[u] + k];
+        if (stamp[v] == cur_stamp || placed[v]) continue;
+        stamp[v] = cur_stamp;
+        queue[(size_t)tail++] = v;
+      }
+      if (head == level_end && head < tail) {
+        ++ecc;
+        level_begin = level_end;
+        level_end = tail;
+        *width = std::max<int64_t>(*width, level_end - level_begin);
+      }
+    }
+    int32_t best = queue[(size_t)level_begin];
+    for (int64_t q = level_begin; q < tail; ++q)
+      if (deg[queue[(size_t)q]] < deg[best]) best = queue[(size_t)q];
+    *far = best;
+    return ecc;
+  };
+  int64_t pos = 0;
+  std::vector<int32_t> order((size_t)n);
+  for (int64_t cand = 0; cand < n; ++cand) {
+    int32_t s = bydeg[(size_t)cand];
+    if (placed[s]) continue;
+    // George & Liu: walk to a node of (locally) largest eccentricity
+    int32_t far = s;
+    int64_t width = 0;
+    int32_t ecc = bfs_far(s, &far, &width);
+    for (int it = 0; it < 8; ++it) {
+      int32_t far2 = far;
+      int64_t w2 = 0;
+      const int32_t ecc2 = bfs_far(far, &far2, &w2);
+      if (ecc2 <= ecc) { if (w2 < width) s = far; break; }
+      s = far;
+      far = far2;
+      ecc = ecc2;
+      width = w2;
+    }
+    // Cuthill-McKee from s
+    const int64_t first = pos;
+    int64_t head = pos;
+    order[(size_t)pos++] = s;
+    placed[s] = 1;
+    while (head < pos) {
+      const int32_t u = order[(size_t)head++];
+      for (int32_t k = 0; k < deg[u]; ++k) {
+        const int32_t v = adj[(size_t)ap[u] + k];
+        if (placed[v]) continue;
+        placed[v] = 1;
+        order[(size_t)pos++] = v;
+      }
+    }
+    std::reverse(order.begin() + first, order.begin() + pos);      // reverse Cuthill-McKee, component by component
+  }
+  for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = order[(size_t)i];
+  return perm;
+}
+
+// P A P' in CSR with ascending columns per row; src[k] = index of entry k of the result in the original arrays
+inline void permute_csr(int64_t n, const int32_t *rp, const int32_t *ci, const std::vector<int32_t> &perm, std::vector<int32_t> &rp2,
+                        std::vector<int32_t> &ci2, std::vector<int32_t> &src) {
+  std::vector<int32_t> inv((size_t)n);
+  for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+  rp2.assign((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) rp2[(size_t)i + 1] = rp2[(size_t)i] + (rp[perm[(size_t)i] + 1] - rp[perm[(size_t)i]]);
+  const size_t nnz = (size_t)rp2[(size_t)n];
+  ci2.resize(nnz);
+  src.resize(nnz);
+  std::vector<std::pair<int32_t, int32_t>> row;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t r = perm[(size_t)i];
+    row.clear();
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) row.emplace_back(inv[(size_t)ci[k]], k);
+    std::sort(row.begin(), row.end());      // (duplicates of a column keep their original order: pairs compare by source index next)
+    int32_t o = rp2[(size_t)i];
+    for (const auto &e : row) { ci2[(size_t)o] = e.first; src[(size_t)o] = e.second; ++o; }
+  }
+}
+
+inline int64_t bandwidth(int64_t n, const int32_t *rp, const int32_t *ci) {
+  int64_t w = 0;
+  for (int64_t r = 0; r < n; ++r)
+    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) w = std::max<int64_t>(w, ci[k] > r ? ci[k] - r : r - ci[k]);
+  return w;
+}
+
+}  // namespace reorder
+}  // namespace expv_mi
