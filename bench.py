@@ -546,8 +546,20 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
     import scipy.sparse.linalg as spl
     for key, kind in (("general_sparse_random", "random"), ("general_sparse_local", "local"), ("general_sparse_local_narrow", "local_narrow"),
-                      ("irregular_sparse_powerlaw", "powerlaw")):
-        Ag = general_sparse_operator(kind, n)
+                      ("irregular_sparse_powerlaw", "powerlaw"), ("general_sparse_rcm", "shuffled_band"), ("general_sparse_rcm_grid", "shuffled_grid")):
+        if kind == "shuffled_band":
+            # the headline operator under a random symmetric permutation of its unknowns (an "unstructured" numbering of a banded
+            # problem): operator creation finds a bandwidth-reducing ordering (reverse Cuthill-McKee, reorder.h) and keeps P A P'
+            q_ = np.random.default_rng(17).permutation(n)
+            Ag = c2_operator(n)[q_][:, q_].tocsr()
+        elif kind == "shuffled_grid":
+            kq = int(round(np.sqrt(n)))
+            q_ = np.random.default_rng(18).permutation(kq * kq)
+            Ag = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-kq, -1, 0, 1, kq], shape=(kq * kq, kq * kq), format="csr")[q_][:, q_].tocsr()
+            if kq * kq != n:
+                continue
+        else:
+            Ag = general_sparse_operator(kind, n)
         t0 = time.perf_counter()
         opx = eu.MIOperator(Ag, ctx)
         t_set = time.perf_counter() - t0
@@ -560,10 +572,12 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         truth = spl.expm_multiply(Ag * T_FINAL, b.cpu().numpy())
         rl = np.diff(Ag.indptr)
         e = entry("expv, %s rows / %s columns, n=%d nnz=%d m=%d" % ("irregular (Zipf)" if kind == "powerlaw" else "regular",
-                  {"local": "local (+-2 %% of the row)", "local_narrow": "local (+-0.2 %% of the row)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
+                  {"local": "local (+-2 %% of the row)", "local_narrow": "local (+-0.2 %% of the row)",
+                   "shuffled_band": "the C2 operator under a random symmetric permutation (reordered at creation)",
+                   "shuffled_grid": "a 2-D 5-point grid operator under a random symmetric permutation (reordered at creation)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
                   tx, m, alg_bytes_expv(n, Ag.nnz, m),
                   path=pathx, setup_s=t_set, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
-                  storage=eu.host_pattern_info(Ag)["path"],
+                  storage=eu.host_pattern_info(Ag)["path"], reorder=opx.reorder_info,
                   verified_vs_scipy_expm_multiply=float(np.linalg.norm(wx - truth) / np.linalg.norm(truth)))
         if e["verified_vs_scipy_expm_multiply"] > 1e-9:
             raise SystemExit("%s: result differs from scipy's expm_multiply: %.3e" % (key, e["verified_vs_scipy_expm_multiply"]))

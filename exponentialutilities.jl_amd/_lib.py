@@ -89,6 +89,7 @@ PROTOTYPES = {
     "expv_mi_op_destroy": (_i, [_vp]),
     "expv_mi_op_update_values": (_i, [_vp, _vp, _i]),
     "expv_mi_op_info": (_i, [_vp, _pi64, _pi64, _pi, _pd, _pi]),
+    "expv_mi_op_reorder_info": (_i, [_vp, _vp]),
     "expv_mi_op_apply": (_i, [_vp, _vp, _i, _vp, _i]),
     "expv_mi_gemv_block": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i]),
     "expv_mi_ks_create": (_i, [_vp, _i, _i, _i64, _i, _i, _pvp]),
@@ -123,6 +124,7 @@ PROTOTYPES = {
     "expv_mi_abi_sizeof": (C.c_size_t, [_i]),
     "expv_mi_abi_layout": (C.c_char_p, [_i]),
     "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),
+    "expv_mi_host_rcm": (_i, [C.c_int64, _vp, _vp, _i, _vp, _vp]),
     "expv_mi_host_wrapsum": (_i, [_vp, C.c_uint64, _vp]),
     "expv_mi_host_expm": (_i, [_i, _i, _vp, _i]),
     "expv_mi_host_symtridiag_expcol": (_i, [_i, _pd, _pd, _d, _d, _pd]),

@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "clear_operator_cache",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "clear_operator_cache",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -460,6 +460,15 @@ class MIOperator:
         self.ishermitian = bool(herm.value) if ishermitian is None else bool(ishermitian)
         self.opnorm_inf = float(opn.value)
         self.dtype = np.dtype({L.F64: np.float64, L.C64: np.complex128, L.F32: np.float32, L.C32: np.complex64}[dtc.value])
+
+    @property
+    def reorder_info(self):
+        """How the operator is stored (expv_mi_op_reorder_info): ``reordered`` -- as P A P' with P a bandwidth-reducing ordering
+        (context option "reorder"; every call permutes vectors on entry and exit, results are those of the natural ordering) --
+        and the bandwidth before / after, the ordering's share of the creation time."""
+        out = (C.c_int64 * 4)()
+        _check(L.load().expv_mi_op_reorder_info(self._h, out))
+        return {"reordered": bool(out[0]), "bandwidth_before": int(out[1]), "bandwidth_after": int(out[2]), "setup_s": 1e-6 * int(out[3])}
 
     def update_values(self, A):
         """New values on the same sparsity pattern (expv_mi_op_update_values): ``A`` is the matrix the operator was created
@@ -1108,6 +1117,22 @@ def host_pattern_info(A, dtype=np.float64):
     else:
         info["path"] = "two-kernel step"
     return info
+
+
+def host_rcm(A, dtype=np.float64):
+    """The bandwidth-reducing ordering operator creation computes for a pattern (reverse Cuthill-McKee on A + A'; host only, no
+    reference counterpart): perm with perm[i] = the row that becomes row i, and what it does to the bandwidth / the step form."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+    perm = np.zeros(n, dtype=np.int32)
+    out = np.zeros(4, dtype=np.int64)
+    _check(L.load().expv_mi_host_rcm(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), perm.ctypes.data, out.ctypes.data))
+    names = {3: "single-pass step, halo form", 2: "single-pass step, wave form", 1: "two-kernel step", 0: "two-kernel step + overflow pass"}
+    return perm, {"bandwidth_before": int(out[0]), "bandwidth_after": int(out[1]), "form_before": names[int(out[2]) & 255],
+                  "form_after": names[int(out[3])], "would_reorder": bool(int(out[2]) & 256)}
 
 
 def host_phiv_dense(A, v, k):

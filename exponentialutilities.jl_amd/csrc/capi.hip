@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "engine.h"
+#include "reorder.h"
 
 using namespace expv_mi;
 using dense::cd;
@@ -457,6 +458,74 @@ static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long 
   }
 }
 
+// Which Krylov step form a pattern gets (engine_core.hip: choose_step_form, restated on the host analysis): 3 = single-pass step,
+// halo form; 2 = its wave form (a few diagonals with any offsets, or SELL slots whose columns stay near the row); 1 = two-kernel
+// step; 0 = two-kernel step + overflow pass (irregular rows).  Decides whether a reordering is worth keeping.
+struct PatClass { int cls; int64_t reach; bool dia; };
+static PatClass pattern_class_ex(const PatternPlan &P, int64_t n, int dtype) {
+  if (!P.sell_ok) return {1, 0, false};
+  if (P.overflow) return {0, 0, false};
+  if (P.bandwidth <= dev::PIPE_WMAX && (dtype == EXPV_MI_F64 || P.pipe_dia)) return {3, P.bandwidth, P.pipe_dia};
+  const bool real_t = dtype == EXPV_MI_F64 || dtype == EXPV_MI_F32;
+  const bool wave_dia = P.general_dia && real_t;
+  const bool wave_sell = !wave_dia && dtype == EXPV_MI_F64 && P.tile_reach >= 0;
+  if (wave_dia || wave_sell) {
+    const int64_t trw = (int64_t)(16 / dtype_size(dtype)) * dev::BLOCK;
+    const int64_t ntiles = (n + trw - 1) / trw;
+    const int64_t reach = wave_dia ? std::max<int64_t>(std::llabs((long long)P.offsets.front()), std::llabs((long long)P.offsets.back())) : P.tile_reach;
+    if (ntiles <= 400 || (reach / trw + 2) * 4 <= 400) return {2, reach, wave_dia};
+  }
+  return {1, P.bandwidth, false};
+}
+static int pattern_class(const PatternPlan &P, int64_t n, int dtype) { return pattern_class_ex(P, n, dtype).cls; }
+
+// Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
+// On return rp / ci / va hold P A P' and op.perm the ordering; op.csc_pos maps the caller's entries to the reordered CSR arrays.
+template <class V>
+static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+  const int mode = op.ctx->opt.reorder;
+  if (mode == 0 || n < 2 || ci.empty()) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  const PatternPlan P0 = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  const PatClass c0 = pattern_class_ex(P0, n, op.dtype);
+  // worth a try: the two-kernel step, or the wave form on SELL slots whose columns reach far (every tile then waits for many
+  // others).  Not: the halo form, diagonals of a structured grid in its natural ordering, irregular rows (an ordering does not
+  // change row lengths)
+  const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
+  if (mode == 1 && !candidate) return;
+  const std::vector<int32_t> perm = reorder::rcm(n, rp.data(), ci.data());
+  std::vector<int32_t> rp2, ci2, src;
+  reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
+  const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
+  const PatClass c1 = pattern_class_ex(P1, n, op.dtype);
+  const bool better = c1.cls > c0.cls || (c1.cls == c0.cls && c1.cls == 2 && 4 * c1.reach <= c0.reach);
+  if (mode == 1 && !better) return;
+  std::vector<V> va2(va.size());
+  for (size_t k = 0; k < va2.size(); ++k) va2[k] = va[(size_t)src[k]];
+  // caller's entry j -> its place in the reordered arrays (values-only updates scatter through this map)
+  std::vector<int32_t> place(src.size());
+  for (size_t k = 0; k < src.size(); ++k) place[(size_t)src[k]] = (int32_t)k;
+  if (op.csc_pos.empty()) op.csc_pos = place;
+  else for (auto &q : op.csc_pos) q = place[(size_t)q];
+  auto pm = std::make_shared<RowPerm>();
+  pm->n = n;
+  pm->hp = perm;
+  std::vector<int32_t> inv((size_t)n);
+  for (int64_t i = 0; i < n; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+  pm->p.alloc(sizeof(int32_t) * (size_t)n);
+  pm->pinv.alloc(sizeof(int32_t) * (size_t)n);
+  HIPCHECK(hipMemcpyAsync(pm->p.p, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(pm->pinv.p, inv.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipStreamSynchronize(op.ctx->stream));
+  pm->bandwidth_before = P0.bandwidth;
+  pm->bandwidth_after = P1.bandwidth;
+  pm->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  rp.swap(rp2);
+  ci.swap(ci2);
+  va.swap(va2);
+  op.perm = pm;
+}
+
 template <class V>
 void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
   static const bool tm = std::getenv("EXPV_MI_OP_TIMING") != nullptr;      // developer diagnostic: phases of an operator build
@@ -470,8 +539,10 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.kind = OP_CSR;
   op.n = n;
   op.nnz = (int64_t)ci.size();
-  csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);
+  csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);      // (both invariant under a symmetric permutation)
   lap("ishermitian + opnorm");
+  maybe_reorder<V>(op, n, rp, ci, va);
+  lap("reordering (RCM)");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size());
@@ -587,6 +658,22 @@ static void op_update_values_T(Op &op, const void *vals, int loc) {
     csr_props<V>(op.n, rp, ci, va, &op.ishermitian, &dummy);
   }
 }
+
+namespace {
+// a caller's n-vector as a device vector in the ordering the operator is stored in (natural, or P x for a reordered operator)
+const void *vector_in(Ctx *c, Op &op, const void *x, int loc, int64_t n, size_t esz, DevBuf &tmp) {
+  if (!op.perm || op.n != n) return stage_in(c, x, loc, (size_t)n * esz, tmp);      // (a size mismatch is reported by checkdims)
+  int64_t ld = n;
+  return permute_in(c, *op.perm, x, loc, 1, n, esz, tmp, &ld);
+}
+// The ordering the basis of `ks` has to be in for a factorisation with `op`: a fresh call simply takes the operator's over, a
+// continuation (init > 0) converts the stored columns when they are in another one.
+void ks_bind_row_order(Ks &ks, Op &op, int init) {
+  if (ks.vperm.get() == op.perm.get()) return;
+  if (init > 0) ks_set_row_order(ks, op.perm);
+  else ks.vperm = op.perm;
+}
+}  // namespace
 
 extern "C" {
 
@@ -931,6 +1018,15 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
   return EXPV_MI_OK;
 }
 
+int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]) {
+  if (!op || !out) return EXPV_MI_ARGUMENT_ERROR;
+  out[0] = op->perm ? 1 : 0;
+  out[1] = op->perm ? op->perm->bandwidth_before : op->bandwidth;
+  out[2] = op->perm ? op->perm->bandwidth_after : op->bandwidth;
+  out[3] = op->perm ? (int64_t)(op->perm->setup_ms * 1000.0) : 0;
+  return EXPV_MI_OK;
+}
+
 int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc) {
   if (!op) return EXPV_MI_ARGUMENT_ERROR;
   return guarded(op->ctx, [&] {
@@ -952,6 +1048,15 @@ int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_l
     c->use();
     const size_t bytes = (size_t)op->n * dtype_size(op->dtype);
     DevBuf xt, yt;
+    if (op->perm) {      // stored as P A P':  y = P' ((P A P') (P x))
+      int64_t ldx = op->n;
+      const void *xp = permute_in(c, *op->perm, x, x_loc, 1, op->n, dtype_size(op->dtype), xt, &ldx);
+      yt.take_from(c, bytes + 16);
+      op_apply_dev(*op, xp, yt.p, nullptr, 0);
+      permute_out(c, *op->perm, yt.p, op->n, y, y_loc, op->n, 1, dtype_size(op->dtype));
+      HIPCHECK(hipStreamSynchronize(c->stream));
+      return;
+    }
     const void *xd = stage_in(c, x, x_loc, bytes, xt);
     void *yd = y;
     if (y_loc == EXPV_MI_HOST) { yt.alloc(bytes + 16); yd = yt.p; }
@@ -1055,6 +1160,7 @@ int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_set_row_order(*ks, nullptr);      // (a basis kept in a reordered operator's ordering: rows back to their natural places)
     ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
     copy_out_2d(ks->ctx, dst, EXPV_MI_HOST, ld_dst, ks->V.as<char>() + (size_t)col0 * ks->ldv * esz, ks->ldv,
@@ -1065,6 +1171,7 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_set_row_order(*ks, nullptr);
     ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
     if (ncols > 0 && ks->rows() > 0)
@@ -1076,7 +1183,7 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
 }
 int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv) {
   if (!ks) return EXPV_MI_ARGUMENT_ERROR;
-  const int rc = guarded(ks->ctx, [&] { ks_materialize(*ks); });
+  const int rc = guarded(ks->ctx, [&] { ks_set_row_order(*ks, nullptr); ks_materialize(*ks); });
   if (rc != EXPV_MI_OK) return rc;
   if (V) *V = ks->V.p;
   if (ldv) *ldv = ks->ldv;
@@ -1098,7 +1205,8 @@ int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     DevBuf tmp;
-    const void *bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
+    const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
+    ks_bind_row_order(*ks, *op, o.init);
     arnoldi_run(*ks, *op, bd, o, nullptr, false);
   });
 }
@@ -1107,7 +1215,8 @@ int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     DevBuf tmp;
-    const void *bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
+    const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
+    ks_bind_row_order(*ks, *op, o.init);
     arnoldi_run(*ks, *op, bd, o, nullptr, true);
   });
 }
@@ -1120,10 +1229,18 @@ int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t
     DevBuf bt, wt;
     int64_t ldbd = ldb;
     ArnoldiAug aug;
-    aug.B = stage_in_2d(ks->ctx, B, b_loc, ks->n, p, ldb, esz, bt, &ldbd);
+    if (op->perm) {
+      if (op->n != ks->n) fail(EXPV_MI_DIMENSION_MISMATCH, "length(b') == size(A,1) == size(A,2) == size(V,1)-p doesn't hold");
+      int64_t ldw_ = ks->n;
+      aug.B = permute_in(ks->ctx, *op->perm, B, b_loc, p, ldb, esz, bt, &ldbd);
+      aug.w = permute_in(ks->ctx, *op->perm, w, w_loc, 1, ks->n, esz, wt, &ldw_);
+    } else {
+      aug.B = stage_in_2d(ks->ctx, B, b_loc, ks->n, p, ldb, esz, bt, &ldbd);
+      aug.w = stage_in(ks->ctx, w, w_loc, (size_t)ks->n * esz, wt);
+    }
+    ks_bind_row_order(*ks, *op, o.init);
     aug.ldb = ldbd;
     aug.p = p;
-    aug.w = stage_in(ks->ctx, w, w_loc, (size_t)ks->n * esz, wt);
     aug.w_aug_host = w_aug_host;
     aug.t = t;
     aug.mu = mu;
@@ -1172,7 +1289,8 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     expv_mi_ks_s &ks = *kp;
     ks.skip_tail = true;
     DevBuf tmp;
-    const void *bd = stage_in(ctx, b, b_loc, (size_t)op->n * dtype_size(op->dtype), tmp);
+    const void *bd = vector_in(ctx, *op, b, b_loc, op->n, dtype_size(op->dtype), tmp);
+    ks.vperm = op->perm;      // (expv_eval puts the rows of w back in their natural places)
     const int mv = arnoldi_run(ks, *op, bd, o, nullptr, false);
     expv_eval(ks, t_re, t_im, w, w_loc, w_dtype);
     if (stats) {
@@ -1187,7 +1305,17 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
 
 int expv_mi_expv_error_estimate(expv_mi_ks_t ks, expv_mi_op_t op, double t_re, double t_im, const void *b, int b_loc,
                                 void *w, int w_loc, double atol, double rtol, int m, int ishermitian) {
-  return guarded(ks->ctx, [&] { expv_error_estimate_run(*ks, *op, t_re, t_im, b, b_loc, w, w_loc, atol, rtol, m, ishermitian); });
+  return guarded(ks->ctx, [&] {
+    if (op->perm && op->n == ks->n) {
+      DevBuf tmp;
+      const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
+      ks->vperm = op->perm;
+      expv_error_estimate_run(*ks, *op, t_re, t_im, bd, EXPV_MI_DEVICE, w, w_loc, atol, rtol, m, ishermitian);
+      return;
+    }
+    ks->vperm.reset();
+    expv_error_estimate_run(*ks, *op, t_re, t_im, b, b_loc, w, w_loc, atol, rtol, m, ishermitian);
+  });
 }
 
 // ------------------------------------------------------------------ time stepping -----------
@@ -1339,6 +1467,28 @@ int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *c
     out[5] = P.tile_reach;
     out[6] = P.sorted_unique;
     out[7] = P.sell_cut;                     // > 0: irregular rows, SELL slots up to this many per row + overflow pass
+  });
+}
+int expv_mi_host_rcm(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int64_t out[4]) {
+  return guarded(nullptr, [&] {
+    if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && !colind)) fail(EXPV_MI_ARGUMENT_ERROR, "host_rcm: bad arguments");
+    check_device_dtype(dtype, "host_rcm");
+    const int64_t nnz = n > 0 ? (int64_t)rowptr[n] : 0;
+    const std::vector<int32_t> pv = reorder::rcm(n, rowptr, colind);
+    if (perm) std::copy(pv.begin(), pv.end(), perm);
+    if (out) {
+      std::vector<int32_t> rp2, ci2, src;
+      reorder::permute_csr(n, rowptr, colind, pv, rp2, ci2, src);
+      const PatternPlan P0 = analyze_pattern(n, rowptr, colind, nnz, (int)dtype_size(dtype));
+      const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), nnz, (int)dtype_size(dtype));
+      out[0] = P0.bandwidth;
+      out[1] = P1.bandwidth;
+      const PatClass c0 = pattern_class_ex(P0, n, dtype), c1 = pattern_class_ex(P1, n, dtype);
+      const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
+      const bool better = c1.cls > c0.cls || (c1.cls == c0.cls && c1.cls == 2 && 4 * c1.reach <= c0.reach);
+      out[2] = (n > 0 ? c0.cls : 1) | ((n > 0 && candidate && better) ? 256 : 0);      // bit 8: creation would keep the ordering
+      out[3] = n > 0 ? c1.cls : 1;
+    }
   });
 }
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {

@@ -80,6 +80,9 @@ struct Options {
   int nontemporal = -1;    // non-temporal loads in the single-pass step: -1 by footprint, 0 never, 1 always  (EXPV_MI_NONTEMPORAL=0|1)
   int recycle = 1;         // a destroyed KrylovSubspace's storage is kept (one per context) for the next create of the same shape (EXPV_MI_NO_RECYCLE=1 -> 0)
   int ee_blocked = 1;      // error-estimate mode: blocks of Lanczos steps through the ordinary factorisation          (EXPV_MI_EE_STEPWISE=1 -> 0)
+  int reorder = 1;         // sparse operators without a single-pass form in their natural ordering: 1 = try reverse Cuthill-McKee at
+                           // creation and keep P A P' when that gives one (vectors permuted on entry / exit, capi.hip); 0 = never;
+                           // 2 = always keep the reordered form (tests)                          (EXPV_MI_REORDER=0|1|2)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();
@@ -232,6 +235,16 @@ struct ProfScope {  // brackets one launch with events when profiling is on
 
 enum OpKind { OP_CSR = 0, OP_DENSE = 1, OP_CALLBACK = 2 };
 
+// Row ordering of a reordered sparse operator (reorder.h): position i of every stored vector holds natural row p[i].  Shared by the
+// operator and by every KrylovSubspace whose basis it produced (the basis stays in that order until someone asks for its rows).
+struct RowPerm {
+  int64_t n = 0;
+  DevBuf p, pinv;                 // device: p[i] = natural row at position i; pinv[r] = position of natural row r
+  std::vector<int32_t> hp;        // host copy of p
+  int64_t bandwidth_before = 0, bandwidth_after = 0;
+  double setup_ms = 0.0;
+};
+
 struct Op {
   Ctx *ctx = nullptr;       // (nullptr once the context has been destroyed: only op_destroy is legal then)
   int device = 0;
@@ -278,6 +291,9 @@ struct Op {
   int gemv_split = 1;
   expv_mi_matvec_fn fn = nullptr;
   void *user = nullptr;
+  // stored as P A P' (reorder.h; nullptr: natural ordering).  Everything below capi.hip works in the stored ordering and never
+  // looks at this; the C entry points permute vectors on their way in and out.
+  std::shared_ptr<RowPerm> perm;
 };
 }  // namespace expv_mi
 struct expv_mi_op_s : expv_mi::Op {};
@@ -333,6 +349,10 @@ struct Ks {
   bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed
   int scale_cols = 0;
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
+  // rows of V are in the ordering of the reordered operator that produced the basis (nullptr: natural).  Set / converted by the C
+  // entry points (capi.hip: ks_bind_row_order); the evaluation entry points un-permute their results, the raw accessors of V
+  // convert the basis back in place first.
+  std::shared_ptr<RowPerm> vperm;
   int64_t rows() const { return n + augmented; }
 };
 void ks_finish_tail(Ks &ks);   // engine_core.hip
@@ -426,6 +446,12 @@ const void *stage_in_2d(Ctx *ctx, const void *p, int loc, int64_t rows, int64_t 
                         DevBuf &tmp, int64_t *ld_out);
 void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_dev, int64_t ld_src, int64_t rows,
                  int64_t cols, size_t esz);
+// reordered operators (reorder.h): vectors natural -> stored ordering on the way in, stored -> natural on the way out
+const void *permute_in(Ctx *ctx, const RowPerm &pm, const void *p, int loc, int64_t cols, int64_t ld, size_t esz, DevBuf &out,
+                       int64_t *ld_out);
+void permute_out(Ctx *ctx, const RowPerm &pm, const void *src_dev, int64_t ld_src, void *dst, int loc, int64_t ld_dst, int64_t cols,
+                 size_t esz);
+void ks_set_row_order(Ks &ks, const std::shared_ptr<RowPerm> &want);
 
 // ---- engine_batch.hip ---------------------------------------------------------------------
 void expv_batch_run(Ctx *ctx, int dtype, int64_t n, int nprob, const int32_t *rowptr, const int32_t *colind,

@@ -78,6 +78,63 @@ void copy_out_2d(Ctx *ctx, void *dst, int loc, int64_t ld_dst, const void *src_d
 }
 
 // ------------------------------------------------------------------------------------------
+// vectors of a reordered operator (reorder.h) on their way in and out
+// ------------------------------------------------------------------------------------------
+// natural -> stored ordering: rows x cols elements of `esz` bytes (host or device, leading dimension ld) into a packed device
+// matrix owned by `out` (leading dimension *ld_out)
+const void *permute_in(Ctx *ctx, const RowPerm &pm, const void *p, int loc, int64_t cols, int64_t ld, size_t esz, DevBuf &out,
+                       int64_t *ld_out) {
+  DevBuf stage;
+  int64_t lds = ld;
+  const void *sd = stage_in_2d(ctx, p, loc, pm.n, cols, ld, esz, stage, &lds);
+  const int64_t ldp = (pm.n + 3) / 4 * 4;      // every column stays 16-byte aligned for every element size
+  out.take_from(ctx, (size_t)std::max<int64_t>(ldp * cols, 1) * esz + 16);
+  dev::gather_rows(ctx->stream, esz, out.p, ldp, sd, lds, pm.p.as<int32_t>(), pm.n, (int)cols);
+  if (stage.p) HIPCHECK(hipStreamSynchronize(ctx->stream));      // (the staged copy goes back to the context's spares)
+  *ld_out = ldp;
+  return out.p;
+}
+// stored -> natural ordering, from a device matrix into the caller's buffer (host or device); complete on return unless the
+// context's outputs are stream-ordered and the destination is on the device
+void permute_out(Ctx *ctx, const RowPerm &pm, const void *src_dev, int64_t ld_src, void *dst, int loc, int64_t ld_dst, int64_t cols,
+                 size_t esz) {
+  if (pm.n <= 0 || cols <= 0) return;
+  if (loc == EXPV_MI_DEVICE) {
+    dev::gather_rows(ctx->stream, esz, dst, ld_dst, src_dev, ld_src, pm.pinv.as<int32_t>(), pm.n, (int)cols);
+    if (!ctx->async_out) HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return;
+  }
+  DevBuf tmp;
+  tmp.take_from(ctx, (size_t)pm.n * cols * esz + 16);
+  dev::gather_rows(ctx->stream, esz, tmp.p, pm.n, src_dev, ld_src, pm.pinv.as<int32_t>(), pm.n, (int)cols);
+  copy_out_2d(ctx, dst, EXPV_MI_HOST, ld_dst, tmp.p, pm.n, pm.n, cols, esz);
+}
+// The basis of a KrylovSubspace from one row ordering to another, in place (nullptr = natural), column by column through a
+// scratch column.  Raw access to V (expv_mi_ks_V_*) and a continuation with an operator of another ordering need it; the
+// ordinary calls never do.
+void ks_set_row_order(Ks &ks, const std::shared_ptr<RowPerm> &want) {
+  if (ks.vperm.get() == want.get()) return;
+  Ctx *c = ks.ctx;
+  c->use();
+  ks_materialize(ks);
+  const size_t esz = dtype_size(ks.dtypeT);
+  const int ncols = ks.maxiter + 1;
+  DevBuf scratch;
+  scratch.take_from(c, (size_t)ks.ldv * esz);
+  auto apply = [&](const int32_t *idx, int64_t n) {      // V[i, :] <- V[idx[i], :] for the first n rows (augmented rows stay)
+    for (int q = 0; q < ncols; ++q) {
+      char *col = ks.V.as<char>() + (size_t)q * ks.ldv * esz;
+      dev::gather_rows(c->stream, esz, scratch.p, ks.ldv, col, ks.ldv, idx, n, 1);
+      HIPCHECK(hipMemcpyAsync(col, scratch.p, (size_t)n * esz, hipMemcpyDeviceToDevice, c->stream));
+    }
+  };
+  if (ks.vperm) apply(ks.vperm->pinv.as<int32_t>(), ks.vperm->n);      // stored -> natural
+  if (want) apply(want->p.as<int32_t>(), want->n);                       // natural -> the new ordering
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  ks.vperm = want;
+}
+
+// ------------------------------------------------------------------------------------------
 // KrylovSubspace storage                                              arnoldi.jl:63-93
 // ------------------------------------------------------------------------------------------
 static void ks_alloc_aux(Ks &ks) {
@@ -147,6 +204,7 @@ void ks_recycle(Ks &ks) {
   ks.defer_tail_req = false;
   ks.pipe_closed = false;
   ks.mbox_armed = false;
+  ks.vperm.reset();
   hipStream_t s = ks.ctx->stream;
   HIPCHECK(hipMemsetAsync(ks.Hdev.p, 0, ks.Hdev.bytes, s));
   HIPCHECK(hipMemsetAsync(ks.gram.p, 0, ks.gram.bytes, s));
@@ -327,6 +385,7 @@ Options Options::from_env() {
   if (flag("EXPV_MI_PIPE_SERIAL")) o.pipeline_serial = 1;
   if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
   if (const char *v = std::getenv("EXPV_MI_BATCH_ROUNDS")) o.batch_rounds = std::max(1, std::atoi(v));
+  if (const char *v = std::getenv("EXPV_MI_REORDER")) o.reorder = std::min(2, std::max(0, std::atoi(v)));
   return o;
 }
 int *Options::find(const char *name) {
@@ -343,6 +402,7 @@ int *Options::find(const char *name) {
   if (n == "stencil") return &stencil;
   if (n == "nontemporal") return &nontemporal;
   if (n == "pipeline_serial") return &pipeline_serial;
+  if (n == "reorder") return &reorder;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
   return nullptr;
@@ -1247,7 +1307,10 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   DevBuf wtmp;
   void *Wd = W;
   int64_t ldwd = ldw;
-  if (w_loc == EXPV_MI_HOST) {
+  // a basis in the ordering of a reordered operator: the combination is formed in that ordering and its rows go to their natural
+  // places on the way out (a linear-combination tail belongs to a driver that works in the stored ordering throughout)
+  const bool unperm = ks.vperm != nullptr && !lc;
+  if (w_loc == EXPV_MI_HOST || unperm) {
     wtmp.take_from(c, (size_t)rows * ncols * wsz + 16);
     Wd = wtmp.p;
     ldwd = rows;
@@ -1266,7 +1329,8 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
       else combine_launch<cplx32, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
     }
   }
-  if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
+  if (unperm) permute_out(c, *ks.vperm, Wd, ldwd, W, w_loc, ldw, ncols, wsz);
+  else if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
   else if (!c->async_out) HIPCHECK(hipStreamSynchronize(c->stream));
 }
 

@@ -398,10 +398,12 @@ void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int
   const size_t esz = dtype_size(op.dtype);
   DevBuf btmp, utmp;
   int64_t ldbd = ldb;
-  const void *Bd = stage_in_2d(ctx, B, b_loc, n, ncoef, ldb, esz, btmp, &ldbd);
+  // a reordered operator (reorder.h): the whole controller runs in the stored ordering -- B in, the snapshots out
+  const void *Bd = op.perm ? permute_in(ctx, *op.perm, B, b_loc, ncoef, ldb, esz, btmp, &ldbd)
+                           : stage_in_2d(ctx, B, b_loc, n, ncoef, ldb, esz, btmp, &ldbd);
   void *Ud = U;
   int64_t ldud = ldu;
-  if (u_loc == EXPV_MI_HOST) {
+  if (u_loc == EXPV_MI_HOST || op.perm) {
     utmp.alloc((size_t)n * nts * esz + 16);
     Ud = utmp.p;
     ldud = n;
@@ -410,7 +412,8 @@ void phiv_timestep_run(Ctx *ctx, Op &op, int nts, double *ts, const void *B, int
     using T = typename decltype(tag)::type;
     phiv_timestep_T<T>(ctx, op, nts, ts, (const T *)Bd, ldbd, ncoef, (T *)Ud, ldud, o, cache, stats);
   });
-  if (u_loc == EXPV_MI_HOST) copy_out_2d(ctx, U, EXPV_MI_HOST, ldu, Ud, ldud, n, nts, esz);
+  if (op.perm) permute_out(ctx, *op.perm, Ud, ldud, U, u_loc, ldu, nts, esz);
+  else if (u_loc == EXPV_MI_HOST) copy_out_2d(ctx, U, EXPV_MI_HOST, ldu, Ud, ldud, n, nts, esz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -644,13 +647,14 @@ void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols,
   const size_t esz = dtype_size(op.dtype);
   DevBuf utmp, wtmp;
   int64_t ldud = ldu;
-  const void *ud = stage_in_2d(ctx, u, u_loc, n, ncols_u, ldu, esz, utmp, &ldud);
+  const void *ud = op.perm ? permute_in(ctx, *op.perm, u, u_loc, ncols_u, ldu, esz, utmp, &ldud)      // (reordered operator: stored ordering throughout)
+                           : stage_in_2d(ctx, u, u_loc, n, ncols_u, ldu, esz, utmp, &ldud);
   // norm(u[:, 2:end], 1), entrywise (:94): u is staged in HBM already -- per-column device reductions, finished on the host
   double normU = 0.0;
   for (int cidx = 1; cidx < ncols_u; ++cidx)
     normU += abs_reduce_dev(ctx, op.dtype, reinterpret_cast<const char *>(ud) + (size_t)cidx * ldud * esz, n, 1);
   void *wd = w;
-  if (w_loc == EXPV_MI_HOST) {
+  if (w_loc == EXPV_MI_HOST || op.perm) {
     wtmp.alloc((size_t)n * esz + 16);
     wd = wtmp.p;
   }
@@ -658,7 +662,8 @@ void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols,
     kiops_T<cplx>(ctx, op, tau_out, ntau, tau_ncols, (const cplx *)ud, ldud, ncols_u, &normU, (cplx *)wd, o, stats);
   else
     kiops_T<double>(ctx, op, tau_out, ntau, tau_ncols, (const double *)ud, ldud, ncols_u, &normU, (double *)wd, o, stats);
-  if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, n, wd, n, n, 1, esz);
+  if (op.perm) permute_out(ctx, *op.perm, wd, n, w, w_loc, n, 1, esz);
+  else if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, n, wd, n, n, 1, esz);
 }
 
 }  // namespace expv_mi

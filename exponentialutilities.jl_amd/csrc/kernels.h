@@ -81,6 +81,10 @@ struct OpUpdateArgs {
                                 // [16 + d] bits of the first entry of diagonal d
 };
 template <class T> void op_scatter_values(hipStream_t s, T *dst, const T *src, const int32_t *pos, int64_t nnz);
+// dst[i + c ld_dst] = src[idx[i] + c ld_src], i < n, c < ncols: rows of `esz`-byte elements (4, 8 or 16) picked through an index
+// vector -- the permutation of a reordered operator applied to vectors on their way in (idx = perm) and out (idx = inverse)
+void gather_rows(hipStream_t s, size_t esz, void *dst, int64_t ld_dst, const void *src, int64_t ld_src, const int32_t *idx, int64_t n,
+                 int ncols);
 template <class T> void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a);
 int device_cus();
 // device self-test of the VALU lane exchanges: in = 32 * BLOCK doubles, out = 8 zeroed counters

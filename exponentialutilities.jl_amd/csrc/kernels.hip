@@ -1111,6 +1111,27 @@ void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a) {
     hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd, (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, a.n / (4 * BLOCK)))), dim3(BLOCK), 0, s, a.dia,
                        a.dia_ld, a.dia_off, a.n, a.out);
 }
+template <class W>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(W *__restrict__ dst, int64_t ld_dst, const W *__restrict__ src, int64_t ld_src,
+                                                       const int32_t *__restrict__ idx, int64_t n) {
+  const int64_t c = blockIdx.y;
+  dst += c * ld_dst;
+  src += c * ld_src;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = src[idx[i]];
+}
+void gather_rows(hipStream_t s, size_t esz, void *dst, int64_t ld_dst, const void *src, int64_t ld_src, const int32_t *idx, int64_t n,
+                 int ncols) {
+  if (n <= 0 || ncols <= 0) return;
+  const dim3 g((unsigned)grid_for(n, BLOCK * 2), (unsigned)ncols);
+  if (esz == 4)
+    hipLaunchKernelGGL(k_gather_rows<uint32_t>, g, dim3(BLOCK), 0, s, (uint32_t *)dst, ld_dst, (const uint32_t *)src, ld_src, idx, n);
+  else if (esz == 8)
+    hipLaunchKernelGGL(k_gather_rows<unsigned long long>, g, dim3(BLOCK), 0, s, (unsigned long long *)dst, ld_dst,
+                       (const unsigned long long *)src, ld_src, idx, n);
+  else
+    hipLaunchKernelGGL(k_gather_rows<uint4>, g, dim3(BLOCK), 0, s, (uint4 *)dst, ld_dst, (const uint4 *)src, ld_src, idx, n);
+}
+
 template void op_scatter_values<double>(hipStream_t, double *, const double *, const int32_t *, int64_t);
 template void op_scatter_values<cplx>(hipStream_t, cplx *, const cplx *, const int32_t *, int64_t);
 template void op_update_forms<double>(hipStream_t, const OpUpdateArgs<double> &);

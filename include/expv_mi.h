@@ -96,10 +96,13 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *                       convenience methods costs no hipMalloc / hipFree.  0: destroy frees at once
  *   "ee_blocked" 1      error-estimate mode: blocks of Lanczos steps through the ordinary factorisation, every step of a block
  *                       tested on the host when the block is there; 0: one step at a time (same stopping step, same result)
+ *   "reorder" 1         sparse operators with no single-pass form in their natural ordering: 1 = try a bandwidth-reducing
+ *                       ordering (reverse Cuthill-McKee) at creation and keep P A P' when it gives one; 0 = never; 2 = always keep it
+ *                       (expv_mi_op_reorder_info says what happened; read when an operator is created)
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
- * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE, _EE_STEPWISE (read once, at creation) -- nothing reads the environment later.
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE, _EE_STEPWISE, _REORDER (read once, at creation) -- nothing reads the environment later.
  * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
 int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
 int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
@@ -172,6 +175,12 @@ int expv_mi_op_destroy(expv_mi_op_t op);
 /* size(A,1), nnz (NA of krylov_phiv_adaptive.jl:335-342), LinearAlgebra.ishermitian(A), opnorm(A,Inf) */
 int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian, double *opnorm_inf,
                     int *dtype);
+/* Row ordering of a sparse operator (context option "reorder", default 1): an operator that would take the two-kernel step in its
+ * natural ordering is stored as P A P' (P = reverse Cuthill-McKee on the pattern of A + A') when that puts it on the single-pass
+ * step; every entry point permutes vectors on their way in and out, H / beta / the results are those of the natural ordering
+ * (rounding apart).  out[0] = 1 when reordered, out[1] / out[2] = max |col - row| before / after, out[3] = the reordering's share
+ * of the creation time in microseconds.  No reference counterpart (the reference applies A in the caller's ordering). */
+int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]);
 /* mul!(y, A, x)  (arnoldi.jl:185) */
 int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc);
 
@@ -367,6 +376,11 @@ const char *expv_mi_abi_layout(int kind);
  * out[6] rows sorted and free of duplicates, out[7] slot cut-off of the SELL form (0: regular rows, every slice keeps its longest
  * row; > 0: irregular rows -- the entries of a row beyond the cut are applied from the CSR arrays by the overflow pass).  No reference counterpart (the reference stores CSC only). */
 int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int64_t out[8]);
+/* The ordering expv_mi_op_create_* would compute for this pattern (host only: reverse Cuthill-McKee on A + A'): perm[i] = the row
+ * that becomes row i; out[0] / out[1] = max |col - row| before / after, out[2] / out[3] = step form before / after (3 single-pass
+ * halo form, 2 wave form, 1 two-kernel step, 0 two-kernel step + overflow pass); out[2] has bit 8 (256) set when operator
+ * creation would keep the ordering (option "reorder" = 1).  perm may be NULL. */
+int expv_mi_host_rcm(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int64_t out[4]);
 /* Content hash of a host buffer: out = {whole 8-byte words, sum_i mix64(x_i ^ (i + 1) g) mod 2^64 (+ the tail bytes as one more
  * word)}, mix64 = the two-round multiply / xor-shift finaliser, g = 0x9e3779b97f4a7c15; threaded.  Position-salted AND non-linear:
  * a permutation of the contents changes it (the linear index-weighted sum of round 3 did not, for mantissa-free values at

@@ -234,6 +234,14 @@ function update_values!(op::MIOperator{T}, A::SparseMatrixCSC{T, Int64}) where {
     op.opnorm_inf = on[]
     op
 end
+# How the library stores a sparse operator: reordered = true when it kept P A P' (P = reverse Cuthill-McKee, context option
+# "reorder") because that puts an unstructured operator on the single-pass Krylov step.  Nothing changes for the caller: vectors
+# go in and come out in A's own ordering, H / beta / results are those of arnoldi(A, b) (rounding apart).
+function reorder_info(op::MIOperator)
+    out = zeros(Int64, 4)
+    check(ccall((:expv_mi_op_reorder_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), op.h, out), ctx().h)
+    (reordered = out[1] != 0, bandwidth_before = out[2], bandwidth_after = out[3], setup_s = 1.0e-6 * out[4])
+end
 MIOperator(A::SparseMatrixCSC{T}) where {T <: MIScalar} = MIOperator(SparseMatrixCSC{T, Int64}(A))      # (other index types: converted once)
 function MIOperator(A::Matrix{T}) where {T <: MIScalar}
     r = Ref{Ptr{Cvoid}}(C_NULL)

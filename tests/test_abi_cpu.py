@@ -437,3 +437,54 @@ def test_julia_shim_expv_methods_do_not_collide_with_the_reference():
     kinds = sorted(re.search(r"t::(\w+)", ln).group(1) for ln in three_arg)
     assert kinds == ["Complex", "Real"], three_arg
     assert "ExponentialUtilities._expv_ee(t::Tt, A::MIOperator{T}, b::MIVector{T}" in src
+
+
+def _shuffled(A, seed):
+    q = np.random.default_rng(seed).permutation(A.shape[0])
+    return A[q][:, q].tocsr(), q
+
+
+def test_host_rcm_recovers_banded_and_grid_orderings(eu):
+    """The ordering operator creation computes for unstructured patterns (reorder.h: reverse Cuthill-McKee on A + A', VERDICT r3
+    item 1): a permutation; a shuffled 5-diagonal matrix gets its bandwidth back (halo form of the single-pass step), a shuffled
+    2-D grid the grid width (wave form), a uniformly random pattern stays where it was; structured and irregular patterns are
+    not candidates at all."""
+    import scipy.sparse as sp
+    n = 30_000
+    band = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-2, -1, 0, 1, 2], shape=(n, n), format="csr")
+    Bs, _ = _shuffled(band, 1)
+    perm, info = eu.host_rcm(Bs)
+    assert sorted(perm.tolist()) == list(range(n))
+    assert info["bandwidth_before"] > n // 2 and info["bandwidth_after"] <= 4
+    assert info["form_after"] == "single-pass step, halo form" and info["would_reorder"]
+    P = Bs[perm][:, perm].tocsr()                                   # P A P': row i of the result is row perm[i] of A
+    assert int(np.max(np.abs(P.tocoo().row - P.tocoo().col))) == info["bandwidth_after"]
+    k = 600                                                         # n = 360 000 > 400 tiles: the reach decides
+    grid = sp.diags([1.0, 1.0, -4.0, 1.0, 1.0], [-k, -1, 0, 1, k], shape=(k * k, k * k), format="csr")
+    Gs, _ = _shuffled(grid, 2)
+    perm, info = eu.host_rcm(Gs)
+    assert sorted(perm.tolist()) == list(range(k * k))
+    assert info["bandwidth_after"] <= 2 * k and info["form_before"] == "two-kernel step"
+    assert info["form_after"] == "single-pass step, wave form" and info["would_reorder"]
+    assert not eu.host_rcm(grid)[1]["would_reorder"]                # natural ordering of a structured grid: diagonals, left alone
+    assert not eu.host_rcm(band)[1]["would_reorder"]
+    rng = np.random.default_rng(3)
+    m = 300_000
+    rows = np.repeat(np.arange(m), 4)
+    R = (sp.coo_matrix((np.ones(4 * m), (rows, rng.integers(0, m, size=4 * m))), shape=(m, m)).tocsr() + sp.eye(m)).tocsr()
+    perm, info = eu.host_rcm(R)
+    assert sorted(perm.tolist()) == list(range(m)) and not info["would_reorder"]        # no ordering helps a random graph
+    ragged = sp.lil_matrix((5000, 5000))
+    ragged[0, :400] = 1.0
+    ragged.setdiag(2.0)
+    assert not eu.host_rcm(ragged.tocsr())[1]["would_reorder"]      # irregular rows: an ordering does not change row lengths
+    # disconnected pieces, empty rows, a 1 x 1 and an empty matrix
+    blocks = sp.block_diag([band[:50, :50], sp.csr_matrix((3, 3)), band[:20, :20]], format="csr")
+    perm, _ = eu.host_rcm(_shuffled(blocks, 4)[0])
+    assert sorted(perm.tolist()) == list(range(73))
+    assert eu.host_rcm(sp.csr_matrix(np.ones((1, 1))))[0].tolist() == [0]
+    assert eu.host_rcm(sp.csr_matrix((0, 0)))[0].size == 0
+    # an unsymmetric pattern is ordered through A + A'
+    U = sp.diags([1.0, 1.0], [0, 3], shape=(400, 400), format="csr")
+    perm, info = eu.host_rcm(_shuffled(U, 5)[0])
+    assert info["bandwidth_after"] <= 6

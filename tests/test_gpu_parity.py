@@ -834,3 +834,130 @@ def test_randomised_parity_hunt_short():
     last = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(last)
     assert p.returncode == 0 and r["failures"] == 0 and r["cases"] > 100, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ reordered operators (reorder.h) --------
+def _shuffle(A, seed):
+    q = np.random.default_rng(seed).permutation(A.shape[0])
+    return A[q][:, q].tocsr()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["band_f64", "band_c64", "band_f32", "grid_f64", "band_csc"])
+def test_reordered_operator_matches_the_oracle_on_the_natural_ordering(eu, case):
+    """an unstructured operator is stored as P A P' (reverse Cuthill-McKee at creation) when that puts it on
+    the single-pass step; vectors are permuted on entry and exit, the basis stays permuted.  H and beta do not depend on the
+    ordering, V and every result come back in the caller's ordering: all of it against the oracle run on the caller's matrix, at
+    the fixed 1e-12 bars (fp32: the fp32 bars).  arnoldi! + getH / getV, expv!, phiv!, the whole-call expv (host and device
+    vectors), mul!, a continuation after the basis has been looked at, lanczos!, the error-estimate mode, phiv_timestep! and
+    kiops."""
+    import torch
+    rng = np.random.default_rng(21)
+    T = {"band_f64": np.float64, "band_c64": np.complex128, "band_f32": np.float32, "grid_f64": np.float64, "band_csc": np.float64}[case]
+    cplx = np.dtype(T).kind == "c"
+    if case == "grid_f64":
+        k = 600
+        n = k * k                                                  # 360 000 rows: > 400 tiles, so the reach decides the form
+        A0 = sp.diags([0.7, 1.1, -4.0, 0.9, 1.3], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+        m = 12
+    else:
+        n = 70_001
+        A0 = c2_operator(n)
+        m = 20
+    A = _shuffle(A0 * ((1 + 0.25j) if cplx else 1.0), 8).astype(T)
+    if case == "band_csc":
+        A = A.tocsc()
+    A64 = A.astype(np.complex128 if cplx else np.float64)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    b64 = b.astype(A64.dtype)
+    tol = 2e-5 if np.dtype(T).itemsize <= 4 else TOL
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    ri = op.reorder_info
+    assert ri["reordered"] and ri["bandwidth_after"] < ri["bandwidth_before"] // 50, ri
+    plain_ctx = eu.Context()
+    plain_ctx.set_option("reorder", 0)
+    assert not eu.MIOperator(A, plain_ctx).reorder_info["reordered"]
+    # mul!
+    close(np.asarray(op.matvec(b)), A64 @ b64, 5e-6 if tol > TOL else 1e-14, "reordered %s: mul! vs scipy" % case)
+    # arnoldi! -> H, beta, V
+    Ks = eu.KrylovSubspace(T, T, n, m, 0, ctx)
+    eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+    Ko = ko.KrylovSubspace(A64.dtype.type, A64.dtype.type, n, m)
+    ko.arnoldi_(Ko, A64.tocsr(), b64, m=m, ishermitian=False)
+    assert Ks.m == Ko.m
+    assert abs(Ks.beta - Ko.beta) <= (1e-6 if tol > TOL else 1e-14) * Ko.beta
+    close(np.asarray(Ks.getH()).astype(A64.dtype), Ko.getH(), tol, "reordered %s: H of arnoldi! vs oracle (natural ordering)" % case, mat=True)
+    # expv! / phiv! BEFORE anybody looked at V: the basis is still in the stored ordering
+    w = eu.expv_(np.empty(n, dtype=T), 0.7, Ks)
+    close(np.asarray(w).astype(A64.dtype), ko.expv_(np.empty(n, dtype=A64.dtype), 0.7, Ko), tol, "reordered %s: expv! vs oracle" % case)
+    W = eu.phiv_(np.empty((n, 3), dtype=T, order="F"), 0.7, Ks, 2)
+    close(np.asarray(W).astype(A64.dtype), ko.phiv_(np.empty((n, 3), dtype=A64.dtype), 0.7, Ko, 2), 10 * tol, "reordered %s: phiv! k=2 vs oracle" % case)
+    wd = torch.empty(n, dtype=torch.as_tensor(b).dtype, device="cuda")
+    eu.expv_(wd, 0.7, Ks)
+    ctx.sync()
+    close(wd.cpu().numpy().astype(A64.dtype), np.asarray(w).astype(A64.dtype), 0.0 if tol == TOL else 1e-7, "reordered %s: expv! into a device vector == into a host vector" % case)
+    # getV: rows back in the caller's ordering (the basis is converted in place) ...
+    close(np.asarray(Ks.getV()).astype(A64.dtype), Ko.getV(), tol, "reordered %s: V vs oracle (max abs)" % case, absolute=True)
+    # ... and everything still works afterwards: expv! from the converted basis, a continuation (converted back)
+    w2 = eu.expv_(np.empty(n, dtype=T), 0.7, Ks)
+    close(np.asarray(w2).astype(A64.dtype), np.asarray(w).astype(A64.dtype), 1e-6 if tol > TOL else 1e-14, "reordered %s: expv! after getV" % case)
+    if case in ("band_f64", "grid_f64"):
+        Ks.resize(m + 6)
+        eu.arnoldi_(Ks, op, b, m=m + 6, init=m, ishermitian=False)
+        Ko.resize(m + 6)
+        ko.arnoldi_(Ko, A64.tocsr(), b64, m=m + 6, init=m, ishermitian=False)
+        close(Ks.getH(), Ko.getH(), TOL, "reordered %s: H after a continuation (init = m) vs oracle" % case, mat=True)
+        close(Ks.getV(), Ko.getV(), TOL, "reordered %s: V after a continuation vs oracle (max abs)" % case, absolute=True)
+    # whole-call expv: host vectors and device vectors
+    wv = eu.expv(0.7, op, b, m=m, ishermitian=False)
+    wo = ko.expv(0.7, A64.tocsr(), b64, m=m, ishermitian=False)
+    close(np.asarray(wv).astype(A64.dtype), wo, tol, "reordered %s: expv(t, A, b) vs oracle" % case)
+    assert "pipeline" in " ".join(eu.expv.last_stats["path"]) or "single" in " ".join(eu.expv.last_stats["path"]), eu.expv.last_stats
+    bd = torch.as_tensor(b, device="cuda")
+    out = torch.empty_like(bd)
+    eu.expv(0.7, op, bd, m=m, ishermitian=False, out=out)
+    ctx.sync()
+    close(out.cpu().numpy().astype(A64.dtype), wo, tol, "reordered %s: expv with device vectors vs oracle" % case)
+
+
+@pytest.mark.gpu
+def test_reordered_operator_drivers_and_value_updates(eu):
+    """The drivers on a reordered operator -- lanczos! / error-estimate mode on a symmetric one, adaptive phiv_timestep!, kiops --
+    against the oracle on the caller's ordering, and a values-only update through the caller's (CSC) entry order."""
+    rng = np.random.default_rng(5)
+    n = 50_000
+    As = _shuffle(c2_operator(n, sym=True), 3)
+    b = rng.standard_normal(n)
+    ctx = eu.Context()
+    ops = eu.MIOperator(As.tocsc(), ctx)
+    assert ops.reorder_info["reordered"] and ops.ishermitian
+    w = eu.expv(0.5, ops, b, m=25)
+    close(w, ko.expv(0.5, As, b, m=25), TOL, "reordered symmetric operator: expv (Lanczos) vs oracle")
+    we = eu.expv(0.5, ops, b, m=30, mode="error_estimate", rtol=1e-9)
+    woe = ko.expv(0.5, As, b, m=30, mode="error_estimate", rtol=1e-9)
+    close(we, woe, 1e-11, "reordered symmetric operator: error-estimate mode vs oracle")
+    A = _shuffle(c2_operator(n), 4)
+    op = eu.MIOperator(A.tocsc(), ctx)
+    B = np.asfortranarray(rng.standard_normal((n, 3)))
+    st, so = {}, {}
+    ts = np.array([0.4, 1.0])
+    U = eu.phiv_timestep(ts.copy(), op, B, adaptive=True, tol=1e-8, stats=st)
+    Uo = ko.phiv_timestep(ts.copy(), A, B, adaptive=True, tol=1e-8, stats=so)
+    assert (st["num_timesteps"], st["matvecs"], st["m"]) == (so["num_timesteps"], so["matvecs"], so["m"]), (st, so)
+    close(U, Uo, 1e-11, "reordered operator: adaptive phiv_timestep (K = 2, two snapshots) vs oracle")
+    wk, sk = eu.kiops(1.0, op, B, ishermitian=False)
+    wko, sko = ko.kiops(1.0, A, B, ishermitian=False)
+    assert tuple(sk) == tuple(sko), (sk, sko)
+    close(wk, wko, 1e-10, "reordered operator: kiops with three columns vs oracle")
+    # values-only update in the caller's entry order (CSC here): the map goes through CSC -> CSR -> P A P'
+    Ac = A.tocsc()
+    Ac.sort_indices()
+    op2 = eu.MIOperator(Ac, ctx)
+    Ac2 = Ac.copy()
+    Ac2.data = Ac.data * (1.0 + 0.3 * rng.random(Ac.nnz))
+    op2.update_values(Ac2)
+    assert op2.reorder_info["reordered"]
+    close(eu.expv(0.6, op2, b, m=20, ishermitian=False), ko.expv(0.6, Ac2.tocsr(), b, m=20, ishermitian=False), TOL,
+          "reordered operator after update_values vs oracle on the new matrix")
+    close(op2.opnorm_inf, float(np.max(np.abs(Ac2).sum(axis=1))), 1e-14, "reordered operator: opnorm(A, Inf) after update_values")
