@@ -863,7 +863,7 @@ def test_reordered_operator_matches_the_oracle_on_the_natural_ordering(eu, case)
     else:
         n = 70_001
         A0 = c2_operator(n)
-        m = 20
+        m = 14 if cplx else 20                                     # (complex windows beyond 15 columns take the two-kernel step)
     A = _shuffle(A0 * ((1 + 0.25j) if cplx else 1.0), 8).astype(T)
     if case == "band_csc":
         A = A.tocsc()
@@ -881,11 +881,11 @@ def test_reordered_operator_matches_the_oracle_on_the_natural_ordering(eu, case)
     # mul!
     close(np.asarray(op.matvec(b)), A64 @ b64, 5e-6 if tol > TOL else 1e-14, "reordered %s: mul! vs scipy" % case)
     # arnoldi! -> H, beta, V
-    Ks = eu.KrylovSubspace(T, T, n, m, 0, ctx)
+    Ks = eu.KrylovSubspace(T, T, n, m + 6, 0, ctx)
     eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
-    Ko = ko.KrylovSubspace(A64.dtype.type, A64.dtype.type, n, m)
+    Ko = ko.KrylovSubspace(A64.dtype.type, A64.dtype.type, n, m + 6)
     ko.arnoldi_(Ko, A64.tocsr(), b64, m=m, ishermitian=False)
-    assert Ks.m == Ko.m
+    assert Ks.m == Ko.m == m
     assert abs(Ks.beta - Ko.beta) <= (1e-6 if tol > TOL else 1e-14) * Ko.beta
     close(np.asarray(Ks.getH()).astype(A64.dtype), Ko.getH(), tol, "reordered %s: H of arnoldi! vs oracle (natural ordering)" % case, mat=True)
     # expv! / phiv! BEFORE anybody looked at V: the basis is still in the stored ordering
@@ -903,9 +903,7 @@ def test_reordered_operator_matches_the_oracle_on_the_natural_ordering(eu, case)
     w2 = eu.expv_(np.empty(n, dtype=T), 0.7, Ks)
     close(np.asarray(w2).astype(A64.dtype), np.asarray(w).astype(A64.dtype), 1e-6 if tol > TOL else 1e-14, "reordered %s: expv! after getV" % case)
     if case in ("band_f64", "grid_f64"):
-        Ks.resize(m + 6)
         eu.arnoldi_(Ks, op, b, m=m + 6, init=m, ishermitian=False)
-        Ko.resize(m + 6)
         ko.arnoldi_(Ko, A64.tocsr(), b64, m=m + 6, init=m, ishermitian=False)
         close(Ks.getH(), Ko.getH(), TOL, "reordered %s: H after a continuation (init = m) vs oracle" % case, mat=True)
         close(Ks.getV(), Ko.getV(), TOL, "reordered %s: V after a continuation vs oracle (max abs)" % case, absolute=True)
