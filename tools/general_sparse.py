@@ -58,6 +58,10 @@ def make(kind, n, seed=11):
         A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags([-0.5 * np.ones(n)], [0], format="csr")
         A.sum_duplicates()
         return A.tocsr()
+    if kind.startswith("shuf_"):            # any of the above under a random symmetric permutation of the unknowns
+        A = make(kind[5:], n, seed).tocsr()
+        q = np.random.default_rng(seed + 1).permutation(A.shape[0])
+        return A[q][:, q].tocsr()
     raise SystemExit("unknown kind " + kind)
 
 
@@ -92,7 +96,7 @@ def main():
         balg = bench.alg_bytes_expv(n, A.nnz, m, s=A.dtype.itemsize)
         rl = np.diff(A.indptr)
         print(json.dumps({"kind": kind, "opts": opts, "n": n, "nnz": int(A.nnz), "row_len_max": int(rl.max()), "row_len_mean": float(rl.mean()),
-                          "setup_s": t_setup, "pattern": {k: (v if isinstance(v, (bool, str)) else int(v)) for k, v in info.items()},
+                          "setup_s": t_setup, "reorder": op.reorder_info, "pattern": {k: (v if isinstance(v, (bool, str)) else int(v)) for k, v in info.items()},
                           "path": list(path), "ms_per_expv": 1e3 * t, "matvecs_per_s": m / t, "alg_GB": balg / 1e9,
                           "frac": balg / t / 8e12,
                           "kernels": {k: {"n": v["launches"] // 5, "avg_us": 1e3 * v["total_ms"] / v["launches"]} for k, v in prof.items()}}))
