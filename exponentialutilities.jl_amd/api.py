@@ -254,7 +254,7 @@ def _work_dtype(*dts):
 
 
 def _work64(*dts):
-    """the 64-bit work type (entry points whose reference method is Float64-only: kiops; the batched step)"""
+    """the 64-bit work type (entry points whose reference method is Float64-only: kiops)"""
     return np.dtype(np.complex128 if any(np.dtype(d).kind == "c" for d in dts) else np.float64)
 
 
@@ -991,14 +991,13 @@ def expv_batch(ts, pattern, vals, B, *, m=None, tol=1e-7, iop=0, ishermitian=Fal
     n = P.shape[0]
     nnz = int(P.nnz)
     vdt, bdt = _np_dtype_of(vals), _np_dtype_of(B)
-    T = _work64(vdt, bdt)
+    T = _work_dtype(vdt, bdt)          # every BlasFloat: Float32 / ComplexF32 batches are computed on 32-bit storage
     class _Raw:          # problem-major (nprob, nnz) values: row-major is the wanted layout here
         pass
     va = _Raw()
     if _is_torch(vals):
         import torch
-        want = torch.complex128 if T.kind == "c" else torch.float64
-        vt = vals.to(want).contiguous()
+        vt = vals.to(_torch_dtype(T)).contiguous()
         if not vt.is_cuda:
             raise TypeError("torch tensors must live on the GPU (or pass a numpy array)")
         va.ptr, va.loc, va.keep, nprob = vt.data_ptr(), L.DEVICE, vt, int(vt.shape[0])

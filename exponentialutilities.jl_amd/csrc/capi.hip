@@ -1537,7 +1537,7 @@ int expv_mi_expv_batch(expv_mi_ctx_t ctx, int dtype, int64_t n, int nprob, const
                        const void *vals, int64_t nnz_per_prob, int mat_loc, const double *t, const void *b, int64_t ldb,
                        int b_loc, void *w, int64_t ldw, int w_loc, const expv_mi_arnoldi_opts *opts, int32_t *m_used) {
   return guarded(ctx, [&] {
-    check_64bit_dtype(dtype, "expv_batch");
+    check_device_dtype(dtype, "expv_batch");
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     expv_batch_run(ctx, dtype, n, nprob, rowptr, colind, vals, nnz_per_prob, mat_loc, t, b, ldb, b_loc, w, ldw, w_loc, o,

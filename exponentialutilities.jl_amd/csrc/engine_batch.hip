@@ -84,21 +84,25 @@ struct BatchPatternCache {
 // Banded pattern, fp64: every problem of a chunk advances by ONE k_pipe launch per Krylov step (problem index in
 // blockIdx.y) -- the single-pass step of pipe.hip, V of each problem read once per step, diagonals without column
 // indices.  Only H[1:m, 1:m] is needed (krylov_phiv.jl:223), so v_{m+1} is never formed.
-static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P, bool *perm_uploaded, const double *vals_dev, int64_t nnz,
-                            const double *t, const double *b_dev, int64_t ldb, double *w_dev, int64_t ldw,
+template <class T>
+static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P, bool *perm_uploaded, const T *vals_dev, int64_t nnz,
+                            const double *t, const T *b_dev, int64_t ldb, T *w_dev, int64_t ldw,
                             const expv_mi_arnoldi_opts &o, int32_t *m_used, int m, int herm, int iop) {
+  static_assert(std::is_same<T, double>::value || std::is_same<T, float>::value, "batched single-pass step: Float64 / Float32");
+  constexpr int NP = 16 / (int)sizeof(T);         // rows per 16-byte pack
+  constexpr int64_t RPAD = 64 * NP;               // library vectors: whole waves of packs
   hipStream_t s = ctx->stream;
   const double tol = o.tol;
   const bool tm = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t_begin = now();
-  const int64_t ldv = (n + 127) / 128 * 128;
+  const int64_t ldv = (n + RPAD - 1) / RPAD * RPAD;
   const int64_t strideV = ldv * (m + 1);
   const int ldhd = m + 2;
   const int64_t strideH = (int64_t)ldhd * (m + 1);
   const int ldg = m + 1;
   const int64_t dia_words = (int64_t)P.ndiag * P.ld;
-  const size_t per_prob = sizeof(double) * (size_t)(strideV + 2 * ldv + dia_words);
+  const size_t per_prob = sizeof(T) * (size_t)(strideV + 2 * ldv + dia_words);
   size_t free_b = 0, total_b = 0;
   HIPCHECK(hipMemGetInfo(&free_b, &total_b));
   // the chunk buffers of earlier calls stay allocated in the context: they are available to this call too, so the chunk
@@ -106,7 +110,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   if (ctx->ws_batch) free_b += ctx->ws_batch_bytes;
   int PC = (int)std::min<size_t>((size_t)nprob, std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / std::max<size_t>(per_prob, 1)));
   PC = std::min(PC, 512);
-  const int64_t ntiles = (n + 2 * dev::BLOCK - 1) / (2 * dev::BLOCK);
+  const int64_t ntiles = (n + NP * dev::BLOCK - 1) / (NP * dev::BLOCK);
   const int64_t ngpart = (int64_t)64 * dev::MAX_GROUPS;
   if (ntiles > dev::MAX_GRID) fail(EXPV_MI_UNSUPPORTED, "expv_batch: problem too large for the batched pipeline");
   // the buffers of a chunk are tens of GB: allocating and freeing them per call costs far more than the kernels
@@ -115,6 +119,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     DevBuf perm, V, Ya, Yb, Dia, H, G, hca, hcb, sc, part, gpart, st, coef, beta, mcols;
     int64_t n = -1;
     int m = -1;
+    size_t esz = 0;
     // pinned host mirrors of what comes back per sub-chunk (H, step states, column scales): a copy into pageable memory
     // would block the host until the sub-chunk's kernels have run, and nothing would overlap
     void *pin = nullptr;
@@ -133,28 +138,29 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       if (zero) HIPCHECK(hipMemsetAsync(b.p, 0, bytes, s));   // padding rows must be zero; they are never written
     }
   };
-  if (ws->n != n || ws->m != m) {   // another layout: what used to be data may now be padding -> zero the vectors again
+  if (ws->n != n || ws->m != m || ws->esz != sizeof(T)) {   // another layout: what used to be data may now be padding -> zero the vectors again
     ws->V.release();
     ws->Ya.release();
     ws->Yb.release();
     ws->n = n;
     ws->m = m;
+    ws->esz = sizeof(T);
   }
   if (ws->perm.bytes < sizeof(int32_t) * P.perm.size()) *perm_uploaded = false;      // (a new buffer: nothing in it yet)
   need(ws->perm, sizeof(int32_t) * P.perm.size(), false);
-  need(ws->V, sizeof(double) * (size_t)strideV * PC, true);
-  need(ws->Ya, sizeof(double) * (size_t)ldv * PC, true);
-  need(ws->Yb, sizeof(double) * (size_t)ldv * PC, true);
-  need(ws->Dia, sizeof(double) * (size_t)dia_words * PC + 16, false);
-  need(ws->H, sizeof(double) * (size_t)strideH * PC, false);
-  need(ws->G, sizeof(double) * (size_t)ldg * ldg * PC, false);
-  need(ws->hca, sizeof(double) * (size_t)(m + 2) * PC, false);
-  need(ws->hcb, sizeof(double) * (size_t)(m + 2) * PC, false);
+  need(ws->V, sizeof(T) * (size_t)strideV * PC, true);
+  need(ws->Ya, sizeof(T) * (size_t)ldv * PC, true);
+  need(ws->Yb, sizeof(T) * (size_t)ldv * PC, true);
+  need(ws->Dia, sizeof(T) * (size_t)dia_words * PC + 16, false);
+  need(ws->H, sizeof(T) * (size_t)strideH * PC, false);
+  need(ws->G, sizeof(T) * (size_t)ldg * ldg * PC, false);
+  need(ws->hca, sizeof(T) * (size_t)(m + 2) * PC, false);
+  need(ws->hcb, sizeof(T) * (size_t)(m + 2) * PC, false);
   need(ws->sc, sizeof(double) * (size_t)(m + 2) * PC, false);
   need(ws->part, sizeof(double) * (size_t)dev::MAX_GRID * 64 * (size_t)PC, false);
   need(ws->gpart, sizeof(double) * (size_t)ngpart * PC, false);
   need(ws->st, sizeof(StepState) * (size_t)PC, false);
-  need(ws->coef, sizeof(double) * (size_t)(m + 1) * PC, false);
+  need(ws->coef, sizeof(T) * (size_t)(m + 1) * PC, false);
   need(ws->beta, sizeof(double) * PC, false);
   need(ws->mcols, sizeof(int32_t) * PC, false);
   ctx->ws_batch_bytes = ws->perm.bytes + ws->V.bytes + ws->Ya.bytes + ws->Yb.bytes + ws->Dia.bytes + ws->H.bytes + ws->G.bytes +
@@ -167,7 +173,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     HIPCHECK(hipMemcpyAsync(d_perm.p, P.perm.data(), sizeof(int32_t) * P.perm.size(), hipMemcpyHostToDevice, s));
     *perm_uploaded = true;
   }
-  const size_t pin_need = sizeof(double) * ((size_t)strideH * PC + (size_t)(m + 2) * PC) + sizeof(StepState) * (size_t)PC + 64;
+  const size_t pin_need = sizeof(double) * ((size_t)strideH * PC + (size_t)(m + 2) * PC) + sizeof(StepState) * (size_t)PC + 64;      // (H: T-typed, in a double-sized slot)
   if (ws->pin_bytes < pin_need) {
     if (ws->pin) (void)hipHostFree(ws->pin);
     ws->pin = nullptr;
@@ -175,10 +181,13 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
     ws->pin_bytes = pin_need;
   }
   struct Span { double *p; double *data() const { return p; } };
-  const Span Hh{reinterpret_cast<double *>(ws->pin)}, sch{Hh.p + (size_t)strideH * PC};
+  struct HSpan { T *p; T *data() const { return p; } };
+  const HSpan Hh{reinterpret_cast<T *>(ws->pin)};
+  const Span sch{reinterpret_cast<double *>(ws->pin) + (size_t)strideH * PC};
   struct SSpan { StepState *p; StepState *data() const { return p; } StepState &operator[](size_t i) const { return p[i]; } };
   const SSpan sth{reinterpret_cast<StepState *>(sch.p + (size_t)(m + 2) * PC)};
-  std::vector<double> coefh((size_t)(m + 1) * PC), betah(PC);
+  std::vector<T> coefh((size_t)(m + 1) * PC);
+  std::vector<double> betah(PC);
   std::vector<int32_t> mch(PC);
   if (tm) { HIPCHECK(hipStreamSynchronize(s)); std::fprintf(stderr, "[batch timing] alloc+memset %.1f ms (PC=%d)\n", std::chrono::duration<double, std::milli>(now() - t_begin).count(), PC); }
   // A chunk (the problems whose vectors fit the workspace together) is cut into SUB-CHUNKS that are pipelined: while the host
@@ -188,33 +197,33 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
   for (auto &e : ev_done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{ev_done};
   auto factorise = [&](int p0, int q0, int pc) {   // problems [p0 + q0, p0 + q0 + pc) of the call = slots [q0, q0 + pc) of the chunk
-    dev::permute_values<double>(s, dDia.as<double>() + (int64_t)q0 * dia_words, dia_words, vals_dev + (int64_t)(p0 + q0) * nnz, nnz,
+    dev::permute_values<T>(s, dDia.as<T>() + (int64_t)q0 * dia_words, dia_words, vals_dev + (int64_t)(p0 + q0) * nnz, nnz,
                                 d_perm.as<int32_t>(), dia_words, pc);
     HIPCHECK(hipMemsetAsync(dst.as<StepState>() + q0, 0, sizeof(StepState) * (size_t)pc, s));
-    HIPCHECK(hipMemsetAsync(dH.as<double>() + (int64_t)q0 * strideH, 0, sizeof(double) * (size_t)strideH * pc, s));
+    HIPCHECK(hipMemsetAsync(dH.as<T>() + (int64_t)q0 * strideH, 0, sizeof(T) * (size_t)strideH * pc, s));
     for (int j = 1; j <= m; ++j) {
       const int i0 = herm ? j : std::max(1, j - iop + 1);
       const int nd = j - i0 + 1;
-      dev::PipeArgs pa{};
-      pa.dia_val = dDia.as<double>() + (int64_t)q0 * dia_words; pa.dia_ld = P.ld; pa.ndiag = P.ndiag;
+      dev::PipeArgsT<T> pa{};
+      pa.dia_val = dDia.as<T>() + (int64_t)q0 * dia_words; pa.dia_ld = P.ld; pa.ndiag = P.ndiag;
       for (int d = 0; d < P.ndiag; ++d) pa.dia_off[d] = P.off[d];
       pa.w = P.bandwidth;
-      pa.yprev = ((j & 1) ? dYb.as<double>() : dYa.as<double>()) + (int64_t)q0 * ldv;
-      pa.ybuf = ((j & 1) ? dYa.as<double>() : dYb.as<double>()) + (int64_t)q0 * ldv;
+      pa.yprev = ((j & 1) ? dYb.as<T>() : dYa.as<T>()) + (int64_t)q0 * ldv;
+      pa.ybuf = ((j & 1) ? dYa.as<T>() : dYb.as<T>()) + (int64_t)q0 * ldv;
       pa.u0 = (j == 1) ? b_dev + (int64_t)(p0 + q0) * ldb : nullptr;
-      dev::DotsArgs<double> &d = pa.d;
-      d.V = dV.as<double>() + (int64_t)q0 * strideV; d.ldv = ldv; d.n = n;
+      dev::DotsArgs<T> &d = pa.d;
+      d.V = dV.as<T>() + (int64_t)q0 * strideV; d.ldv = ldv; d.n = n;
       d.c0 = i0 - 1; d.dir = 1; d.nd = nd;
       d.part = dpart.as<double>() + (int64_t)q0 * dev::MAX_GRID * 64; d.gpart = dgpart.as<double>() + (int64_t)q0 * ngpart;
       d.st = dst.as<StepState>() + q0;
       d.mode = herm ? dev::DOTS_LANCZOS : (nd >= 2 ? dev::DOTS_LOWSYNC : dev::DOTS_STRICT);
-      d.Hdev = dH.as<double>() + (int64_t)q0 * strideH; d.ldh = ldhd; d.jcol = j - 1;
-      d.gram = dG.as<double>() + (int64_t)q0 * ldg * ldg; d.ldg = ldg; d.jrow = j - 1;
+      d.Hdev = dH.as<T>() + (int64_t)q0 * strideH; d.ldh = ldhd; d.jcol = j - 1;
+      d.gram = dG.as<T>() + (int64_t)q0 * ldg * ldg; d.ldg = ldg; d.jrow = j - 1;
       if (j == 1) { pa.uc0 = 0; pa.udir = 1; pa.und = 0; }
       else if (herm) { pa.uc0 = j - 2; pa.udir = -1; pa.und = (j - 1 > 1) ? 2 : 1; }
       else { const int i0p = std::max(1, (j - 1) - iop + 1); pa.uc0 = i0p - 1; pa.udir = 1; pa.und = (j - 1) - i0p + 1; }
-      pa.hcoef_in = ((j & 1) ? dhcb.as<double>() : dhca.as<double>()) + (int64_t)q0 * (m + 2);
-      pa.hcoef_out = ((j & 1) ? dhca.as<double>() : dhcb.as<double>()) + (int64_t)q0 * (m + 2);
+      pa.hcoef_in = ((j & 1) ? dhcb.as<T>() : dhca.as<T>()) + (int64_t)q0 * (m + 2);
+      pa.hcoef_out = ((j & 1) ? dhca.as<T>() : dhcb.as<T>()) + (int64_t)q0 * (m + 2);
       pa.scales = dsc.as<double>() + (int64_t)q0 * (m + 2);
       pa.step = j;
       pa.tol = tol;
@@ -225,7 +234,7 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       ProfScope ps(ctx, EXPV_MI_K_BATCH);
       dev::pipe_step(s, pa, pc, ctx->opt.batch_rounds);
     }
-    HIPCHECK(hipMemcpyAsync(Hh.data() + (size_t)q0 * strideH, dH.as<double>() + (int64_t)q0 * strideH, sizeof(double) * (size_t)strideH * pc,
+    HIPCHECK(hipMemcpyAsync(Hh.data() + (size_t)q0 * strideH, dH.as<T>() + (int64_t)q0 * strideH, sizeof(T) * (size_t)strideH * pc,
                             hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(sth.data() + q0, dst.as<StepState>() + q0, sizeof(StepState) * (size_t)pc, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(sch.data() + (size_t)q0 * (m + 2), dsc.as<double>() + (int64_t)q0 * (m + 2), sizeof(double) * (size_t)(m + 2) * pc,
@@ -242,24 +251,24 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       mch[q] = (beta == 0.0) ? 0 : mm;
       if (m_used) m_used[p0 + q] = mm;
       if (beta == 0.0) return;
-      const double *Hq = Hh.data() + (size_t)q * strideH;
-      double *cq = coefh.data() + (size_t)q * (m + 1);
+      const T *Hq = Hh.data() + (size_t)q * strideH;
+      T *cq = coefh.data() + (size_t)q * (m + 1);
       const double tq = t[p0 + q];
       if (herm) {   // lanczos!: v[j] = H[j+1, j] mirrors onto the superdiagonal (arnoldi.jl:488); eigen path of expv!
         std::vector<double> dd(mm), ee(mm > 1 ? mm - 1 : 0);
-        for (int i = 0; i < mm; ++i) dd[i] = Hq[(size_t)i * ldhd + i];
-        for (int i = 0; i + 1 < mm; ++i) ee[i] = Hq[(size_t)i * ldhd + i + 1];
+        for (int i = 0; i < mm; ++i) dd[i] = (double)Hq[(size_t)i * ldhd + i];
+        for (int i = 0; i + 1 < mm; ++i) ee[i] = (double)Hq[(size_t)i * ldhd + i + 1];
         std::vector<double> cf = dense::symtridiag_expcol<double>(dd, ee, tq);
-        for (int i = 0; i < mm; ++i) cq[i] = cf[i];
+        for (int i = 0; i < mm; ++i) cq[i] = (T)cf[i];
       } else {
         Mat<double> Hm(mm, mm);
         for (int jj = 0; jj < mm; ++jj)
-          for (int i = 0; i < mm; ++i) Hm(i, jj) = Hq[(size_t)jj * ldhd + i] * tq;
+          for (int i = 0; i < mm; ++i) Hm(i, jj) = (double)Hq[(size_t)jj * ldhd + i] * tq;
         dense::expm_higham2005base(Hm);
-        for (int i = 0; i < mm; ++i) cq[i] = Hm(i, 0);
+        for (int i = 0; i < mm; ++i) cq[i] = (T)Hm(i, 0);
       }
       const double *sq = sch.data() + (size_t)q * (m + 2);      // stored columns are v_c / s_c
-      for (int i = 0; i < mm; ++i) cq[i] *= sq[i];
+      for (int i = 0; i < mm; ++i) cq[i] = (T)((double)cq[i] * sq[i]);
     };
     {
       // a few problems per thread: creating a thread costs about as much as one 30 x 30 exponential
@@ -283,13 +292,13 @@ static void expv_batch_pipe(Ctx *ctx, int64_t n, int nprob, const DiaPattern &P,
       for (auto &e : errs)
         if (!e.empty()) fail(EXPV_MI_SINGULAR, e);
     }
-    HIPCHECK(hipMemcpyAsync(dcoef.as<double>() + (size_t)q0 * (m + 1), coefh.data() + (size_t)q0 * (m + 1), sizeof(double) * (size_t)(m + 1) * pc,
+    HIPCHECK(hipMemcpyAsync(dcoef.as<T>() + (size_t)q0 * (m + 1), coefh.data() + (size_t)q0 * (m + 1), sizeof(T) * (size_t)(m + 1) * pc,
                             hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(dbeta.as<double>() + q0, betah.data() + q0, sizeof(double) * pc, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(dmcols.as<int32_t>() + q0, mch.data() + q0, sizeof(int32_t) * pc, hipMemcpyHostToDevice, s));
     {
       ProfScope ps(ctx, EXPV_MI_K_COMBINE);
-      dev::combine_batch<double>(s, n, dV.as<double>() + (int64_t)q0 * strideV, ldv, strideV, dcoef.as<double>() + (size_t)q0 * (m + 1), m + 1,
+      dev::combine_batch<T>(s, n, dV.as<T>() + (int64_t)q0 * strideV, ldv, strideV, dcoef.as<T>() + (size_t)q0 * (m + 1), m + 1,
                                  dbeta.as<double>() + q0, dmcols.as<int32_t>() + q0, w_dev + (int64_t)(p0 + q0) * ldw, ldw, pc);
     }
   };
@@ -328,7 +337,7 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
   const int iop = (o.iop == 0) ? m : o.iop;
   if (!herm && std::min(iop, m) > dev::LOWSYNC_MAX) fail(EXPV_MI_UNSUPPORTED, "expv_batch: window longer than 64 columns");
   if (m > dev::LOWSYNC_MAX * 2) fail(EXPV_MI_UNSUPPORTED, "expv_batch: m > 128");
-  if constexpr (std::is_same<T, double>::value) {
+  if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
     if (ctx->opt.pipeline && m <= dev::PIPE_CH && m >= 1) {
       BatchPatternCache *pc = reinterpret_cast<BatchPatternCache *>(ctx->ws_batch_pat);
       if (!pc) {
@@ -343,7 +352,7 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
         pc->perm_uploaded = false;
       }
       if (pc->P.ndiag > 0) {
-        expv_batch_pipe(ctx, n, nprob, pc->P, &pc->perm_uploaded, vals_dev, nnz, t, b_dev, ldb, w_dev, ldw, o, m_used, m, herm, iop);
+        expv_batch_pipe<T>(ctx, n, nprob, pc->P, &pc->perm_uploaded, vals_dev, nnz, t, b_dev, ldb, w_dev, ldw, o, m_used, m, herm, iop);
         return;
       }
     }
@@ -375,7 +384,7 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
   HIPCHECK(hipMemcpyAsync(d_perm.p, perm.data(), sizeof(int32_t) * perm.size(), hipMemcpyHostToDevice, s));
 
   // ---- per-chunk storage ---------------------------------------------------------------------------
-  const int64_t ldv = (n + 127) / 128 * 128;
+  const int64_t ldv = (n + SH - 1) / SH * SH;      // whole waves of 16-byte packs (128 rows; 256 for Float32)
   const int64_t strideV = ldv * (m + 1);
   const int ldhd = m + 2;
   const int64_t strideH = (int64_t)ldhd * (m + 1);
@@ -462,7 +471,7 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
       const T *Hq = Hh.data() + (size_t)q * strideH;
       auto at = [&](int i, int jj) -> cd {
         if constexpr (ST<T>::is_complex) return cd(Hq[(size_t)jj * ldhd + i].re, Hq[(size_t)jj * ldhd + i].im);
-        else return cd(Hq[(size_t)jj * ldhd + i], 0.0);
+        else return cd((double)Hq[(size_t)jj * ldhd + i], 0.0);
       };
       T *cq = coefh.data() + (size_t)q * (m + 1);
       const double tq = t[p0 + q];
@@ -477,13 +486,16 @@ static void expv_batch_T(Ctx *ctx, int64_t n, int nprob, const int32_t *rowptr_h
         for (int jj = 0; jj < mm; ++jj)
           for (int i = 0; i < mm; ++i) Hm(i, jj) = at(i, jj) * tq;
         dense::expm_higham2005base(Hm);
-        for (int i = 0; i < mm; ++i) cq[i] = make_cplx(Hm(i, 0).real(), Hm(i, 0).imag());
+        for (int i = 0; i < mm; ++i) {
+          cq[i].re = (typename ST<T>::real_t)Hm(i, 0).real();
+          cq[i].im = (typename ST<T>::real_t)Hm(i, 0).imag();
+        }
       } else {
         Mat<double> Hm(mm, mm);
         for (int jj = 0; jj < mm; ++jj)
           for (int i = 0; i < mm; ++i) Hm(i, jj) = at(i, jj).real() * tq;
         dense::expm_higham2005base(Hm);
-        for (int i = 0; i < mm; ++i) cq[i] = Hm(i, 0);
+        for (int i = 0; i < mm; ++i) cq[i] = ST<T>::from_real(Hm(i, 0));
       }
     };
     {
@@ -532,11 +544,10 @@ void expv_batch_run(Ctx *ctx, int dtype, int64_t n, int nprob, const int32_t *ro
     wd = wt.p;
     ldwd = n;
   }
-  if (dtype == EXPV_MI_C64)
-    expv_batch_T<cplx>(ctx, n, nprob, rowptr, colind, (const cplx *)vd, nnz, t, (const cplx *)bd, ldbd, (cplx *)wd, ldwd, o, m_used);
-  else
-    expv_batch_T<double>(ctx, n, nprob, rowptr, colind, (const double *)vd, nnz, t, (const double *)bd, ldbd, (double *)wd,
-                         ldwd, o, m_used);
+  dispatch_dtype(dtype, [&](auto tag) {      // every BlasFloat (ExponentialUtilities.jl:19): Float32 / ComplexF32 batches stay 32-bit
+    using T = typename decltype(tag)::type;
+    expv_batch_T<T>(ctx, n, nprob, rowptr, colind, (const T *)vd, nnz, t, (const T *)bd, ldbd, (T *)wd, ldwd, o, m_used);
+  });
   if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, ldw, wd, ldwd, n, nprob, esz);
 }
 

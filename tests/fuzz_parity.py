@@ -338,8 +338,8 @@ def one_case(seed, index, verbose=False):
         w = eu.expv(0.7, op, b, **kw)
         err = rel(w, ko.expv(0.7, A64, b64, **kw))
     elif call == "batch":
-        if single or not sp.issparse(A) or n > 5000 or herm:
-            return desc, 0.0, tol, {"skipped": "batch: 64-bit sparse operators"}
+        if not sp.issparse(A) or n > 5000 or herm:
+            return desc, 0.0, tol, {"skipped": "batch: sparse operators"}
         nprob = int(rng.integers(1, 6))
         P = A.tocsr()
         P.sort_indices()

@@ -403,6 +403,44 @@ def test_expv_batch_matches_single_problem_loop(eu, sym):
         assert mu[p] == m
 
 
+@pytest.mark.parametrize("T", [np.float32, np.complex64, np.complex128])
+@pytest.mark.parametrize("kind", ["banded", "general"])
+def test_expv_batch_other_element_types(eu, T, kind):
+    """the batched step for every BlasFloat (ExponentialUtilities.jl:19) -- Float32 batches on the batched
+    single-pass step (32-bit storage, tiles of 1024 rows), everything else through the batched two-kernel step -- against a
+    loop of the oracle's expv over the problems, at the bars of the element type; sizes off the tile boundaries, one problem
+    with a zero right-hand side."""
+    rng = np.random.default_rng(23)
+    cplx = np.dtype(T).kind == "c"
+    n, nprob, m = 2500, 5, 16
+    if kind == "banded":
+        A0 = (c2_operator(n) * ((1 + 0.25j) if cplx else 1.0)).tocsr()
+    else:
+        rows = np.repeat(np.arange(n), 3)
+        A0 = (sp.coo_matrix((rng.standard_normal(3 * n) * 0.3, (rows, rng.integers(0, n, size=3 * n))), shape=(n, n)).tocsr()
+              + sp.diags([np.full(n, -0.5)], [0], format="csr")).tocsr()
+        A0.sum_duplicates()
+        if cplx:
+            A0 = (A0 * (1 + 0.25j)).tocsr()
+    A0.sort_indices()
+    A0 = A0.astype(T)
+    vals = np.stack([A0.data * s for s in (1 + 0.1 * rng.random(nprob))]).astype(T)
+    B = np.asfortranarray((rng.standard_normal((n, nprob)) + (1j * rng.standard_normal((n, nprob)) if cplx else 0)).astype(T))
+    B[:, 3] = 0
+    T64 = np.complex128 if cplx else np.float64
+    tol = 3e-5 if np.dtype(T).itemsize <= 8 and T != np.float64 and T != np.complex128 else TOL
+    W, mu = eu.expv_batch(0.8, A0, vals, B, m=m, return_m=True)
+    assert np.asarray(W).dtype == np.dtype(T)
+    for p in range(nprob):
+        Ap = A0.astype(T64).copy()
+        Ap.data = vals[p].astype(T64)
+        wo = ko.expv(0.8, Ap, B[:, p].astype(T64), m=m, ishermitian=False)
+        if p == 3:
+            assert np.all(np.asarray(W)[:, p] == 0) and mu[p] == 0
+        else:
+            close(np.asarray(W)[:, p].astype(T64), wo, tol, "expv_batch %s %s: problem %d vs the oracle's expv" % (kind, np.dtype(T).name, p))
+
+
 def test_expv_batch_breakdown_and_zero_columns(eu):
     """Per-problem state: one problem breaks down early, one has a zero right-hand side."""
     n, m = 256, 20
