@@ -189,6 +189,17 @@ void upload_csr(Op &op, const std::vector<int32_t> &rp, const std::vector<int32_
 // a row holds beyond that stays in the CSR arrays and is applied by the overflow pass (kernels.hip: spmv_ovf), in segments of
 // at most OVF_SEG entries.  cut == 0: every slice keeps its longest row (padding <= 30 %: regular rows, no overflow).
 constexpr int OVF_SEG = 256;
+// what an overflow entry / an overflow row costs in units of one SELL slot (12 bytes streamed + one gather).  Packed overflow
+// entries are streamed and gathered like slots (+ the products' pass through LDS), a row adds a piece descriptor and a scattered
+// 8-byte store: 1.1 / 3 (EXPV_MI_OVF_COST="entry,row" overrides, for tuning; round 3's 8-lane groups: 2 / 6)
+static double g_ovf_entry_cost = 1.1, g_ovf_row_cost = 3.0;
+static const bool g_ovf_cost_env = [] {
+  if (const char *e = std::getenv("EXPV_MI_OVF_COST")) {
+    double a = 0, b = 0;
+    if (std::sscanf(e, "%lf,%lf", &a, &b) == 2 && a > 0 && b >= 0) { g_ovf_entry_cost = a; g_ovf_row_cost = b; }
+  }
+  return true;
+}();
 struct SellPlan {
   int cut = 0;
   int64_t padded = 0;             // SELL slots, padding included
@@ -226,7 +237,7 @@ static SellPlan plan_sell(int64_t n, const int32_t *rp, int64_t nnz, int SH) {
   for (int L = 1; L <= Lmax; ++L) {
     const double slots = (double)SH * ((double)sl_short[L] + (double)L * (double)sl_longer[L]);
     const double ov = (double)(ent_longer[L] - (int64_t)L * rows_longer[L]);
-    const double cost = slots + 2.0 * ov + 6.0 * (double)rows_longer[L];
+    const double cost = slots + g_ovf_entry_cost * ov + g_ovf_row_cost * (double)rows_longer[L];
     if (cost < best) { best = cost; bestL = L; }
   }
   S.cut = bestL;
@@ -312,12 +323,12 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
 // SELL-C-sigma (sigma = 1: no row sorting) with C = 128 rows (fp64) / 64 rows (complex): slot-major
 // inside a slice so one wave reads 1 KiB of values per slot.  Built only when padding stays small.
 template <class V>
-void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) {   // layout only: the slots are filled on the device (op_fill_forms)
+void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz, const int32_t *ci_of_entry) {   // layout only: the slots are filled on the device (op_fill_forms)
   const int SH = 64 * (16 / (int)sizeof(V));
   const int64_t nsl = (n + SH - 1) / SH;
   op.sell_ok = false;
   op.sell_cut = 0;
-  op.ovf_nseg = op.ovf_nmulti = 0;
+  op.ovf_nseg = op.ovf_nmulti = op.ovf_nent = 0;
   if (n == 0) return;
   const SellPlan S = plan_sell(n, rp.data(), nnz, SH);
   const int cut = S.cut > 0 ? S.cut : INT_MAX;
@@ -336,30 +347,64 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) 
   HIPCHECK(hipMemcpyAsync(op.sell_off.p, off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipMemsetAsync(op.sell_col.p, 0, op.sell_col.bytes, c->stream));     // slots of the rows beyond n: column 0, value 0
   HIPCHECK(hipMemsetAsync(op.sell_val.p, 0, op.sell_val.bytes, c->stream));
-  // overflow: the entries of a row beyond the cut, in segments of <= OVF_SEG entries of the CSR arrays.  {row, first entry,
-  // entries, destination}: destination -1 = the row's only segment (its sum goes straight to ovf_y[row]); otherwise the index
-  // of its partial sum, added up per row in segment order by the combine pass {row, first partial, partials, 0}
-  std::vector<int32_t> seg, multi;
+  // overflow: the entries of a row beyond the cut, PACKED in row order and cut into chunks of <= OVF_CHUNK entries (kernels.hip:
+  // k_spmv_ovf).  chunk {first packed entry, entries, first piece, pieces}; piece {row, offset in the chunk, entries, destination}:
+  // destination -1 = the row's only piece (its sum goes straight to ovf_y[row]); otherwise the index of its partial sum, added up
+  // per row in piece order by the combine pass, multi {row, first partial, partials, 0}.  ovf_src[k] = CSR index of packed entry k.
+  std::vector<int32_t> chunk, piece, multi, src;
   if (S.cut > 0) {
-    seg.reserve((size_t)S.ovf_segments * 4);
+    const int CH = dev::OVF_CHUNK;
+    src.reserve((size_t)S.ovf_entries);
     int32_t npart = 0;
+    int32_t cur_e0 = 0, cur_cnt = 0, cur_p0 = 0;      // the chunk being filled
+    auto flush = [&]() {
+      if (cur_cnt == 0) return;
+      chunk.push_back(cur_e0); chunk.push_back(cur_cnt); chunk.push_back(cur_p0); chunk.push_back((int32_t)(piece.size() / 4) - cur_p0);
+      cur_e0 += cur_cnt;
+      cur_cnt = 0;
+      cur_p0 = (int32_t)(piece.size() / 4);
+    };
     for (int64_t r = 0; r < n; ++r) {
       const int l = rp[r + 1] - rp[r];
       if (l <= S.cut) continue;
-      const int over = l - S.cut;
-      const int nseg = (over + OVF_SEG - 1) / OVF_SEG;
-      if (nseg > 1) { multi.push_back((int32_t)r); multi.push_back(npart); multi.push_back(nseg); multi.push_back(0); }
-      for (int q = 0; q < nseg; ++q) {
-        seg.push_back((int32_t)r);
-        seg.push_back(rp[r] + S.cut + q * OVF_SEG);
-        seg.push_back(std::min(OVF_SEG, over - q * OVF_SEG));
-        seg.push_back(nseg > 1 ? npart++ : -1);
+      int over = l - S.cut;
+      int32_t k = rp[r] + S.cut;
+      if (cur_cnt + over > CH) flush();                  // a row never straddles a chunk it does not fill
+      if (over <= CH) {                                  // the row's only piece
+        piece.push_back((int32_t)r); piece.push_back(cur_cnt); piece.push_back(over); piece.push_back(-1);
+        for (int q = 0; q < over; ++q) src.push_back(k + q);
+        cur_cnt += over;
+        continue;
+      }
+      // a long row: whole chunks of its own, partial sums combined in order
+      const int np = (over + CH - 1) / CH;
+      multi.push_back((int32_t)r); multi.push_back(npart); multi.push_back(np); multi.push_back(0);
+      while (over > 0) {
+        const int take = std::min(over, CH);
+        piece.push_back((int32_t)r); piece.push_back(0); piece.push_back(take); piece.push_back(npart++);
+        for (int q = 0; q < take; ++q) src.push_back(k + q);
+        cur_cnt = take;
+        flush();
+        k += take;
+        over -= take;
       }
     }
-    op.ovf_nseg = (int64_t)seg.size() / 4;
+    flush();
+    op.ovf_nseg = (int64_t)chunk.size() / 4;
     op.ovf_nmulti = (int64_t)multi.size() / 4;
-    op.ovf_seg.alloc(sizeof(int32_t) * std::max<size_t>(seg.size(), 4));
-    HIPCHECK(hipMemcpyAsync(op.ovf_seg.p, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice, c->stream));
+    op.ovf_nent = (int64_t)src.size();
+    op.ovf_seg.alloc(sizeof(int32_t) * std::max<size_t>(chunk.size(), 4));
+    op.ovf_piece.alloc(sizeof(int32_t) * std::max<size_t>(piece.size(), 4));
+    op.ovf_src.alloc(sizeof(int32_t) * std::max<size_t>(src.size(), 4));
+    op.ovf_col.alloc(sizeof(int32_t) * std::max<size_t>(src.size(), 4) + 16);
+    op.ovf_val.alloc(sizeof(V) * std::max<size_t>(src.size(), 1) + 16);
+    std::vector<int32_t> pcol(src.size());
+    for (size_t q = 0; q < src.size(); ++q) pcol[q] = ci_of_entry ? ci_of_entry[src[q]] : 0;
+    HIPCHECK(hipMemcpyAsync(op.ovf_seg.p, chunk.data(), sizeof(int32_t) * chunk.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.ovf_piece.p, piece.data(), sizeof(int32_t) * piece.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.ovf_src.p, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.ovf_col.p, pcol.data(), sizeof(int32_t) * pcol.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));      // (`pcol` leaves scope)
     if (!multi.empty()) {
       op.ovf_multi.alloc(sizeof(int32_t) * multi.size());
       HIPCHECK(hipMemcpyAsync(op.ovf_multi.p, multi.data(), sizeof(int32_t) * multi.size(), hipMemcpyHostToDevice, c->stream));
@@ -368,7 +413,7 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz) 
     op.ovf_y.alloc(sizeof(V) * (size_t)((n + 255) / 256 * 256));      // (whole waves of 16-byte packs for every element type)
     HIPCHECK(hipMemsetAsync(op.ovf_y.p, 0, op.ovf_y.bytes, c->stream));     // rows without overflow stay zero for good
   }
-  HIPCHECK(hipStreamSynchronize(c->stream));      // (`off`, `seg`, `multi` leave scope)
+  HIPCHECK(hipStreamSynchronize(c->stream));      // (`off`, `chunk`, `piece`, `multi`, `src` leave scope)
   op.nslices = nsl;
   op.sell_cut = S.cut;
   op.sell_ok = true;
@@ -446,6 +491,8 @@ static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long 
   a.check_herm = check_herm ? 1 : 0;
   a.out = op.upd_out.as<unsigned long long>();
   dev::op_update_forms<T>(s, a);
+  if (op.ovf_nent > 0)      // packed overflow entries: values through their CSR positions (creation and every values-only update)
+    dev::permute_values<T>(s, op.ovf_val.as<T>(), 0, op.val.as<T>(), 0, op.ovf_src.as<int32_t>(), op.ovf_nent, 1);
   HIPCHECK(hipMemcpyAsync(out, op.upd_out.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
   if (op.ndiag > 0 && std::is_same<T, double>::value) {
@@ -545,7 +592,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("reordering (RCM)");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
-  build_sell<V>(op, n, rp, (int64_t)ci.size());
+  build_sell<V>(op, n, rp, (int64_t)ci.size(), ci.data());
   lap("SELL layout");
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
   op.rows_sorted_unique = P.sorted_unique;

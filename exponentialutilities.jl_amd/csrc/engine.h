@@ -265,8 +265,9 @@ struct Op {
   // irregular rows: SELL slots up to sell_cut per row (0: no cut), the rest applied from the CSR arrays by the overflow pass
   // (kernels.hip: spmv_ovf) into ovf_y, a dense vector that is zero on every row without overflow
   int sell_cut = 0;
-  int64_t ovf_nseg = 0, ovf_nmulti = 0;
-  DevBuf ovf_seg, ovf_multi, ovf_part, ovf_y;
+  int64_t ovf_nseg = 0, ovf_nmulti = 0, ovf_nent = 0;      // chunks of <= 256 packed overflow entries, rows of several chunks, packed entries
+  DevBuf ovf_seg, ovf_piece, ovf_multi, ovf_part, ovf_y;     // chunk / piece descriptors (kernels.h: OvfView)
+  DevBuf ovf_val, ovf_col, ovf_src;                          // packed overflow entries (values, columns) and where each sits in the CSR arrays
   int64_t bandwidth = -1;   // max |col - row| (CSR operators)
   DevBuf dia_val;           // DIA form of a narrow-banded fp64 operator (pipe.hip): [ndiag][dia_ld], ascending offsets
   int ndiag = 0;

@@ -106,13 +106,16 @@ void cont_reset(hipStream_t s, StepState *st, size_t state_bytes, double hnorm, 
 
 // Overflow pass of a SELL operator with a slot cut-off (irregular rows): the entries of a row beyond the cut, taken from the
 // CSR arrays in segments of <= 256 entries; ovf_y[row] = their sum (rows without overflow are never written and stay zero).
-// seg: int32 x 4 per segment {row, first entry, entries, partial index or -1}; multi: {row, first partial, partials, 0}.
+// chunk: int32 x 4 per chunk {first packed entry, entries (<= OVF_CHUNK), first piece, pieces}; piece: {row, offset in the chunk,
+// entries, partial index or -1}; multi: {row, first partial, partials, 0}.
+constexpr int OVF_CHUNK = 256;        // packed overflow entries a wave takes at a time (4 per lane)
 template <class T>
 struct OvfView {
-  const int32_t *seg; int64_t nseg;
+  const int32_t *chunk; int64_t nchunk;
+  const int32_t *piece;
   const int32_t *multi; int64_t nmulti;
   T *part;
-  const int32_t *col; const T *val;   // the CSR arrays
+  const int32_t *col; const T *val;   // the PACKED overflow entries (row order; capi.hip: build_sell)
   T *y;                               // dense, zero outside the overflow rows
 };
 template <class T> void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride = 0,

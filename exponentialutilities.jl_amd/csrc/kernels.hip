@@ -263,57 +263,69 @@ void fill_zero(hipStream_t s, T *dst, int64_t n) {
 // ------------------------------------------------------------------------------------------
 // K2: operator application
 // ------------------------------------------------------------------------------------------
-// Overflow pass of the SELL form with a slot cut-off (irregular rows; capi.hip: build_sell).  A segment is <= 256 consecutive
-// entries of one row in the CSR arrays; 8 lanes share a segment (coalesced 8-entry chunks of val / col, 4 chunks in flight),
-// their sums are combined in a fixed order (lane pairs at distance 4, 2, 1), so the result is reproducible run to run.
-template <class T>
-__device__ __forceinline__ T group8_sum(T v);
-template <>
-__device__ __forceinline__ double group8_sum<double>(double v) {
-  v += lane_xor<4>(v);
-  v += lane_xor<2>(v);
-  v += lane_xor<1>(v);
-  return v;
-}
-template <>
-__device__ __forceinline__ cplx group8_sum<cplx>(cplx v) { return make_cplx(group8_sum<double>(v.re), group8_sum<double>(v.im)); }
-template <>
-__device__ __forceinline__ float group8_sum<float>(float v) { return (float)group8_sum<double>((double)v); }      // (the 8 partial sums are added in fp64)
-template <>
-__device__ __forceinline__ cplx32 group8_sum<cplx32>(cplx32 v) {
-  return make_cplx32((float)group8_sum<double>((double)v.re), (float)group8_sum<double>((double)v.im));
-}
+// Overflow pass of the SELL form with a slot cut-off (irregular rows; capi.hip: build_sell).  The entries a row holds beyond the
+// cut are PACKED in row order; a wave takes a chunk of <= 256 consecutive packed entries (4 per lane: the value / column loads are
+// fully coalesced and every lane has four gathers in flight whatever the row lengths are), leaves the products in LDS and then
+// sums them per row piece, one lane per piece, in entry order; a chunk that is one piece of one long row is summed by the whole
+// wave with the fixed wave_sum tree.  A row longer than a chunk is several single-piece chunks whose partial sums k_ovf_combine
+// adds in order.  Fixed summation order everywhere: reproducible run to run.  (Round 3 gave every row piece 8 lanes of its own:
+// rows with one or two entries beyond the cut -- most of them -- left six lanes idle and cost three small requests per piece;
+// 63 us per pass on the power-law operator of the bench, 2.4 x the time its gathers need.)
+template <class A> __device__ __forceinline__ A ovf_wave_sum(A v);
+template <> __device__ __forceinline__ double ovf_wave_sum<double>(double v) { return wave_sum(v); }
+template <> __device__ __forceinline__ cplx ovf_wave_sum<cplx>(cplx v) { return make_cplx(wave_sum(v.re), wave_sum(v.im)); }
+template <class T, class A> __device__ __forceinline__ T ovf_narrow(const A &a);
+template <> __device__ __forceinline__ double ovf_narrow<double, double>(const double &a) { return a; }
+template <> __device__ __forceinline__ cplx ovf_narrow<cplx, cplx>(const cplx &a) { return a; }
+template <> __device__ __forceinline__ float ovf_narrow<float, double>(const double &a) { return (float)a; }
+template <> __device__ __forceinline__ cplx32 ovf_narrow<cplx32, cplx>(const cplx &a) { return make_cplx32((float)a.re, (float)a.im); }
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_spmv_ovf(OvfView<T> o, const T *__restrict__ x, const StepState *st, int step,
                                                     int64_t x_stride) {
+  using A = typename ST<T>::acc_t;                     // products of 32-bit entries are formed and summed in fp64
+  __shared__ A p_s[BLOCK / 64][OVF_CHUNK];
   if (blockIdx.y != 0) { x += (int64_t)blockIdx.y * x_stride; if (st) st += blockIdx.y; }
   if (step_skipped(st, step)) return;
-  const int t = threadIdx.x & 7;
-  for (int64_t g = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 3; g < o.nseg; g += ((int64_t)gridDim.x * BLOCK) >> 3) {
-    const int4 sg = reinterpret_cast<const int4 *>(o.seg)[g];      // (the 8 lanes of a group share g: a group is in the loop as a whole)
-    const int32_t *cp = o.col + sg.y;
-    const T *vp = o.val + sg.y;
-    T acc = ST<T>::zero();
-    for (int k = t; k < sg.z; k += 32) {              // 4 chunks of 8 entries in flight per group; entries beyond the segment: value 0
-      T v[4], xv[4];
-      int32_t c[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t ch = (int64_t)blockIdx.x * (BLOCK / 64) + wave; ch < o.nchunk; ch += (int64_t)gridDim.x * (BLOCK / 64)) {
+    const int4 cd = reinterpret_cast<const int4 *>(o.chunk)[ch];      // {first entry, entries, first piece, pieces}
+    const int32_t *cp = o.col + cd.x;
+    const T *vp = o.val + cd.x;
+    T v[4], xv[4];
+    int32_t c[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool in = k + 8 * q < sg.z;
-        const int e = in ? k + 8 * q : 0;             // (entry 0 of the segment: a column this group reads anyway)
-        c[q] = cp[e];
-        v[q] = in ? vp[e] : ST<T>::zero();
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      const bool in = e < cd.y;
+      c[q] = cp[in ? e : 0];                            // (entry 0 of the chunk: a column this wave reads anyway)
+      v[q] = in ? vp[e] : ST<T>::zero();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xv[q] = x[c[q]];
+    A pr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pr[q] = ST<A>::zero(); ST<T>::cfma(pr[q], ST<T>::conj(v[q]), xv[q]); }      // conj(conj(v)) x = v x, in the sum type
+    if (cd.w == 1) {                                    // one piece (a row's only overflow, or 256 entries of a long row): the whole wave sums it
+      const A s = ovf_wave_sum<A>(ST<A>::add(ST<A>::add(pr[0], pr[1]), ST<A>::add(pr[2], pr[3])));
+      if (lane == 0) {
+        const int4 pd = reinterpret_cast<const int4 *>(o.piece)[cd.z];
+        if (pd.w < 0) o.y[pd.x] = ovf_narrow<T, A>(s);
+        else o.part[pd.w] = ovf_narrow<T, A>(s);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xv[q] = x[c[q]];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ST<T>::fma_(acc, v[q], xv[q]);
+      continue;
     }
-    acc = group8_sum<T>(acc);
-    if (t == 0) {
-      if (sg.w < 0) o.y[sg.x] = acc;
-      else o.part[sg.w] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p_s[wave][lane + 64 * q] = pr[q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes have landed (no other wave touches its row of p_s)
+    __builtin_amdgcn_wave_barrier();
+    for (int pi = lane; pi < cd.w; pi += 64) {
+      const int4 pd = reinterpret_cast<const int4 *>(o.piece)[cd.z + pi];      // {row, offset in the chunk, entries, partial index or -1}
+      A s = ST<A>::zero();
+      for (int k = 0; k < pd.z; ++k) s = ST<A>::add(s, p_s[wave][pd.y + k]);
+      if (pd.w < 0) o.y[pd.x] = ovf_narrow<T, A>(s);
+      else o.part[pd.w] = ovf_narrow<T, A>(s);
     }
+    __builtin_amdgcn_wave_barrier();                    // (the next chunk overwrites p_s[wave])
   }
 }
 template <class T>
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(BLOCK) void k_ovf_combine(OvfView<T> o, const StepS
 }
 template <class T>
 void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride, int nbatch) {
-  if (o.nseg <= 0) return;
-  int64_t g = (o.nseg * 8 + BLOCK - 1) / BLOCK;
+  if (o.nchunk <= 0) return;
+  int64_t g = (o.nchunk + (BLOCK / 64) - 1) / (BLOCK / 64);
   if (g > 4 * MAX_GRID) g = 4 * MAX_GRID;
   hipLaunchKernelGGL(k_spmv_ovf<T>, dim3((unsigned)g, nbatch), dim3(BLOCK), 0, s, o, x, st, step, x_stride);
   if (o.nmulti > 0)
