@@ -9,11 +9,12 @@ eu = expv_mi_loader.load()
 from exponentialutilities_jl_amd import _lib as L
 n, m = int(float(os.environ.get("TRACE_N", "1e6"))), 30
 offs = [-1000, -1, 0, 1, 1000] if (len(sys.argv) > 2 and sys.argv[2] == "stencil") else [-2, -1, 0, 1, 2]
-A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], offs, shape=(n, n), format="csc")
+sym = os.environ.get("TRACE_SYM", "0") == "1"      # symmetric operator: the Lanczos variant (window 2)
+A = sp.diags([0.5, 1.0, -3.0, 1.0, 0.5] if sym else [0.3, 1.2, -2.0, 0.8, -0.1], offs, shape=(n, n), format="csc")
 op = eu.MIOperator(A)
 b = torch.randn(n, dtype=torch.float64, device="cuda")
 for _ in range(12):
-    w = eu.expv(1.0, op, b, m=m, ishermitian=False)
+    w = eu.expv(1.0, op, b, m=m, ishermitian=sym)
 torch.cuda.synchronize()
 lib = L.load()
 lib.expv_mi_pipe_trace_dump.argtypes = [ctypes.c_char_p]
