@@ -1108,10 +1108,9 @@ def host_pattern_info(A, dtype=np.float64):
         info["path"] = "modular (empty operator)"
     elif info["sell_cut"] > 0:
         info["path"] = "two-kernel step, SELL slots up to the cut + overflow pass (irregular rows)"
-    elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) == np.float64 and info["bandwidth"] <= 8):
+    elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.float32)) and info["bandwidth"] <= 8):
         info["path"] = "pipeline, halo form"
-    elif (np.dtype(dtype) == np.float64 and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0)) or \
-            (np.dtype(dtype) == np.float32 and info["general_dia_diagonals"]):
+    elif np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.float32)) and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0):
         info["path"] = "pipeline, wave form (when the reach is small against the resident grid), else two-kernel step"
     else:
         info["path"] = "two-kernel step"

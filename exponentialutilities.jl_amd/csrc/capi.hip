@@ -306,8 +306,8 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
   const bool dia_base = P.sell_ok && !P.overflow && P.sorted_unique && P.fill_ok;   // fp64 and complex-fp64
   P.pipe_dia = dia_base && P.bandwidth <= dev::PIPE_WMAX && nd <= dev::PIPE_DIA_MAX;
   P.general_dia = !P.pipe_dia && dia_base && P.bandwidth <= INT32_MAX;   // fp64 and complex
-  if (P.sell_ok && !P.overflow && value_bytes == 8 && !P.pipe_dia && !P.general_dia) {
-    const int64_t TR = 512;
+  if (P.sell_ok && !P.overflow && (value_bytes == 8 || value_bytes == 4) && !P.pipe_dia && !P.general_dia) {
+    const int64_t TR = (16 / value_bytes) * 256;      // rows of a tile of the single-pass step: 512 (fp64), 1024 (Float32)
     P.tile_reach = 0;
     for (int64_t t0 = 0; t0 < n; t0 += TR) {
       int64_t cmin = INT64_MAX, cmax = -1;
@@ -512,10 +512,10 @@ struct PatClass { int cls; int64_t reach; bool dia; };
 static PatClass pattern_class_ex(const PatternPlan &P, int64_t n, int dtype) {
   if (!P.sell_ok) return {1, 0, false};
   if (P.overflow) return {0, 0, false};
-  if (P.bandwidth <= dev::PIPE_WMAX && (dtype == EXPV_MI_F64 || P.pipe_dia)) return {3, P.bandwidth, P.pipe_dia};
   const bool real_t = dtype == EXPV_MI_F64 || dtype == EXPV_MI_F32;
+  if (P.bandwidth <= dev::PIPE_WMAX && (real_t || P.pipe_dia)) return {3, P.bandwidth, P.pipe_dia};
   const bool wave_dia = P.general_dia && real_t;
-  const bool wave_sell = !wave_dia && dtype == EXPV_MI_F64 && P.tile_reach >= 0;
+  const bool wave_sell = !wave_dia && real_t && P.tile_reach >= 0;
   if (wave_dia || wave_sell) {
     const int64_t trw = (int64_t)(16 / dtype_size(dtype)) * dev::BLOCK;
     const int64_t ntiles = (n + trw - 1) / trw;
@@ -609,7 +609,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("device fill of the forms");
   if (op.sell_ok && P.tile_reach >= 0) {
     // wave form on SELL slots: which tiles does a tile's piece of A read u from?
-    const int64_t TR = 512, nt = (n + TR - 1) / TR;
+    const int64_t TR = (16 / (int64_t)sizeof(V)) * 256, nt = (n + TR - 1) / TR;      // (the tile of the element type: analyze_pattern)
     std::vector<int32_t> lo(nt), hi(nt);
     for (int64_t t = 0; t < nt; ++t) {
       int64_t cmin = INT64_MAX, cmax = -1;

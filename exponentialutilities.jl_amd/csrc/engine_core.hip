@@ -522,7 +522,7 @@ struct ArnoldiCall {
       const bool have_dia = op.ndiag > 0 && !no_dia_env;
       use_pipe = kPipeType<T> && use_fused && single_red && !no_pipe && op.sell_cut == 0 && op.bandwidth >= 0 && op.bandwidth <= dev::PIPE_WMAX &&
                  wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
-                 (have_dia || (std::is_same<T, double>::value && !isaug)) &&          // everything but plain fp64: DIA form only
+                 (have_dia || ((std::is_same<T, double>::value || std::is_same<T, float>::value) && !isaug)) &&      // SELL slots: the real element types; everything else: DIA form only
                  (!isaug || !dtype_is_32bit(ks.dtypeT)) &&
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
   }
@@ -535,7 +535,7 @@ struct ArnoldiCall {
     const int64_t ntiles_w = (ks.n + trw - 1) / trw;
     if (ks.wave_off && ++ks.wave_off_calls > 64) { ks.wave_off = false; ks.wave_off_calls = 0; }
     const bool wave_dia = op.gndiag > 0 && !no_dia_env;
-    const bool wave_sell = std::is_same<T, double>::value && !wave_dia && op.tile_reach >= 0;
+    const bool wave_sell = !wave_dia && op.tile_reach >= 0;      // (double and Float32: this branch)
     const int64_t reach_rows = wave_dia ? op.gdia_maxoff : op.tile_reach;
     if (!use_pipe && use_fused && single_red && !isaug && !no_pipe && !no_wave && !ks.wave_off && (wave_dia || wave_sell) &&
         m <= dev::PIPE_CH && !real_coeff && fresh && (ntiles_w <= 400 || (reach_rows / trw + 2) * 4 <= 400)) {

@@ -199,13 +199,25 @@ __device__ __forceinline__ double pack_prod(const Pack<cplx32> &v, const Pack<cp
   }
   return (double)s;
 }
+// the column indices of one SELL slot of a lane's N rows: one 8- / 16-byte load (fp64: 2 rows, Float32: 4 rows per lane)
+template <int N> struct ColPack;
+template <> struct ColPack<2> {
+  int c[2];
+  __device__ __forceinline__ void load(const int32_t *p) { const int2 v = *reinterpret_cast<const int2 *>(p); c[0] = v.x; c[1] = v.y; }
+};
+template <> struct ColPack<4> {
+  int c[4];
+  __device__ __forceinline__ void load(const int32_t *p) { const int4 v = *reinterpret_cast<const int4 *>(p); c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
+};
+template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(const int32_t *p) { c[0] = *p; } };
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
 template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
   static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
-  constexpr bool IS_F64 = std::is_same<T, double>::value;      // SELL slots, constant diagonals: fp64 only
-  constexpr bool IS_F32 = std::is_same<T, float>::value;       // (the wave form on general diagonals also runs in Float32)
+  constexpr bool IS_F64 = std::is_same<T, double>::value;      // constant diagonals: fp64 only
+  constexpr bool IS_F32 = std::is_same<T, float>::value;
+  constexpr bool SELL_T = IS_F64 || IS_F32;                    // SELL slots (halo and wave form): the real element types
   constexpr int N = Pack<T>::N;               // elements per 16-byte pack: 2 (fp64), 1 (complex-fp64), 4 (fp32), 2 (complex-fp32)
   constexpr int NR = ST<T>::nreal;
   constexpr int TR = N * BLOCK;               // rows per tile
@@ -215,9 +227,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
   static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
   static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
-  static_assert(!WAVE || IS_F64 || (DIA && IS_F32), "the wave form: fp64, or Float32 on the general diagonal form");
+  static_assert(!WAVE || SELL_T, "the wave form: the real element types");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
-  static_assert(DIA || IS_F64, "every element type but fp64 uses the DIA form");
+  static_assert(DIA || SELL_T, "the complex element types use the DIA form");
   T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
   T(&hs)[32] = sh.hs;
   double(&red_s)[BLOCK / 64][64] = sh.red_s;
@@ -323,7 +335,8 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     // SELL wave form: the column indices of up to 6 slots are fetched ahead of the flag wait even when the register budget has
     // no room for their values (PS = 0): the gather behind the wait then needs one memory round trip, not two (index -> u_j[index])
     constexpr int PSI = (WAVE && !DIA && PS < 6) ? 6 : (PS > 0 ? PS : 1);
-    int2 aci[PSI];
+    constexpr int SLICE = 64 * N;                 // rows of a SELL slice: one wave of 16-byte packs
+    ColPack<N> aci[PSI];
     int L = 0;
     const T *avp = nullptr;
     const int32_t *acp = nullptr;
@@ -343,21 +356,21 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           }
       }
     } else if (i < a.n) {
-      if constexpr (IS_F64) {
-        const int64_t slice = i >> 7;
+      if constexpr (SELL_T) {
+        const int64_t slice = i / SLICE;
         const int64_t off = pa.A.slice_off[slice];
-        L = (int)((pa.A.slice_off[slice + 1] - off) >> 7);
-        avp = pa.A.val + off + 2 * lane;
-        acp = pa.A.col + off + 2 * lane;
+        L = (int)((pa.A.slice_off[slice + 1] - off) / SLICE);
+        avp = pa.A.val + off + N * lane;
+        acp = pa.A.col + off + N * lane;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
-            av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
-            aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
+            av[sl] = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
+            aci[sl].load(acp + (int64_t)sl * SLICE);
           }
 #pragma unroll
         for (int sl = PS; sl < PSI; ++sl)
-          if (sl < L) aci[sl] = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
+          if (sl < L) aci[sl].load(acp + (int64_t)sl * SLICE);
       }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
@@ -589,29 +602,32 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     for (int e = 0; e < N; ++e) y.v[e] = ST<T>::zero();
     if (pa.final) {
     } else if constexpr (WAVE && !DIA) {
-      if constexpr (IS_F64) {
+      if constexpr (SELL_T) {
       if (i < a.n) {   // SELL slots, u_j gathered straight from its column in memory
         const T *ucol = a.V + (int64_t)jcol * a.ldv;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
-            y.v[0] = fma(av[sl].v[0], ucol[aci[sl].x], y.v[0]);   // padding entries: value 0, column 0
-            y.v[1] = fma(av[sl].v[1], ucol[aci[sl].y], y.v[1]);
+#pragma unroll
+            for (int e = 0; e < N; ++e) y.v[e] = fma(av[sl].v[e], ucol[aci[sl].c[e]], y.v[e]);   // padding entries: value 0, column 0
           }
 #pragma unroll
         for (int sl = PS; sl < PSI; ++sl)          // indices in registers, values fetched together with the gather
           if (sl < L) {
-            const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
-            y.v[0] = fma(v2.v[0], ucol[aci[sl].x], y.v[0]);
-            y.v[1] = fma(v2.v[1], ucol[aci[sl].y], y.v[1]);
+            const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
+#pragma unroll
+            for (int e = 0; e < N; ++e) y.v[e] = fma(v2.v[e], ucol[aci[sl].c[e]], y.v[e]);
           }
         for (int sl = PSI; sl < L; ++sl) {
-          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
-          const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
-          y.v[0] = fma(v2.v[0], ucol[ci.x], y.v[0]);
-          y.v[1] = fma(v2.v[1], ucol[ci.y], y.v[1]);
+          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
+          ColPack<N> ci;
+          ci.load(acp + (int64_t)sl * SLICE);
+#pragma unroll
+          for (int e = 0; e < N; ++e) y.v[e] = fma(v2.v[e], ucol[ci.c[e]], y.v[e]);
         }
-        if (i + 1 >= a.n) y.v[1] = 0.0;
+#pragma unroll
+        for (int e = 1; e < N; ++e)
+          if (i + e >= a.n) y.v[e] = ST<T>::zero();
       }
       }
     } else if constexpr (WAVE) {
@@ -675,23 +691,31 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         }
       }
     } else if (i < a.n) {
-      if constexpr (IS_F64) {
-      const int lim = TR + 2 * w, shift = (int)(w - r0);
+      if constexpr (SELL_T) {
+      const int lim = TR + 2 * w;
+      const int64_t shift = (int64_t)w - r0;
 #pragma unroll
       for (int sl = 0; sl < PS; ++sl)
         if (sl < L) {
-          const int i0 = aci[sl].x + shift, i1 = aci[sl].y + shift;
-          y.v[0] = fma(av[sl].v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);   // padding entries carry value 0
-          y.v[1] = fma(av[sl].v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
+#pragma unroll
+          for (int e = 0; e < N; ++e) {
+            const int64_t q = aci[sl].c[e] + shift;
+            y.v[e] = fma(av[sl].v[e], us[(q >= 0 && q < lim) ? (int)q : 0], y.v[e]);   // padding entries carry value 0
+          }
         }
       for (int sl = PS; sl < L; ++sl) {
-        const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * 128);
-        const int2 ci = *reinterpret_cast<const int2 *>(acp + (int64_t)sl * 128);
-        const int i0 = ci.x + shift, i1 = ci.y + shift;
-        y.v[0] = fma(v2.v[0], us[(i0 >= 0 && i0 < lim) ? i0 : 0], y.v[0]);
-        y.v[1] = fma(v2.v[1], us[(i1 >= 0 && i1 < lim) ? i1 : 0], y.v[1]);
+        const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
+        ColPack<N> ci;
+        ci.load(acp + (int64_t)sl * SLICE);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int64_t q = ci.c[e] + shift;
+          y.v[e] = fma(v2.v[e], us[(q >= 0 && q < lim) ? (int)q : 0], y.v[e]);
+        }
       }
-      if (i + 1 >= a.n) y.v[1] = 0.0;
+#pragma unroll
+      for (int e = 1; e < N; ++e)
+        if (i + e >= a.n) y.v[e] = ST<T>::zero();
       }
     }
     if (AUG && !pa.final && act) {
@@ -1319,6 +1343,15 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_r
 // Float32 / ComplexF32: the DIA halo form (tiles of 1024 / 512 rows: 4 / 2 rows per 16-byte pack), same register budgets per
 // window as their 64-bit counterparts
 void pipe_step(hipStream_t s, const PipeArgsT<float> &pa, int nbatch, int batch_rounds) {
+  if (pa.ndiag <= 0) {      // SELL slots (banded pattern with more than 8 distinct offsets / too much fill for the diagonal form)
+    switch (pipe_variant(pa.und)) {
+      case 0: pipe_launch<float, 8, 4, 6, false>(s, pa, nbatch, batch_rounds); break;
+      case 1: pipe_launch<float, 16, 3, 6, false>(s, pa, nbatch, batch_rounds); break;
+      case 2: pipe_launch<float, 24, 3, 0, false>(s, pa, nbatch, batch_rounds); break;
+      default: pipe_launch<float, 32, 2, 5, false>(s, pa, nbatch, batch_rounds); break;
+    }
+    return;
+  }
   switch (pipe_variant(pa.und)) {
     case 0: pipe_launch<float, 8, 4, 5, true>(s, pa, nbatch, batch_rounds); break;
     case 1: pipe_launch<float, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
@@ -1354,8 +1387,15 @@ bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) {
 #undef PIPE_WCASE
   return false;
 }
-bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off) {      // Float32: general diagonals only
-  if (pa.ndiag <= 0) return false;
+bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off) {      // Float32: general diagonals, or SELL slots with local columns
+  if (pa.ndiag <= 0) {
+    switch (pipe_variant(pa.und)) {
+      case 0: return pipe_wave_launch<float, 8, 4, 6, false>(s, pa, max_abs_off);
+      case 1: return pipe_wave_launch<float, 16, 3, 6, false>(s, pa, max_abs_off);
+      case 2: return pipe_wave_launch<float, 24, 3, 0, false>(s, pa, max_abs_off);
+      default: return pipe_wave_launch<float, 32, 2, 5, false>(s, pa, max_abs_off);
+    }
+  }
   switch (pipe_variant(pa.und)) {
     case 0: return pipe_wave_launch<float, 8, 4, 6, true>(s, pa, max_abs_off);
     case 1: return pipe_wave_launch<float, 16, 3, 6, true>(s, pa, max_abs_off);
@@ -1403,7 +1443,14 @@ int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off) 
   return 0;
 }
 int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off) {
-  if (pa.ndiag <= 0) return 0;
+  if (pa.ndiag <= 0) {
+    switch (pipe_variant(pa.und)) {
+      case 0: return pipe_wave_live_launch<float, 8, 4, 6, false>(s, pa, max_abs_off);
+      case 1: return pipe_wave_live_launch<float, 16, 3, 6, false>(s, pa, max_abs_off);
+      case 2: return pipe_wave_live_launch<float, 24, 3, 0, false>(s, pa, max_abs_off);
+      default: return pipe_wave_live_launch<float, 32, 2, 5, false>(s, pa, max_abs_off);
+    }
+  }
   switch (pipe_variant(pa.und)) {
     case 0: return pipe_wave_live_launch<float, 8, 4, 6, true>(s, pa, max_abs_off);
     case 1: return pipe_wave_live_launch<float, 16, 3, 6, true>(s, pa, max_abs_off);
@@ -1443,6 +1490,14 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
 }
 
 int pipe_step_live(hipStream_t s, const PipeArgsT<float> &pa) {
+  if (pa.ndiag <= 0) {
+    switch (pipe_variant(pa.und)) {
+      case 0: return pipe_live_launch<float, 8, 4, 6, false>(s, pa);
+      case 1: return pipe_live_launch<float, 16, 3, 6, false>(s, pa);
+      case 2: return pipe_live_launch<float, 24, 3, 0, false>(s, pa);
+      default: return pipe_live_launch<float, 32, 2, 5, false>(s, pa);
+    }
+  }
   switch (pipe_variant(pa.und)) {
     case 0: return pipe_live_launch<float, 8, 4, 5, true>(s, pa);
     case 1: return pipe_live_launch<float, 16, 3, 6, true>(s, pa);

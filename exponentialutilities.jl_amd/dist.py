@@ -167,8 +167,12 @@ class RowShardedDense:
     def operator(self, eu, ctx=None, ishermitian=False):
         """The library operator (device vectors in, device vectors out, on the library's stream)."""
         if self.on_gpu:
+            import torch
             self._ctx = ctx or eu.default_context()
             self._lib = eu._lib.load()
+            # the row block was produced on torch's stream (a copy, a transposition, a generator); the local GEMV reads it on the
+            # library's own non-blocking stream, which does not wait for the legacy default stream: order them once, here
+            torch.cuda.synchronize(self.rows.device)
         return eu.MIOperator(None, ctx, dtype=_np_dtype(self.rows.dtype), ishermitian=ishermitian, matvec=self.matvec,
                              shape=(self.n, self.n))
 

@@ -1431,3 +1431,62 @@ def test_slow_progress_of_the_reference_controller_is_reported_not_changed(eu):
         warnings.simplefilter("error")                                  # an ordinary run: no notice, field zero
         eu.expv_timestep(1.0, A, b, adaptive=True, tol=1e-6, stats=st2)
     assert st2["stalled_steps"] == 0 and st2["num_timesteps"] < 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["nine_offsets_halo", "irregular_band_wave", "shuffled_grid_reordered"])
+def test_float32_sell_slot_forms_of_the_single_pass_step(eu, shape):
+    """the SELL-slot forms of the single-pass step in Float32 (4 rows per lane, slices of 256 rows, tiles of 1024):
+    the halo form for a banded pattern that has no diagonal form (nine offsets with gaps), the wave form for columns within a band of
+    the row without any diagonal structure, and an unstructured 2-D grid numbering that operator creation reorders onto the wave
+    form.  Path, expv / H against the fp64 oracle at fp32 bars, overlapped = one launch after the other bit for bit, an IOP window,
+    sizes off the tile boundaries."""
+    rng = np.random.default_rng(29)
+    want = ["pipeline"]
+    if shape == "nine_offsets_halo":
+        n = 70_003
+        offs = [-8, -6, -5, -3, 0, 1, 2, 4, 7, -1]                       # 10 distinct offsets: no DIA form (> 8), bandwidth 8
+        d = [(0.1 + 0.05 * rng.random(n - abs(o))) * (1 if o else -6.0) for o in offs]
+        A = sp.diags(d, offs, shape=(n, n), format="csr")
+    elif shape == "irregular_band_wave":
+        n, band, k = 90_001, 1500, 5
+        rows = np.repeat(np.arange(n), k)
+        cols = np.clip(rows + rng.integers(-band, band + 1, size=n * k), 0, n - 1)
+        A = sp.csr_matrix((rng.standard_normal(n * k) * 0.3, (rows, cols)), shape=(n, n))
+        A.sum_duplicates()
+        A = (A - 0.5 * sp.eye(n)).tocsr()                              # (a dominant diagonal makes y = A v ~ d v: MGS cancellation amplifies fp32 rounding per column)
+        want.append("wave")
+    else:
+        k = 640
+        n = k * k                                                      # 409 600 rows: 400 Float32 tiles -- the reach decides
+        G = sp.diags([0.7, 1.1, -4.0, 0.9, 1.3], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+        q = rng.permutation(n)
+        A = G[q][:, q].tocsr()
+        want.append("wave")
+    A = A.astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    A64, b64 = A.astype(np.float64), b.astype(np.float64)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    if shape == "shuffled_grid_reordered":
+        assert op.reorder_info["reordered"] and op.reorder_info["bandwidth_after"] <= 2 * k, op.reorder_info
+    for m, iop in ((12, 0), (31, 0), (20, 3)):
+        if shape == "shuffled_grid_reordered" and m == 31:
+            continue
+        ctx.set_pipeline_overlap(True)
+        w = np.asarray(eu.expv(0.3, op, b, m=m, iop=iop, ishermitian=False)).copy()
+        path = list(eu.expv.last_stats["path"])
+        assert all(p in path for p in want), (path, want)
+        ctx.set_pipeline_overlap(False)
+        w2 = np.asarray(eu.expv(0.3, op, b, m=m, iop=iop, ishermitian=False)).copy()
+        assert np.array_equal(w, w2), "overlapped and serial forms differ"
+        assert w.dtype == np.float32
+        close(w.astype(np.float64), ko.expv(0.3, A64, b64, m=m, iop=iop, ishermitian=False), 2e-5,
+              "Float32 SELL-slot form %s m=%d iop=%d: expv (fp32 bar)" % (shape, m, iop))
+    ctx.set_pipeline_overlap(True)
+    Ks = eu.arnoldi(op, b, m=6, ishermitian=False)
+    Ko = ko.arnoldi(A64, b64, m=6, ishermitian=False)
+    K32 = ko.arnoldi(A, b, m=6, ishermitian=False)                     # the oracle in Float32 arithmetic: the scale of the bar
+    rH = close(K32.getH().astype(np.float64), Ko.getH(), 1e-3, "  the oracle in float32 arithmetic vs the fp64 oracle: H (%s)" % shape, mat=True)
+    eH = close(np.asarray(Ks.getH()).astype(np.float64), Ko.getH(), max(2e-5, 20 * rH), "Float32 SELL-slot form %s: H of 6 steps incl. H[7, 6] (fp32 bar)" % shape, mat=True)
+    close(np.asarray(Ks.getV()).astype(np.float64), Ko.getV(), max(2e-5, 20 * rH), "Float32 SELL-slot form %s: V (max abs, fp32 bar)" % shape, absolute=True)
