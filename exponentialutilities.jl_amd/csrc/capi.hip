@@ -540,7 +540,11 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // change row lengths)
   const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
   if (mode == 1 && !candidate) return;
-  const std::vector<int32_t> perm = reorder::rcm(n, rp.data(), ci.data());
+  // (a level wider than the reach the wave form can use cannot lead anywhere: give up after the first breadth-first searches)
+  const int64_t trw = (int64_t)(16 / sizeof(V)) * dev::BLOCK;
+  const int64_t useful = std::max<int64_t>(98 * trw, (n + trw - 1) / trw <= 400 ? n : 0);
+  const std::vector<int32_t> perm = reorder::rcm(n, rp.data(), ci.data(), mode == 1 ? useful : 0);
+  if (perm.empty()) return;
   std::vector<int32_t> rp2, ci2, src;
   reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));

@@ -18,8 +18,11 @@
 namespace expv_mi {
 namespace reorder {
 
-// perm[i] = the row of A that becomes row i of P A P'
-inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci) {
+// perm[i] = the row of A that becomes row i of P A P'.  give_up_width > 0: return an EMPTY vector as soon as a level of the
+// rooted level structure of a component is wider than that -- the bandwidth of the Cuthill-McKee ordering is at least the widest
+// level, so an ordering that cannot get below the caller's useful reach (a random graph: levels of n/4 nodes) is not worth
+// finishing (operator creation: the adjacency + one breadth-first search instead of the whole ordering).
+inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t give_up_width = 0) {
   std::vector<int32_t> perm((size_t)n);
   if (n <= 0) return perm;
   // --- symmetric adjacency without self loops: count, fill, sort + unique per node ---
@@ -49,11 +52,8 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci)
     std::sort(b, e);
     deg[i] = (int32_t)(std::unique(b, e) - b);      // (entries beyond deg[i] of the node's range are unused)
   }
-  // neighbours by ascending degree (ties: ascending index): the Cuthill-McKee visiting order, fixed once
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t *b = adj.data() + ap[i];
-    std::sort(b, b + deg[i], [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
-  }
+  // (neighbours are put in ascending-degree order -- the Cuthill-McKee visiting order -- when a node is expanded, below: the
+  //  level structures of the start-node search do not need it, and a hopeless pattern is given up before any of it)
   // nodes by ascending degree: candidates for the start of each component
   std::vector<int32_t> bydeg((size_t)n);
   std::iota(bydeg.begin(), bydeg.end(), 0);
@@ -111,6 +111,7 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci)
       ecc = ecc2;
       width = w2;
     }
+    if (give_up_width > 0 && width > give_up_width) return std::vector<int32_t>();
     // Cuthill-McKee from s
     const int64_t first = pos;
     int64_t head = pos;
@@ -118,8 +119,10 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci)
     placed[s] = 1;
     while (head < pos) {
       const int32_t u = order[(size_t)head++];
+      int32_t *nb = adj.data() + ap[u];
+      if (deg[u] > 1) std::sort(nb, nb + deg[u], [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
       for (int32_t k = 0; k < deg[u]; ++k) {
-        const int32_t v = adj[(size_t)ap[u] + k];
+        const int32_t v = nb[k];
         if (placed[v]) continue;
         placed[v] = 1;
         order[(size_t)pos++] = v;
