@@ -193,6 +193,7 @@ constexpr int OVF_SEG = 256;
 // entries are streamed and gathered like slots (+ the products' pass through LDS), a row adds a piece descriptor and a scattered
 // 8-byte store: 1.1 / 3 (EXPV_MI_OVF_COST="entry,row" overrides, for tuning; round 3's 8-lane groups: 2 / 6)
 static double g_ovf_entry_cost = 1.1, g_ovf_row_cost = 3.0;
+static const bool g_cbf_enabled = std::getenv("EXPV_MI_NO_CBF") == nullptr;      // A/B switch of the column-blocked form of irregular rows
 static const bool g_ovf_cost_env = [] {
   if (const char *e = std::getenv("EXPV_MI_OVF_COST")) {
     double a = 0, b = 0;
@@ -331,7 +332,12 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz, 
   op.ovf_nseg = op.ovf_nmulti = op.ovf_nent = 0;
   if (n == 0) return;
   const SellPlan S = plan_sell(n, rp.data(), nnz, SH);
-  const int cut = S.cut > 0 ? S.cut : INT_MAX;
+  // Irregular rows of an operator whose vector does not fit an XCD's L2 next to the streams (n * sizeof(V) >= 2 MB): the
+  // column-blocked form -- every entry packed by (column block of 2 MB of x, row), no SELL slots (round 4; the slots + overflow
+  // pass moved 64 bytes through the fabric per gathered 8: profiles/r04_pmc_traffic_general_sparse.txt)
+  op.cbf = false;
+  const bool want_cbf = S.cut > 0 && ci_of_entry != nullptr && (size_t)n * sizeof(V) >= ((size_t)2 << 20) && g_cbf_enabled && nnz < (int64_t)1 << 31;
+  const int cut = want_cbf ? 0 : (S.cut > 0 ? S.cut : INT_MAX);
   std::vector<int64_t> off(nsl + 1, 0);
   for (int64_t s = 0; s < nsl; ++s) {
     int L = 0;
@@ -352,7 +358,95 @@ void build_sell(Op &op, int64_t n, const std::vector<int32_t> &rp, int64_t nnz, 
   // destination -1 = the row's only piece (its sum goes straight to ovf_y[row]); otherwise the index of its partial sum, added up
   // per row in piece order by the combine pass, multi {row, first partial, partials, 0}.  ovf_src[k] = CSR index of packed entry k.
   std::vector<int32_t> chunk, piece, multi, src;
-  if (S.cut > 0) {
+  if (want_cbf) {
+    const int CH = dev::OVF_CHUNK;
+    const int64_t CB = (int64_t)(((size_t)2 << 20) / sizeof(V));      // columns per block: 2 MB of x
+    const int ncb = (int)((n + CB - 1) / CB);
+    // entries per block in (row, column) order
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> blk((size_t)ncb);      // {row, CSR index}
+    for (auto &b : blk) b.reserve((size_t)(nnz / ncb + 1024));
+    std::vector<std::pair<int32_t, int32_t>> rowe;
+    for (int64_t r = 0; r < n; ++r) {
+      rowe.clear();
+      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) rowe.emplace_back(ci_of_entry[k], k);
+      std::sort(rowe.begin(), rowe.end());                             // (ascending columns; a sorted row is left as it is)
+      for (const auto &e : rowe) blk[(size_t)(e.first / CB)].emplace_back((int32_t)r, e.second);
+    }
+    src.reserve((size_t)nnz);
+    std::vector<uint16_t> r16;
+    r16.reserve((size_t)nnz);
+    std::vector<int32_t> pcol;
+    pcol.reserve((size_t)nnz);
+    int32_t npart = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+      const auto &B = blk[(size_t)cb];
+      size_t q = 0;
+      int32_t c_e0 = (int32_t)src.size(), c_cnt = 0, c_base = -1;
+      bool c_scan = false;
+      auto flush = [&]() {
+        if (c_cnt == 0) return;
+        chunk.push_back(c_e0); chunk.push_back(c_cnt | (c_scan ? dev::CBF_SCAN_BIT : 0)); chunk.push_back(c_base); chunk.push_back(cb);
+        c_e0 += c_cnt;
+        c_cnt = 0;
+        c_base = -1;
+        c_scan = false;
+      };
+      while (q < B.size()) {
+        size_t q1 = q;
+        while (q1 < B.size() && B[q1].first == B[q].first) ++q1;      // the group (row, cb)
+        const int32_t row = B[q].first;
+        const int len = (int)(q1 - q);
+        if (len > CH) {                                                // a long group: chunks of its own, partial sums
+          flush();
+          const int np = (len + CH - 1) / CH;
+          multi.push_back(row); multi.push_back(npart); multi.push_back(np); multi.push_back(cb);
+          for (int t = 0; t < np; ++t) {
+            const int take = std::min(CH, len - t * CH);
+            chunk.push_back((int32_t)src.size()); chunk.push_back(take | dev::CBF_LONG_BIT); chunk.push_back(row); chunk.push_back(npart++);
+            for (int z = 0; z < take; ++z) { src.push_back(B[q + (size_t)t * CH + z].second); r16.push_back(0); pcol.push_back(ci_of_entry[B[q + (size_t)t * CH + z].second]); }
+          }
+          c_e0 = (int32_t)src.size();
+          q = q1;
+          continue;
+        }
+        if (c_cnt + len > CH || (c_base >= 0 && row - c_base > 65000)) flush();
+        if (c_base < 0) { c_base = row; c_e0 = (int32_t)src.size(); }
+        for (size_t z = q; z < q1; ++z) { src.push_back(B[z].second); r16.push_back((uint16_t)(row - c_base)); pcol.push_back(ci_of_entry[B[z].second]); }
+        c_cnt += len;
+        c_scan = c_scan || len > 6;
+        q = q1;
+      }
+      flush();
+    }
+    blk.clear();
+    blk.shrink_to_fit();
+    const int64_t npad = (n + 255) / 256 * 256;
+    op.cbf = true;
+    op.cbf_ncb = ncb;
+    op.cbf_pstride = npad;
+    op.ovf_nseg = (int64_t)chunk.size() / 4;
+    op.ovf_nmulti = (int64_t)multi.size() / 4;
+    op.ovf_nent = (int64_t)src.size();
+    op.ovf_seg.alloc(sizeof(int32_t) * std::max<size_t>(chunk.size(), 4));
+    op.ovf_src.alloc(sizeof(int32_t) * std::max<size_t>(src.size(), 4));
+    op.ovf_col.alloc(sizeof(int32_t) * std::max<size_t>(src.size(), 4) + 16);
+    op.ovf_val.alloc(sizeof(V) * std::max<size_t>(src.size(), 1) + 16);
+    op.cbf_row16.alloc(sizeof(uint16_t) * std::max<size_t>(r16.size(), 8) + 16);
+    op.cbf_P.alloc(sizeof(V) * (size_t)npad * (size_t)ncb);
+    op.ovf_y.alloc(sizeof(V) * (size_t)npad);
+    HIPCHECK(hipMemcpyAsync(op.ovf_seg.p, chunk.data(), sizeof(int32_t) * chunk.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.ovf_src.p, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.ovf_col.p, pcol.data(), sizeof(int32_t) * pcol.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(op.cbf_row16.p, r16.data(), sizeof(uint16_t) * r16.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemsetAsync(op.cbf_P.p, 0, op.cbf_P.bytes, c->stream));      // rows without an entry in a block stay zero for good
+    HIPCHECK(hipMemsetAsync(op.ovf_y.p, 0, op.ovf_y.bytes, c->stream));
+    if (!multi.empty()) {
+      op.ovf_multi.alloc(sizeof(int32_t) * multi.size());
+      HIPCHECK(hipMemcpyAsync(op.ovf_multi.p, multi.data(), sizeof(int32_t) * multi.size(), hipMemcpyHostToDevice, c->stream));
+      op.ovf_part.alloc(sizeof(V) * (size_t)npart);
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));      // (the host vectors leave scope)
+  } else if (S.cut > 0) {
     const int CH = dev::OVF_CHUNK;
     src.reserve((size_t)S.ovf_entries);
     int32_t npart = 0;
@@ -481,7 +575,7 @@ static void op_fill_forms(Op &op, bool creation, bool check_herm, unsigned long 
   dev::OpUpdateArgs<T> a{};
   a.n = op.n;
   a.rp = op.rowptr.as<int32_t>(); a.ci = op.col.as<int32_t>(); a.val = op.val.as<T>();
-  if (op.sell_ok) {
+  if (op.sell_ok && !op.cbf) {      // (column-blocked form: no SELL slots to fill)
     a.sell_val = op.sell_val.as<T>(); a.sell_off = op.sell_off.as<int64_t>(); a.sell_rows = 64 * (16 / (int)sizeof(T));
     a.sell_col = creation ? op.sell_col.as<int32_t>() : nullptr;
     a.sell_cut = op.sell_cut;

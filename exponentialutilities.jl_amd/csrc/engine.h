@@ -268,6 +268,12 @@ struct Op {
   int64_t ovf_nseg = 0, ovf_nmulti = 0, ovf_nent = 0;      // chunks of <= 256 packed overflow entries, rows of several chunks, packed entries
   DevBuf ovf_seg, ovf_piece, ovf_multi, ovf_part, ovf_y;     // chunk / piece descriptors (kernels.h: OvfView)
   DevBuf ovf_val, ovf_col, ovf_src;                          // packed overflow entries (values, columns) and where each sits in the CSR arrays
+  // column-blocked form of an operator with irregular rows (kernels.h: OvfView, ncb > 0): ALL entries packed by (column block, row),
+  // no SELL slots; ovf_y is the operator's whole product
+  bool cbf = false;
+  int cbf_ncb = 0;
+  int64_t cbf_pstride = 0;
+  DevBuf cbf_row16, cbf_P;
   int64_t bandwidth = -1;   // max |col - row| (CSR operators)
   DevBuf dia_val;           // DIA form of a narrow-banded fp64 operator (pipe.hip): [ndiag][dia_ld], ascending offsets
   int ndiag = 0;

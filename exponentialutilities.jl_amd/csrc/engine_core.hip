@@ -266,7 +266,8 @@ void ks_materialize(Ks &ks) {
 template <class T>
 static dev::OvfView<T> ovf_view(const Op &op) {
   return dev::OvfView<T>{op.ovf_seg.as<int32_t>(), op.ovf_nseg, op.ovf_piece.as<int32_t>(), op.ovf_multi.as<int32_t>(), op.ovf_nmulti,
-                         op.ovf_part.as<T>(), op.ovf_col.as<int32_t>(), op.ovf_val.as<T>(), op.ovf_y.as<T>()};
+                         op.ovf_part.as<T>(), op.ovf_col.as<int32_t>(), op.ovf_val.as<T>(), op.ovf_y.as<T>(),
+                         op.cbf_row16.as<uint16_t>(), op.cbf_P.as<T>(), op.cbf_pstride, op.cbf ? op.cbf_ncb : 0, op.n};
 }
 template <class T>
 static void op_apply_T(Op &op, const T *x, T *y, const StepState *st, int step) {

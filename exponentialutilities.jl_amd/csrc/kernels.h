@@ -117,7 +117,15 @@ struct OvfView {
   T *part;
   const int32_t *col; const T *val;   // the PACKED overflow entries (row order; capi.hip: build_sell)
   T *y;                               // dense, zero outside the overflow rows
+  // Column-blocked form (ncb > 0; irregular rows of a large operator: ALL entries, no SELL slots).  The packed entries are sorted
+  // by (column block, row, column); chunk {first entry, entries | long << 30, base row, column block or partial index}; row16[k] =
+  // row of entry k minus the chunk's base row; every chunk writes the sums of its rows into the partial vector of its column
+  // block, P[cb * pstride + row] (rows without an entry in the block stay zero for good), and y = sum over cb of P[cb] afterwards.
+  // The chunks in flight at any time belong to one or two column blocks, so the gathers of the whole chip stay inside 2-4 MB of x.
+  const uint16_t *row16;
+  T *P; int64_t pstride; int ncb; int64_t n;
 };
+constexpr int CBF_LONG_BIT = 1 << 30, CBF_SCAN_BIT = 1 << 29;      // chunk flags: one piece of a long (row, block) group / a row of > 6 entries inside
 template <class T> void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride = 0,
                                  int nbatch = 1);
 template <class T>

@@ -328,6 +328,117 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ovf(OvfView<T> o, const T *__res
     __builtin_amdgcn_wave_barrier();                    // (the next chunk overwrites p_s[wave])
   }
 }
+// Column-blocked pass over ALL entries of an operator with irregular rows (kernels.h: OvfView, ncb > 0).  One wave per chunk of
+// <= 256 packed entries of ONE column block: coalesced value / column / row-offset loads, four gathers in flight per lane (from the
+// 2 MB of x the chunks in flight share), products to LDS, then every entry that starts a row sums that row's entries in order and
+// stores the sum into the block's partial vector.  A (row, block) group longer than a chunk is cut into chunks of its own ("long":
+// the whole wave sums one, k_cbf_combine adds a row's partials in order).  Fixed order everywhere.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_spmv_cbf(OvfView<T> o, const T *__restrict__ x, const StepState *st, int step) {
+  using A = typename ST<T>::acc_t;
+  __shared__ A p_s[BLOCK / 64][OVF_CHUNK];
+  __shared__ unsigned short r_s[BLOCK / 64][OVF_CHUNK];
+  if (step_skipped(st, step)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t ch = (int64_t)blockIdx.x * (BLOCK / 64) + wave; ch < o.nchunk; ch += (int64_t)gridDim.x * (BLOCK / 64)) {
+    const int4 cd = reinterpret_cast<const int4 *>(o.chunk)[ch];      // {first entry, entries | long, base row, block / partial}
+    const int cnt = cd.y & 0xffff;
+    const bool is_long = (cd.y & CBF_LONG_BIT) != 0;
+    const int32_t *cp = o.col + cd.x;
+    const T *vp = o.val + cd.x;
+    const unsigned short *rp16 = o.row16 + cd.x;
+    T v[4], xv[4];
+    int32_t c[4];
+    unsigned short rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      const bool in = e < cnt;
+      c[q] = cp[in ? e : 0];
+      v[q] = in ? vp[e] : ST<T>::zero();
+      rr[q] = in ? rp16[e] : (unsigned short)0xffff;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xv[q] = x[c[q]];
+    A pr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pr[q] = ST<A>::zero(); ST<T>::cfma(pr[q], ST<T>::conj(v[q]), xv[q]); }
+    if (is_long) {
+      const A s = ovf_wave_sum<A>(ST<A>::add(ST<A>::add(pr[0], pr[1]), ST<A>::add(pr[2], pr[3])));
+      if (lane == 0) o.part[cd.w] = ovf_narrow<T, A>(s);
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { p_s[wave][lane + 64 * q] = pr[q]; r_s[wave][lane + 64 * q] = rr[q]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    T *Pb = o.P + (int64_t)cd.w * o.pstride + cd.z;
+    if (cd.y & CBF_SCAN_BIT) {
+      // a chunk with longer rows: segmented inclusive scan over its 256 entries (rows are sorted: equal row offsets are
+      // contiguous), 8 steps whatever the row lengths -- a single lane summing a 200-entry row made the pass 2 x slower on
+      // Zipf rows (tools/cbj_probe.hip); the last entry of a row then holds its sum
+      for (int d = 1; d < OVF_CHUNK; d <<= 1) {
+        A add[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = lane + 64 * q;
+          add[q] = (e >= d && r_s[wave][e - d] == rr[q]) ? p_s[wave][e - d] : ST<A>::zero();
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p_s[wave][lane + 64 * q] = ST<A>::add(p_s[wave][lane + 64 * q], add[q]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        if (e < cnt && (e == cnt - 1 || r_s[wave][e + 1] != rr[q])) Pb[rr[q]] = ovf_narrow<T, A>(p_s[wave][e]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      if (e < cnt) {
+        const unsigned short r0 = r_s[wave][e];
+        if (e == 0 || r_s[wave][e - 1] != r0) {        // first entry of its row in this chunk: sum the row
+          A s = p_s[wave][e];
+          for (int k = e + 1; k < cnt && r_s[wave][k] == r0; ++k) s = ST<A>::add(s, p_s[wave][k]);
+          Pb[r0] = ovf_narrow<T, A>(s);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// rows whose entries in one column block fill several chunks: multi {row, first partial, partials, column block}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_cbf_combine(OvfView<T> o, const StepState *st, int step) {
+  if (step_skipped(st, step)) return;
+  for (int64_t m = (int64_t)blockIdx.x * BLOCK + threadIdx.x; m < o.nmulti; m += (int64_t)gridDim.x * BLOCK) {
+    const int4 d = reinterpret_cast<const int4 *>(o.multi)[m];
+    T s = o.part[d.y];
+    for (int q = 1; q < d.z; ++q) s = ST<T>::add(s, o.part[d.y + q]);
+    o.P[(int64_t)d.w * o.pstride + d.x] = s;
+  }
+}
+// y = P[0] + P[1] + ... (column blocks in ascending order: ascending columns, like the row's own sum)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_cbf_sum(OvfView<T> o, const StepState *st, int step) {
+  constexpr int N = Pack<T>::N;
+  if (step_skipped(st, step)) return;
+  for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * N; i < o.n; i += (int64_t)gridDim.x * BLOCK * N) {
+    Pack<T> acc = *reinterpret_cast<const Pack<T> *>(o.P + i);
+    for (int cb = 1; cb < o.ncb; ++cb) {
+      const Pack<T> p = *reinterpret_cast<const Pack<T> *>(o.P + (int64_t)cb * o.pstride + i);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc.v[k] = ST<T>::add(acc.v[k], p.v[k]);
+    }
+    *reinterpret_cast<Pack<T> *>(o.y + i) = acc;
+  }
+}
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_ovf_combine(OvfView<T> o, const StepState *st, int step) {
   if (blockIdx.y != 0 && st) st += blockIdx.y;
@@ -343,6 +454,14 @@ template <class T>
 void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride, int nbatch) {
   if (o.nchunk <= 0) return;
   int64_t g = (o.nchunk + (BLOCK / 64) - 1) / (BLOCK / 64);
+  if (o.ncb > 0) {      // column-blocked form: every workgroup takes consecutive chunks, dispatched in order = one block after the other
+    if (nbatch != 1) return;                               // (single problems only)
+    hipLaunchKernelGGL(k_spmv_cbf<T>, dim3((unsigned)g), dim3(BLOCK), 0, s, o, x, st, step);
+    if (o.nmulti > 0)
+      hipLaunchKernelGGL(k_cbf_combine<T>, dim3((unsigned)std::min<int64_t>(MAX_GRID, (o.nmulti + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, o, st, step);
+    hipLaunchKernelGGL(k_cbf_sum<T>, dim3((unsigned)grid_for(o.n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, o, st, step);
+    return;
+  }
   if (g > 4 * MAX_GRID) g = 4 * MAX_GRID;
   hipLaunchKernelGGL(k_spmv_ovf<T>, dim3((unsigned)g, nbatch), dim3(BLOCK), 0, s, o, x, st, step, x_stride);
   if (o.nmulti > 0)

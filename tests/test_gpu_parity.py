@@ -997,3 +997,47 @@ def test_reordered_operator_drivers_and_value_updates(eu):
     close(eu.expv(0.6, op2, b, m=20, ishermitian=False), ko.expv(0.6, Ac2.tocsr(), b, m=20, ishermitian=False), TOL,
           "reordered operator after update_values vs oracle on the new matrix")
     close(op2.opnorm_inf, float(np.max(np.abs(Ac2).sum(axis=1))), 1e-14, "reordered operator: opnorm(A, Inf) after update_values")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["real", "complex", "float32", "real_csc_update"])
+def test_irregular_rows_column_blocked_form(eu, case):
+    """Round 4: irregular rows of an operator whose vector does not fit an XCD's L2 next to the streams (n * sizeof(T) >= 2 MB) are
+    stored in the column-blocked form -- every entry packed by (2 MB column block, row), chunks of 256 entries per wave, per-row sums
+    through LDS, one partial vector per block, no SELL slots (kernels.hip: k_spmv_cbf).  mul!, H of arnoldi!, expv against the
+    oracle at the fixed bars; a row of several thousand entries (several chunks in one block: the partial-sum path), an empty row,
+    complex and Float32 values, CSC input and a values-only update; the small-operator path (SELL cut + overflow pass) keeps its own
+    tests above."""
+    T = {"real": np.float64, "complex": np.complex128, "float32": np.float32, "real_csc_update": np.float64}[case]
+    cplx = np.dtype(T).kind == "c"
+    n = {"real": 300_001, "complex": 140_003, "float32": 600_007, "real_csc_update": 270_000}[case]
+    A = powerlaw_matrix(n, 9, cplx=cplx, longest=3000).astype(T)
+    if case == "real_csc_update":
+        A = A.tocsc()
+        A.sort_indices()
+    rng = np.random.default_rng(12)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    T64 = np.complex128 if cplx else np.float64
+    A64, b64 = A.astype(T64), b.astype(T64)
+    tol = 2e-5 if T == np.float32 else TOL
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    info = eu.host_pattern_info(A.tocsr(), T)
+    assert info["sell_cut"] > 0                                    # irregular rows
+    close(np.asarray(op.matvec(b)).astype(T64), A64 @ b64, 5e-6 if T == np.float32 else 1e-13, "column-blocked form %s: mul! vs scipy" % case)
+    m = 16
+    Ks = eu.arnoldi(op, b, m=m, ishermitian=False)
+    Ko = ko.arnoldi(A64.tocsr(), b64, m=m, ishermitian=False)
+    assert Ks.m == Ko.m
+    close(np.asarray(Ks.getH()).astype(T64), Ko.getH(), tol, "column-blocked form %s: H of arnoldi! vs oracle" % case, mat=True)
+    w = eu.expv(0.6, op, b, m=m, ishermitian=False)
+    assert eu.expv.last_stats["path"] == ("two_kernel",) or list(eu.expv.last_stats["path"]) == ["two_kernel"]
+    close(np.asarray(w).astype(T64), ko.expv(0.6, A64.tocsr(), b64, m=m, ishermitian=False), tol, "column-blocked form %s: expv vs oracle" % case)
+    w1 = np.asarray(eu.expv(0.6, op, b, m=m, ishermitian=False))
+    assert np.array_equal(np.asarray(w), w1)                       # fixed summation order: reproducible run to run
+    if case == "real_csc_update":
+        A2 = A.copy()
+        A2.data = A.data * (1.0 + 0.2 * rng.random(A.nnz))
+        op.update_values(A2)
+        close(eu.expv(0.6, op, b, m=m, ishermitian=False), ko.expv(0.6, A2.tocsr(), b64, m=m, ishermitian=False), TOL,
+              "column-blocked form after update_values (CSC entry order) vs oracle on the new matrix")

@@ -92,6 +92,93 @@ __global__ __launch_bounds__(BLOCK) void k_cbj(int64_t n, int ntiles, int ncb, c
   }
 }
 
+// FLAT column-blocked form (what the library builds for irregular rows: kernels.hip k_spmv_cbf): entries packed by (column block,
+// row, column); a wave takes a chunk of CHN entries (EPL per lane), products to LDS, per-row sums by the row's first entry.
+// MODE 0: the real thing; 1: no LDS phase (every lane adds its products into one register and lane 0 stores: the ceiling of the
+// load + gather part); 2: no gathers either (x[lane]).
+struct FlatChunk { int32_t e0, cnt, base, cb; };
+template <int EPL, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_flat(int64_t nchunk, const FlatChunk *__restrict__ chunk, const double *__restrict__ val,
+                                                const int32_t *__restrict__ col, const uint16_t *__restrict__ r16,
+                                                const double *__restrict__ x, double *__restrict__ P, int64_t pstride) {
+  constexpr int CHN = 64 * EPL;
+  __shared__ double p_s[BLOCK / 64][CHN];
+  __shared__ unsigned short r_s[BLOCK / 64][CHN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t ch = (int64_t)blockIdx.x * (BLOCK / 64) + wave; ch < nchunk; ch += (int64_t)gridDim.x * (BLOCK / 64)) {
+    const FlatChunk cd = chunk[ch];
+    double v[EPL], xv[EPL];
+    int32_t c[EPL];
+    unsigned short rr[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+      const int e = lane + 64 * q;
+      const bool in = e < cd.cnt;
+      c[q] = col[cd.e0 + (in ? e : 0)];
+      v[q] = in ? val[cd.e0 + e] : 0.0;
+      rr[q] = in ? r16[cd.e0 + e] : (unsigned short)0xffff;
+    }
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) xv[q] = (MODE == 2) ? x[lane] : x[c[q]];
+    double *Pb = P + (int64_t)cd.cb * pstride + cd.base;
+    if constexpr (MODE >= 1) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) s = fma(v[q], xv[q], s);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) Pb[rr[0] == 0xffff ? 0 : rr[0]] = s;
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) { p_s[wave][lane + 64 * q] = v[q] * xv[q]; r_s[wave][lane + 64 * q] = rr[q]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (MODE == -1) {      // segmented inclusive scan over the chunk (rows are sorted: equal row ids are contiguous), log2(CHN) steps
+      for (int d = 1; d < CHN; d <<= 1) {
+        double add[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+          const int e = lane + 64 * q;
+          add[q] = (e >= d && r_s[wave][e - d] == rr[q]) ? p_s[wave][e - d] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) p_s[wave][lane + 64 * q] += add[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) {
+        const int e = lane + 64 * q;
+        if (e < cd.cnt && (e == cd.cnt - 1 || r_s[wave][e + 1] != rr[q])) Pb[rr[q]] = p_s[wave][e];      // the last entry of a row holds its sum
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+      const int e = lane + 64 * q;
+      if (e < cd.cnt) {
+        const unsigned short r0 = r_s[wave][e];
+        if (e == 0 || r_s[wave][e - 1] != r0) {
+          double s = p_s[wave][e];
+          for (int k = e + 1; k < cd.cnt && r_s[wave][k] == r0; ++k) s += p_s[wave][k];
+          Pb[r0] = s;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_flat_sum(int64_t n, int ncb, const double *__restrict__ P, int64_t pstride, double *__restrict__ y) {
+  for (int64_t i = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * BLOCK * 2) {
+    double2 a = *reinterpret_cast<const double2 *>(P + i);
+    for (int cb = 1; cb < ncb; ++cb) { const double2 p = *reinterpret_cast<const double2 *>(P + (int64_t)cb * pstride + i); a.x += p.x; a.y += p.y; }
+    *reinterpret_cast<double2 *>(y + i) = a;
+  }
+}
+
 // reference point: plain SELL-128 (slot-major slices, 2 rows per lane), what the library's two-kernel step applies today
 __global__ __launch_bounds__(BLOCK) void k_sell(int64_t nslices, const int64_t *__restrict__ off, const double *__restrict__ val,
                                                 const int32_t *__restrict__ col, const double *__restrict__ x, double *__restrict__ y) {
@@ -312,6 +399,67 @@ int main(int argc, char **argv) {
   if (K == 8) run("column-blocked jagged slices", [&] { hipLaunchKernelGGL(k_cbj<8>, dim3(grid), dim3(BLOCK), 0, 0, n, ntiles, ncb, d_desc, d_val, d_col, d_rid, d_lseg, d_x, d_y); }, bytes_cbj, true);
   else if (K == 4) run("column-blocked jagged slices", [&] { hipLaunchKernelGGL(k_cbj<4>, dim3(grid), dim3(BLOCK), 0, 0, n, ntiles, ncb, d_desc, d_val, d_col, d_rid, d_lseg, d_x, d_y); }, bytes_cbj, true);
   else run("column-blocked jagged slices", [&] { hipLaunchKernelGGL(k_cbj<6>, dim3(grid), dim3(BLOCK), 0, 0, n, ntiles, ncb, d_desc, d_val, d_col, d_rid, d_lseg, d_x, d_y); }, bytes_cbj, true);
+  // ---- flat column-blocked form ----
+  for (int EPLv : {4, 8}) {
+    const int CHN = 64 * EPLv;
+    std::vector<FlatChunk> fch;
+    std::vector<double> fval;
+    std::vector<int32_t> fcol;
+    std::vector<uint16_t> fr16;
+    fval.reserve(nnz); fcol.reserve(nnz); fr16.reserve(nnz);
+    const int ncbf = (int)((n + CB - 1) / CB);
+    {
+      std::vector<std::vector<std::pair<int32_t, int32_t>>> blk(ncbf);
+      for (int64_t r = 0; r < n; ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) blk[ci[k] / CB].emplace_back((int32_t)r, k);
+      for (int cb = 0; cb < ncbf; ++cb) {
+        const auto &B = blk[cb];
+        size_t q = 0;
+        FlatChunk cur{(int32_t)fval.size(), 0, -1, cb};
+        auto flush = [&]() { if (cur.cnt) fch.push_back(cur); cur = FlatChunk{(int32_t)fval.size(), 0, -1, cb}; };
+        while (q < B.size()) {
+          size_t q1 = q;
+          while (q1 < B.size() && B[q1].first == B[q].first) ++q1;
+          int len = (int)(q1 - q);
+          if (len > CHN) len = CHN, q1 = q + CHN;      // (probe: a long group is simply cut; its pieces overwrite each other -- timing only)
+          if (cur.cnt + len > CHN || (cur.base >= 0 && B[q].first - cur.base > 65000)) flush();
+          if (cur.base < 0) cur.base = B[q].first;
+          for (size_t z = q; z < q1; ++z) { fval.push_back(va[B[z].second]); fcol.push_back(ci[B[z].second]); fr16.push_back((uint16_t)(B[z].first - cur.base)); }
+          cur.cnt += len;
+          q = q1;
+        }
+        flush();
+      }
+    }
+    const int64_t npad = (n + 255) / 256 * 256;
+    FlatChunk *d_fch = (FlatChunk *)up(fch.data(), fch.size() * sizeof(FlatChunk));
+    double *d_fval = (double *)up(fval.data(), fval.size() * 8);
+    int32_t *d_fcol = (int32_t *)up(fcol.data(), fcol.size() * 4);
+    uint16_t *d_fr16 = (uint16_t *)up(fr16.data(), fr16.size() * 2);
+    double *d_P;
+    CK(hipMalloc(&d_P, sizeof(double) * npad * ncbf));
+    CK(hipMemset(d_P, 0, sizeof(double) * npad * ncbf));
+    const int64_t nch = (int64_t)fch.size();
+    const double fb = 14.0 * fval.size() + 16.0 * nch + 8.0 * n * (ncbf + 1) + 8.0 * n * ncbf;
+    std::printf("  flat form, %d entries per lane: %lld chunks\n", EPLv, (long long)nch);
+    auto go = [&](const char *name, auto kern, int gridw, bool check) {
+      run(name, [&] { hipLaunchKernelGGL(kern, dim3(gridw), dim3(BLOCK), 0, 0, nch, d_fch, d_fval, d_fcol, d_fr16, d_x, d_P, npad);
+                      hipLaunchKernelGGL(k_flat_sum, dim3(1024), dim3(BLOCK), 0, 0, n, ncbf, d_P, npad, d_y); }, fb, check);
+    };
+    const int gfull = (int)((nch + 3) / 4);
+    if (EPLv == 4) {
+      go("flat, one chunk per wave", k_flat<4, 0>, gfull, kind == "random");
+      go("flat, segmented scan in LDS", k_flat<4, -1>, gfull, kind == "random");
+      go("flat, no LDS phase", k_flat<4, 1>, gfull, false);
+      go("flat, no LDS, no gathers", k_flat<4, 2>, gfull, false);
+    } else {
+      go("flat, one chunk per wave", k_flat<8, 0>, gfull, kind == "random");
+      go("flat, segmented scan in LDS", k_flat<8, -1>, gfull, kind == "random");
+      go("flat, no LDS phase", k_flat<8, 1>, gfull, false);
+    }
+    run("  (the sum of the partial vectors alone)", [&] { hipLaunchKernelGGL(k_flat_sum, dim3(1024), dim3(BLOCK), 0, 0, n, ncbf, d_P, npad, d_y); }, 8.0 * n * (ncbf + 1), false);
+    CK(hipFree(d_fch)); CK(hipFree(d_fval)); CK(hipFree(d_fcol)); CK(hipFree(d_fr16)); CK(hipFree(d_P));
+  }
   run("SELL-128 slots (today's layout)", [&] { hipLaunchKernelGGL(k_sell, dim3(2048), dim3(BLOCK), 0, 0, nsl, d_soff, d_sval, d_scol, d_x, d_y); },
       12.0 * sval.size() + 16.0 * n, kind == "random");
   return 0;
