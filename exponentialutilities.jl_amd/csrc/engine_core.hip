@@ -901,8 +901,15 @@ struct ArnoldiCall {
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       if (op.ovf_nseg > 0) {               // irregular rows: the entries beyond the SELL slot cut-off, from the CSR arrays
         ProfScope ps(c, EXPV_MI_K_MATVEC);
-        dev::spmv_ovf<T>(s, ovf_view<T>(op), fa.u, st, j);
-        fa.ovf_y = op.ovf_y.as<T>();
+        if (op.cbf) {      // column-blocked form: the step's first kernel adds the blocks' partial vectors itself (no sum pass)
+          dev::spmv_ovf<T>(s, ovf_view<T>(op), fa.u, st, j, 0, 1, false);
+          fa.ovf_y = op.cbf_P.as<T>();
+          fa.ovf_ncb = op.cbf_ncb;
+          fa.ovf_pstride = op.cbf_pstride;
+        } else {
+          dev::spmv_ovf<T>(s, ovf_view<T>(op), fa.u, st, j);
+          fa.ovf_y = op.ovf_y.as<T>();
+        }
       }
       if (op.gndiag > 0 && c->opt.dia) {   // structured-grid stencil: diagonals instead of SELL slots + column indices
         fa.dia_val = op.gdia_ptr<T>(); fa.dia_ld = op.gdia_ld; fa.ndiag = op.gndiag; fa.dia_off = op.gdia_off.as<int32_t>();

@@ -352,7 +352,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
         else if (fa.ndiag == 0 && slice < fa.A.nslices) {
           sell_rows<T>(fa.A, slice, lane, u, yv.v);
           if (fa.ovf_y) {   // irregular rows: + what the overflow pass summed for these rows (spmv_ovf ran on the same u)
-            const Pack<T> o = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + i);
+            Pack<T> o = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + i);
+            for (int cb = 1; cb < fa.ovf_ncb; ++cb) {      // column-blocked form: the blocks' partial vectors, in ascending order
+              const Pack<T> p2 = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + (int64_t)cb * fa.ovf_pstride + i);
+#pragma unroll
+              for (int k = 0; k < N; ++k) o.v[k] = ST<T>::add(o.v[k], p2.v[k]);
+            }
 #pragma unroll
             for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::add(yv.v[k], o.v[k]);
           }

@@ -126,8 +126,9 @@ struct OvfView {
   T *P; int64_t pstride; int ncb; int64_t n;
 };
 constexpr int CBF_LONG_BIT = 1 << 30, CBF_SCAN_BIT = 1 << 29;      // chunk flags: one piece of a long (row, block) group / a row of > 6 entries inside
+// (sum_blocks = false, column-blocked form: the partial vectors are left unsummed -- the consumer adds P[0..ncb) itself)
 template <class T> void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride = 0,
-                                 int nbatch = 1);
+                                 int nbatch = 1, bool sum_blocks = true);
 template <class T>
 void gemv_dense(hipStream_t s, int64_t n, const T *A, int64_t lda, const T *x, T *y, T *scratch, int nsplit,
                 const StepState *st, int step, int64_t ncols = -1);   // n rows x ncols columns (ncols < 0: square)
@@ -189,6 +190,7 @@ struct FusedAArgs {
   const int32_t *dia_off;   // device, ascending
   int64_t n_dia;            // operator rows (the DIA arrays cover rows < n_dia, padded to 512)
   const T *ovf_y;           // SELL with a slot cut-off: what the overflow pass left for these rows (nullptr: none)
+  int ovf_ncb; int64_t ovf_pstride;      // > 0: ovf_y is the first of ovf_ncb partial vectors, ovf_pstride apart, to be added in order
 };
 constexpr int FUSED_AUG_MAX = 8;
 constexpr int GDIA_MAX = 32;       // most diagonals of the general DIA form   // widest augmentation the fused step handles (kiops: p = number of extra columns)

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void k_ovf_combine(OvfView<T> o, const StepS
   }
 }
 template <class T>
-void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride, int nbatch) {
+void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *st, int step, int64_t x_stride, int nbatch, bool sum_blocks) {
   if (o.nchunk <= 0) return;
   int64_t g = (o.nchunk + (BLOCK / 64) - 1) / (BLOCK / 64);
   if (o.ncb > 0) {      // column-blocked form: every workgroup takes consecutive chunks, dispatched in order = one block after the other
@@ -459,7 +459,7 @@ void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *s
     hipLaunchKernelGGL(k_spmv_cbf<T>, dim3((unsigned)g), dim3(BLOCK), 0, s, o, x, st, step);
     if (o.nmulti > 0)
       hipLaunchKernelGGL(k_cbf_combine<T>, dim3((unsigned)std::min<int64_t>(MAX_GRID, (o.nmulti + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, o, st, step);
-    hipLaunchKernelGGL(k_cbf_sum<T>, dim3((unsigned)grid_for(o.n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, o, st, step);
+    if (sum_blocks) hipLaunchKernelGGL(k_cbf_sum<T>, dim3((unsigned)grid_for(o.n, BLOCK * Pack<T>::N * 2)), dim3(BLOCK), 0, s, o, st, step);
     return;
   }
   if (g > 4 * MAX_GRID) g = 4 * MAX_GRID;
@@ -1029,7 +1029,7 @@ void widen_real_to_complex(hipStream_t s, cplx *dst, const double *src, int64_t 
   template void scale_copy<T>(hipStream_t, T *, const T *, int64_t, double, int);                                  \
   template void scale_by_state<T>(hipStream_t, T *, int64_t, const StepState *, int);                              \
   template void fill_zero<T>(hipStream_t, T *, int64_t);                                                           \
-  template void spmv_ovf<T>(hipStream_t, const OvfView<T> &, const T *, const StepState *, int, int64_t, int);      \
+  template void spmv_ovf<T>(hipStream_t, const OvfView<T> &, const T *, const StepState *, int, int64_t, int, bool);      \
   template void gemv_dense<T>(hipStream_t, int64_t, const T *, int64_t, const T *, T *, T *, int,                  \
                               const StepState *, int, int64_t);                                                                \
   template void aug_apply<T>(hipStream_t, int64_t, int, const T *, int64_t, const T *, T *, const StepState *,     \
