@@ -207,7 +207,10 @@ int expv_mi_ks_get(expv_mi_ks_t ks, int *m, int *maxiter, int *augmented, double
 int expv_mi_ks_set_m(expv_mi_ks_t ks, int m);
 /* Ks.H: pointer to the host matrix (valid until resize/destroy), its leading dimension and shape */
 int expv_mi_ks_H(expv_mi_ks_t ks, void **H, int *ldh, int *nrows, int *ncols);
-/* copy columns [col0, col0+ncols) of Ks.V to / from the host (ld of the host array = ldh_host) */
+/* copy columns [col0, col0+ncols) of Ks.V to / from the host (ld of the host array = ldh_host).
+ * Rows are ALWAYS in the caller's (natural) ordering: a basis produced by a reordered operator (expv_mi_op_reorder_info) is kept in
+ * the operator's stored ordering until one of these three accessors is called, which converts it back in place first (and a later
+ * continuation with that operator converts it forth again); expv_mi_expv_ks / _phiv_ks / _combine un-permute their results. */
 int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64_t ld_dst);
 int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, int64_t ld_src);
 int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv);   /* ldv: rows padded to whole waves of 16-byte packs (128; 256 for F32), padding = 0 */
