@@ -620,6 +620,10 @@ static PatClass pattern_class_ex(const PatternPlan &P, int64_t n, int dtype) {
 }
 static int pattern_class(const PatternPlan &P, int64_t n, int dtype) { return pattern_class_ex(P, n, dtype).cls; }
 
+template <class V>
+static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &perm, const std::vector<int32_t> &src, std::vector<int32_t> &rp,
+                              std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> &rp2, std::vector<int32_t> &ci2, int64_t bw0, int64_t bw1,
+                              std::chrono::steady_clock::time_point t0);
 // Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
 // On return rp / ci / va hold P A P' and op.perm the ordering; op.csc_pos maps the caller's entries to the reordered CSR arrays.
 template <class V>
@@ -645,6 +649,90 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   const PatClass c1 = pattern_class_ex(P1, n, op.dtype);
   const bool better = c1.cls > c0.cls || (c1.cls == c0.cls && c1.cls == 2 && 4 * c1.reach <= c0.reach);
   if (mode == 1 && !better) return;
+  install_row_order<V>(op, n, perm, src, rp, ci, va, rp2, ci2, P0.bandwidth, P1.bandwidth, t0);
+}
+
+// ---- grid-patch ordering (context option "patch"; round 4) ----------------------------------------------------------------------
+// A 5- / 9-point stencil on a 2-D grid with rows of k cells (offsets within +-2 of 0 and of +-k) in its natural ordering reaches k
+// rows up and down: no halo form, and the wave form pays a flag chain per tile.  Stored in an ordering where a 512-row tile is a
+// 16 x 32 PATCH of the grid, every neighbour of a cell is in the tile or in a RING of ~100 cells around it, and the single-pass
+// step recomputes u_j on the ring like the banded form does on its halo rows (pipe.hip: patch form).  The ordering runs through the
+// grid in bands of R grid rows, boustrophedon, a tile taking TR / R whole columns of its band (where a band ends inside a tile the
+// tile is an L of two rectangles); inside a rectangle the cells go perimeter first, as a cycle, then the interior -- so each edge
+// of a patch, which is a piece of its neighbour's ring, is contiguous in memory.  Rings are computed from the PATTERN (any entry
+// whose column is outside the tile), so correctness does not depend on the grid having been recognised properly.
+static bool detect_grid2d(const PatternPlan &P, int64_t n, int64_t *k_out) {
+  if (!P.general_dia || P.offsets.empty()) return false;
+  const int64_t S = 2;
+  int64_t lo = 0, hi = 0;      // the far positive offsets lie in [lo, hi]
+  bool havep = false, haven = false;
+  int64_t nlo = 0, nhi = 0;
+  for (int64_t o : P.offsets) {
+    if (std::llabs((long long)o) <= S) continue;
+    if (o > 0) { if (!havep) { lo = hi = o; havep = true; } lo = std::min(lo, o); hi = std::max(hi, o); }
+    else { if (!haven) { nlo = nhi = -o; haven = true; } nlo = std::min(nlo, -o); nhi = std::max(nhi, -o); }
+  }
+  if (!havep && !haven) return false;
+  if (havep && hi - lo > 2 * S) return false;
+  if (haven && nhi - nlo > 2 * S) return false;
+  const int64_t k = havep ? (lo + hi) / 2 : (nlo + nhi) / 2;
+  if (havep && haven && (nlo + nhi) / 2 != k) return false;
+  if ((havep && (hi - k > S || k - lo > S)) || (haven && (nhi - k > S || k - nlo > S))) return false;
+  if (k < 64 || n < 8 * k) return false;
+  *k_out = k;
+  return true;
+}
+static std::vector<int32_t> patch_order(int64_t n, int64_t k, int64_t R, int64_t TR) {
+  const int64_t grows = (n + k - 1) / k;
+  std::vector<int32_t> seq;      // strip order: bands of R grid rows, boustrophedon, one column of the band after the other
+  seq.reserve((size_t)n);
+  int64_t band = 0;
+  for (int64_t R0 = 0; R0 < grows; R0 += R, ++band) {
+    const int64_t Rn = std::min<int64_t>(R, grows - R0);
+    for (int64_t q = 0; q < k; ++q) {
+      const int64_t gc = (band & 1) ? k - 1 - q : q;
+      for (int64_t r = 0; r < Rn; ++r) {
+        const int64_t i = (R0 + r) * k + gc;
+        if (i < n) seq.push_back((int32_t)i);
+      }
+    }
+  }
+  std::vector<int32_t> perm;
+  perm.reserve((size_t)n);
+  auto emit_rect = [&](int64_t r0, int64_t r1, int64_t c0, int64_t c1) {      // inclusive bounds; perimeter cycle, then the interior
+    auto put = [&](int64_t r, int64_t c) { perm.push_back((int32_t)(r * k + c)); };
+    if (r0 == r1) { for (int64_t c = c0; c <= c1; ++c) put(r0, c); return; }
+    if (c0 == c1) { for (int64_t r = r0; r <= r1; ++r) put(r, c0); return; }
+    for (int64_t c = c0; c <= c1; ++c) put(r0, c);
+    for (int64_t r = r0 + 1; r <= r1; ++r) put(r, c1);
+    for (int64_t c = c1 - 1; c >= c0; --c) put(r1, c);
+    for (int64_t r = r1 - 1; r > r0; --r) put(r, c0);
+    for (int64_t r = r0 + 1; r < r1; ++r)
+      for (int64_t c = c0 + 1; c < c1; ++c) put(r, c);
+  };
+  for (int64_t t0 = 0; t0 < n; t0 += TR) {
+    const int64_t t1 = std::min<int64_t>(n, t0 + TR);
+    int64_t q = t0;
+    while (q < t1) {      // runs of one band
+      const int64_t b = (seq[(size_t)q] / k) / R;
+      int64_t q1 = q, rmin = INT64_MAX, rmax = -1, cmin = INT64_MAX, cmax = -1;
+      while (q1 < t1 && (seq[(size_t)q1] / k) / R == b) {
+        const int64_t r = seq[(size_t)q1] / k, c = seq[(size_t)q1] % k;
+        rmin = std::min(rmin, r); rmax = std::max(rmax, r); cmin = std::min(cmin, c); cmax = std::max(cmax, c);
+        ++q1;
+      }
+      if ((rmax - rmin + 1) * (cmax - cmin + 1) == q1 - q) emit_rect(rmin, rmax, cmin, cmax);      // whole columns of the band: a rectangle
+      else for (int64_t z = q; z < q1; ++z) perm.push_back(seq[(size_t)z]);
+      q = q1;
+    }
+  }
+  return perm;
+}
+
+template <class V>
+static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &perm, const std::vector<int32_t> &src, std::vector<int32_t> &rp,
+                              std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> &rp2, std::vector<int32_t> &ci2, int64_t bw0, int64_t bw1,
+                              std::chrono::steady_clock::time_point t0) {
   std::vector<V> va2(va.size());
   for (size_t k = 0; k < va2.size(); ++k) va2[k] = va[(size_t)src[k]];
   // caller's entry j -> its place in the reordered arrays (values-only updates scatter through this map)
@@ -662,13 +750,85 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   HIPCHECK(hipMemcpyAsync(pm->p.p, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipMemcpyAsync(pm->pinv.p, inv.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
-  pm->bandwidth_before = P0.bandwidth;
-  pm->bandwidth_after = P1.bandwidth;
+  pm->bandwidth_before = bw0;
+  pm->bandwidth_after = bw1;
   pm->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   rp.swap(rp2);
   ci.swap(ci2);
   va.swap(va2);
   op.perm = pm;
+}
+
+// returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
+// per-tile rings and the tile-local column array)
+template <class V>
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+  if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
+  if (sizeof(V) != 8 && sizeof(V) != 4) return false;      // the real element types (pipe.hip: SELL slots)
+  const auto t0 = std::chrono::steady_clock::now();
+  const PatternPlan P0 = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  int64_t k = 0;
+  if (!detect_grid2d(P0, n, &k)) return false;
+  const int64_t TR = (int64_t)(16 / sizeof(V)) * dev::BLOCK;      // rows of a tile: 512 (fp64), 1024 (Float32)
+  const int64_t R = sizeof(V) == 8 ? 16 : 32;
+  const std::vector<int32_t> perm = patch_order(n, k, R, TR);
+  if ((int64_t)perm.size() != n) return false;
+  std::vector<int32_t> rp2, ci2, src;
+  reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
+  // rings: per tile the columns outside it, ascending
+  const int64_t nt = (n + TR - 1) / TR;
+  std::vector<std::vector<int32_t>> ring((size_t)nt);
+  int maxring = 0;
+  for (int64_t t = 0; t < nt; ++t) {
+    auto &g = ring[(size_t)t];
+    const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
+    for (int64_t r = r0; r < r1; ++r)
+      for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e)
+        if (ci2[(size_t)e] < r0 || ci2[(size_t)e] >= r1) g.push_back(ci2[(size_t)e]);
+    std::sort(g.begin(), g.end());
+    g.erase(std::unique(g.begin(), g.end()), g.end());
+    maxring = std::max(maxring, (int)g.size());
+  }
+  if (maxring > dev::BLOCK) return false;
+  const int RP = maxring <= 64 ? 64 : maxring <= 128 ? 128 : 256;
+  std::vector<int32_t> rows((size_t)nt * RP, -1), cnt((size_t)nt, 0);
+  for (int64_t t = 0; t < nt; ++t) {
+    std::copy(ring[(size_t)t].begin(), ring[(size_t)t].end(), rows.begin() + t * RP);
+    cnt[(size_t)t] = (int32_t)ring[(size_t)t].size();
+  }
+  // the SELL column array of build_sell (same slices, no cut) restated as LDS positions
+  const int SH = 64 * (16 / (int)sizeof(V));
+  const int64_t nsl = (n + SH - 1) / SH;
+  std::vector<int64_t> off((size_t)nsl + 1, 0);
+  for (int64_t sl = 0; sl < nsl; ++sl) {
+    int L = 0;
+    for (int64_t r = sl * SH; r < std::min<int64_t>(n, (sl + 1) * SH); ++r) L = std::max(L, rp2[(size_t)r + 1] - rp2[(size_t)r]);
+    off[(size_t)sl + 1] = off[(size_t)sl] + (int64_t)L * SH;
+  }
+  std::vector<int32_t> lcol((size_t)std::max<int64_t>(off[(size_t)nsl], 1) + 4, 0);
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t t = r / TR, r0 = t * TR, sl = r / SH;
+    const auto &g = ring[(size_t)t];
+    for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e) {
+      const int64_t c = ci2[(size_t)e];
+      const int32_t loc = (c >= r0 && c < r0 + TR) ? (int32_t)(c - r0) : (int32_t)(TR + (std::lower_bound(g.begin(), g.end(), (int32_t)c) - g.begin()));
+      lcol[(size_t)(off[(size_t)sl] + (int64_t)(e - rp2[(size_t)r]) * SH + (r - sl * SH))] = loc;
+    }
+  }
+  const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
+  if (P1.overflow) return false;
+  op.ring_rows.alloc(sizeof(int32_t) * rows.size());
+  op.ring_cnt.alloc(sizeof(int32_t) * cnt.size());
+  op.ring_col.alloc(sizeof(int32_t) * lcol.size() + 16);
+  HIPCHECK(hipMemcpyAsync(op.ring_rows.p, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.ring_cnt.p, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.ring_col.p, lcol.data(), sizeof(int32_t) * lcol.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipStreamSynchronize(op.ctx->stream));
+  op.ring_pad = RP;
+  op.ring_max = maxring;
+  op.grid_k = k;
+  install_row_order<V>(op, n, perm, src, rp, ci, va, rp2, ci2, P0.bandwidth, P1.bandwidth, t0);
+  return true;
 }
 
 template <class V>
@@ -688,6 +848,8 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("ishermitian + opnorm");
   maybe_reorder<V>(op, n, rp, ci, va);
   lap("reordering (RCM)");
+  (void)try_patch_order<V>(op, n, rp, ci, va);
+  lap("grid-patch ordering");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size(), ci.data());

@@ -83,6 +83,9 @@ struct Options {
   int reorder = 1;         // sparse operators without a single-pass form in their natural ordering: 1 = try reverse Cuthill-McKee at
                            // creation and keep P A P' when that gives one (vectors permuted on entry / exit, capi.hip); 0 = never;
                            // 2 = always keep the reordered form (tests)                          (EXPV_MI_REORDER=0|1|2)
+  int patch = 0;           // 2-D grid stencils: 1 = store the operator in a grid-patch ordering at creation (a 512-row tile = a 16 x 32 patch of
+                           // the grid; pipe.hip: patch form of the single-pass step, ring recomputed instead of per-tile flags);
+                           // 0 = natural ordering, wave form                                     (EXPV_MI_PATCH=0|1)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();
@@ -283,6 +286,12 @@ struct Op {
   int dia_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // general DIA form (fp64, any offsets, <= GDIA_MAX diagonals, <= 30 % zero fill): structured-grid stencils; read by
   // the two-kernel step instead of the SELL slots (fused.hip) when the operator is too wide for the pipeline
+  // patch form (grid-patch ordering, capi.hip): per tile the rows outside it that its operator rows read (ring_pad per tile, ascending,
+  // -1 = none) and the SELL column array restated as positions in the tile's LDS image (tile row, or tile rows + ring position)
+  DevBuf ring_rows, ring_cnt, ring_col;
+  int ring_pad = 0;          // 0: no patch form
+  int ring_max = 0;          // longest ring of a tile
+  int64_t grid_k = 0;        // row length of the detected grid
   DevBuf tile_lo, tile_hi;   // per 512-row tile: first / last tile its columns lie in (wave form on SELL slots)
   int64_t tile_reach = -1;   // largest distance (rows) between a tile and a tile it reads from; -1: not computed
   DevBuf gdia_val, gdia_off;

@@ -387,6 +387,7 @@ Options Options::from_env() {
   if (const char *v = std::getenv("EXPV_MI_PIPE_SPIN_LIMIT")) o.spin_limit = std::atoi(v);
   if (const char *v = std::getenv("EXPV_MI_BATCH_ROUNDS")) o.batch_rounds = std::max(1, std::atoi(v));
   if (const char *v = std::getenv("EXPV_MI_REORDER")) o.reorder = std::min(2, std::max(0, std::atoi(v)));
+  if (const char *v = std::getenv("EXPV_MI_PATCH")) o.patch = std::atoi(v) ? 1 : 0;
   return o;
 }
 int *Options::find(const char *name) {
@@ -404,6 +405,7 @@ int *Options::find(const char *name) {
   if (n == "nontemporal") return &nontemporal;
   if (n == "pipeline_serial") return &pipeline_serial;
   if (n == "reorder") return &reorder;
+  if (n == "patch") return &patch;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
   return nullptr;
@@ -461,7 +463,7 @@ struct ArnoldiCall {
   bool h_zeroed = false;
   bool cont_reset_done = false; // reset_device_state() did the whole reset of a continued single-pass factorisation in one launch
   bool tail_deferred = false;   // read_back() returned at the early mailbox flag (Ks::defer_tail_req)   // first_step() zeroed this call's columns of Hdev together with the step state
-  bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, mbox_generic = false;
+  bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, use_ring = false, mbox_generic = false;
 
   ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
       : ks(ks_), op(op_), b(b_), o(o_), aug(aug_), lanczos(lanczos_), c(ks_.ctx), s(ks_.ctx->stream), isaug(aug_ != nullptr),
@@ -526,6 +528,15 @@ struct ArnoldiCall {
                  (have_dia || ((std::is_same<T, double>::value || std::is_same<T, float>::value) && !isaug)) &&      // SELL slots: the real element types; everything else: DIA form only
                  (!isaug || !dtype_is_32bit(ks.dtypeT)) &&
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
+      // patch form of the same step: an operator stored in a grid-patch ordering (capi.hip) -- SELL slots with tile-local columns,
+      // the ring of a tile recomputed like the banded form's halo
+      if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
+        if (!use_pipe && op.ring_pad > 0 && c->opt.patch && use_fused && single_red && !no_pipe && op.sell_cut == 0 && !isaug &&
+            wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS) {
+          use_pipe = true;
+          use_ring = true;
+        }
+      }
   }
   if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
     // wave form of the same single-pass step: operators made of a few diagonals with arbitrary offsets (general DIA
@@ -663,6 +674,7 @@ struct ArnoldiCall {
     T *ya = ks.ybuf.as<T>(), *yb2 = ks.ubuf.as<T>();
     T *hca = ks.hcoef.as<T>(), *hcb = ks.hcoef2.as<T>();
     dev::SellView<T> A{op.sell_off.as<int64_t>(), op.sell_col.as<int32_t>(), op.sell_val.as<T>(), op.nslices};
+    if (use_ring) A.col = op.ring_col.as<int32_t>();      // patch form: the columns as positions in the tile's LDS image
     // Overlapped form (default): consecutive steps on two streams, the next step's kernel starts while this one
     // finishes (pipe.hip).  EXPV_MI_PIPE_SERIAL=1 / profiling / a previous expired wait: one stream, one launch
     // after the other.
@@ -689,7 +701,7 @@ struct ArnoldiCall {
       HIPCHECK(hipMemcpyAsync(ks.colscale.p, ks.colscale_host.data(), sizeof(double) * (size_t)jstart, hipMemcpyHostToDevice, s));
       HIPCHECK(hipMemsetAsync(ks.state.as<char>() + sizeof(StepState), 0, ks.state.bytes - sizeof(StepState), s));
   }
-  if (live && !use_wave) {   // per-tile "previous pass done" flags of the overlapped banded form (pipe.hip: tiles_ready)
+  if (live && !use_wave && !use_ring) {   // per-tile "previous pass done" flags of the overlapped banded form (pipe.hip: tiles_ready)
     const size_t tb = sizeof(uint32_t) * (size_t)(rows / dev::BLOCK + 2);
     if (ks.tflags.bytes < tb) {
       ks.tflags.alloc(tb);
@@ -776,7 +788,7 @@ struct ArnoldiCall {
           pa.spin_limit = spin_limit;
         }
       }
-      if (live && !use_wave) {
+      if (live && !use_wave && !use_ring) {
         pa.tile_flags = ks.tflags.as<uint32_t>();
         pa.tile_stamp = (ks.pipe_seq << 12) | (uint32_t)j;
       }
@@ -788,7 +800,8 @@ struct ArnoldiCall {
           for (int d = 0; d < op.ndiag; ++d) pa.dia_c[d] = op.dia_const[d];
         }
       }
-      pa.w = (int)op.bandwidth;
+      pa.w = use_ring ? 0 : (int)op.bandwidth;
+      if (use_ring) { pa.ring_rows = op.ring_rows.as<int32_t>(); pa.ring_cnt = op.ring_cnt.as<int32_t>(); pa.ring_pad = op.ring_pad; }
       pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
       pa.ybuf = (j & 1) ? ya : yb2;
       pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
@@ -839,7 +852,7 @@ struct ArnoldiCall {
         const bool gate = use_wave || 2 * live_tiles > dev::device_cus();
         if (j > jstart && gate) dev::pipe_gate(sj, arr + (size_t)(j - 1) * dev::PIPE_ARRIVE_STEP, prev_grid, st, spin_limit);
         if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
-          prev_grid = use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
+          prev_grid = use_ring ? dev::pipe_step_ring(sj, pa, true) : use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
         } else {
           prev_grid = dev::pipe_step_live(sj, pa);
         }
@@ -848,6 +861,11 @@ struct ArnoldiCall {
         if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
           ProfScope ps1(c, EXPV_MI_K_FUSED_A);
           if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
+        }
+      } else if (use_ring) {
+        if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
+          ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+          (void)dev::pipe_step_ring(s, pa, false);
         }
       } else {
         ProfScope ps1(c, EXPV_MI_K_FUSED_A);
@@ -1162,7 +1180,7 @@ struct ArnoldiCall {
   }
   c->cnt_steps += jlast - jstart + 1;
   ++c->cnt_fact;
-  c->last_path = use_pipe ? (EXPV_MI_PATH_PIPELINE | (use_wave ? EXPV_MI_PATH_WAVE : 0) | (ks.pipe_live_used ? EXPV_MI_PATH_OVERLAPPED : 0) | (ks.pipe_resident_used ? EXPV_MI_PATH_RESIDENT : 0))
+  c->last_path = use_pipe ? (EXPV_MI_PATH_PIPELINE | (use_wave ? EXPV_MI_PATH_WAVE : 0) | (use_ring ? EXPV_MI_PATH_PATCH : 0) | (ks.pipe_live_used ? EXPV_MI_PATH_OVERLAPPED : 0) | (ks.pipe_resident_used ? EXPV_MI_PATH_RESIDENT : 0))
                           : (use_fused ? EXPV_MI_PATH_TWO_KERNEL : EXPV_MI_PATH_MODULAR);
   if (use_pipe) { ++c->cnt_pipe; if (ks.pipe_live_used) ++c->cnt_live; }
   return jlast - jstart + 1;

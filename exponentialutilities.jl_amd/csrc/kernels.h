@@ -286,6 +286,10 @@ struct PipeArgsT {
   const T *B;
   int64_t ldb;
   T u0_tail[PIPE_AUG_MAX];     // step 1 of an augmented factorisation: rows n_op.. of u_1 (by value: no staging copy)
+  // patch form (pipe.hip: RING): A.col holds positions in LDS (tile row, or PIPE tile rows + ring position); ring_rows[tile *
+  // ring_pad + p] = the row behind ring position p of the tile (-1: none)
+  const int32_t *ring_rows, *ring_cnt;      // ring_cnt[tile]: rows in the tile's ring
+  int ring_pad;                // entries per tile in ring_rows: 64, 128 or 256
 };
 using PipeArgs = PipeArgsT<double>;
 // resident form (pipe.hip): one cooperative launch per factorisation
@@ -312,6 +316,9 @@ bool pipe_step_wave(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   /
 int pipe_step_wave_live(hipStream_t s, const PipeArgs &pa, int64_t max_abs_off);   // overlapped form; workgroups launched, 0: refused
 bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off);      // Float32: general diagonal form only
 int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_off);
+// patch form (operators stored in a grid-patch ordering); live: the overlapped form.  Returns the workgroups launched
+int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live);
+int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa);
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa);

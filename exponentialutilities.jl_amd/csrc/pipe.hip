@@ -101,9 +101,9 @@ __device__ unsigned long long g_wave_trace[33][128][6][6];
 #define PIPE_STAMP(step, slot) do { } while (0)
 #define WAVE_STAMP(step, tl, slot) do { } while (0)
 #endif
-template <class T>
+template <class T, int EXTRA = 0>     // EXTRA: more room behind the tile rows of u_j (patch form: the ring of a tile + its partial sums)
 struct PipeSharedT {
-  T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX];
+  T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX + EXTRA];
   T hs[32];                        // update coefficients (h_i s_i): LDS broadcast, no SGPRs
   T ut[PIPE_AUG_MAX];              // augmented operator: rows n_op.. of u_j
   int doff[PIPE_DIA_MAX];          // DIA offsets (a dynamically indexed kernel argument would be copied to scratch)
@@ -212,9 +212,11 @@ template <> struct ColPack<4> {
 template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(const int32_t *p) { c[0] = *p; } };
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
-template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
-__device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, PipeSharedT<T> &sh) {
+template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false,
+          class SH = PipeSharedT<T>>
+__device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, SH &sh) {
   static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
+  static_assert(!RING || (!DIA && !WAVE && !AUG), "the patch form: SELL slots with tile-local columns");
   constexpr bool IS_F64 = std::is_same<T, double>::value;      // constant diagonals: fp64 only
   constexpr bool IS_F32 = std::is_same<T, float>::value;
   constexpr bool SELL_T = IS_F64 || IS_F32;                    // SELL slots (halo and wave form): the real element types
@@ -230,7 +232,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   static_assert(!WAVE || SELL_T, "the wave form: the real element types");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
   static_assert(DIA || SELL_T, "the complex element types use the DIA form");
-  T(&us)[N * BLOCK + 2 * PIPE_WMAX] = sh.us;
+  auto &us = sh.us;
   T(&hs)[32] = sh.hs;
   double(&red_s)[BLOCK / 64][64] = sh.red_s;
   double(&vals_s)[64] = sh.vals_s;
@@ -404,7 +406,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       hr = (hrow < w) ? r0 - w + hrow : r0 + TR + (hrow - w);
       return hr >= 0 && hr < n_op;
     };
-    if constexpr (LIVE && !WAVE) {
+    if constexpr (LIVE && !WAVE && !RING) {
       if (!ready) {
         have_hpre = true;
         int k;
@@ -421,7 +423,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         u = *reinterpret_cast<const Pack<T> *>(yprev + i);
         have_ypre = true;
       }
-      if constexpr (!WAVE) {
+      if constexpr (!WAVE && !RING) {
         int k;
         int64_t hr;
         if (tid < 2 * w * 32 && halo_elem(tid, k, hr)) {
@@ -431,7 +433,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
     };
     bool prefetched = false;
-    if constexpr (LIVE && !WAVE) {
+    if constexpr (LIVE && !WAVE && !RING) {
       if (!ready && pa.tile_flags != nullptr) {   // the owners of this tile and its two neighbours are done: fetch now, before the flag
         prefetched = tiles_ready(pa.tile_flags, tile > 0 ? tile - 1 : tile, tile, tile + 1 < ntiles ? tile + 1 : tile,
                                  pa.tile_stamp - 1u, pa.flags, pa.seq, pa.step - 1, &flag_s, pa.spin_limit);
@@ -457,7 +459,45 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         ready = true;
       }
     }
-    if constexpr (!WAVE) {
+    if constexpr (RING) {
+      // ---- patch form: u_j on the RING of the tile -- the rows outside the tile that its operator rows read (at most ring_pad of
+      // them, ascending, -1 = none; capi.hip builds the lists).  Ring position p = tid % ring_pad; the window columns are dealt to
+      // the BLOCK / ring_pad threads of a position, their partial sums meet in LDS.  Ring rows that are contiguous in memory (the
+      // edges of the neighbouring patches, by the ordering the operator was given) are contiguous across the lanes of a wave.
+      if (!pa.final) {
+        const int cnt = pa.ring_cnt[tile];
+        const int RP = cnt <= 64 ? 64 : cnt <= 128 ? 128 : BLOCK, p = tid & (RP - 1), g = tid / RP, G = BLOCK / RP;
+        const int64_t rr = (p < cnt) ? pa.ring_rows[tile * pa.ring_pad + p] : -1;
+        T acc = ST<T>::zero();
+        if (rr >= 0) {
+          if (g == 0) acc = first ? u0[rr] : ST<T>::mul_real(yprev[rr], inv);
+          if (!first) {
+            const T *vp = a.V + (int64_t)pa.uc0 * a.ldv + rr;
+            constexpr int UN = 4;
+            for (int k0 = g; k0 < und; k0 += G * UN) {
+              T v[UN];
+#pragma unroll
+              for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q * G;
+                v[q] = (k < und) ? vp[(int64_t)k * cstep] : ST<T>::zero();
+              }
+#pragma unroll
+              for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q * G;
+                if (k < und) ST<T>::nfma(acc, hs[k], v[q]);
+              }
+            }
+          }
+        }
+        us[TR + BLOCK + tid] = acc;
+        __syncthreads();
+        if (tid < RP) {
+          T sum = us[TR + BLOCK + tid];
+          for (int q = 1; q < G; ++q) sum += us[TR + BLOCK + q * RP + tid];
+          us[TR + tid] = sum;      // (visible behind the barrier that follows the tile's own rows of u_j, below)
+        }
+      }
+    } else if constexpr (!WAVE) {
     // ---- halo rows (w above, w below): one (row, column) element per lane, 32 lanes per row --------
 #pragma unroll
     for (int it = 0; it < 2; ++it) {          // 2 w <= 16 halo rows x 32 lanes: at most two rounds
@@ -690,6 +730,25 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           }
         }
       }
+    } else if constexpr (RING) {
+      if (i < a.n) {      // SELL slots whose column indices are positions in LDS: the tile's own rows, then its ring
+#pragma unroll
+        for (int sl = 0; sl < PS; ++sl)
+          if (sl < L) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) y.v[e] = fma(av[sl].v[e], us[aci[sl].c[e]], y.v[e]);      // padding entries: value 0, position 0
+          }
+        for (int sl = PS; sl < L; ++sl) {
+          const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
+          ColPack<N> ci;
+          ci.load(acp + (int64_t)sl * SLICE);
+#pragma unroll
+          for (int e = 0; e < N; ++e) y.v[e] = fma(v2.v[e], us[ci.c[e]], y.v[e]);
+        }
+#pragma unroll
+        for (int e = 1; e < N; ++e)
+          if (i + e >= a.n) y.v[e] = ST<T>::zero();
+      }
     } else if (i < a.n) {
       if constexpr (SELL_T) {
       const int lim = TR + 2 * w;
@@ -896,13 +955,23 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
   hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false>
+template <class T> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX>;      // tile rows + ring (<= BLOCK) + BLOCK partial sums
+// ---- patch form: single-pass step for operators stored in a grid-patch ordering (capi.hip: a tile of rows is a patch of a 2-D
+// grid, its +-k neighbours are in the tile or in a ring of ~100 rows that is recomputed like the banded form's halo) ----
+template <class T, int CH, int WAVES, int PS>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> pa, int tiles_per_block) {
+  __shared__ PipeSharedRing<T> sh;
+  (void)pipe_pass<T, CH, PS, false, false, false, false, false, true, PipeSharedRing<T>>(pa, tiles_per_block, sh);
+}
+
+template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
-  __shared__ PipeSharedT<T> sh;
+  using SH = typename std::conditional<RING, PipeSharedRing<T>, PipeSharedT<T>>::type;
+  __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG, NT>(pa, tiles_per_block, sh);
+  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG, NT, RING, SH>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
     PIPE_STAMP(pa.step, 5);
     EPI_STAMP(pa.step, 4);
@@ -1458,6 +1527,31 @@ int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_a
     default: return pipe_wave_live_launch<float, 32, 2, 5, true>(s, pa, max_abs_off);
   }
 }
+// patch form (SELL slots with tile-local columns + ring lists): same register budgets per window as the SELL halo form
+template <class T, int CH, int WAVES, int PS>
+static int pipe_ring_launch(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
+  const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
+  const int maxb = live ? resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, false, false, false, false, true>)
+                        : resident_blocks((const void *)k_pipe_ring<T, CH, WAVES, PS>);
+  int64_t tpb = (ntiles + maxb - 1) / maxb;
+  if (tpb < 1) tpb = 1;
+  const int nb = (int)((ntiles + tpb - 1) / tpb);
+  if (live) hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, false, false, false, false, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  else hipLaunchKernelGGL((k_pipe_ring<T, CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  return nb;
+}
+template <class T>
+static int pipe_step_ring_T(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
+  switch (pipe_variant(pa.und)) {
+    case 0: return pipe_ring_launch<T, 8, 4, 6>(s, pa, live);
+    case 1: return pipe_ring_launch<T, 16, 3, 6>(s, pa, live);
+    case 2: return pipe_ring_launch<T, 24, 3, 0>(s, pa, live);
+    default: return pipe_ring_launch<T, 32, 2, 5>(s, pa, live);
+  }
+}
+int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live) { return pipe_step_ring_T<double>(s, pa, live); }
+int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live) { return pipe_step_ring_T<float>(s, pa, live); }
+
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {

@@ -122,7 +122,8 @@ int expv_mi_ctx_selftest(expv_mi_ctx_t ctx, int64_t out[8]);
 enum {
   EXPV_MI_PATH_MODULAR = 1, EXPV_MI_PATH_TWO_KERNEL = 2, EXPV_MI_PATH_PIPELINE = 4, EXPV_MI_PATH_WAVE = 8,
   EXPV_MI_PATH_OVERLAPPED = 16, EXPV_MI_PATH_REDO_SERIAL = 32, EXPV_MI_PATH_REDO_WAVE_OFF = 64,
-  EXPV_MI_PATH_RESIDENT = 128   /* the whole factorisation ran as one resident (cooperative) kernel */
+  EXPV_MI_PATH_RESIDENT = 128,  /* the whole factorisation ran as one resident (cooperative) kernel */
+  EXPV_MI_PATH_PATCH = 256      /* single-pass step, patch form: operator stored in a grid-patch ordering, ring recomputed */
 };
 const char *expv_mi_last_error(expv_mi_ctx_t ctx);
 const char *expv_mi_version(void);
