@@ -6,6 +6,8 @@
 #include <thread>
 #include <cstddef>
 #include <type_traits>
+#include <cstring>
+#include <unordered_map>
 
 #include "engine.h"
 #include "reorder.h"
@@ -805,7 +807,7 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
     for (int64_t r = sl * SH; r < std::min<int64_t>(n, (sl + 1) * SH); ++r) L = std::max(L, rp2[(size_t)r + 1] - rp2[(size_t)r]);
     off[(size_t)sl + 1] = off[(size_t)sl] + (int64_t)L * SH;
   }
-  std::vector<int32_t> lcol((size_t)std::max<int64_t>(off[(size_t)nsl], 1) + 4, 0);
+  std::vector<int32_t> lcol((size_t)std::max<int64_t>(off[(size_t)nsl], 1), 0);
   for (int64_t r = 0; r < n; ++r) {
     const int64_t t = r / TR, r0 = t * TR, sl = r / SH;
     const auto &g = ring[(size_t)t];
@@ -817,6 +819,33 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
   }
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
   if (P1.overflow) return false;
+  // the column blocks of the slices of equal patches are equal (positions in the tile's LDS image, not rows of the matrix): keep
+  // one copy of each -- the step then reads its column indices from a few kB that stay in L2 instead of 4 bytes per entry from HBM
+  std::vector<int64_t> soff((size_t)nsl, 0);
+  {
+    std::vector<int32_t> pool;
+    std::unordered_map<uint64_t, std::vector<int64_t>> seen;      // hash of a block -> pool offsets of the blocks with that hash
+    for (int64_t sl = 0; sl < nsl; ++sl) {
+      const int32_t *blk = lcol.data() + off[(size_t)sl];
+      const int64_t len = off[(size_t)sl + 1] - off[(size_t)sl];
+      uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+      for (int64_t z = 0; z < len; ++z) { h ^= (uint32_t)blk[z]; h *= 1099511628211ull; }
+      int64_t at = -1;
+      for (int64_t cand : seen[h])
+        if (cand + len <= (int64_t)pool.size() && std::memcmp(pool.data() + cand, blk, sizeof(int32_t) * (size_t)len) == 0) { at = cand; break; }
+      if (at < 0) {
+        at = (int64_t)pool.size();
+        pool.insert(pool.end(), blk, blk + len);
+        seen[h].push_back(at);
+      }
+      soff[(size_t)sl] = at;
+    }
+    op.ring_col_unique = (int64_t)pool.size();
+    lcol.swap(pool);
+    lcol.resize(lcol.size() + 4, 0);
+  }
+  op.ring_soff.alloc(sizeof(int64_t) * soff.size());
+  HIPCHECK(hipMemcpyAsync(op.ring_soff.p, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice, op.ctx->stream));
   op.ring_rows.alloc(sizeof(int32_t) * rows.size());
   op.ring_cnt.alloc(sizeof(int32_t) * cnt.size());
   op.ring_col.alloc(sizeof(int32_t) * lcol.size() + 16);

@@ -288,7 +288,8 @@ struct Op {
   // the two-kernel step instead of the SELL slots (fused.hip) when the operator is too wide for the pipeline
   // patch form (grid-patch ordering, capi.hip): per tile the rows outside it that its operator rows read (ring_pad per tile, ascending,
   // -1 = none) and the SELL column array restated as positions in the tile's LDS image (tile row, or tile rows + ring position)
-  DevBuf ring_rows, ring_cnt, ring_col;
+  DevBuf ring_rows, ring_cnt, ring_col, ring_soff;
+  int64_t ring_col_unique = 0;      // SELL column blocks kept after sharing equal ones (slices)
   int ring_pad = 0;          // 0: no patch form
   int ring_max = 0;          // longest ring of a tile
   int64_t grid_k = 0;        // row length of the detected grid

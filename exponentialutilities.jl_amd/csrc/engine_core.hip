@@ -411,6 +411,7 @@ int *Options::find(const char *name) {
   return nullptr;
 }
 
+static const int g_patch_xcd = std::getenv("EXPV_MI_PATCH_NO_XCD") ? 0 : 1;      // developer A/B of the patch form's tile mapping
 // host-side phase timing is a developer diagnostic (process-wide, printed when a context is destroyed), not library behaviour
 static const bool g_ht_on = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
 static double g_ht_sum[16];
@@ -801,7 +802,7 @@ struct ArnoldiCall {
         }
       }
       pa.w = use_ring ? 0 : (int)op.bandwidth;
-      if (use_ring) { pa.ring_rows = op.ring_rows.as<int32_t>(); pa.ring_cnt = op.ring_cnt.as<int32_t>(); pa.ring_pad = op.ring_pad; }
+      if (use_ring) { pa.ring_rows = op.ring_rows.as<int32_t>(); pa.ring_cnt = op.ring_cnt.as<int32_t>(); pa.ring_soff = op.ring_soff.as<int64_t>(); pa.ring_pad = op.ring_pad; pa.xcd_map = g_patch_xcd; }
       pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
       pa.ybuf = (j & 1) ? ya : yb2;
       pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;

@@ -289,7 +289,9 @@ struct PipeArgsT {
   // patch form (pipe.hip: RING): A.col holds positions in LDS (tile row, or PIPE tile rows + ring position); ring_rows[tile *
   // ring_pad + p] = the row behind ring position p of the tile (-1: none)
   const int32_t *ring_rows, *ring_cnt;      // ring_cnt[tile]: rows in the tile's ring
+  const int64_t *ring_soff;                 // per SELL slice: where its column block starts in A.col (identical blocks are shared)
   int ring_pad;                // entries per tile in ring_rows: 64, 128 or 256
+  int xcd_map;                 // 1: the workgroups of an XCD take a contiguous eighth of the tiles
 };
 using PipeArgs = PipeArgsT<double>;
 // resident form (pipe.hip): one cooperative launch per factorisation

@@ -323,12 +323,30 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   double acc = 0.0;                           // running total of one value of one set (see below)
 
   const int64_t ntiles = (a.n + TR - 1) / TR;
+  // patch form: the workgroups of one XCD (blockIdx.x % 8 on this chip) share a CONTIGUOUS eighth of the tiles and take them
+  // round-robin, so at any time an XCD works on a few whole bands of the grid: a tile and the neighbours that own its ring (the
+  // next tile, and those a band up and down) go through the same L2 at about the same time.  xcd_map 0 (or a small grid):
+  // consecutive tiles per workgroup, like the banded form.
+  int64_t rr_T0 = 0, rr_T1 = 0, rr_W = 0, rr_q = 0;
+  int tiles_here = tiles_per_block;
+  bool rr_map = false;
+  if constexpr (RING) {
+    if (pa.xcd_map && gridDim.x >= 64) {
+      rr_map = true;
+      const int64_t per = gridDim.x / 8, rem = gridDim.x % 8, x = blockIdx.x % 8;
+      rr_q = blockIdx.x / 8;
+      rr_W = per + (x < rem ? 1 : 0);
+      rr_T0 = ntiles * x / 8;
+      rr_T1 = ntiles * (x + 1) / 8;
+      tiles_here = (int)((rr_T1 - rr_T0 + rr_W - 1) / rr_W);
+    }
+  }
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
-  for (int tl = 0; tl < tiles_per_block; ++tl) {
+  for (int tl = 0; tl < tiles_here; ++tl) {
     // WAVE: tiles are dealt round-robin, so the tiles a tile waits for are in flight in neighbouring workgroups
-    const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : t0 + tl;
-    if (tile >= (WAVE ? ntiles : t1)) break;
+    const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl : t0 + tl;
+    if (tile >= (WAVE ? ntiles : rr_map ? rr_T1 : t1)) break;
     const int64_t r0 = tile * TR, i = r0 + N * (int64_t)tid;
     const bool act = i < nb;   // whole waves: nb is a multiple of the rows a wave owns
     if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 0);
@@ -363,7 +381,8 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         const int64_t off = pa.A.slice_off[slice];
         L = (int)((pa.A.slice_off[slice + 1] - off) / SLICE);
         avp = pa.A.val + off + N * lane;
-        acp = pa.A.col + off + N * lane;
+        if constexpr (RING) acp = pa.A.col + pa.ring_soff[slice] + N * lane;      // (equal column blocks of slices are stored once)
+        else acp = pa.A.col + off + N * lane;
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
@@ -415,6 +434,47 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
       }
     }
+    // patch form: ring geometry of this tile (uniform per workgroup)
+    [[maybe_unused]] int r_cnt = 0, r_RP = BLOCK, r_p = 0, r_g = 0, r_G = 1;
+    [[maybe_unused]] int64_t r_row = -1;
+    [[maybe_unused]] bool r_staged = false;
+    [[maybe_unused]] T r_new = ST<T>::zero(), r_y = ST<T>::zero();
+    constexpr int RSTAGE = 128;                       // ring positions whose raw window values fit the LDS staging area
+    constexpr int RAW0 = N * BLOCK + 2 * BLOCK;       // ... which starts here in us[] (overlapped patch form only)
+    if constexpr (RING) {
+      if (!pa.final) {
+        r_cnt = pa.ring_cnt[tile];
+        r_RP = r_cnt <= 64 ? 64 : r_cnt <= 128 ? 128 : BLOCK;
+        r_p = tid & (r_RP - 1);
+        r_g = tid / r_RP;
+        r_G = BLOCK / r_RP;
+        r_row = (r_p < r_cnt) ? pa.ring_rows[tile * pa.ring_pad + r_p] : -1;
+      }
+      if constexpr (LIVE) {
+        // first tile of an overlapped step: the older window columns on the ring are fetched BEFORE the wait and parked in LDS (each
+        // thread reads back only what it wrote: no barrier); behind the flag only the column the previous step wrote and its y~ remain
+        if (!ready && !pa.final && r_RP <= RSTAGE) {
+          r_staged = true;
+          if (r_row >= 0) {
+            const T *vp = a.V + (int64_t)pa.uc0 * a.ldv + r_row;
+            constexpr int UN = 4;
+            for (int k0 = r_g; k0 < und; k0 += r_G * UN) {
+              T v[UN];
+#pragma unroll
+              for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q * r_G;
+                v[q] = (k < und && k != knew) ? vp[(int64_t)k * cstep] : ST<T>::zero();
+              }
+#pragma unroll
+              for (int q = 0; q < UN; ++q) {
+                const int k = k0 + q * r_G;
+                if (k < und) us[RAW0 + k * RSTAGE + r_p] = v[q];
+              }
+            }
+          }
+        }
+      }
+    }
     auto fetch_prev = [&]() {   // what the previous step wrote on (and around) this tile: its column of V and its y~
       if (wload) {
 #pragma unroll
@@ -422,6 +482,12 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           if (k == knew && k < und) vreg[k] = *reinterpret_cast<const Pack<T> *>(vp0 + (int64_t)k * cstep);
         u = *reinterpret_cast<const Pack<T> *>(yprev + i);
         have_ypre = true;
+      }
+      if constexpr (RING) {
+        if (r_staged && r_row >= 0) {
+          if (knew >= 0 && knew < und && (knew % r_G) == r_g) r_new = a.V[r_row + (int64_t)(pa.uc0 + pa.udir * knew) * a.ldv];
+          if (r_g == 0) r_y = yprev[r_row];
+        }
       }
       if constexpr (!WAVE && !RING) {
         int k;
@@ -465,26 +531,30 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       // the BLOCK / ring_pad threads of a position, their partial sums meet in LDS.  Ring rows that are contiguous in memory (the
       // edges of the neighbouring patches, by the ordering the operator was given) are contiguous across the lanes of a wave.
       if (!pa.final) {
-        const int cnt = pa.ring_cnt[tile];
-        const int RP = cnt <= 64 ? 64 : cnt <= 128 ? 128 : BLOCK, p = tid & (RP - 1), g = tid / RP, G = BLOCK / RP;
-        const int64_t rr = (p < cnt) ? pa.ring_rows[tile * pa.ring_pad + p] : -1;
+        const int RP = r_RP, p = r_p, g = r_g, G = r_G;
+        const int64_t rr = r_row;
         T acc = ST<T>::zero();
         if (rr >= 0) {
-          if (g == 0) acc = first ? u0[rr] : ST<T>::mul_real(yprev[rr], inv);
-          if (!first) {
-            const T *vp = a.V + (int64_t)pa.uc0 * a.ldv + rr;
-            constexpr int UN = 4;
-            for (int k0 = g; k0 < und; k0 += G * UN) {
-              T v[UN];
+          if (r_staged) {      // (first tile of an overlapped step: see above)
+            if (g == 0) acc = ST<T>::mul_real(r_y, inv);
+            for (int k = g; k < und; k += G) ST<T>::nfma(acc, hs[k], (k == knew) ? r_new : us[RAW0 + k * RSTAGE + p]);
+          } else {
+            if (g == 0) acc = first ? u0[rr] : ST<T>::mul_real(yprev[rr], inv);
+            if (!first) {
+              const T *vp = a.V + (int64_t)pa.uc0 * a.ldv + rr;
+              constexpr int UN = 8;
+              for (int k0 = g; k0 < und; k0 += G * UN) {
+                T v[UN];
 #pragma unroll
-              for (int q = 0; q < UN; ++q) {
-                const int k = k0 + q * G;
-                v[q] = (k < und) ? vp[(int64_t)k * cstep] : ST<T>::zero();
-              }
+                for (int q = 0; q < UN; ++q) {
+                  const int k = k0 + q * G;
+                  v[q] = (k < und) ? vp[(int64_t)k * cstep] : ST<T>::zero();
+                }
 #pragma unroll
-              for (int q = 0; q < UN; ++q) {
-                const int k = k0 + q * G;
-                if (k < und) ST<T>::nfma(acc, hs[k], v[q]);
+                for (int q = 0; q < UN; ++q) {
+                  const int k = k0 + q * G;
+                  if (k < und) ST<T>::nfma(acc, hs[k], v[q]);
+                }
               }
             }
           }
@@ -955,7 +1025,8 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
   hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, s, arrive, expected, st, spin_limit);
 }
 
-template <class T> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX>;      // tile rows + ring (<= BLOCK) + BLOCK partial sums
+// tile rows + ring (<= BLOCK) + BLOCK partial sums; the overlapped form adds the staging area of its first tile (CH-1 columns x 128 positions)
+template <class T, int STAGE_COLS = 0> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX + STAGE_COLS * 128>;
 // ---- patch form: single-pass step for operators stored in a grid-patch ordering (capi.hip: a tile of rows is a patch of a 2-D
 // grid, its +-k neighbours are in the tile or in a ring of ~100 rows that is recomputed like the banded form's halo) ----
 template <class T, int CH, int WAVES, int PS>
@@ -966,7 +1037,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> p
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
-  using SH = typename std::conditional<RING, PipeSharedRing<T>, PipeSharedT<T>>::type;
+  using SH = typename std::conditional<RING, PipeSharedRing<T, CH - 1>, PipeSharedT<T>>::type;
   __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
