@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "clear_operator_cache",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "host_patch_order", "clear_operator_cache",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -469,6 +469,15 @@ class MIOperator:
         out = (C.c_int64 * 4)()
         _check(L.load().expv_mi_op_reorder_info(self._h, out))
         return {"reordered": bool(out[0]), "bandwidth_before": int(out[1]), "bandwidth_after": int(out[2]), "setup_s": 1e-6 * int(out[3])}
+
+    @property
+    def patch_info(self):
+        """Grid-patch storage of a 2-D grid stencil (expv_mi_op_patch_info; context option "patch")."""
+        out = (C.c_int64 * 8)()
+        _check(L.load().expv_mi_op_patch_info(self._h, out))
+        return {"patch_form": bool(out[0]), "grid_row_length": int(out[1]), "tiles": int(out[2]), "longest_ring": int(out[3]),
+                "mean_ring": (float(out[4]) / int(out[2])) if out[2] else 0.0, "tiles_ring_over_128": int(out[5]),
+                "column_indices_stored": int(out[6]), "ring_entries_per_tile": int(out[7])}
 
     def update_values(self, A):
         """New values on the same sparsity pattern (expv_mi_op_update_values): ``A`` is the matrix the operator was created
@@ -1131,6 +1140,26 @@ def host_rcm(A, dtype=np.float64):
     names = {3: "single-pass step, halo form", 2: "single-pass step, wave form", 1: "two-kernel step", 0: "two-kernel step + overflow pass"}
     return perm, {"bandwidth_before": int(out[0]), "bandwidth_after": int(out[1]), "form_before": names[int(out[2]) & 255],
                   "form_after": names[int(out[3])], "would_reorder": bool(int(out[2]) & 256)}
+
+
+def host_patch_order(A, dtype=np.float64):
+    """The grid-patch ordering operator creation would store a 2-D grid stencil in under context option ``patch`` (host only, no
+    reference counterpart): (perm, ring_count per tile, info) -- perm is None when no 2-D grid is recognised in the pattern."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+    perm = np.zeros(n, dtype=np.int32)
+    tr = (16 // np.dtype(dtype).itemsize) * 256
+    cnt = np.zeros((n + tr - 1) // tr, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int64)
+    _check(L.load().expv_mi_host_patch_order(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), perm.ctypes.data, cnt.ctypes.data,
+                                             out.ctypes.data))
+    info = {"patch_form": bool(out[0]), "grid_row_length": int(out[1]), "tiles": int(out[2]), "longest_ring": int(out[3]),
+            "mean_ring": (float(out[4]) / int(out[2])) if out[2] else 0.0, "tiles_ring_over_128": int(out[5]),
+            "column_indices_stored": int(out[6]), "ring_entries_per_tile": int(out[7])}
+    return (perm if out[0] else None), cnt, info
 
 
 def host_phiv_dense(A, v, k):

@@ -761,26 +761,30 @@ static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &per
   op.perm = pm;
 }
 
-// returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
-// per-tile rings and the tile-local column array)
-template <class V>
-static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
-  if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
-  if (sizeof(V) != 8 && sizeof(V) != 4) return false;      // the real element types (pipe.hip: SELL slots)
-  const auto t0 = std::chrono::steady_clock::now();
-  const PatternPlan P0 = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
-  int64_t k = 0;
-  if (!detect_grid2d(P0, n, &k)) return false;
-  const int64_t TR = (int64_t)(16 / sizeof(V)) * dev::BLOCK;      // rows of a tile: 512 (fp64), 1024 (Float32)
-  const int64_t R = sizeof(V) == 8 ? 16 : 32;
-  const std::vector<int32_t> perm = patch_order(n, k, R, TR);
-  if ((int64_t)perm.size() != n) return false;
-  std::vector<int32_t> rp2, ci2, src;
-  reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
+// Host plan of the patch form: the ordering, P A P' in CSR, the per-tile rings, the SELL column array as LDS positions (equal
+// column blocks of slices stored once).  false: no 2-D grid recognised, or a tile's ring does not fit.
+struct PatchPlan {
+  int64_t k = 0, nt = 0, bw0 = 0, bw1 = 0;
+  std::vector<int32_t> perm, rp2, ci2, src, rows, cnt, lcol;
+  std::vector<int64_t> soff;
+  int RP = 0, maxring = 0;
+  int64_t ring_sum = 0, over128 = 0;
+};
+static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, PatchPlan &pl) {
+  if (n < 2 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;      // the real element types (pipe.hip: SELL slots)
+  const PatternPlan P0 = analyze_pattern(n, rp, ci, nnz, value_bytes);
+  if (!detect_grid2d(P0, n, &pl.k)) return false;
+  const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;      // rows of a tile: 512 (fp64), 1024 (Float32)
+  const int64_t R = value_bytes == 8 ? 16 : 32;
+  pl.perm = patch_order(n, pl.k, R, TR);
+  if ((int64_t)pl.perm.size() != n) return false;
+  reorder::permute_csr(n, rp, ci, pl.perm, pl.rp2, pl.ci2, pl.src);
+  const std::vector<int32_t> &rp2 = pl.rp2, &ci2 = pl.ci2;
   // rings: per tile the columns outside it, ascending
   const int64_t nt = (n + TR - 1) / TR;
+  pl.nt = nt;
   std::vector<std::vector<int32_t>> ring((size_t)nt);
-  int maxring = 0;
+  pl.maxring = 0;
   for (int64_t t = 0; t < nt; ++t) {
     auto &g = ring[(size_t)t];
     const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
@@ -789,17 +793,21 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
         if (ci2[(size_t)e] < r0 || ci2[(size_t)e] >= r1) g.push_back(ci2[(size_t)e]);
     std::sort(g.begin(), g.end());
     g.erase(std::unique(g.begin(), g.end()), g.end());
-    maxring = std::max(maxring, (int)g.size());
+    pl.maxring = std::max(pl.maxring, (int)g.size());
   }
-  if (maxring > dev::BLOCK) return false;
-  const int RP = maxring <= 64 ? 64 : maxring <= 128 ? 128 : 256;
-  std::vector<int32_t> rows((size_t)nt * RP, -1), cnt((size_t)nt, 0);
+  if (pl.maxring > dev::BLOCK) return false;
+  const int RP = pl.maxring <= 64 ? 64 : pl.maxring <= 128 ? 128 : 256;
+  pl.RP = RP;
+  pl.rows.assign((size_t)nt * RP, -1);
+  pl.cnt.assign((size_t)nt, 0);
   for (int64_t t = 0; t < nt; ++t) {
-    std::copy(ring[(size_t)t].begin(), ring[(size_t)t].end(), rows.begin() + t * RP);
-    cnt[(size_t)t] = (int32_t)ring[(size_t)t].size();
+    std::copy(ring[(size_t)t].begin(), ring[(size_t)t].end(), pl.rows.begin() + t * RP);
+    pl.cnt[(size_t)t] = (int32_t)ring[(size_t)t].size();
+    pl.ring_sum += pl.cnt[(size_t)t];
+    pl.over128 += pl.cnt[(size_t)t] > 128 ? 1 : 0;
   }
   // the SELL column array of build_sell (same slices, no cut) restated as LDS positions
-  const int SH = 64 * (16 / (int)sizeof(V));
+  const int SH = 64 * (16 / value_bytes);
   const int64_t nsl = (n + SH - 1) / SH;
   std::vector<int64_t> off((size_t)nsl + 1, 0);
   for (int64_t sl = 0; sl < nsl; ++sl) {
@@ -817,46 +825,60 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
       lcol[(size_t)(off[(size_t)sl] + (int64_t)(e - rp2[(size_t)r]) * SH + (r - sl * SH))] = loc;
     }
   }
-  const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
+  const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), nnz, value_bytes);
   if (P1.overflow) return false;
+  pl.bw0 = P0.bandwidth;
+  pl.bw1 = P1.bandwidth;
   // the column blocks of the slices of equal patches are equal (positions in the tile's LDS image, not rows of the matrix): keep
   // one copy of each -- the step then reads its column indices from a few kB that stay in L2 instead of 4 bytes per entry from HBM
-  std::vector<int64_t> soff((size_t)nsl, 0);
-  {
-    std::vector<int32_t> pool;
-    std::unordered_map<uint64_t, std::vector<int64_t>> seen;      // hash of a block -> pool offsets of the blocks with that hash
-    for (int64_t sl = 0; sl < nsl; ++sl) {
-      const int32_t *blk = lcol.data() + off[(size_t)sl];
-      const int64_t len = off[(size_t)sl + 1] - off[(size_t)sl];
-      uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
-      for (int64_t z = 0; z < len; ++z) { h ^= (uint32_t)blk[z]; h *= 1099511628211ull; }
-      int64_t at = -1;
-      for (int64_t cand : seen[h])
-        if (cand + len <= (int64_t)pool.size() && std::memcmp(pool.data() + cand, blk, sizeof(int32_t) * (size_t)len) == 0) { at = cand; break; }
-      if (at < 0) {
-        at = (int64_t)pool.size();
-        pool.insert(pool.end(), blk, blk + len);
-        seen[h].push_back(at);
-      }
-      soff[(size_t)sl] = at;
+  pl.soff.assign((size_t)nsl, 0);
+  std::vector<int32_t> pool;
+  std::unordered_map<uint64_t, std::vector<int64_t>> seen;      // hash of a block -> pool offsets of the blocks with that hash
+  for (int64_t sl = 0; sl < nsl; ++sl) {
+    const int32_t *blk = lcol.data() + off[(size_t)sl];
+    const int64_t len = off[(size_t)sl + 1] - off[(size_t)sl];
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+    for (int64_t z = 0; z < len; ++z) { h ^= (uint32_t)blk[z]; h *= 1099511628211ull; }
+    int64_t at = -1;
+    for (int64_t cand : seen[h])
+      if (cand + len <= (int64_t)pool.size() && std::memcmp(pool.data() + cand, blk, sizeof(int32_t) * (size_t)len) == 0) { at = cand; break; }
+    if (at < 0) {
+      at = (int64_t)pool.size();
+      pool.insert(pool.end(), blk, blk + len);
+      seen[h].push_back(at);
     }
-    op.ring_col_unique = (int64_t)pool.size();
-    lcol.swap(pool);
-    lcol.resize(lcol.size() + 4, 0);
+    pl.soff[(size_t)sl] = at;
   }
-  op.ring_soff.alloc(sizeof(int64_t) * soff.size());
-  HIPCHECK(hipMemcpyAsync(op.ring_soff.p, soff.data(), sizeof(int64_t) * soff.size(), hipMemcpyHostToDevice, op.ctx->stream));
-  op.ring_rows.alloc(sizeof(int32_t) * rows.size());
-  op.ring_cnt.alloc(sizeof(int32_t) * cnt.size());
-  op.ring_col.alloc(sizeof(int32_t) * lcol.size() + 16);
-  HIPCHECK(hipMemcpyAsync(op.ring_rows.p, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, op.ctx->stream));
-  HIPCHECK(hipMemcpyAsync(op.ring_cnt.p, cnt.data(), sizeof(int32_t) * cnt.size(), hipMemcpyHostToDevice, op.ctx->stream));
-  HIPCHECK(hipMemcpyAsync(op.ring_col.p, lcol.data(), sizeof(int32_t) * lcol.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  pl.lcol.swap(pool);
+  return true;
+}
+
+// returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
+// per-tile rings and the tile-local column array)
+template <class V>
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+  if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
+  const auto t0 = std::chrono::steady_clock::now();
+  PatchPlan pl;
+  if (!plan_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), pl)) return false;
+  op.ring_col_unique = (int64_t)pl.lcol.size();
+  pl.lcol.resize(pl.lcol.size() + 4, 0);
+  op.ring_soff.alloc(sizeof(int64_t) * pl.soff.size());
+  op.ring_rows.alloc(sizeof(int32_t) * pl.rows.size());
+  op.ring_cnt.alloc(sizeof(int32_t) * pl.cnt.size());
+  op.ring_col.alloc(sizeof(int32_t) * pl.lcol.size() + 16);
+  HIPCHECK(hipMemcpyAsync(op.ring_soff.p, pl.soff.data(), sizeof(int64_t) * pl.soff.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.ring_rows.p, pl.rows.data(), sizeof(int32_t) * pl.rows.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.ring_cnt.p, pl.cnt.data(), sizeof(int32_t) * pl.cnt.size(), hipMemcpyHostToDevice, op.ctx->stream));
+  HIPCHECK(hipMemcpyAsync(op.ring_col.p, pl.lcol.data(), sizeof(int32_t) * pl.lcol.size(), hipMemcpyHostToDevice, op.ctx->stream));
   HIPCHECK(hipStreamSynchronize(op.ctx->stream));
-  op.ring_pad = RP;
-  op.ring_max = maxring;
-  op.grid_k = k;
-  install_row_order<V>(op, n, perm, src, rp, ci, va, rp2, ci2, P0.bandwidth, P1.bandwidth, t0);
+  op.ring_pad = pl.RP;
+  op.ring_max = pl.maxring;
+  op.grid_k = pl.k;
+  op.ring_tiles = pl.nt;
+  op.ring_sum = pl.ring_sum;
+  op.ring_over128 = pl.over128;
+  install_row_order<V>(op, n, pl.perm, pl.src, rp, ci, va, pl.rp2, pl.ci2, pl.bw0, pl.bw1, t0);
   return true;
 }
 
@@ -1363,6 +1385,19 @@ int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]) {
   return EXPV_MI_OK;
 }
 
+int expv_mi_op_patch_info(expv_mi_op_t op, int64_t out[8]) {
+  if (!op || !out) return EXPV_MI_ARGUMENT_ERROR;
+  out[0] = op->ring_pad > 0 ? 1 : 0;
+  out[1] = op->grid_k;
+  out[2] = op->ring_tiles;
+  out[3] = op->ring_max;
+  out[4] = op->ring_sum;
+  out[5] = op->ring_over128;
+  out[6] = op->ring_col_unique;
+  out[7] = op->ring_pad;
+  return EXPV_MI_OK;
+}
+
 int expv_mi_op_update_values(expv_mi_op_t op, const void *vals, int loc) {
   if (!op) return EXPV_MI_ARGUMENT_ERROR;
   return guarded(op->ctx, [&] {
@@ -1825,6 +1860,19 @@ int expv_mi_host_rcm(int64_t n, const int32_t *rowptr, const int32_t *colind, in
       out[2] = (n > 0 ? c0.cls : 1) | ((n > 0 && candidate && better) ? 256 : 0);      // bit 8: creation would keep the ordering
       out[3] = n > 0 ? c1.cls : 1;
     }
+  });
+}
+int expv_mi_host_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count, int64_t out[8]) {
+  return guarded(nullptr, [&] {
+    if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && !colind) || !out) fail(EXPV_MI_ARGUMENT_ERROR, "host_patch_order: bad arguments");
+    check_device_dtype(dtype, "host_patch_order");
+    for (int q = 0; q < 8; ++q) out[q] = 0;
+    PatchPlan pl;
+    if (!plan_patch(n, rowptr, colind, n > 0 ? (int64_t)rowptr[n] : 0, (int)dtype_size(dtype), pl)) return;
+    if (perm) std::copy(pl.perm.begin(), pl.perm.end(), perm);
+    if (ring_count) std::copy(pl.cnt.begin(), pl.cnt.end(), ring_count);
+    out[0] = 1; out[1] = pl.k; out[2] = pl.nt; out[3] = pl.maxring; out[4] = pl.ring_sum; out[5] = pl.over128;
+    out[6] = (int64_t)pl.lcol.size(); out[7] = pl.RP;
   });
 }
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {

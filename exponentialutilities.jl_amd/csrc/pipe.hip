@@ -336,8 +336,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       const int64_t per = gridDim.x / 8, rem = gridDim.x % 8, x = blockIdx.x % 8;
       rr_q = blockIdx.x / 8;
       rr_W = per + (x < rem ? 1 : 0);
-      rr_T0 = ntiles * x / 8;
-      rr_T1 = ntiles * (x + 1) / 8;
+      const int64_t w0 = x * per + (x < rem ? x : rem);      // workgroups on the XCDs before this one: tiles in proportion
+      rr_T0 = ntiles * w0 / gridDim.x;
+      rr_T1 = ntiles * (w0 + rr_W) / gridDim.x;
       tiles_here = (int)((rr_T1 - rr_T0 + rr_W - 1) / rr_W);
     }
   }

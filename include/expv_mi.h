@@ -182,6 +182,19 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
  * (rounding apart).  out[0] = 1 when reordered, out[1] / out[2] = max |col - row| before / after, out[3] = the reordering's share
  * of the creation time in microseconds.  No reference counterpart (the reference applies A in the caller's ordering). */
 int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]);
+/* Grid-patch ordering (context option "patch", default 0; read when an operator is created): a 5- / 9-point stencil on a 2-D grid
+ * with rows of k cells (every offset within 2 of 0 or of +-k) is stored in an ordering in which a tile of the single-pass step is a
+ * 16 x 32 patch of the grid, and the step recomputes u_j on the ring of rows around each tile (patch form) instead of waiting for
+ * per-tile flags (wave form).  A special case of the reordering above: expv_mi_op_reorder_info reports it too, vectors are permuted
+ * the same way.  out[0] = 1 when the operator is stored that way, out[1] = k, out[2] = tiles, out[3] = longest ring, out[4] = sum
+ * of the ring lengths, out[5] = tiles whose ring is longer than 128 rows, out[6] = column indices kept after sharing the equal
+ * column blocks of slices, out[7] = ring entries stored per tile. */
+int expv_mi_op_patch_info(expv_mi_op_t op, int64_t out[8]);
+/* The same analysis on the host, no device needed (tests; what expv_mi_op_create_csr would do with option patch = 1): CSR pattern with
+ * 0-based int32 indices; perm (n entries, may be null): row i of the stored operator is row perm[i] of A; ring_count (one entry per
+ * tile of 4096 / sizeof(element) rows, may be null); out as in expv_mi_op_patch_info (all zero when no 2-D grid is recognised). */
+int expv_mi_host_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count,
+                             int64_t out[8]);
 /* mul!(y, A, x)  (arnoldi.jl:185) */
 int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc);
 

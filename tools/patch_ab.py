@@ -51,7 +51,7 @@ for k in ks:
         t = sorted(ts)[2]
         frac = alg_bytes(n, A.nnz, m, A.dtype.itemsize) / t / 8e12
         res[patch] = (t, w.clone(), path)
-        info = op.reorder_info
+        info = dict(op.reorder_info, **(op.patch_info if patch else {}))
         print("k=%d n=%d %s patch=%d: %.3f ms per expv (%.2f us/step), %.3f of the contract; path %s; setup %.2f s; reorder %s"
               % (k, n, dt.__name__, patch, 1e3 * t, 1e6 * t / m, frac, path, setup, info), flush=True)
         del op, ctx
