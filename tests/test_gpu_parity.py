@@ -999,6 +999,143 @@ def test_reordered_operator_drivers_and_value_updates(eu):
     close(op2.opnorm_inf, float(np.max(np.abs(Ac2).sum(axis=1))), 1e-14, "reordered operator: opnorm(A, Inf) after update_values")
 
 
+def _grid_operator(case, rng):
+    """2-D grid stencils for the patch form: (A, m).  pure: five full diagonals (the bench's operator: the +-1 diagonals run across
+    the row ends); laplace: a 5-point operator with per-entry coefficients and NO entries across row ends (kron structure); nine: a
+    9-point stencil (offsets +-k, +-k+-1); ragged: the last grid row is incomplete; big: n = 10^6, several tiles per workgroup."""
+    def five_point(k, rows, wrap):
+        n = k * rows
+        i = np.arange(n)
+        parts = []
+        for off in (-k, -1, 0, 1, k):
+            j = i + off
+            ok = (j >= 0) & (j < n)
+            if not wrap and abs(off) == 1:
+                ok &= (j // k) == (i // k)
+            v = (-4.0 if off == 0 else 1.0) + 0.3 * rng.standard_normal(n)
+            parts.append(sp.csr_matrix((v[ok], (i[ok], j[ok])), shape=(n, n)))
+        return sum(parts).tocsr()
+    if case in ("pure_f64", "pure_f32", "pure_serial"):
+        k, rows = 320, 300
+        n = k * rows
+        return sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr"), 30
+    if case == "laplace_f64":
+        return five_point(250, 260, False), 20
+    if case == "nine_f64":
+        k, rows = 200, 333
+        n = k * rows
+        offs = [-k - 1, -k, -k + 1, -1, 0, 1, k - 1, k, k + 1]
+        return sp.diags([0.05, 0.4, -0.07, 1.1, -3.0, 0.9, 0.06, 0.5, 0.03], offs, shape=(n, n), format="csr"), 16
+    if case == "ragged_f64":
+        k = 131
+        n = k * 257 + 77
+        return sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr"), 24
+    if case == "big_f64":
+        k = 1000
+        return sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(k * k, k * k), format="csr"), 12
+    raise ValueError(case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["pure_f64", "pure_serial", "pure_f32", "laplace_f64", "nine_f64", "ragged_f64", "big_f64"])
+def test_patch_form_of_the_single_pass_step(eu, case):
+    """a 2-D grid stencil stored in a grid-patch ordering (context option patch = 1: a tile of the single-pass step
+    is a 16 x 32 patch of the grid, the ring of rows around it is recomputed like the banded form's halo -- no per-tile flags).  The
+    caller sees the natural ordering: H, beta, V, expv!, phiv!, a continuation, the whole-call expv with host and device vectors,
+    mul!, a short window (iop = 3) and a values-only update, all against the oracle on the caller's matrix at the fixed bars."""
+    import torch
+    rng = np.random.default_rng(33)
+    T = np.float32 if case == "pure_f32" else np.float64
+    A0, m = _grid_operator(case, rng)
+    A = A0.astype(T)
+    n = A.shape[0]
+    A64 = A.astype(np.float64)
+    b = rng.standard_normal(n).astype(T)
+    b64 = b.astype(np.float64)
+    tol = 2e-5 if T == np.float32 else TOL
+    ctx = eu.Context()
+    ctx.set_option("patch", 1)
+    if case == "pure_serial":
+        ctx.set_option("pipeline_serial", 1)
+    op = eu.MIOperator(A, ctx)
+    pi = op.patch_info
+    assert pi["patch_form"] and op.reorder_info["reordered"] and pi["longest_ring"] <= 256, pi
+    if case == "big_f64":
+        assert pi["tiles"] == 1954 and pi["tiles_ring_over_128"] == 0 and 90 < pi["mean_ring"] < 100, pi
+    close(np.asarray(op.matvec(b)), A64 @ b64, 5e-6 if tol > TOL else 1e-14, "patch form %s: mul! vs scipy" % case)
+    Ks = eu.KrylovSubspace(T, T, n, m + 6, 0, ctx)
+    eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+    Ko = ko.KrylovSubspace(np.float64, np.float64, n, m + 6)
+    ko.arnoldi_(Ko, A64, b64, m=m, ishermitian=False)
+    assert Ks.m == Ko.m == m
+    close(np.asarray(Ks.getH()).astype(np.float64), Ko.getH(), tol, "patch form %s: H of arnoldi! vs oracle" % case, mat=True)
+    w = eu.expv_(np.empty(n, dtype=T), 0.7, Ks)
+    close(np.asarray(w).astype(np.float64), ko.expv_(np.empty(n), 0.7, Ko), tol, "patch form %s: expv! vs oracle" % case)
+    W = eu.phiv_(np.empty((n, 3), dtype=T, order="F"), 0.7, Ks, 2)
+    close(np.asarray(W).astype(np.float64), ko.phiv_(np.empty((n, 3)), 0.7, Ko, 2), 10 * tol, "patch form %s: phiv! k=2 vs oracle" % case)
+    close(np.asarray(Ks.getV()).astype(np.float64), Ko.getV(), tol, "patch form %s: V vs oracle (max abs)" % case, absolute=True)
+    if T == np.float64 and case != "big_f64":
+        eu.arnoldi_(Ks, op, b, m=m + 6, init=m, ishermitian=False)
+        ko.arnoldi_(Ko, A64, b64, m=m + 6, init=m, ishermitian=False)
+        close(Ks.getH(), Ko.getH(), TOL, "patch form %s: H after a continuation (init = m) vs oracle" % case, mat=True)
+        close(Ks.getV(), Ko.getV(), TOL, "patch form %s: V after a continuation vs oracle (max abs)" % case, absolute=True)
+    wo = ko.expv(0.7, A64, b64, m=m, ishermitian=False)
+    close(np.asarray(eu.expv(0.7, op, b, m=m, ishermitian=False)).astype(np.float64), wo, tol, "patch form %s: expv(t, A, b) vs oracle" % case)
+    assert "patch" in eu.expv.last_stats["path"] and ("overlapped" in eu.expv.last_stats["path"]) == (case != "pure_serial"), eu.expv.last_stats
+    bd = torch.as_tensor(b, device="cuda")
+    out = torch.empty_like(bd)
+    eu.expv(0.7, op, bd, m=m, ishermitian=False, out=out)
+    ctx.sync()
+    close(out.cpu().numpy().astype(np.float64), wo, tol, "patch form %s: expv with device vectors vs oracle" % case)
+    if case == "big_f64":
+        return
+    # a short orthogonalisation window (incomplete orthogonalisation, iop = 3)
+    close(np.asarray(eu.expv(0.5, op, b, m=m, iop=3, ishermitian=False)).astype(np.float64), ko.expv(0.5, A64, b64, m=m, iop=3, ishermitian=False),
+          10 * tol, "patch form %s: expv with iop = 3 vs oracle" % case)
+    assert "patch" in eu.expv.last_stats["path"], eu.expv.last_stats
+    # new values on the same pattern, in the caller's entry order
+    A2 = A.copy()
+    A2.data = (A.data * (1.0 + 0.2 * rng.random(A.nnz))).astype(T)
+    op.update_values(A2)
+    close(np.asarray(eu.expv(0.6, op, b, m=m, ishermitian=False)).astype(np.float64), ko.expv(0.6, A2.astype(np.float64), b64, m=m, ishermitian=False), tol,
+          "patch form %s: expv after update_values vs oracle on the new matrix" % case)
+    assert "patch" in eu.expv.last_stats["path"], eu.expv.last_stats
+
+
+@pytest.mark.gpu
+def test_patch_form_drivers(eu):
+    """The drivers on an operator stored in the grid-patch ordering: lanczos! and the error-estimate mode on a symmetric stencil
+    (window 2 on the patch form), adaptive phiv_timestep! and kiops (augmented operator: the two-kernel step on the stored ordering),
+    each against the oracle on the caller's ordering."""
+    rng = np.random.default_rng(34)
+    k, rows = 256, 200
+    n = k * rows
+    As = sp.diags([0.5, 1.0, -3.0, 1.0, 0.5], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+    b = rng.standard_normal(n)
+    ctx = eu.Context()
+    ctx.set_option("patch", 1)
+    ops = eu.MIOperator(As, ctx)
+    assert ops.patch_info["patch_form"] and ops.ishermitian
+    close(eu.expv(0.5, ops, b, m=25), ko.expv(0.5, As, b, m=25), TOL, "patch form, symmetric stencil: expv (Lanczos) vs oracle")
+    assert "patch" in eu.expv.last_stats["path"], eu.expv.last_stats
+    close(eu.expv(0.5, ops, b, m=30, mode="error_estimate", rtol=1e-9), ko.expv(0.5, As, b, m=30, mode="error_estimate", rtol=1e-9), 1e-11,
+          "patch form, symmetric stencil: error-estimate mode vs oracle")
+    A = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+    op = eu.MIOperator(A.tocsc(), ctx)
+    assert op.patch_info["patch_form"]
+    B = np.asfortranarray(rng.standard_normal((n, 3)))
+    st, so = {}, {}
+    ts = np.array([0.4, 1.0])
+    U = eu.phiv_timestep(ts.copy(), op, B, adaptive=True, tol=1e-8, stats=st)
+    Uo = ko.phiv_timestep(ts.copy(), A, B, adaptive=True, tol=1e-8, stats=so)
+    assert (st["num_timesteps"], st["matvecs"], st["m"]) == (so["num_timesteps"], so["matvecs"], so["m"]), (st, so)
+    close(U, Uo, 1e-11, "patch form: adaptive phiv_timestep (K = 2, two snapshots) vs oracle")
+    wk, sk = eu.kiops(1.0, op, B, ishermitian=False)
+    wko, sko = ko.kiops(1.0, A, B, ishermitian=False)
+    assert tuple(sk) == tuple(sko), (sk, sko)
+    close(wk, wko, 1e-10, "patch form: kiops with three columns vs oracle")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["real", "complex", "float32", "real_csc_update"])
 def test_irregular_rows_column_blocked_form(eu, case):
