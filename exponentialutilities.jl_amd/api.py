@@ -1120,7 +1120,8 @@ def host_pattern_info(A, dtype=np.float64):
     elif info["pipeline_dia_diagonals"] or (np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.float32)) and info["bandwidth"] <= 8):
         info["path"] = "pipeline, halo form"
     elif np.dtype(dtype) in (np.dtype(np.float64), np.dtype(np.float32)) and (info["general_dia_diagonals"] or info["sell_wave_reach"] >= 0):
-        info["path"] = "pipeline, wave form (when the reach is small against the resident grid), else two-kernel step"
+        info["path"] = ("pipeline, wave form (when the reach is small against the resident grid), else two-kernel step; a 2-D grid "
+                        "stencil: pipeline, patch form under context option patch (host_patch_order)")
     else:
         info["path"] = "two-kernel step"
     return info

@@ -83,9 +83,9 @@ struct Options {
   int reorder = 1;         // sparse operators without a single-pass form in their natural ordering: 1 = try reverse Cuthill-McKee at
                            // creation and keep P A P' when that gives one (vectors permuted on entry / exit, capi.hip); 0 = never;
                            // 2 = always keep the reordered form (tests)                          (EXPV_MI_REORDER=0|1|2)
-  int patch = 0;           // 2-D grid stencils: 1 = store the operator in a grid-patch ordering at creation (a 512-row tile = a 16 x 32 patch of
-                           // the grid; pipe.hip: patch form of the single-pass step, ring recomputed instead of per-tile flags);
-                           // 0 = natural ordering, wave form                                     (EXPV_MI_PATCH=0|1)
+  int patch = 1;           // 2-D grid stencils: 1 = store the operator in a grid-patch ordering at creation (a 512-row tile = a 16 x 32 patch of
+                           // the grid; pipe.hip: patch form of the single-pass step, ring recomputed instead of per-tile flags: 11-18 %
+                           // faster than the wave form at every size measured); 0 = natural ordering, wave form  (EXPV_MI_PATCH=0|1)
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();

@@ -99,10 +99,14 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *   "reorder" 1         sparse operators with no single-pass form in their natural ordering: 1 = try a bandwidth-reducing
  *                       ordering (reverse Cuthill-McKee) at creation and keep P A P' when it gives one; 0 = never; 2 = always keep it
  *                       (expv_mi_op_reorder_info says what happened; read when an operator is created)
+ *   "patch" 1           2-D grid stencils (every offset within 2 of 0 or of +-k): 1 = stored in a grid-patch ordering at creation, the
+ *                       single-pass step runs in its patch form (a tile = a 16 x 32 patch of the grid, the ring of rows around it
+ *                       recomputed: no per-tile flags); 0 = natural ordering, wave form (expv_mi_op_patch_info; read when an
+ *                       operator is created)
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
- * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE, _EE_STEPWISE, _REORDER (read once, at creation) -- nothing reads the environment later.
+ * _NO_MAILBOX, _PIPE_SERIAL, _PIPE_SPIN_LIMIT, _BATCH_ROUNDS, _NONTEMPORAL, _RESIDENT, _STENCIL, _NO_RECYCLE, _EE_STEPWISE, _REORDER, _PATCH (read once, at creation) -- nothing reads the environment later.
  * Unknown names return EXPV_MI_ARGUMENT_ERROR. */
 int expv_mi_ctx_set_option(expv_mi_ctx_t ctx, const char *name, int64_t value);
 int expv_mi_ctx_get_option(expv_mi_ctx_t ctx, const char *name, int64_t *value);
@@ -182,7 +186,7 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
  * (rounding apart).  out[0] = 1 when reordered, out[1] / out[2] = max |col - row| before / after, out[3] = the reordering's share
  * of the creation time in microseconds.  No reference counterpart (the reference applies A in the caller's ordering). */
 int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]);
-/* Grid-patch ordering (context option "patch", default 0; read when an operator is created): a 5- / 9-point stencil on a 2-D grid
+/* Grid-patch ordering (context option "patch", default 1; read when an operator is created): a 5- / 9-point stencil on a 2-D grid
  * with rows of k cells (every offset within 2 of 0 or of +-k) is stored in an ordering in which a tile of the single-pass step is a
  * 16 x 32 patch of the grid, and the step recomputes u_j on the ring of rows around each tile (patch form) instead of waiting for
  * per-tile flags (wave form).  A special case of the reordering above: expv_mi_op_reorder_info reports it too, vectors are permuted

@@ -1298,6 +1298,7 @@ def test_float32_wave_form_on_general_diagonals(eu, shape):
     b = rng.standard_normal(n).astype(np.float32)
     A64, b64 = A.astype(np.float64), b.astype(np.float64)
     ctx = eu.Context()
+    ctx.set_option("patch", 0)                     # (the 2-D grid in its natural ordering: the patch form has its own tests)
     op = eu.MIOperator(A, ctx)
     for m, iop in ((20, 0), (31, 0), (25, 4)):
         ctx.set_pipeline_overlap(True)

@@ -713,7 +713,7 @@ def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
         np.save(sys.argv[1], np.stack([w, g]))
     """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n, m, m)
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "expv_mi_fallback_%d.npy" % os.getpid())
-    env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1")
+    env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1", EXPV_MI_PATCH="0")      # (the grid in its natural ordering: wave form)
     r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out)
@@ -729,6 +729,7 @@ def test_overlapped_and_serial_pipeline_are_bitwise_identical(eu):
     over ragged sizes, short and long windows, IOP, Lanczos and a mid-run happy breakdown."""
     rng = np.random.default_rng(21)
     ctx = eu.Context()
+    ctx.set_option("patch", 0)             # (grids in their natural ordering: the wave form; the patch form is compared the same way in its own test)
     cases = [(513, 5, 0, False), (1024, 31, 0, False), (4097, 30, 0, False), (10001, 32, 0, False), (3000, 25, 3, False),
              (2500, 30, 0, True), (777, 12, 2, False), (70000, 30, 0, False), (256, 30, 0, False),
              (-40001, 30, 0, False), (-300000, 24, 0, False), (-9000, 31, 4, False), (-25000, 20, 0, True)]
@@ -764,7 +765,7 @@ def test_overlapped_and_serial_pipeline_are_bitwise_identical(eu):
 
 
 @pytest.mark.parametrize("case", ["grid2d_small", "grid2d_multi_round", "odd_offsets", "symmetric_grid", "many_diagonals"])
-def test_wide_diagonal_operators_wave_form(eu, case):
+def test_wide_diagonal_operators_wave_form(eu, case, natural_grid_ordering):
     """Operators made of a few diagonals with arbitrary offsets (structured grids) take the wave form of the single-pass
     step: tiles publish their piece of u_j and wait for the tiles their diagonals reach into.  Parity with the oracle
     (small sizes) and with the strict-MGS modular path (every size)."""
@@ -1087,6 +1088,13 @@ def test_patch_form_of_the_single_pass_step(eu, case):
     eu.expv(0.7, op, bd, m=m, ishermitian=False, out=out)
     ctx.sync()
     close(out.cpu().numpy().astype(np.float64), wo, tol, "patch form %s: expv with device vectors vs oracle" % case)
+    if case != "pure_serial":              # one launch after the other: same kernels, same sums -- bit for bit
+        ctx.set_pipeline_overlap(False)
+        out2 = torch.empty_like(bd)
+        eu.expv(0.7, op, bd, m=m, ishermitian=False, out=out2)
+        ctx.sync()
+        ctx.set_pipeline_overlap(True)
+        assert "overlapped" not in eu.expv.last_stats["path"] and torch.equal(out, out2), "patch form %s: overlapped and serial runs differ" % case
     if case == "big_f64":
         return
     # a short orthogonalisation window (incomplete orthogonalisation, iop = 3)
