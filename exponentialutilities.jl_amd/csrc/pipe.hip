@@ -1038,7 +1038,10 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> p
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
-  using SH = typename std::conditional<RING, PipeSharedRing<T, CH - 1>, PipeSharedT<T>>::type;
+  // (the 16- and the 24-column variant run at the same 3 workgroups per CU and follow each other in a factorisation: the same LDS
+  //  size for both, so that a workgroup of step 17 fits the hole a workgroup of step 16 leaves -- with different sizes the first
+  //  24-column step waited ~25 us for two adjacent holes: profiles/r04_ab_variants.txt)
+  using SH = typename std::conditional<RING, PipeSharedRing<T, (CH == 16 ? 24 : CH) - 1>, PipeSharedT<T>>::type;
   __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
@@ -1615,7 +1618,7 @@ static int pipe_ring_launch(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
 template <class T>
 static int pipe_step_ring_T(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
   switch (pipe_variant(pa.und)) {
-    case 0: return pipe_ring_launch<T, 8, 4, 6>(s, pa, live);
+    case 0: return pipe_ring_launch<T, 8, 4, 5>(s, pa, live);
     case 1: return pipe_ring_launch<T, 16, 3, 6>(s, pa, live);
     case 2: return pipe_ring_launch<T, 24, 3, 0>(s, pa, live);
     default: return pipe_ring_launch<T, 32, 2, 5>(s, pa, live);
