@@ -865,6 +865,7 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
   pl.lcol.resize(pl.lcol.size() + 4, 0);
   op.ring_soff.alloc(sizeof(int64_t) * pl.soff.size());
   op.ring_rows.alloc(sizeof(int32_t) * pl.rows.size());
+  pl.cnt.resize(pl.cnt.size() + 2, 0);      // (the rows of an augmented operator may open one more tile: an empty ring)
   op.ring_cnt.alloc(sizeof(int32_t) * pl.cnt.size());
   op.ring_col.alloc(sizeof(int32_t) * pl.lcol.size() + 16);
   HIPCHECK(hipMemcpyAsync(op.ring_soff.p, pl.soff.data(), sizeof(int64_t) * pl.soff.size(), hipMemcpyHostToDevice, op.ctx->stream));

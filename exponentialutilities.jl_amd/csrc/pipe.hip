@@ -215,8 +215,8 @@ template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(c
 template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false,
           class SH = PipeSharedT<T>>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, SH &sh) {
-  static_assert(!AUG || (DIA && !WAVE), "the augmented operator runs on the DIA halo form");
-  static_assert(!RING || (!DIA && !WAVE && !AUG), "the patch form: SELL slots with tile-local columns");
+  static_assert(!AUG || ((DIA || RING) && !WAVE), "the augmented operator runs on the DIA halo form and on the patch form");
+  static_assert(!RING || (!DIA && !WAVE), "the patch form: SELL slots with tile-local columns");
   constexpr bool IS_F64 = std::is_same<T, double>::value;      // constant diagonals: fp64 only
   constexpr bool IS_F32 = std::is_same<T, float>::value;
   constexpr bool SELL_T = IS_F64 || IS_F32;                    // SELL slots (halo and wave form): the real element types
@@ -376,7 +376,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             av[sl] = ld_stream<NT, T>(avp + (int64_t)sl * pa.dia_ld);
           }
       }
-    } else if (i < a.n) {
+    } else if (i < n_op) {      // (rows of the augmentation carry no operator entries)
       if constexpr (SELL_T) {
         const int64_t slice = i / SLICE;
         const int64_t off = pa.A.slice_off[slice];
@@ -1030,10 +1030,10 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
 template <class T, int STAGE_COLS = 0> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX + STAGE_COLS * 128>;
 // ---- patch form: single-pass step for operators stored in a grid-patch ordering (capi.hip: a tile of rows is a patch of a 2-D
 // grid, its +-k neighbours are in the tile or in a ring of ~100 rows that is recomputed like the banded form's halo) ----
-template <class T, int CH, int WAVES, int PS>
+template <class T, int CH, int WAVES, int PS, bool AUG = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> pa, int tiles_per_block) {
   __shared__ PipeSharedRing<T> sh;
-  (void)pipe_pass<T, CH, PS, false, false, false, false, false, true, PipeSharedRing<T>>(pa, tiles_per_block, sh);
+  (void)pipe_pass<T, CH, PS, false, false, false, AUG, false, true, PipeSharedRing<T>>(pa, tiles_per_block, sh);
 }
 
 template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false>
@@ -1603,16 +1603,16 @@ int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_a
   }
 }
 // patch form (SELL slots with tile-local columns + ring lists): same register budgets per window as the SELL halo form
-template <class T, int CH, int WAVES, int PS>
+template <class T, int CH, int WAVES, int PS, bool AUG = false>
 static int pipe_ring_launch(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
   const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
-  const int maxb = live ? resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, false, false, false, false, true>)
-                        : resident_blocks((const void *)k_pipe_ring<T, CH, WAVES, PS>);
+  const int maxb = live ? resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, false, false, AUG, false, true>)
+                        : resident_blocks((const void *)k_pipe_ring<T, CH, WAVES, PS, AUG>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if (live) hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, false, false, false, false, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
-  else hipLaunchKernelGGL((k_pipe_ring<T, CH, WAVES, PS>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  if (live) hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, false, false, AUG, false, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  else hipLaunchKernelGGL((k_pipe_ring<T, CH, WAVES, PS, AUG>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 template <class T>
@@ -1624,7 +1624,13 @@ static int pipe_step_ring_T(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
     default: return pipe_ring_launch<T, 32, 2, 5>(s, pa, live);
   }
 }
-int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live) { return pipe_step_ring_T<double>(s, pa, live); }
+int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live) {
+  if (pa.aug_p > 0) {      // augmented operator (kiops): windows <= 7, like the banded form
+    if (pa.und <= 3) return pipe_ring_launch<double, 4, 4, 6, true>(s, pa, live);
+    return pipe_ring_launch<double, 8, 4, 5, true>(s, pa, live);
+  }
+  return pipe_step_ring_T<double>(s, pa, live);
+}
 int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live) { return pipe_step_ring_T<float>(s, pa, live); }
 
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched

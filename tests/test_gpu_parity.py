@@ -1142,6 +1142,10 @@ def test_patch_form_drivers(eu):
     wko, sko = ko.kiops(1.0, A, B, ishermitian=False)
     assert tuple(sk) == tuple(sko), (sk, sko)
     close(wk, wko, 1e-10, "patch form: kiops with three columns vs oracle")
+    wk1, sk1 = eu.kiops(0.8, op, b, ishermitian=False)            # p = 1: the augmented operator on the patch form of the step
+    wko1, sko1 = ko.kiops(0.8, A, b, ishermitian=False)
+    assert tuple(sk1) == tuple(sko1), (sk1, sko1)
+    close(wk1, wko1, 1e-10, "patch form: kiops with a vector vs oracle")
 
 
 @pytest.mark.gpu
