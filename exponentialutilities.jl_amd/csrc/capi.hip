@@ -1577,9 +1577,16 @@ int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     DevBuf tmp;
-    const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
+    const void *bd;
+    if (op->perm && op->n == ks->n && o.init == 0) {      // b stays in the caller's ordering: the engine gathers it in its first step
+      bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
+      ks->b_natural = true;
+    } else {
+      bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
+    }
     ks_bind_row_order(*ks, *op, o.init);
     arnoldi_run(*ks, *op, bd, o, nullptr, false);
+    ks->b_natural = false;
   });
 }
 int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, const expv_mi_arnoldi_opts *opts) {
@@ -1661,9 +1668,16 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     expv_mi_ks_s &ks = *kp;
     ks.skip_tail = true;
     DevBuf tmp;
-    const void *bd = vector_in(ctx, *op, b, b_loc, op->n, dtype_size(op->dtype), tmp);
+    const void *bd;
+    if (op->perm) {      // b stays in the caller's ordering: the engine gathers it in its first step
+      bd = stage_in(ctx, b, b_loc, (size_t)op->n * dtype_size(op->dtype), tmp);
+      ks.b_natural = true;
+    } else {
+      bd = vector_in(ctx, *op, b, b_loc, op->n, dtype_size(op->dtype), tmp);
+    }
     ks.vperm = op->perm;      // (expv_eval puts the rows of w back in their natural places)
     const int mv = arnoldi_run(ks, *op, bd, o, nullptr, false);
+    ks.b_natural = false;
     expv_eval(ks, t_re, t_im, w, w_loc, w_dtype);
     if (stats) {
       stats->m_used = ks.m;

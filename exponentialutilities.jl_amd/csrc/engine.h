@@ -371,6 +371,9 @@ struct Ks {
   // entry points (capi.hip: ks_bind_row_order); the evaluation entry points un-permute their results, the raw accessors of V
   // convert the basis back in place first.
   std::shared_ptr<RowPerm> vperm;
+  bool b_natural = false;            // the starting vector of the next fresh factorisation is a DEVICE vector in the caller's ordering: the
+                                     // engine gathers it inside the first step (single-pass forms) or permutes it itself (capi.hip)
+  DevBuf b_stored;                   // ... the permuted copy in the second case
   int64_t rows() const { return n + augmented; }
 };
 void ks_finish_tail(Ks &ks);   // engine_core.hip

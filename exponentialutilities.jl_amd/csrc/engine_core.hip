@@ -412,6 +412,7 @@ int *Options::find(const char *name) {
 }
 
 static const int g_patch_xcd = std::getenv("EXPV_MI_PATCH_NO_XCD") ? 0 : 1;      // developer A/B of the patch form's tile mapping
+static const bool g_perm_fused = std::getenv("EXPV_MI_NO_PERM_FUSION") == nullptr;      // developer A/B: permutations of b / w inside the first step / the combine
 // host-side phase timing is a developer diagnostic (process-wide, printed when a context is destroyed), not library behaviour
 static const bool g_ht_on = std::getenv("EXPV_MI_HOST_TIMING") != nullptr;
 static double g_ht_sum[16];
@@ -465,6 +466,8 @@ struct ArnoldiCall {
   bool cont_reset_done = false; // reset_device_state() did the whole reset of a continued single-pass factorisation in one launch
   bool tail_deferred = false;   // read_back() returned at the early mailbox flag (Ks::defer_tail_req)   // first_step() zeroed this call's columns of Hdev together with the step state
   bool use_fused = false, single_red = false, use_pipe = false, use_wave = false, use_ring = false, mbox_generic = false;
+  const int32_t *b_map = nullptr;     // the first step gathers b through this (b in the caller's ordering, basis in the operator's)
+  bool b_nat = false;                 // ... b arrived that way (a redo of the call has to be told again)
 
   ArnoldiCall(Ks &ks_, Op &op_, const T *b_, const expv_mi_arnoldi_opts &o_, const ArnoldiAug *aug_, bool lanczos_)
       : ks(ks_), op(op_), b(b_), o(o_), aug(aug_), lanczos(lanczos_), c(ks_.ctx), s(ks_.ctx->stream), isaug(aug_ != nullptr),
@@ -489,6 +492,18 @@ struct ArnoldiCall {
     hview_cols = m + (isaug ? 1 : 0);
 
     choose_step_form();
+    if (ks.b_natural) {
+      ks.b_natural = false;
+      b_nat = true;
+      if (fresh && ks.vperm) {
+        if (use_pipe && !isaug && !c->opt.resident && g_perm_fused) b_map = ks.vperm->p.as<int32_t>();
+        else {
+          int64_t ld = ks.n;
+          b = reinterpret_cast<const T *>(permute_in(c, *ks.vperm, b, EXPV_MI_DEVICE, 1, ks.n, sizeof(T), ks.b_stored, &ld));
+          b_nat = false;      // (from here on `b` is in the stored ordering: a redo takes it as it is)
+        }
+      }
+    }
     if (fresh) first_step();
     if (ks.beta == 0.0) return 0;
     iop = o.iop;
@@ -807,6 +822,7 @@ struct ArnoldiCall {
       pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
       pa.ybuf = (j & 1) ? ya : yb2;
       pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
+      pa.u0_map = (j == 1 && fresh && !isaug) ? b_map : nullptr;
       if (isaug) {
         pa.aug_p = p; pa.n_op = ks.n; pa.B = reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;
         if (j == 1 && fresh)
@@ -1123,6 +1139,7 @@ struct ArnoldiCall {
       ks.wave_off = true;
       ks.wave_off_calls = 0;
       ++c->cnt_wave_redo;
+      ks.b_natural = b_nat;
       const int r = arnoldi_T<T>(ks, op, b, o, aug, lanczos);
       c->last_path |= EXPV_MI_PATH_REDO_WAVE_OFF;
       return r;
@@ -1130,6 +1147,7 @@ struct ArnoldiCall {
     if (!ks.pipe_live_used || ks.pipe_serial) fail(EXPV_MI_HIP_ERROR, "pipelined factorisation: bounded wait expired");
     ks.pipe_serial = true;
     ++c->cnt_serial_redo;
+    ks.b_natural = b_nat;
     const int r = arnoldi_T<T>(ks, op, b, o, aug, lanczos);
     c->last_path |= EXPV_MI_PATH_REDO_SERIAL;
     return r;
@@ -1256,7 +1274,7 @@ template <> inline cplx32 coef_as<cplx32>(const std::vector<double> &b, size_t k
 
 template <class TV, class TC>
 static void combine_launch(Ks &ks, Ctx *c, int mcols, int ncols, const std::vector<double> &cbuf, bool cplx_buf, double scale, void *Wd,
-                           int64_t ldwd, int64_t rows, bool by_value, const LcSpec *lc) {
+                           int64_t ldwd, int64_t rows, bool by_value, const LcSpec *lc, const int32_t *rowmap = nullptr) {
   const int mc = std::max(mcols, 0);
   const TV *V = ks.V.as<TV>();
   if (by_value) {
@@ -1271,7 +1289,7 @@ static void combine_launch(Ks &ks, Ctx *c, int mcols, int ncols, const std::vect
         dev::combine1_lc<TV, TC>(c->stream, rows, V, ks.ldv, mc, cv, scale, lt, (TC *)Wd);
       }
     } else {
-      dev::combine1<TV, TC>(c->stream, rows, V, ks.ldv, mc, cv, scale, (TC *)Wd);
+      dev::combine1<TV, TC>(c->stream, rows, V, ks.ldv, mc, cv, scale, (TC *)Wd, rowmap);
     }
     return;
   }
@@ -1338,7 +1356,11 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
   // a basis in the ordering of a reordered operator: the combination is formed in that ordering and its rows go to their natural
   // places on the way out (a linear-combination tail belongs to a driver that works in the stored ordering throughout)
   const bool unperm = ks.vperm != nullptr && !lc;
-  if (w_loc == EXPV_MI_HOST || unperm) {
+  // one output column with the coefficients in the kernel arguments (expv!): the combine kernel stores row i of the stored ordering
+  // straight to its natural place -- no second pass over w
+  const bool fuse_out = unperm && by_value && ncols == 1 && rows == ks.vperm->n && g_perm_fused;
+  const int32_t *rowmap = fuse_out ? ks.vperm->p.as<int32_t>() : nullptr;
+  if (w_loc == EXPV_MI_HOST || (unperm && !fuse_out)) {
     wtmp.take_from(c, (size_t)rows * ncols * wsz + 16);
     Wd = wtmp.p;
     ldwd = rows;
@@ -1348,16 +1370,16 @@ void combine_host_coef(Ks &ks, int mcols, int ncols, const void *coef_host, int 
     ProfScope ps(c, EXPV_MI_K_COMBINE);
     const bool w32 = dtype_is_32bit(w_dtype);
     if (!w32) {
-      if (!Cc) combine_launch<double, double>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
-      else if (!Tc) combine_launch<double, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
-      else combine_launch<cplx, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      if (!Cc) combine_launch<double, double>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
+      else if (!Tc) combine_launch<double, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
+      else combine_launch<cplx, cplx>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
     } else {
-      if (!Cc) combine_launch<float, float>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
-      else if (!Tc) combine_launch<float, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
-      else combine_launch<cplx32, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc);
+      if (!Cc) combine_launch<float, float>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
+      else if (!Tc) combine_launch<float, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
+      else combine_launch<cplx32, cplx32>(ks, c, mcols, ncols, cbuf, Cc, scale, Wd, ldwd, rows, by_value, lc, rowmap);
     }
   }
-  if (unperm) permute_out(c, *ks.vperm, Wd, ldwd, W, w_loc, ldw, ncols, wsz);
+  if (unperm && !fuse_out) permute_out(c, *ks.vperm, Wd, ldwd, W, w_loc, ldw, ncols, wsz);
   else if (w_loc == EXPV_MI_HOST) copy_out_2d(c, W, EXPV_MI_HOST, ldw, Wd, ldwd, rows, ncols, wsz);
   else if (!c->async_out) HIPCHECK(hipStreamSynchronize(c->stream));
 }

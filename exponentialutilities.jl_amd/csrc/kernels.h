@@ -288,6 +288,7 @@ struct PipeArgsT {
   T u0_tail[PIPE_AUG_MAX];     // step 1 of an augmented factorisation: rows n_op.. of u_1 (by value: no staging copy)
   // patch form (pipe.hip: RING): A.col holds positions in LDS (tile row, or PIPE tile rows + ring position); ring_rows[tile *
   // ring_pad + p] = the row behind ring position p of the tile (-1: none)
+  const int32_t *u0_map;       // step 1: u_1[i] = u0[u0_map[i]] (the starting vector in the caller's ordering, the basis in a stored one); null: u0[i]
   const int32_t *ring_rows, *ring_cnt;      // ring_cnt[tile]: rows in the tile's ring
   const int64_t *ring_soff;                 // per SELL slice: where its column block starts in A.col (identical blocks are shared)
   int ring_pad;                // entries per tile in ring_rows: 64, 128 or 256
@@ -351,7 +352,8 @@ template <class TC> struct CoefMat { TC c[COEF_MAT_MAX]; };
 template <class TV, class TC>
 void combine_v(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefMat<TC> &cm, int ncols, double scale, TC *W, int64_t ldw);
 template <class TV, class TC>
-void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W);
+void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W,
+              const int32_t *rowmap = nullptr);      // rowmap: row i of the result goes to W[rowmap[i]] (a basis kept in a stored row ordering)
 // the same with a tail of linear-combination terms:  W = ((scale * V c) * pscale) + sum_l coef[l] in[l]   (l < nterms <= 6)
 // -- Part 3 of phiv_timestep! (krylov_phiv_adaptive.jl:425-431: u = tau^p P[:, end-1] + sum_j c_j W[:, j]) in the pass that
 // forms the one column of P it reads, instead of a n x (p+2) product followed by a second pass

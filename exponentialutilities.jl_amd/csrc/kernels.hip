@@ -871,7 +871,8 @@ __device__ __forceinline__ void combine_body(int64_t n, const TV *__restrict__ V
 // between the host Pade and the launch (expv!: w = beta * V[:, 1:m] * expHe, krylov_phiv.jl:229,242)
 template <class TV, class TC>
 __global__ __launch_bounds__(BLOCK) void k_combine1(int64_t n, const TV *__restrict__ V, int64_t ldv, int m,
-                                                    CoefVec<TC> cv, double scale, TC *__restrict__ W, int64_t rpb) {
+                                                    CoefVec<TC> cv, double scale, TC *__restrict__ W, int64_t rpb,
+                                                    const int32_t *__restrict__ rowmap) {
   constexpr int N = Pack<TV>::N;
   const bool al = ((ldv * sizeof(TV)) % 16 == 0) && is_al16(V);
   const int64_t r0 = (int64_t)blockIdx.x * rpb, r1 = (r0 + rpb < n) ? r0 + rpb : n;
@@ -896,14 +897,14 @@ __global__ __launch_bounds__(BLOCK) void k_combine1(int64_t n, const TV *__restr
     }
 #pragma unroll
     for (int k = 0; k < N; ++k)
-      if (i + k < n) W[i + k] = ST<TC>::mul_real(acc[k], scale);
+      if (i + k < n) W[rowmap ? (int64_t)rowmap[i + k] : i + k] = ST<TC>::mul_real(acc[k], scale);
   }
 }
 template <class TV, class TC>
-void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W) {
+void combine1(hipStream_t s, int64_t n, const TV *V, int64_t ldv, int m, const CoefVec<TC> &cv, double scale, TC *W, const int32_t *rowmap) {
   const RowPlan p = plan_rows(n, 64 * Pack<TV>::N, resident_blocks((const void *)k_combine1<TV, TC>));
   hipLaunchKernelGGL((k_combine1<TV, TC>), dim3(p.nblocks), dim3(BLOCK), 0, s, n, V, ldv, m, cv, scale, W,
-                     p.rows_per_block);
+                     p.rows_per_block, rowmap);
 }
 
 template <class TV, class TC>
@@ -1045,9 +1046,9 @@ template void combine1_lc<float, float>(hipStream_t, int64_t, const float *, int
                                         const LcTerms<float> &, float *);
 template void combine1_lc<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double,
                                           const LcTerms<cplx32> &, cplx32 *);
-template void combine1<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<float> &, double, float *);
-template void combine1<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
-template void combine1<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *);
+template void combine1<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<float> &, double, float *, const int32_t *);
+template void combine1<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *, const int32_t *);
+template void combine1<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefVec<cplx32> &, double, cplx32 *, const int32_t *);
 template void combine_v<float, float>(hipStream_t, int64_t, const float *, int64_t, int, const CoefMat<float> &, int, double, float *, int64_t);
 template void combine_v<float, cplx32>(hipStream_t, int64_t, const float *, int64_t, int, const CoefMat<cplx32> &, int, double, cplx32 *, int64_t);
 template void combine_v<cplx32, cplx32>(hipStream_t, int64_t, const cplx32 *, int64_t, int, const CoefMat<cplx32> &, int, double, cplx32 *, int64_t);
@@ -1062,11 +1063,11 @@ template void combine1_lc<double, double>(hipStream_t, int64_t, const double *, 
 template void combine1_lc<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefVec<cplx> &, double,
                                       const LcTerms<cplx> &, cplx *);
 template void combine1<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<double> &,
-                                       double, double *);
+                                       double, double *, const int32_t *);
 template void combine1<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const CoefVec<cplx> &, double,
-                                     cplx *);
+                                     cplx *, const int32_t *);
 template void combine1<cplx, cplx>(hipStream_t, int64_t, const cplx *, int64_t, int, const CoefVec<cplx> &, double,
-                                   cplx *);
+                                   cplx *, const int32_t *);
 template void combine<double, double>(hipStream_t, int64_t, const double *, int64_t, int, const double *, int, int,
                                       double, double *, int64_t);
 template void combine<double, cplx>(hipStream_t, int64_t, const double *, int64_t, int, const cplx *, int, int, double,

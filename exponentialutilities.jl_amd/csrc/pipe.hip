@@ -540,7 +540,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
             if (g == 0) acc = ST<T>::mul_real(r_y, inv);
             for (int k = g; k < und; k += G) ST<T>::nfma(acc, hs[k], (k == knew) ? r_new : us[RAW0 + k * RSTAGE + p]);
           } else {
-            if (g == 0) acc = first ? u0[rr] : ST<T>::mul_real(yprev[rr], inv);
+            if (g == 0) acc = first ? u0[pa.u0_map ? (int64_t)pa.u0_map[rr] : rr] : ST<T>::mul_real(yprev[rr], inv);
             if (!first) {
               const T *vp = a.V + (int64_t)pa.uc0 * a.ldv + rr;
               constexpr int UN = 8;
@@ -578,7 +578,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       int64_t hr;
       T val = ST<T>::zero();
       if (halo_elem(e, k, hr)) {        // (operator rows only read operator columns: rows of the augmentation never matter here)
-        if (k == 31) val = first ? u0[hr] : ST<T>::mul_real((have_hpre && it == 0) ? hpre : yprev[hr], inv);
+        if (k == 31) val = first ? u0[pa.u0_map ? (int64_t)pa.u0_map[hr] : hr] : ST<T>::mul_real((have_hpre && it == 0) ? hpre : yprev[hr], inv);
         else if (!first && k < und) {
           const T hv = (have_hpre && it == 0) ? hpre : a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
           if constexpr (ST<T>::is_complex) ST<T>::nfma(val, hs[k], hv);
@@ -601,13 +601,17 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const int64_t r = i + e;
-          if (r < n_op) u.v[e] = u0[r];
+          if (r < n_op) u.v[e] = u0[pa.u0_map ? (int64_t)pa.u0_map[r] : r];
           else if (r < a.n) {
 #pragma unroll
             for (int q = 0; q < PIPE_AUG_MAX; ++q)
               if (r - n_op == q) u.v[e] = pa.u0_tail[q];
           }
         }
+      } else if (pa.u0_map) {
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+          if (i + e < a.n) u.v[e] = u0[pa.u0_map[i + e]];
       } else {
         u = ld_pack_user(u0, i, a.n, is_al16(u0));
       }
