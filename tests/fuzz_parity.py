@@ -19,7 +19,7 @@ eu = expv_mi_loader.load()
 
 
 def make_operator(rng, n, cplx):
-    kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense"])
+    kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense", "grid2d"])
     def vals(shape, scale):
         v = rng.standard_normal(shape) * scale
         return v + 1j * rng.standard_normal(shape) * scale if cplx else v
@@ -33,6 +33,27 @@ def make_operator(rng, n, cplx):
         if kind == "symmetric_banded":
             A = ((A + A.conj().T) * 0.5).tocsr()
         A = A - 0.5 * sp.identity(n, format="csr")
+    elif kind == "grid2d":
+        # 5- / 9-point stencil on a 2-D grid (rows of k >= 64 cells, >= 8 grid rows, the last one possibly incomplete), with or without
+        # entries across the row ends: the real element types are stored in the grid-patch ordering (patch form of the step)
+        k = int(rng.integers(64, 200))
+        n = k * int(rng.integers(8, 70)) + (int(rng.integers(0, k)) if rng.random() < 0.4 else 0)
+        offs = [-k, -1, 0, 1, k] if rng.random() < 0.7 else [-k - 1, -k, -k + 1, -1, 0, 1, k - 1, k, k + 1]
+        if rng.random() < 0.3:
+            offs = [o for o in offs if o != offs[0]] or offs          # one-sided coupling
+        i = np.arange(n)
+        wrap = rng.random() < 0.5
+        parts = []
+        for o in offs:
+            ok = (i + o >= 0) & (i + o < n)
+            if not wrap and abs(o) <= 2:
+                ok &= ((i + o) // k) == (i // k)
+            v = vals(n, 0.3 / np.sqrt(len(offs)))
+            parts.append(sp.csr_matrix((v[ok], (i[ok], i[ok] + o)), shape=(n, n)))
+        A = (sum(parts) - 0.5 * sp.identity(n, format="csr")).tocsr()
+        if rng.random() < 0.3:
+            A = ((A + A.conj().T) * 0.5).tocsr()
+            kind = "grid2d_symmetric"
     elif kind == "wide_diagonals":
         nd = int(rng.integers(2, 7))
         offs = sorted(set([0] + [int(o) for o in rng.integers(-(n - 1), n, size=nd)]))
@@ -112,7 +133,7 @@ def one_case(seed, index, verbose=False):
     tq = float(rng.choice([0.7, 0.7, 0.7, -0.4, 1e-8, 0.0, 3.0]))      # the time of the plain calls
     m = int(rng.integers(1, 41))
     iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
-    herm = kind in ("symmetric_banded", "hermitian_dense") and bool(rng.integers(0, 2))
+    herm = kind in ("symmetric_banded", "hermitian_dense", "grid2d_symmetric") and bool(rng.integers(0, 2))
     call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate",
                        "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct", "async_device", "caches"])
     ortho = str(rng.choice(["lowsync", "mgs"]))
