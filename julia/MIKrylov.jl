@@ -242,6 +242,13 @@ function reorder_info(op::MIOperator)
     check(ccall((:expv_mi_op_reorder_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), op.h, out), ctx().h)
     (reordered = out[1] != 0, bandwidth_before = out[2], bandwidth_after = out[3], setup_s = 1.0e-6 * out[4])
 end
+# 2-D grid stencils (context option "patch", default on): stored in a grid-patch ordering -- a special case of the reordering above,
+# equally invisible to the caller.  patch_form, the row length of the recognised grid, tiles, longest / mean ring of a tile.
+function patch_info(op::MIOperator)
+    out = zeros(Int64, 8)
+    check(ccall((:expv_mi_op_patch_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), op.h, out), ctx().h)
+    (patch_form = out[1] != 0, grid_row_length = out[2], tiles = out[3], longest_ring = out[4], mean_ring = out[3] > 0 ? out[5] / out[3] : 0.0)
+end
 MIOperator(A::SparseMatrixCSC{T}) where {T <: MIScalar} = MIOperator(SparseMatrixCSC{T, Int64}(A))      # (other index types: converted once)
 function MIOperator(A::Matrix{T}) where {T <: MIScalar}
     r = Ref{Ptr{Cvoid}}(C_NULL)
