@@ -92,6 +92,7 @@ PROTOTYPES = {
     "expv_mi_op_reorder_info": (_i, [_vp, _vp]),
     "expv_mi_op_patch_info": (_i, [_vp, _vp]),
     "expv_mi_host_patch_order": (_i, [C.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
+    "expv_mi_host_mesh_patch_order": (_i, [C.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
     "expv_mi_op_apply": (_i, [_vp, _vp, _i, _vp, _i]),
     "expv_mi_gemv_block": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i]),
     "expv_mi_ks_create": (_i, [_vp, _i, _i, _i64, _i, _i, _pvp]),

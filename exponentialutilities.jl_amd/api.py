@@ -1143,7 +1143,7 @@ def host_rcm(A, dtype=np.float64):
                   "form_after": names[int(out[3])], "would_reorder": bool(int(out[2]) & 256)}
 
 
-def host_patch_order(A, dtype=np.float64):
+def host_patch_order(A, dtype=np.float64, mesh=False):
     """The grid-patch ordering operator creation would store a 2-D grid stencil in under context option ``patch`` (host only, no
     reference counterpart): (perm, ring_count per tile, info) -- perm is None when no 2-D grid is recognised in the pattern."""
     import scipy.sparse as sp
@@ -1155,8 +1155,8 @@ def host_patch_order(A, dtype=np.float64):
     tr = (16 // np.dtype(dtype).itemsize) * 256
     cnt = np.zeros((n + tr - 1) // tr, dtype=np.int32)
     out = np.zeros(8, dtype=np.int64)
-    _check(L.load().expv_mi_host_patch_order(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), perm.ctypes.data, cnt.ctypes.data,
-                                             out.ctypes.data))
+    f = L.load().expv_mi_host_mesh_patch_order if mesh else L.load().expv_mi_host_patch_order      # mesh: patches of a mesh in any numbering
+    _check(f(n, rp.ctypes.data, ci.ctypes.data, _code(np.dtype(dtype)), perm.ctypes.data, cnt.ctypes.data, out.ctypes.data))
     info = {"patch_form": bool(out[0]), "grid_row_length": int(out[1]), "tiles": int(out[2]), "longest_ring": int(out[3]),
             "mean_ring": (float(out[4]) / int(out[2])) if out[2] else 0.0, "tiles_ring_over_128": int(out[5]),
             "column_indices_stored": int(out[6]), "ring_entries_per_tile": int(out[7])}

@@ -626,6 +626,8 @@ template <class V>
 static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &perm, const std::vector<int32_t> &src, std::vector<int32_t> &rp,
                               std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> &rp2, std::vector<int32_t> &ci2, int64_t bw0, int64_t bw1,
                               std::chrono::steady_clock::time_point t0);
+template <class V>
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0);
 // Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
 // On return rp / ci / va hold P A P' and op.perm the ordering; op.csc_pos maps the caller's entries to the reordered CSR arrays.
 template <class V>
@@ -640,6 +642,9 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // change row lengths)
   const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
   if (mode == 1 && !candidate) return;
+  // a mesh in an arbitrary numbering: patches of the graph (the patch form of the single-pass step) before a bandwidth ordering
+  if (mode == 1 && !P0.overflow && std::is_floating_point<V>::value &&
+      try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth)) return;
   // (a level wider than the reach the wave form can use cannot lead anywhere: give up after the first breadth-first searches)
   const int64_t trw = (int64_t)(16 / sizeof(V)) * dev::BLOCK;
   const int64_t useful = std::max<int64_t>(98 * trw, (n + trw - 1) / trw <= 400 ? n : 0);
@@ -770,6 +775,7 @@ struct PatchPlan {
   int RP = 0, maxring = 0;
   int64_t ring_sum = 0, over128 = 0;
 };
+static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl);
 static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, PatchPlan &pl) {
   if (n < 2 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;      // the real element types (pipe.hip: SELL slots)
   const PatternPlan P0 = analyze_pattern(n, rp, ci, nnz, value_bytes);
@@ -777,6 +783,26 @@ static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t 
   const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;      // rows of a tile: 512 (fp64), 1024 (Float32)
   const int64_t R = value_bytes == 8 ? 16 : 32;
   pl.perm = patch_order(n, pl.k, R, TR);
+  return plan_patch_from_perm(n, rp, ci, nnz, value_bytes, P0.bandwidth, pl);
+}
+// The same for a mesh in any numbering (reorder.h: mesh_patches): patches from two breadth-first distance fields.  Kept when every
+// tile's ring fits and the rings are short on average -- otherwise the caller goes on to reverse Cuthill-McKee.
+static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl) {
+  if (n < 8192 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;
+  const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
+  const int64_t width = (int64_t)(8.0 * std::sqrt((double)n)) + 1024;      // a level of a planar-like mesh is O(sqrt n) wide
+  pl.perm = reorder::mesh_patches(n, rp, ci, TR, value_bytes == 8 ? 16 : 24, width);
+  if (pl.perm.empty()) return false;
+  pl.k = 0;
+  const bool fits = plan_patch_from_perm(n, rp, ci, nnz, value_bytes, bw0, pl);
+  if (std::getenv("EXPV_MI_OP_TIMING"))
+    std::fprintf(stderr, "[op build] mesh patches: %lld tiles, longest ring %d, mean %.1f, fits %d\n", (long long)pl.nt, pl.maxring,
+                 pl.nt ? (double)pl.ring_sum / (double)pl.nt : 0.0, (int)fits);
+  if (!fits) return false;
+  return pl.ring_sum <= 176 * pl.nt * (value_bytes == 8 ? 1 : 2) / 1;      // mean ring: <= 176 rows (fp64 tiles of 512), 352 ... capped by the 256 limit per tile
+}
+static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl) {
+  const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
   if ((int64_t)pl.perm.size() != n) return false;
   reorder::permute_csr(n, rp, ci, pl.perm, pl.rp2, pl.ci2, pl.src);
   const std::vector<int32_t> &rp2 = pl.rp2, &ci2 = pl.ci2;
@@ -795,7 +821,10 @@ static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t 
     g.erase(std::unique(g.begin(), g.end()), g.end());
     pl.maxring = std::max(pl.maxring, (int)g.size());
   }
-  if (pl.maxring > dev::BLOCK) return false;
+  if (pl.maxring > dev::BLOCK) {
+    for (int64_t t = 0; t < nt; ++t) { pl.ring_sum += (int64_t)ring[(size_t)t].size(); pl.over128 += ring[(size_t)t].size() > 128 ? 1 : 0; }
+    return false;
+  }
   const int RP = pl.maxring <= 64 ? 64 : pl.maxring <= 128 ? 128 : 256;
   pl.RP = RP;
   pl.rows.assign((size_t)nt * RP, -1);
@@ -827,7 +856,7 @@ static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t 
   }
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), nnz, value_bytes);
   if (P1.overflow) return false;
-  pl.bw0 = P0.bandwidth;
+  pl.bw0 = bw0;
   pl.bw1 = P1.bandwidth;
   // the column blocks of the slices of equal patches are equal (positions in the tile's LDS image, not rows of the matrix): keep
   // one copy of each -- the step then reads its column indices from a few kB that stay in L2 instead of 4 bytes per entry from HBM
@@ -856,11 +885,13 @@ static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t 
 // returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
 // per-tile rings and the tile-local column array)
 template <class V>
-static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0) {
   if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
+  if (!std::is_floating_point<V>::value) return false;      // the real element types (pipe.hip: the patch form runs on SELL slots)
   const auto t0 = std::chrono::steady_clock::now();
   PatchPlan pl;
-  if (!plan_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), pl)) return false;
+  if (mesh ? !plan_mesh_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), bw0, pl)
+           : !plan_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), pl)) return false;
   op.ring_col_unique = (int64_t)pl.lcol.size();
   pl.lcol.resize(pl.lcol.size() + 4, 0);
   op.ring_soff.alloc(sizeof(int64_t) * pl.soff.size());
@@ -900,7 +931,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("ishermitian + opnorm");
   maybe_reorder<V>(op, n, rp, ci, va);
   lap("reordering (RCM)");
-  (void)try_patch_order<V>(op, n, rp, ci, va);
+  (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
   lap("grid-patch ordering");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
@@ -1877,18 +1908,26 @@ int expv_mi_host_rcm(int64_t n, const int32_t *rowptr, const int32_t *colind, in
     }
   });
 }
-int expv_mi_host_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count, int64_t out[8]) {
+static int host_patch_order_impl(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count, int64_t out[8], bool mesh) {
   return guarded(nullptr, [&] {
     if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && !colind) || !out) fail(EXPV_MI_ARGUMENT_ERROR, "host_patch_order: bad arguments");
     check_device_dtype(dtype, "host_patch_order");
     for (int q = 0; q < 8; ++q) out[q] = 0;
     PatchPlan pl;
-    if (!plan_patch(n, rowptr, colind, n > 0 ? (int64_t)rowptr[n] : 0, (int)dtype_size(dtype), pl)) return;
+    const int64_t nnz = n > 0 ? (int64_t)rowptr[n] : 0;
+    if (dtype_is_complex(dtype)) return;
+    if (mesh ? !plan_mesh_patch(n, rowptr, colind, nnz, (int)dtype_size(dtype), 0, pl) : !plan_patch(n, rowptr, colind, nnz, (int)dtype_size(dtype), pl)) return;
     if (perm) std::copy(pl.perm.begin(), pl.perm.end(), perm);
     if (ring_count) std::copy(pl.cnt.begin(), pl.cnt.end(), ring_count);
     out[0] = 1; out[1] = pl.k; out[2] = pl.nt; out[3] = pl.maxring; out[4] = pl.ring_sum; out[5] = pl.over128;
     out[6] = (int64_t)pl.lcol.size(); out[7] = pl.RP;
   });
+}
+int expv_mi_host_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count, int64_t out[8]) {
+  return host_patch_order_impl(n, rowptr, colind, dtype, perm, ring_count, out, false);
+}
+int expv_mi_host_mesh_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count, int64_t out[8]) {
+  return host_patch_order_impl(n, rowptr, colind, dtype, perm, ring_count, out, true);
 }
 int expv_mi_host_expm(int dtype, int n, void *A, int lda) {
   return guarded(nullptr, [&] {

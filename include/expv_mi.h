@@ -199,6 +199,11 @@ int expv_mi_op_patch_info(expv_mi_op_t op, int64_t out[8]);
  * tile of 4096 / sizeof(element) rows, may be null); out as in expv_mi_op_patch_info (all zero when no 2-D grid is recognised). */
 int expv_mi_host_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count,
                              int64_t out[8]);
+/* The same for a mesh in ANY numbering (what creation tries, under option patch, before reverse Cuthill-McKee for an operator without a
+ * single-pass form in its natural ordering): patches cut from two breadth-first distance fields of the graph of A + A'; kept when
+ * every tile's ring fits (<= 256 rows) and the rings average <= 176 rows (Float32: 352).  out[1] = 0 (no grid row length). */
+int expv_mi_host_mesh_patch_order(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int32_t *ring_count,
+                                  int64_t out[8]);
 /* mul!(y, A, x)  (arnoldi.jl:185) */
 int expv_mi_op_apply(expv_mi_op_t op, const void *x, int x_loc, void *y, int y_loc);
 
