@@ -160,14 +160,14 @@ inline void permute_csr(int64_t n, const int32_t *rp, const int32_t *ci, const s
 
 // ---- patches of a planar-like mesh (round 4) --------------------------------------------------------------------------------------
 // The single-pass step's patch form (pipe.hip) wants an ordering in which every tile of TR consecutive rows is a compact blob of the
-// graph: few rows outside the tile are read by it (its ring).  For a mesh in ANY numbering (a shuffled 2-D grid, a triangulation)
-// two breadth-first distance fields give usable coordinates: a = distance from a pseudo-peripheral node s, b = distance from a node
-// t chosen "at right angles" (among the nodes about as far from s as from its antipode e, the one farthest from an arbitrary member of
-// that set -- on a k x k grid: s, e opposite corners, t a third corner).  Nodes are sorted by (band of H levels of a, b, a), bands
-// alternately ascending and descending in b, and cut into tiles of TR; inside a tile the nodes with neighbours in other tiles come
-// first, grouped by that tile, so each piece of a neighbour's ring is a contiguous run.  Returns an EMPTY vector when the graph is
-// not connected or a level of either field is wider than give_up_width (not mesh-like: nothing to gain).  Whether the result is good
-// enough is decided by the caller from the rings it actually produces.
+// graph: few rows outside the tile are read by it (its ring).  For a mesh in ANY numbering (a 2-D grid or a triangulation numbered at
+// random) breadth-first distances give usable coordinates: a = distance from a pseudo-peripheral node s cuts the graph into BANDS of H
+// consecutive levels; every connected piece of a band is a strip, and the distance from one END of the strip, measured inside it,
+// orders the strip lengthwise.  Nodes are taken band by band, strip by strip, by (length coordinate, a), and cut into tiles of TR: a
+// tile is H levels by ~TR / H' nodes of a strip.  Inside a tile the nodes with neighbours in other tiles come first, grouped by that
+// tile, so each piece of a neighbour's ring is a contiguous run.  Connected components one after the other.  Returns an EMPTY vector
+// when a level is wider than give_up_width (not mesh-like: nothing to gain).  Whether the result is good enough is decided by the caller from the
+// rings it actually produces (a band that closes on itself -- a cylinder -- folds its length coordinate and fails that test).
 inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int32_t *ci, int64_t TR, int H, int64_t give_up_width) {
   std::vector<int32_t> none;
   if (n <= 0) return none;
@@ -197,18 +197,22 @@ inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int
     std::sort(b, e);
     deg[i] = (int32_t)(std::unique(b, e) - b);
   }
-  std::vector<int32_t> queue((size_t)n);
-  // distances from `root`; returns false when some node is not reached or a level is too wide; *far = a last-level node of least degree
-  auto bfs = [&](int32_t root, std::vector<int32_t> &dist, int32_t *far) {
-    dist.assign((size_t)n, -1);
+  std::vector<int32_t> queue((size_t)n), stamp((size_t)n, 0), dist_a((size_t)n, 0), dist_b((size_t)n, 0);
+  int32_t cur = 0;
+  // distances from `root` inside its connected component (valid where stamp == the returned stamp); *count = nodes reached, *far = a
+  // last-level node of least degree; false when a level is too wide
+  auto bfs = [&](int32_t root, std::vector<int32_t> &dist, int32_t *far, int64_t *count) {
+    ++cur;
     int64_t head = 0, tail = 0, level_begin = 0, level_end = 1;
     queue[(size_t)tail++] = root;
+    stamp[(size_t)root] = cur;
     dist[(size_t)root] = 0;
     while (head < tail) {
       const int32_t u = queue[(size_t)head++];
       for (int32_t k = 0; k < deg[u]; ++k) {
         const int32_t v = adj[(size_t)ap[u] + k];
-        if (dist[(size_t)v] >= 0) continue;
+        if (stamp[(size_t)v] == cur) continue;
+        stamp[(size_t)v] = cur;
         dist[(size_t)v] = dist[(size_t)u] + 1;
         queue[(size_t)tail++] = v;
       }
@@ -218,48 +222,76 @@ inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int
         if (give_up_width > 0 && level_end - level_begin > give_up_width) return false;
       }
     }
-    if (tail != n) return false;
     int32_t best = queue[(size_t)level_begin];
     for (int64_t q = level_begin; q < tail; ++q)
       if (deg[queue[(size_t)q]] < deg[best]) best = queue[(size_t)q];
     *far = best;
+    *count = tail;
     return true;
   };
-  int32_t s = 0;
-  for (int64_t i = 1; i < n; ++i)
-    if (deg[i] < deg[s]) s = (int32_t)i;
-  std::vector<int32_t> ds, de, dt, dc;
-  int32_t e = s, tmp = s;
-  if (!bfs(s, ds, &e)) return none;
-  for (int it = 0; it < 6; ++it) {      // George & Liu: walk to a pair of (locally) largest distance
-    if (!bfs(e, de, &tmp)) return none;
-    if (de[(size_t)tmp] <= ds[(size_t)e]) break;
-    s = e;
-    e = tmp;
-    ds.swap(de);
+  std::vector<int32_t> len((size_t)n, -1), mark((size_t)n, -1), order, comp, members, ds((size_t)n, 0);
+  std::vector<char> placed((size_t)n, 0);
+  order.reserve((size_t)n);
+  // breadth-first search from `root` inside band b (of the current component) among the nodes whose mark is `from` (they get mark
+  // `to`); the visited nodes in `comp` in visiting order, their distances in len
+  auto strip_bfs = [&](int32_t root, int32_t b, int32_t from, int32_t to) {
+    comp.clear();
+    comp.push_back(root);
+    mark[(size_t)root] = to;
+    len[(size_t)root] = 0;
+    for (size_t head = 0; head < comp.size(); ++head) {
+      const int32_t u = comp[head];
+      for (int32_t k = 0; k < deg[u]; ++k) {
+        const int32_t v = adj[(size_t)ap[u] + k];
+        if (ds[(size_t)v] / H != b || mark[(size_t)v] != from) continue;
+        mark[(size_t)v] = to;
+        len[(size_t)v] = len[(size_t)u] + 1;
+        comp.push_back(v);
+      }
+    }
+  };
+  for (int64_t seed = 0; seed < n; ++seed) {      // one connected component after the other
+    if (placed[(size_t)seed]) continue;
+    if (deg[(size_t)seed] == 0) { placed[(size_t)seed] = 1; order.push_back((int32_t)seed); continue; }
+    int32_t s = (int32_t)seed, e = s, tmp = s;
+    int64_t cnt = 0;
+    if (!bfs(s, dist_a, &e, &cnt)) return none;
+    for (int it = 0; it < 6; ++it) {      // George & Liu: walk to a node of (locally) largest eccentricity
+      const int32_t ecc_s = dist_a[(size_t)e];
+      if (!bfs(e, dist_b, &tmp, &cnt)) return none;
+      if (dist_b[(size_t)tmp] <= ecc_s) break;
+      s = e;
+      e = tmp;
+      dist_a.swap(dist_b);
+    }
+    if (!bfs(s, dist_a, &tmp, &cnt)) return none;
+    members.assign(queue.begin(), queue.begin() + cnt);      // the component, in breadth-first order from s
+    int32_t nlev = 0;
+    for (int32_t v : members) { ds[(size_t)v] = dist_a[(size_t)v]; placed[(size_t)v] = 1; nlev = std::max(nlev, ds[(size_t)v] + 1); }
+    // (members are already sorted by level, hence by band)
+    size_t q0 = 0;
+    for (int32_t b = 0; b * H < nlev; ++b) {
+      size_t q1 = q0;
+      while (q1 < members.size() && ds[(size_t)members[q1]] / H == b) ++q1;
+      for (size_t q = q0; q < q1; ++q) {
+        const int32_t x = members[q];
+        if (mark[(size_t)x] != -1) continue;
+        strip_bfs(x, b, -1, 0);                           // the strip x lies in; its last node is an end of it ...
+        int32_t y = comp.back();
+        for (size_t z = comp.size(); z-- > 0 && len[(size_t)comp[z]] == len[(size_t)comp.back()];)
+          if (deg[comp[z]] < deg[y]) y = comp[z];
+        strip_bfs(y, b, 0, 1);                            // ... and the distance from that end runs along it
+        const size_t first = order.size();
+        order.insert(order.end(), comp.begin(), comp.end());      // (visiting order = ascending length coordinate)
+        std::stable_sort(order.begin() + first, order.end(), [&](int32_t u, int32_t v) {
+          if (len[(size_t)u] != len[(size_t)v]) return len[(size_t)u] < len[(size_t)v];
+          return ds[(size_t)u] < ds[(size_t)v];
+        });
+      }
+      q0 = q1;
+    }
   }
-  if (!bfs(s, ds, &tmp) || !bfs(e, de, &tmp)) return none;
-  // t: among the nodes about equally far from s and e, the one farthest from an arbitrary one of them
-  int32_t c0 = -1;
-  for (int64_t i = 0; i < n && c0 < 0; ++i)
-    if (std::abs(ds[(size_t)i] - de[(size_t)i]) <= 1) c0 = (int32_t)i;
-  if (c0 < 0) return none;
-  if (!bfs(c0, dc, &tmp)) return none;
-  int32_t t = c0;
-  for (int64_t i = 0; i < n; ++i)
-    if (std::abs(ds[(size_t)i] - de[(size_t)i]) <= 1 && dc[(size_t)i] > dc[(size_t)t]) t = (int32_t)i;
-  if (!bfs(t, dt, &tmp)) return none;
-  // sort by (band of a, +-b, a)
-  std::vector<int32_t> order((size_t)n);
-  std::iota(order.begin(), order.end(), 0);
-  std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-    const int32_t bx = ds[(size_t)x] / H, by = ds[(size_t)y] / H;
-    if (bx != by) return bx < by;
-    const int32_t kx = (bx & 1) ? -dt[(size_t)x] : dt[(size_t)x], ky = (by & 1) ? -dt[(size_t)y] : dt[(size_t)y];
-    if (kx != ky) return kx < ky;
-    if (ds[(size_t)x] != ds[(size_t)y]) return ds[(size_t)x] < ds[(size_t)y];
-    return x < y;
-  });
+  if ((int64_t)order.size() != n) return none;
   // inside a tile: boundary nodes first, grouped by the (lowest) other tile they touch
   std::vector<int32_t> tile_of((size_t)n);
   for (int64_t q = 0; q < n; ++q) tile_of[(size_t)order[(size_t)q]] = (int32_t)(q / TR);

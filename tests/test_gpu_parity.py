@@ -911,6 +911,7 @@ def test_reordered_operator_matches_the_oracle_on_the_natural_ordering(eu, case)
     b64 = b.astype(A64.dtype)
     tol = 2e-5 if np.dtype(T).itemsize <= 4 else TOL
     ctx = eu.Context()
+    ctx.set_option("patch", 0)                 # (reverse Cuthill-McKee; with patch = 1 the shuffled grid is cut into patches: test_patch_form_…)
     op = eu.MIOperator(A, ctx)
     ri = op.reorder_info
     assert ri["reordered"] and ri["bandwidth_after"] < ri["bandwidth_before"] // 50, ri
@@ -1034,11 +1035,33 @@ def _grid_operator(case, rng):
     if case == "big_f64":
         k = 1000
         return sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(k * k, k * k), format="csr"), 12
+    if case in ("mesh_f64", "mesh_f32", "trimesh_components_f64"):
+        # meshes in a RANDOM numbering (creation cuts them into patches from breadth-first distances: reorder.h mesh_patches): a planar
+        # 5-point mesh; two triangulated pieces of different size + isolated unknowns
+        def planar(k, rows, tri):
+            n = k * rows
+            i = np.arange(n)
+            parts = []
+            for dr, dc in [(0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)] + ([(1, 1), (-1, -1)] if tri else []):
+                r, c = i // k + dr, i % k + dc
+                ok = (r >= 0) & (r < rows) & (c >= 0) & (c < k)
+                v = (-3.0 if (dr, dc) == (0, 0) else 0.6) + 0.3 * rng.standard_normal(n)
+                parts.append(sp.csr_matrix((v[ok], (i[ok], (r * k + c)[ok])), shape=(n, n)))
+            return sum(parts).tocsr()
+        if case == "trimesh_components_f64":
+            A = sp.block_diag([planar(210, 190, True), planar(97, 160, True), -0.7 * sp.identity(300, format="csr")], format="csr")
+        else:
+            A = planar(330, 290, False)
+        q = rng.permutation(A.shape[0])
+        A = A[q][:, q].tocsr()
+        A.sort_indices()
+        return A, 24
     raise ValueError(case)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["pure_f64", "pure_serial", "pure_f32", "laplace_f64", "nine_f64", "ragged_f64", "big_f64"])
+@pytest.mark.parametrize("case", ["pure_f64", "pure_serial", "pure_f32", "laplace_f64", "nine_f64", "ragged_f64", "big_f64", "mesh_f64", "mesh_f32",
+                                  "trimesh_components_f64"])
 def test_patch_form_of_the_single_pass_step(eu, case):
     """a 2-D grid stencil stored in a grid-patch ordering (context option patch = 1: a tile of the single-pass step
     is a 16 x 32 patch of the grid, the ring of rows around it is recomputed like the banded form's halo -- no per-tile flags).  The
@@ -1046,7 +1069,7 @@ def test_patch_form_of_the_single_pass_step(eu, case):
     mul!, a short window (iop = 3) and a values-only update, all against the oracle on the caller's matrix at the fixed bars."""
     import torch
     rng = np.random.default_rng(33)
-    T = np.float32 if case == "pure_f32" else np.float64
+    T = np.float32 if case in ("pure_f32", "mesh_f32") else np.float64
     A0, m = _grid_operator(case, rng)
     A = A0.astype(T)
     n = A.shape[0]

@@ -1,5 +1,5 @@
 """expv on general (non-banded) sparse operators: which step form runs, per-kernel time, fraction of the SURVEY 8d contract.
-    python tools/general_sparse.py [kind ...]     kinds: c2 rand5 band5[_REACH] grid grid3 powerlaw c2f32"""
+    python tools/general_sparse.py [kind ...]     kinds: c2 rand5 band5[_REACH] grid grid3 powerlaw c2f32 mesh trimesh diskmesh, shuf_<kind>; options name=value (context options)"""
 import json
 import sys
 import time
@@ -58,6 +58,22 @@ def make(kind, n, seed=11):
         A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr() + sp.diags([-0.5 * np.ones(n)], [0], format="csr")
         A.sum_duplicates()
         return A.tocsr()
+    if kind in ("mesh", "trimesh", "diskmesh"):      # planar meshes (no entries across the row ends of the underlying grid): 5-point, 7-point
+        k = int(round(np.sqrt(n)))                   # (a triangulated grid), and a 5-point mesh on a disk; variable coefficients
+        i = np.arange(k * k)
+        offs = [(0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)] + ([(1, 1), (-1, -1)] if kind == "trimesh" else [])
+        parts = []
+        for dr, dc in offs:
+            r, c = i // k + dr, i % k + dc
+            ok = (r >= 0) & (r < k) & (c >= 0) & (c < k)
+            v = (-2.0 if (dr, dc) == (0, 0) else 0.5) + 0.05 * rng.random(k * k)
+            parts.append(sp.csr_matrix((v[ok], (i[ok], (r * k + c)[ok])), shape=(k * k, k * k)))
+        A = sum(parts).tocsr()
+        if kind == "diskmesh":
+            keep = np.nonzero((i // k - k / 2) ** 2 + (i % k - k / 2) ** 2 <= (0.49 * k) ** 2)[0]
+            A = A[keep][:, keep].tocsr()
+        nn = A.shape[0]
+        return sp.block_diag([A, -0.5 * sp.identity(n - nn, format="csr")], format="csr") if n > nn else A
     if kind.startswith("shuf_"):            # any of the above under a random symmetric permutation of the unknowns
         A = make(kind[5:], n, seed).tocsr()
         q = np.random.default_rng(seed + 1).permutation(A.shape[0])
