@@ -572,7 +572,8 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
     import scipy.sparse.linalg as spl
     for key, kind in (("general_sparse_random", "random"), ("general_sparse_local", "local"), ("general_sparse_local_narrow", "local_narrow"),
-                      ("irregular_sparse_powerlaw", "powerlaw"), ("general_sparse_rcm", "shuffled_band"), ("general_sparse_rcm_grid", "shuffled_grid")):
+                      ("irregular_sparse_powerlaw", "powerlaw"), ("general_sparse_rcm", "shuffled_band"), ("general_sparse_rcm_grid", "shuffled_grid"),
+                      ("general_sparse_mesh", "shuffled_trimesh")):
         if kind == "shuffled_band":
             # the headline operator under a random symmetric permutation of its unknowns (an "unstructured" numbering of a banded
             # problem): operator creation finds a bandwidth-reducing ordering (reverse Cuthill-McKee, reorder.h) and keeps P A P'
@@ -584,6 +585,23 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
             Ag = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-kq, -1, 0, 1, kq], shape=(kq * kq, kq * kq), format="csr")[q_][:, q_].tocsr()
             if kq * kq != n:
                 continue
+        elif kind == "shuffled_trimesh":
+            # an "unstructured mesh": a triangulated planar k x k mesh (7 entries per row, no entries across the row ends of the
+            # underlying grid, coefficients vary), numbered at random.  Creation cuts it into patches from breadth-first distances
+            # (reorder.h: mesh_patches) -- the patch form of the single-pass step; with option patch = 0: RCM + wave form
+            kq = int(round(np.sqrt(n)))
+            if kq * kq != n:
+                continue
+            rg_ = np.random.default_rng(19)
+            ii = np.arange(n)
+            parts_ = []
+            for dr, dc in ((0, 0), (0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (-1, -1)):
+                r_, c_ = ii // kq + dr, ii % kq + dc
+                ok_ = (r_ >= 0) & (r_ < kq) & (c_ >= 0) & (c_ < kq)
+                v_ = (-2.0 if (dr, dc) == (0, 0) else 0.4) + 0.05 * rg_.random(n)
+                parts_.append(sp.csr_matrix((v_[ok_], (ii[ok_], (r_ * kq + c_)[ok_])), shape=(n, n)))
+            q_ = rg_.permutation(n)
+            Ag = sum(parts_).tocsr()[q_][:, q_].tocsr()
         else:
             Ag = general_sparse_operator(kind, n)
         t0 = time.perf_counter()
@@ -600,10 +618,11 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         e = entry("expv, %s rows / %s columns, n=%d nnz=%d m=%d" % ("irregular (Zipf)" if kind == "powerlaw" else "regular",
                   {"local": "local (+-2 %% of the row)", "local_narrow": "local (+-0.2 %% of the row)",
                    "shuffled_band": "the C2 operator under a random symmetric permutation (reordered at creation)",
-                   "shuffled_grid": "a 2-D 5-point grid operator under a random symmetric permutation (reordered at creation)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
+                   "shuffled_grid": "a 2-D 5-point grid operator under a random symmetric permutation (cut into patches at creation: patch form)",
+                   "shuffled_trimesh": "a triangulated planar mesh numbered at random (cut into patches at creation: patch form)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
                   tx, m, alg_bytes_expv(n, Ag.nnz, m),
                   path=pathx, setup_s=t_set, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
-                  storage=eu.host_pattern_info(Ag)["path"], reorder=opx.reorder_info,
+                  storage=eu.host_pattern_info(Ag)["path"], reorder=opx.reorder_info, patch_info=opx.patch_info,
                   verified_vs_scipy_expm_multiply=float(np.linalg.norm(wx - truth) / np.linalg.norm(truth)))
         if e["verified_vs_scipy_expm_multiply"] > 1e-9:
             raise SystemExit("%s: result differs from scipy's expm_multiply: %.3e" % (key, e["verified_vs_scipy_expm_multiply"]))
