@@ -54,6 +54,10 @@ def make_operator(rng, n, cplx):
         if rng.random() < 0.3:
             A = ((A + A.conj().T) * 0.5).tocsr()
             kind = "grid2d_symmetric"
+        if rng.random() < 0.35:      # the same mesh in a random numbering: creation cuts it into patches from breadth-first distances (n >= 8192)
+            q = rng.permutation(n)
+            A = A[q][:, q].tocsr()
+            A.sort_indices()
     elif kind == "wide_diagonals":
         nd = int(rng.integers(2, 7))
         offs = sorted(set([0] + [int(o) for o in rng.integers(-(n - 1), n, size=nd)]))
