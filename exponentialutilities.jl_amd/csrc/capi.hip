@@ -645,16 +645,27 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // (a level wider than the reach the wave form can use cannot lead anywhere: give up after the first breadth-first searches)
   const int64_t trw = (int64_t)(16 / sizeof(V)) * dev::BLOCK;
   const int64_t useful = std::max<int64_t>(98 * trw, (n + trw - 1) / trw <= 400 ? n : 0);
-  const std::vector<int32_t> perm = reorder::rcm(n, rp.data(), ci.data(), mode == 1 ? useful : 0);
-  // a mesh in an arbitrary numbering (RCM gave up, or gives the wave form at best): patches of the graph for the patch form of the
-  // single-pass step (reorder.h: mesh_patches).  An ordering that reaches the halo form (a banded operator) is better still.
+  // a mesh in an arbitrary numbering: patches of the graph for the patch form of the single-pass step (reorder.h: mesh_patches).  An
+  // ordering that reaches the halo form (a banded operator) is better still -- but the bandwidth of a Cuthill-McKee ordering is at
+  // least its widest level, so a first attempt that gives up beyond 4 x the halo width tells (one breadth-first search) whether to
+  // bother; only when the patches do not work out either is the full ordering computed.
   auto mesh = [&]() { return mode == 1 && !P0.overflow && std::is_floating_point<V>::value && try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth); };
-  if (perm.empty()) { (void)mesh(); return; }
+  std::vector<int32_t> perm;
+  bool mesh_tried = false;
+  if (mode == 1 && op.ctx->opt.patch && !P0.overflow && std::is_floating_point<V>::value) {
+    perm = reorder::rcm(n, rp.data(), ci.data(), 4 * dev::PIPE_WMAX);
+    if (perm.empty()) {
+      mesh_tried = true;
+      if (mesh()) return;
+    }
+  }
+  if (perm.empty()) perm = reorder::rcm(n, rp.data(), ci.data(), mode == 1 ? useful : 0);
+  if (perm.empty()) return;
   std::vector<int32_t> rp2, ci2, src;
   reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
   const PatClass c1 = pattern_class_ex(P1, n, op.dtype);
-  if (c1.cls < 3 && mesh()) return;
+  if (c1.cls < 3 && !mesh_tried && mesh()) return;
   const bool better = c1.cls > c0.cls || (c1.cls == c0.cls && c1.cls == 2 && 4 * c1.reach <= c0.reach);
   if (mode == 1 && !better) return;
   install_row_order<V>(op, n, perm, src, rp, ci, va, rp2, ci2, P0.bandwidth, P1.bandwidth, t0);
