@@ -803,13 +803,17 @@ static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int
   if (n < 8192 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;
   const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
   const int64_t width = (int64_t)(8.0 * std::sqrt((double)n)) + 1024;      // a level of a planar-like mesh is O(sqrt n) wide
+  const auto tm0 = std::chrono::steady_clock::now();
   pl.perm = reorder::mesh_patches(n, rp, ci, TR, value_bytes == 8 ? 16 : 24, width);
+  const auto tm1 = std::chrono::steady_clock::now();
   if (pl.perm.empty()) return false;
   pl.k = 0;
   const bool fits = plan_patch_from_perm(n, rp, ci, nnz, value_bytes, bw0, pl);
   if (std::getenv("EXPV_MI_OP_TIMING"))
-    std::fprintf(stderr, "[op build] mesh patches: %lld tiles, longest ring %d, mean %.1f, fits %d\n", (long long)pl.nt, pl.maxring,
-                 pl.nt ? (double)pl.ring_sum / (double)pl.nt : 0.0, (int)fits);
+    std::fprintf(stderr, "[op build] mesh patches: %lld tiles, longest ring %d, mean %.1f, fits %d; ordering %.0f ms, rings + columns %.0f ms\n",
+                 (long long)pl.nt, pl.maxring, pl.nt ? (double)pl.ring_sum / (double)pl.nt : 0.0, (int)fits,
+                 std::chrono::duration<double, std::milli>(tm1 - tm0).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm1).count());
   if (!fits) return false;
   return pl.ring_sum <= 176 * pl.nt * (value_bytes == 8 ? 1 : 2) / 1;      // mean ring: <= 176 rows (fp64 tiles of 512), 352 ... capped by the 256 limit per tile
 }

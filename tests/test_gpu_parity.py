@@ -713,13 +713,15 @@ def test_pipeline_overlap_options_and_expired_wait_fallback(eu):
         np.save(sys.argv[1], np.stack([w, g]))
     """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, n, m, m)
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "expv_mi_fallback_%d.npy" % os.getpid())
-    env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1", EXPV_MI_PATCH="0")      # (the grid in its natural ordering: wave form)
-    r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = np.load(out)
-    assert relerr(got[0], wo) < 1e-12
     G = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-150, -1, 0, 1, 150], shape=A.shape, format="csr")
-    close(got[1], ko.expv(0.9, G, b, m=m, ishermitian=False), TOL, "wave -> two-kernel step after the expired wait")
+    wg = ko.expv(0.9, G, b, m=m, ishermitian=False)
+    for patch in ("0", "1"):      # the grid in its natural ordering (wave form -> two-kernel step) and in the grid-patch ordering (patch form -> serial redo)
+        env = dict(os.environ, EXPV_MI_PIPE_SPIN_LIMIT="1", EXPV_MI_PATCH=patch)
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.load(out)
+        assert relerr(got[0], wo) < 1e-12
+        close(got[1], wg, TOL, "grid stencil after the expired wait (EXPV_MI_PATCH=%s)" % patch)
     os.remove(out)
 
 
