@@ -567,6 +567,26 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["path"] = list(eu.expv.last_stats["path"])
     sec["grid_stencil_float32"] = e
     del opg32, Ag32
+    # (3b4) a banded operator WITHOUT a diagonal form: ten distinct offsets within +-8 (more than the 8 diagonals the DIA form holds).  Up to
+    # round 3 (and with patch = 0): halo form on SELL slots, 4 bytes of column index per entry from HBM; round 4: the patch form with the
+    # halo as its ring and tile-local column indices whose equal blocks are stored once
+    offs10 = [-8, -6, -5, -3, -1, 0, 1, 2, 4, 7]
+    rg10 = np.random.default_rng(23)
+    A10 = sp.diags([(0.1 + 0.05 * rg10.random(n - abs(o))) * (1 if o else -6.0) for o in offs10], offs10, shape=(n, n), format="csr")
+    for key10, patch10 in (("banded_ten_offsets", 1), ("banded_ten_offsets_sell_halo", 0)):
+        ctx.set_option("patch", patch10)
+        op10 = eu.MIOperator(A10, ctx)
+        ctx.set_option("patch", 1)
+        f10 = lambda: eu.expv(T_FINAL, op10, b, m=m, ishermitian=False, out=w)
+        f10()
+        env.sync()
+        e = entry("expv, banded operator with ten distinct offsets within +-8 (no diagonal form), context option patch = %d: %s, n=%d nnz=%d m=%d"
+                  % (patch10, "tile-local columns (patch form, halo = ring)" if patch10 else "halo form on SELL slots", n, A10.nnz, m),
+                  timed(f10, max(5, args.steps // 2), 1, env.sync), m, alg_bytes_expv(n, A10.nnz, m))
+        e["path"] = list(eu.expv.last_stats["path"])
+        sec[key10] = e
+        del op10
+    del A10
     # (3c) general sparse operators: no band, no diagonals to exploit.  Regular rows with random columns and
     # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.

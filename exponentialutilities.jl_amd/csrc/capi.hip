@@ -898,6 +898,7 @@ static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci
   return true;
 }
 
+static void upload_patch_plan(Op &op, PatchPlan &pl);
 // returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
 // per-tile rings and the tile-local column array)
 template <class V>
@@ -908,6 +909,28 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
   PatchPlan pl;
   if (mesh ? !plan_mesh_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), bw0, pl)
            : !plan_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), pl)) return false;
+  upload_patch_plan(op, pl);
+  install_row_order<V>(op, n, pl.perm, pl.src, rp, ci, va, pl.rp2, pl.ci2, pl.bw0, pl.bw1, t0);
+  return true;
+}
+// Banded operators that have no diagonal form (more than 8 distinct offsets, or too much fill) run the halo form on SELL slots, whose
+// 4 bytes of column index per entry are HBM traffic.  The patch form does the same job with the halo as its "ring" (2 w rows per
+// tile) and column indices that are positions in the tile -- equal for all interior slices, stored once, read from L2.  No
+// permutation: the plan is made for the operator as it is (natural ordering, or what reverse Cuthill-McKee left).
+template <class V>
+static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci) {
+  static const bool force = std::getenv("EXPV_MI_RING_BANDED") != nullptr;      // developer A/B: also when a diagonal form exists
+  if (!op.ctx->opt.patch || op.ring_pad > 0 || n < 2 || ci.empty() || !std::is_floating_point<V>::value) return false;
+  const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  if (!P.sell_ok || P.overflow || P.bandwidth > dev::PIPE_WMAX || (P.pipe_dia && !force)) return false;
+  PatchPlan pl;
+  pl.perm.resize((size_t)n);
+  std::iota(pl.perm.begin(), pl.perm.end(), 0);
+  if (!plan_patch_from_perm(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), P.bandwidth, pl)) return false;
+  upload_patch_plan(op, pl);
+  return true;
+}
+static void upload_patch_plan(Op &op, PatchPlan &pl) {
   op.ring_col_unique = (int64_t)pl.lcol.size();
   pl.lcol.resize(pl.lcol.size() + 4, 0);
   op.ring_soff.alloc(sizeof(int64_t) * pl.soff.size());
@@ -926,8 +949,6 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
   op.ring_tiles = pl.nt;
   op.ring_sum = pl.ring_sum;
   op.ring_over128 = pl.over128;
-  install_row_order<V>(op, n, pl.perm, pl.src, rp, ci, va, pl.rp2, pl.ci2, pl.bw0, pl.bw1, t0);
-  return true;
 }
 
 template <class V>
@@ -949,6 +970,8 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   lap("reordering (RCM)");
   (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
   lap("grid-patch ordering");
+  (void)try_banded_ring<V>(op, n, rp, ci);
+  lap("tile-local columns of a banded operator");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size(), ci.data());

@@ -547,7 +547,9 @@ struct ArnoldiCall {
       // patch form of the same step: an operator stored in a grid-patch ordering (capi.hip) -- SELL slots with tile-local columns,
       // the ring of a tile recomputed like the banded form's halo
       if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
-        if (!use_pipe && op.ring_pad > 0 && c->opt.patch && use_fused && single_red && !no_pipe && op.sell_cut == 0 &&
+        // (also INSTEAD of the halo form on SELL slots -- a banded operator without a diagonal form: its ring is the halo, its column
+        //  indices come from L2)
+        if ((!use_pipe || !have_dia) && op.ring_pad > 0 && c->opt.patch && use_fused && single_red && !no_pipe && op.sell_cut == 0 &&
             wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
             (!isaug || (std::is_same<T, double>::value && p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7))) {      // augmented (kiops): the two small-window variants
           use_pipe = true;

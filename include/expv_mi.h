@@ -186,7 +186,11 @@ int expv_mi_op_info(expv_mi_op_t op, int64_t *n, int64_t *nnz, int *ishermitian,
  * (rounding apart).  out[0] = 1 when reordered, out[1] / out[2] = max |col - row| before / after, out[3] = the reordering's share
  * of the creation time in microseconds.  No reference counterpart (the reference applies A in the caller's ordering). */
 int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]);
-/* Grid-patch ordering (context option "patch", default 1; read when an operator is created): a 5- / 9-point stencil on a 2-D grid
+/* Patch form (context option "patch", default 1; read when an operator is created).  Besides the grid-patch ordering described here the
+ * same option gives (i) meshes in an arbitrary numbering an ordering cut from breadth-first bands (expv_mi_host_mesh_patch_order) and
+ * (ii) banded operators without a diagonal form the patch form in their OWN ordering (nothing permuted; the halo is the ring): out[0]
+ * = 1 and out[1] = 0 for both.
+ * Grid-patch ordering: a 5- / 9-point stencil on a 2-D grid
  * with rows of k cells (every offset within 2 of 0 or of +-k) is stored in an ordering in which a tile of the single-pass step is a
  * 16 x 32 patch of the grid, and the step recomputes u_j on the ring of rows around each tile (patch form) instead of waiting for
  * per-tile flags (wave form).  A special case of the reordering above: expv_mi_op_reorder_info reports it too, vectors are permuted

@@ -1136,6 +1136,51 @@ def test_patch_form_of_the_single_pass_step(eu, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.float32])
+def test_banded_operator_without_a_diagonal_form_runs_on_tile_local_columns(eu, T):
+    """A banded operator with more than 8 distinct offsets has no diagonal (DIA) form; its halo form on SELL slots reads 4 bytes of
+    column index per entry from HBM.  With option patch (default) the same operator -- in its own ordering, nothing is permuted --
+    runs on the patch form with the halo as its ring and tile-local column indices whose equal blocks are stored once (0.649 ->
+    0.677 of the contract on the C2 pattern).  Both against the oracle; kiops (augmented operator) and a continuation too."""
+    rng = np.random.default_rng(41)
+    n, m = 150_001, 26
+    offs = [-8, -6, -5, -3, -1, 0, 1, 2, 4, 7]
+    d = [(0.1 + 0.05 * rng.random(n - abs(o))) * (1 if o else -6.0) for o in offs]
+    A = sp.diags(d, offs, shape=(n, n), format="csr").astype(T)
+    A64 = A.astype(np.float64)
+    b = rng.standard_normal(n).astype(T)
+    b64 = b.astype(np.float64)
+    tol = 2e-5 if T == np.float32 else TOL
+    wo = ko.expv(0.7, A64, b64, m=m, ishermitian=False)
+    res = {}
+    for patch in (1, 0):
+        ctx = eu.Context()
+        ctx.set_option("patch", patch)
+        op = eu.MIOperator(A, ctx)
+        assert not op.reorder_info["reordered"] and op.patch_info["patch_form"] == bool(patch), (op.reorder_info, op.patch_info)
+        w = np.asarray(eu.expv(0.7, op, b, m=m, ishermitian=False)).astype(np.float64)
+        path = eu.expv.last_stats["path"]
+        assert "pipeline" in path and ("patch" in path) == bool(patch), path
+        close(w, wo, tol, "banded operator, ten offsets, patch = %d (%s): expv vs oracle" % (patch, np.dtype(T).name))
+        res[patch] = w
+        if patch and T == np.float64:
+            pi = op.patch_info
+            assert pi["longest_ring"] <= 16 and pi["column_indices_stored"] < A.nnz // 50, pi
+            Ks = eu.KrylovSubspace(T, T, n, m + 4, 0, ctx)
+            eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+            eu.arnoldi_(Ks, op, b, m=m + 4, init=m, ishermitian=False)
+            Ko = ko.KrylovSubspace(np.float64, np.float64, n, m + 4)
+            ko.arnoldi_(Ko, A64, b64, m=m, ishermitian=False)
+            ko.arnoldi_(Ko, A64, b64, m=m + 4, init=m, ishermitian=False)
+            close(Ks.getH(), Ko.getH(), TOL, "banded operator on tile-local columns: H after a continuation vs oracle", mat=True)
+            wk, sk = eu.kiops(0.8, op, b, ishermitian=False)
+            wko, sko = ko.kiops(0.8, A64, b64, ishermitian=False)
+            assert tuple(sk) == tuple(sko), (sk, sko)
+            close(wk, wko, 1e-10, "banded operator on tile-local columns: kiops vs oracle")
+    close(res[1], res[0], 10 * tol, "patch form == halo form on SELL slots")
+
+
+@pytest.mark.gpu
 def test_patch_form_drivers(eu):
     """The drivers on an operator stored in the grid-patch ordering: lanczos! and the error-estimate mode on a symmetric stencil
     (window 2 on the patch form), adaptive phiv_timestep! and kiops (augmented operator: the two-kernel step on the stored ordering),
