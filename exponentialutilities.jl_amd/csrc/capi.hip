@@ -642,6 +642,8 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // change row lengths)
   const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
   if (mode == 1 && !candidate) return;
+  // (a banded operator of a complex element type has no halo form on SELL slots, but the patch form in its own ordering: try_banded_ring)
+  if (mode == 1 && op.ctx->opt.patch && P0.sell_ok && !P0.overflow && P0.bandwidth <= dev::PIPE_WMAX) return;
   // (a level wider than the reach the wave form can use cannot lead anywhere: give up after the first breadth-first searches)
   const int64_t trw = (int64_t)(16 / sizeof(V)) * dev::BLOCK;
   const int64_t useful = std::max<int64_t>(98 * trw, (n + trw - 1) / trw <= 400 ? n : 0);
@@ -649,10 +651,10 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // ordering that reaches the halo form (a banded operator) is better still -- but the bandwidth of a Cuthill-McKee ordering is at
   // least its widest level, so a first attempt that gives up beyond 4 x the halo width tells (one breadth-first search) whether to
   // bother; only when the patches do not work out either is the full ordering computed.
-  auto mesh = [&]() { return mode == 1 && !P0.overflow && std::is_floating_point<V>::value && try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth); };
+  auto mesh = [&]() { return mode == 1 && !P0.overflow && try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth); };
   std::vector<int32_t> perm;
   bool mesh_tried = false;
-  if (mode == 1 && op.ctx->opt.patch && !P0.overflow && std::is_floating_point<V>::value) {
+  if (mode == 1 && op.ctx->opt.patch && !P0.overflow) {
     perm = reorder::rcm(n, rp.data(), ci.data(), 4 * dev::PIPE_WMAX);
     if (perm.empty()) {
       mesh_tried = true;
@@ -789,22 +791,22 @@ struct PatchPlan {
 };
 static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl);
 static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, PatchPlan &pl) {
-  if (n < 2 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;      // the real element types (pipe.hip: SELL slots)
+  if (n < 2 || nnz == 0 || (value_bytes != 16 && value_bytes != 8 && value_bytes != 4)) return false;
   const PatternPlan P0 = analyze_pattern(n, rp, ci, nnz, value_bytes);
   if (!detect_grid2d(P0, n, &pl.k)) return false;
-  const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;      // rows of a tile: 512 (fp64), 1024 (Float32)
-  const int64_t R = value_bytes == 8 ? 16 : 32;
+  const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;      // rows of a tile: 512 (fp64, ComplexF32), 1024 (Float32), 256 (ComplexF64)
+  const int64_t R = TR >= 1024 ? 32 : 16;                           // patches of 16 x 32, 32 x 32, 16 x 16
   pl.perm = patch_order(n, pl.k, R, TR);
   return plan_patch_from_perm(n, rp, ci, nnz, value_bytes, P0.bandwidth, pl);
 }
 // The same for a mesh in any numbering (reorder.h: mesh_patches): patches from two breadth-first distance fields.  Kept when every
 // tile's ring fits and the rings are short on average -- otherwise the caller goes on to reverse Cuthill-McKee.
 static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl) {
-  if (n < 8192 || nnz == 0 || (value_bytes != 8 && value_bytes != 4)) return false;
+  if (n < 8192 || nnz == 0 || (value_bytes != 16 && value_bytes != 8 && value_bytes != 4)) return false;
   const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
   const int64_t width = (int64_t)(8.0 * std::sqrt((double)n)) + 1024;      // a level of a planar-like mesh is O(sqrt n) wide
   const auto tm0 = std::chrono::steady_clock::now();
-  pl.perm = reorder::mesh_patches(n, rp, ci, TR, value_bytes == 8 ? 16 : 24, width);
+  pl.perm = reorder::mesh_patches(n, rp, ci, TR, TR >= 1024 ? 24 : TR >= 512 ? 16 : 12, width);
   const auto tm1 = std::chrono::steady_clock::now();
   if (pl.perm.empty()) return false;
   pl.k = 0;
@@ -815,7 +817,7 @@ static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int
                  std::chrono::duration<double, std::milli>(tm1 - tm0).count(),
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm1).count());
   if (!fits) return false;
-  return pl.ring_sum <= 176 * pl.nt * (value_bytes == 8 ? 1 : 2) / 1;      // mean ring: <= 176 rows (fp64 tiles of 512), 352 ... capped by the 256 limit per tile
+  return pl.ring_sum * 512 <= 176 * pl.nt * TR;      // mean ring <= 176 rows per 512 rows of a tile (and <= 256 per tile anyway)
 }
 static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl) {
   const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
@@ -904,7 +906,7 @@ static void upload_patch_plan(Op &op, PatchPlan &pl);
 template <class V>
 static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0) {
   if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
-  if (!std::is_floating_point<V>::value) return false;      // the real element types (pipe.hip: the patch form runs on SELL slots)
+  // (every element type: V is double, float or their std::complex)
   const auto t0 = std::chrono::steady_clock::now();
   PatchPlan pl;
   if (mesh ? !plan_mesh_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), bw0, pl)
@@ -920,7 +922,7 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
 template <class V>
 static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci) {
   static const bool force = std::getenv("EXPV_MI_RING_BANDED") != nullptr;      // developer A/B: also when a diagonal form exists
-  if (!op.ctx->opt.patch || op.ring_pad > 0 || n < 2 || ci.empty() || !std::is_floating_point<V>::value) return false;
+  if (!op.ctx->opt.patch || op.ring_pad > 0 || n < 2 || ci.empty()) return false;
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
   if (!P.sell_ok || P.overflow || P.bandwidth > dev::PIPE_WMAX || (P.pipe_dia && !force)) return false;
   PatchPlan pl;
@@ -1954,7 +1956,6 @@ static int host_patch_order_impl(int64_t n, const int32_t *rowptr, const int32_t
     for (int q = 0; q < 8; ++q) out[q] = 0;
     PatchPlan pl;
     const int64_t nnz = n > 0 ? (int64_t)rowptr[n] : 0;
-    if (dtype_is_complex(dtype)) return;
     if (mesh ? !plan_mesh_patch(n, rowptr, colind, nnz, (int)dtype_size(dtype), 0, pl) : !plan_patch(n, rowptr, colind, nnz, (int)dtype_size(dtype), pl)) return;
     if (perm) std::copy(pl.perm.begin(), pl.perm.end(), perm);
     if (ring_count) std::copy(pl.cnt.begin(), pl.cnt.end(), ring_count);

@@ -546,9 +546,9 @@ struct ArnoldiCall {
                  (!isaug || (p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7));          // augmented: the two small-window variants
       // patch form of the same step: an operator stored in a grid-patch ordering (capi.hip) -- SELL slots with tile-local columns,
       // the ring of a tile recomputed like the banded form's halo
-      if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
+      {
         // (also INSTEAD of the halo form on SELL slots -- a banded operator without a diagonal form: its ring is the halo, its column
-        //  indices come from L2)
+        //  indices come from L2.  Every element type: for the complex ones it is the only single-pass form beyond 8 diagonals)
         if ((!use_pipe || !have_dia) && op.ring_pad > 0 && c->opt.patch && use_fused && single_red && !no_pipe && op.sell_cut == 0 &&
             wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
             (!isaug || (std::is_same<T, double>::value && p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7))) {      // augmented (kiops): the two small-window variants
@@ -874,7 +874,7 @@ struct ArnoldiCall {
         if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
           prev_grid = use_ring ? dev::pipe_step_ring(sj, pa, true) : use_wave ? dev::pipe_step_wave_live(sj, pa, wave_reach) : dev::pipe_step_live(sj, pa);
         } else {
-          prev_grid = dev::pipe_step_live(sj, pa);
+          prev_grid = use_ring ? dev::pipe_step_ring(sj, pa, true) : dev::pipe_step_live(sj, pa);
         }
         if (prev_grid == 0) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
       } else if (use_wave) {
@@ -883,10 +883,8 @@ struct ArnoldiCall {
           if (!dev::pipe_step_wave(s, pa, wave_reach)) fail(EXPV_MI_HIP_ERROR, "wave step: diagonals reach too far for the resident grid");
         }
       } else if (use_ring) {
-        if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value) {
-          ProfScope ps1(c, EXPV_MI_K_FUSED_A);
-          (void)dev::pipe_step_ring(s, pa, false);
-        }
+        ProfScope ps1(c, EXPV_MI_K_FUSED_A);
+        (void)dev::pipe_step_ring(s, pa, false);
       } else {
         ProfScope ps1(c, EXPV_MI_K_FUSED_A);
         dev::pipe_step(s, pa);

@@ -322,6 +322,8 @@ int pipe_step_wave_live(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_a
 // patch form (operators stored in a grid-patch ordering); live: the overlapped form.  Returns the workgroups launched
 int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live);
 int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live);
+int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx> &pa, bool live);
+int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx32> &pa, bool live);
 // the same step for the overlapped form (pa.flags / pa.seq set; consecutive steps on two streams)
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa);
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa);

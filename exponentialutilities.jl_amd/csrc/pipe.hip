@@ -231,7 +231,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
   static_assert(!WAVE || SELL_T, "the wave form: the real element types");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
-  static_assert(DIA || SELL_T, "the complex element types use the DIA form");
+  static_assert(DIA || SELL_T || RING, "the complex element types use the DIA form and the patch form");
   auto &us = sh.us;
   T(&hs)[32] = sh.hs;
   double(&red_s)[BLOCK / 64][64] = sh.red_s;
@@ -377,7 +377,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
           }
       }
     } else if (i < n_op) {      // (rows of the augmentation carry no operator entries)
-      if constexpr (SELL_T) {
+      if constexpr (SELL_T || RING) {
         const int64_t slice = i / SLICE;
         const int64_t off = pa.A.slice_off[slice];
         L = (int)((pa.A.slice_off[slice + 1] - off) / SLICE);
@@ -564,7 +564,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         __syncthreads();
         if (tid < RP) {
           T sum = us[TR + BLOCK + tid];
-          for (int q = 1; q < G; ++q) sum += us[TR + BLOCK + q * RP + tid];
+          for (int q = 1; q < G; ++q) {
+            const T other = us[TR + BLOCK + q * RP + tid];
+            if constexpr (ST<T>::is_complex) { sum.re += other.re; sum.im += other.im; }
+            else sum += other;
+          }
           us[TR + tid] = sum;      // (visible behind the barrier that follows the tile's own rows of u_j, below)
         }
       }
@@ -811,14 +815,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
 #pragma unroll
-            for (int e = 0; e < N; ++e) y.v[e] = fma(av[sl].v[e], us[aci[sl].c[e]], y.v[e]);      // padding entries: value 0, position 0
+            for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], av[sl].v[e], us[aci[sl].c[e]]);      // padding entries: value 0, position 0
           }
         for (int sl = PS; sl < L; ++sl) {
           const Pack<T> v2 = *reinterpret_cast<const Pack<T> *>(avp + (int64_t)sl * SLICE);
           ColPack<N> ci;
           ci.load(acp + (int64_t)sl * SLICE);
 #pragma unroll
-          for (int e = 0; e < N; ++e) y.v[e] = fma(v2.v[e], us[ci.c[e]], y.v[e]);
+          for (int e = 0; e < N; ++e) ST<T>::fma_(y.v[e], v2.v[e], us[ci.c[e]]);
         }
 #pragma unroll
         for (int e = 1; e < N; ++e)
@@ -1636,6 +1640,15 @@ int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live) {
   return pipe_step_ring_T<double>(s, pa, live);
 }
 int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live) { return pipe_step_ring_T<float>(s, pa, live); }
+// complex element types: windows <= 15, the register budgets of their diagonal form
+template <class T>
+static int pipe_step_ring_C(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
+  if (pipe_small(pa.und, 1)) return pipe_ring_launch<T, 4, 4, 6>(s, pa, live);
+  if (pipe_variant(pa.und) == 0) return pipe_ring_launch<T, 8, 3, 6>(s, pa, live);
+  return pipe_ring_launch<T, 16, 2, 6>(s, pa, live);
+}
+int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx> &pa, bool live) { return pipe_step_ring_C<cplx>(s, pa, live); }
+int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx32> &pa, bool live) { return pipe_step_ring_C<cplx32>(s, pa, live); }
 
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);

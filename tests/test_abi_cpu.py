@@ -542,7 +542,10 @@ def test_host_patch_order_of_2d_grid_stencils(eu):
     assert eu.host_patch_order(g3)[0] is None
     short = sp.diags([1.0] * 5, [-40, -1, 0, 1, 40], shape=(40 * 900, 40 * 900), format="csr")      # grid rows shorter than 64 cells
     assert eu.host_patch_order(short)[0] is None
-    assert eu.host_patch_order(pure, np.complex128)[0] is None       # the complex element types keep their natural ordering
+    permc, cntc, infoc = eu.host_patch_order(pure, np.complex128)      # ComplexF64: tiles of 256 rows = 16 x 16 patches
+    assert infoc["patch_form"] and infoc["tiles"] == (n + 255) // 256 and sorted(permc.tolist()) == list(range(n))
+    rc = rings(pure, permc, 256)
+    assert np.array_equal(rc, cntc) and rc.max() <= 128 and 55 < infoc["mean_ring"] < 80, (rc.max(), infoc)
     assert eu.host_patch_order(sp.csr_matrix((0, 0)))[0] is None
 
 

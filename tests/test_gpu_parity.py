@@ -1181,6 +1181,71 @@ def test_banded_operator_without_a_diagonal_form_runs_on_tile_local_columns(eu, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["schroedinger_c128", "complex_grid_c128", "complex_grid_c64", "complex_banded_c128", "complex_mesh_c128"])
+def test_patch_form_complex_element_types(eu, case):
+    """The patch form for the complex element types (tiles of 256 ComplexF64 / 512 ComplexF32 rows = 16 x 16 / 16 x 32 patches): the
+    only single-pass form they have beyond 8 full diagonals.  A Schroedinger-type problem -- a REAL symmetric 2-D grid operator, a
+    complex vector and an imaginary time (T = promote(eltype A, eltype b), Lanczos with complex t: krylov_phiv.jl:252-280) --, a
+    complex non-Hermitian grid stencil (Arnoldi, windows up to 15), its ComplexF32 version, a complex banded operator with ten offsets
+    (own ordering) and a complex mesh numbered at random; H, expv!, the whole call and the error-estimate mode against the oracle."""
+    rng = np.random.default_rng(43)
+    T = np.complex64 if case == "complex_grid_c64" else np.complex128
+    tol = 2e-5 if T == np.complex64 else TOL
+    k, rows = 180, 150
+    n = k * rows
+    herm = False
+    t = 0.7
+    if case == "schroedinger_c128":
+        pot = 0.3 * rng.random(n)
+        A0 = sp.diags([np.full(n - k, 1.0), np.full(n - 1, 1.0), -4.0 + pot, np.full(n - 1, 1.0), np.full(n - k, 1.0)], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+        herm, t, m = True, -0.6j, 28
+    elif case in ("complex_grid_c128", "complex_grid_c64"):
+        A0 = (sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr") * (1 + 0.25j)).tocsr()
+        m = 14
+    elif case == "complex_banded_c128":
+        offs = [-8, -6, -5, -3, -1, 0, 1, 2, 4, 7]
+        A0 = sp.diags([(0.1 + 0.05 * rng.random(n - abs(o))) * (1 if o else -6.0) * (1 + 0.3j) for o in offs], offs, shape=(n, n), format="csr")
+        m = 12
+    else:
+        i = np.arange(n)
+        parts = []
+        for dr, dc in [(0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)]:
+            r, c = i // k + dr, i % k + dc
+            ok = (r >= 0) & (r < rows) & (c >= 0) & (c < k)
+            v = ((-3.0 if (dr, dc) == (0, 0) else 0.6) + 0.2 * rng.standard_normal(n)) * (1 - 0.2j)
+            parts.append(sp.csr_matrix((v[ok], (i[ok], (r * k + c)[ok])), shape=(n, n)))
+        q = rng.permutation(n)
+        A0 = sum(parts).tocsr()[q][:, q].tocsr()
+        A0.sort_indices()
+        m = 13
+    A = A0.astype(T if case != "schroedinger_c128" else np.float64)
+    b = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(T)
+    A128, b128 = A.astype(np.complex128), b.astype(np.complex128)
+    ctx = eu.Context()
+    op = eu.MIOperator(A.astype(T), ctx)          # (the Schroedinger case: the operator in the vectors' element type, as the front end would)
+    assert op.patch_info["patch_form"], op.patch_info
+    assert op.reorder_info["reordered"] == (case != "complex_banded_c128"), op.reorder_info
+    w = np.asarray(eu.expv(t, op, b, m=m, ishermitian=herm)).astype(np.complex128)
+    path = eu.expv.last_stats["path"]
+    assert "patch" in path and "pipeline" in path, path
+    close(w, ko.expv(t, A128, b128, m=m, ishermitian=herm), tol, "patch form, %s: expv vs oracle" % case)
+    Ks = eu.KrylovSubspace(T, np.float32 if (herm and T == np.complex64) else (np.float64 if herm else T), n, m, 0, ctx)
+    eu.arnoldi_(Ks, op, b, m=m, ishermitian=herm)
+    Ko = ko.arnoldi(A128, b128, m=m, ishermitian=herm)
+    close(np.asarray(Ks.getH()).astype(np.complex128), Ko.getH(), tol, "patch form, %s: H vs oracle" % case, mat=True)
+    close(np.asarray(eu.expv_(np.empty(n, dtype=T), t, Ks)).astype(np.complex128), ko.expv_(np.empty(n, dtype=np.complex128), t, Ko), tol,
+          "patch form, %s: expv! vs oracle" % case)
+    ctx2 = eu.Context()
+    ctx2.set_option("patch", 0)
+    w0 = np.asarray(eu.expv(t, eu.MIOperator(A.astype(T), ctx2), b, m=m, ishermitian=herm)).astype(np.complex128)
+    assert "patch" not in eu.expv.last_stats["path"]
+    close(w, w0, 10 * tol, "patch form, %s: == the natural-ordering path" % case)
+    if case == "schroedinger_c128":
+        we = eu.expv(t, op, b, m=30, mode="error_estimate", rtol=1e-9)
+        close(we, ko.expv(t, A128, b128, m=30, mode="error_estimate", rtol=1e-9), 1e-11, "patch form, Schroedinger: error-estimate mode vs oracle")
+
+
+@pytest.mark.gpu
 def test_patch_form_drivers(eu):
     """The drivers on an operator stored in the grid-patch ordering: lanczos! and the error-estimate mode on a symmetric stencil
     (window 2 on the patch form), adaptive phiv_timestep! and kiops (augmented operator: the two-kernel step on the stored ordering),
