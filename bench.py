@@ -587,6 +587,32 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         sec[key10] = e
         del op10
     del A10
+    # (3b5) a Schroedinger-type problem: real symmetric 5-point grid operator + potential, COMPLEX vector, imaginary time -- the Krylov
+    # quantities are ComplexF64 (T = promote(eltype A, eltype b), arnoldi.jl:163), the iteration is Lanczos with complex t
+    # (krylov_phiv.jl:252-280).  Round 4: patch form for the complex element types (tiles of 256 rows = 16 x 16 patches); before (and
+    # with patch = 0): two-kernel step.  Contract: Lanczos, s = 16.
+    ks_ = int(round(np.sqrt(n)))
+    if ks_ * ks_ == n:
+        rgs = np.random.default_rng(29)
+        As_ = sp.diags([np.full(n - ks_, 1.0), np.full(n - 1, 1.0), -4.0 + 0.3 * rgs.random(n), np.full(n - 1, 1.0), np.full(n - ks_, 1.0)],
+                       [-ks_, -1, 0, 1, ks_], shape=(n, n), format="csr").astype(np.complex128)
+        bs_ = torch.as_tensor(rgs.standard_normal(n) + 1j * rgs.standard_normal(n), device=env.device)
+        ws_ = torch.empty_like(bs_)
+        ABs = As_.nnz * (16 + 4) + 4 * (n + 1)
+        balg_s = m * (ABs + 16 * n * 4) + 16 * n * (m + 3)
+        for keys_, patchs_ in (("schroedinger_grid_complex", 1), ("schroedinger_grid_complex_two_kernel", 0)):
+            ctx.set_option("patch", patchs_)
+            ops_ = eu.MIOperator(As_, ctx)
+            ctx.set_option("patch", 1)
+            fs_ = lambda: eu.expv(-0.6j, ops_, bs_, m=m, ishermitian=True, out=ws_)
+            fs_()
+            env.sync()
+            e = entry("expv(-0.6im, A, b): real symmetric 5-point grid operator with a potential, complex vector (ComplexF64 Lanczos), patch = %d, n=%d m=%d; "
+                      "contract: Lanczos with s = 16" % (patchs_, n, m), timed(fs_, max(5, args.steps // 2), 1, env.sync), m, balg_s)
+            e["path"] = list(eu.expv.last_stats["path"])
+            sec[keys_] = e
+            del ops_
+        del As_, bs_, ws_
     # (3c) general sparse operators: no band, no diagonals to exploit.  Regular rows with random columns and
     # with local columns, and irregular (power-law) rows; each result is checked against scipy's expm_multiply (a different
     # algorithm: converged regime, bar 1e-9), so a fast wrong answer cannot hide here.
