@@ -551,7 +551,7 @@ struct ArnoldiCall {
         //  indices come from L2.  Every element type: for the complex ones it is the only single-pass form beyond 8 diagonals)
         if ((!use_pipe || !have_dia) && op.ring_pad > 0 && c->opt.patch && use_fused && single_red && !no_pipe && op.sell_cut == 0 &&
             wstep <= dev::pipe_max_window<T>() && m + 2 <= dev::PIPE_MAX_STEPS &&
-            (!isaug || (std::is_same<T, double>::value && p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7))) {      // augmented (kiops): the two small-window variants
+            (!isaug || (!dtype_is_32bit(ks.dtypeT) && p <= dev::PIPE_AUG_MAX && std::min(m, iopw) <= 7))) {      // augmented (kiops): the two small-window variants of the 64-bit types
           use_pipe = true;
           use_ring = true;
         }

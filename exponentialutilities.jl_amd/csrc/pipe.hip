@@ -1647,7 +1647,13 @@ static int pipe_step_ring_C(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
   if (pipe_variant(pa.und) == 0) return pipe_ring_launch<T, 8, 3, 6>(s, pa, live);
   return pipe_ring_launch<T, 16, 2, 6>(s, pa, live);
 }
-int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx> &pa, bool live) { return pipe_step_ring_C<cplx>(s, pa, live); }
+int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx> &pa, bool live) {
+  if (pa.aug_p > 0) {      // augmented operator (kiops with complex operands: this build's extension), windows <= 7
+    if (pa.und <= 3) return pipe_ring_launch<cplx, 4, 4, 6, true>(s, pa, live);
+    return pipe_ring_launch<cplx, 8, 3, 6, true>(s, pa, live);
+  }
+  return pipe_step_ring_C<cplx>(s, pa, live);
+}
 int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx32> &pa, bool live) { return pipe_step_ring_C<cplx32>(s, pa, live); }
 
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched

@@ -1240,6 +1240,11 @@ def test_patch_form_complex_element_types(eu, case):
     w0 = np.asarray(eu.expv(t, eu.MIOperator(A.astype(T), ctx2), b, m=m, ishermitian=herm)).astype(np.complex128)
     assert "patch" not in eu.expv.last_stats["path"]
     close(w, w0, 10 * tol, "patch form, %s: == the natural-ordering path" % case)
+    if case == "complex_grid_c128":      # kiops with complex operands (this build's extension): the augmented operator on the patch form
+        wk, sk = eu.kiops(0.8, op, b, allow_complex=True, ishermitian=False)
+        wko, sko = ko.kiops(0.8, A128, b128, allow_complex=True, ishermitian=False)
+        assert tuple(sk) == tuple(sko), (sk, sko)
+        close(wk, wko, 1e-10, "patch form, complex grid: kiops vs oracle")
     if case == "schroedinger_c128":
         we = eu.expv(t, op, b, m=30, mode="error_estimate", rtol=1e-9)
         close(we, ko.expv(t, A128, b128, m=30, mode="error_estimate", rtol=1e-9), 1e-11, "patch form, Schroedinger: error-estimate mode vs oracle")
