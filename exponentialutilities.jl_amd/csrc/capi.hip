@@ -626,6 +626,8 @@ template <class V>
 static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &perm, const std::vector<int32_t> &src, std::vector<int32_t> &rp,
                               std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> &rp2, std::vector<int32_t> &ci2, int64_t bw0, int64_t bw1,
                               std::chrono::steady_clock::time_point t0);
+// widest band (rows) an operator takes the patch form in its own ordering with: an eighth of a tile (ring <= a quarter of the tile's rows)
+static inline int64_t banded_ring_max(int value_bytes) { return (int64_t)(16 / value_bytes) * dev::BLOCK / 8; }
 template <class V>
 static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0);
 // Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
@@ -643,7 +645,7 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   const bool candidate = c0.cls == 1 || (c0.cls == 2 && !c0.dia && c0.reach > 4096);
   if (mode == 1 && !candidate) return;
   // (a banded operator of a complex element type has no halo form on SELL slots, but the patch form in its own ordering: try_banded_ring)
-  if (mode == 1 && op.ctx->opt.patch && P0.sell_ok && !P0.overflow && P0.bandwidth <= dev::PIPE_WMAX) return;
+  if (mode == 1 && op.ctx->opt.patch && P0.sell_ok && !P0.overflow && P0.bandwidth <= banded_ring_max((int)sizeof(V))) return;
   // (a level wider than the reach the wave form can use cannot lead anywhere: give up after the first breadth-first searches)
   const int64_t trw = (int64_t)(16 / sizeof(V)) * dev::BLOCK;
   const int64_t useful = std::max<int64_t>(98 * trw, (n + trw - 1) / trw <= 400 ? n : 0);
@@ -915,6 +917,7 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
   install_row_order<V>(op, n, pl.perm, pl.src, rp, ci, va, pl.rp2, pl.ci2, pl.bw0, pl.bw1, t0);
   return true;
 }
+// Banded operators wider than the halo form's 8 rows (up to 64) ran the wave form; the patch form in their own ordering replaces it.
 // Banded operators that have no diagonal form (more than 8 distinct offsets, or too much fill) run the halo form on SELL slots, whose
 // 4 bytes of column index per entry are HBM traffic.  The patch form does the same job with the halo as its "ring" (2 w rows per
 // tile) and column indices that are positions in the tile -- equal for all interior slices, stored once, read from L2.  No
@@ -924,7 +927,11 @@ static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, c
   static const bool force = std::getenv("EXPV_MI_RING_BANDED") != nullptr;      // developer A/B: also when a diagonal form exists
   if (!op.ctx->opt.patch || op.ring_pad > 0 || n < 2 || ci.empty()) return false;
   const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
-  if (!P.sell_ok || P.overflow || P.bandwidth > dev::PIPE_WMAX || (P.pipe_dia && !force)) return false;
+  static const int wide_env = std::getenv("EXPV_MI_RING_BAND_MAX") ? std::atoi(std::getenv("EXPV_MI_RING_BAND_MAX")) : -1;      // developer A/B
+  // (beyond the halo form's 8 rows too: a band of up to an eighth of a tile -- 64 rows for fp64: a thin 2-D grid with rows of k < 64
+  //  cells, a block-banded system -- has a ring of <= a quarter of the tile; measured 0.556 (wave form) -> 0.65-0.68: tools/wide_band_ab.py)
+  const int64_t band_max = wide_env >= 0 ? wide_env : banded_ring_max((int)sizeof(V));
+  if (!P.sell_ok || P.overflow || P.bandwidth > band_max || (P.pipe_dia && !force)) return false;
   PatchPlan pl;
   pl.perm.resize((size_t)n);
   std::iota(pl.perm.begin(), pl.perm.end(), 0);

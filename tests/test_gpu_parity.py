@@ -1181,6 +1181,36 @@ def test_banded_operator_without_a_diagonal_form_runs_on_tile_local_columns(eu, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.float32, np.complex128])
+def test_wide_band_operator_in_its_own_ordering_on_the_patch_form(eu, T):
+    """A band wider than the halo form's 8 rows but within 64 -- a thin 2-D grid with rows of 40 cells, coefficients varying -- ran the
+    wave form up to round 3 (the complex types: the two-kernel step).  The patch form takes it in its own ordering (nothing
+    permuted): the ring of a tile is the 2 x 40 rows above and below it.  H, expv and a short window against the oracle."""
+    rng = np.random.default_rng(47)
+    cplx = np.dtype(T).kind == "c"
+    k = 30 if cplx else 40                 # (the band may be an eighth of a tile: 64 rows for Float64, 32 for ComplexF64)
+    n, m = k * 2600 + 17, 14
+    d = [(0.3 + 0.1 * rng.random(n - abs(o))) * (-2.0 if o == 0 else 1.0) * ((1 + 0.2j) if cplx else 1.0) for o in (-k, -1, 0, 1, k)]
+    A = sp.diags(d, [-k, -1, 0, 1, k], shape=(n, n), format="csr").astype(T)
+    T64 = np.complex128 if cplx else np.float64
+    A64 = A.astype(T64)
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    b64 = b.astype(T64)
+    tol = 2e-5 if T == np.float32 else TOL
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    pi = op.patch_info
+    assert pi["patch_form"] and not op.reorder_info["reordered"] and 2 * k <= pi["longest_ring"] <= 2 * k + 4, (pi, op.reorder_info)
+    w = np.asarray(eu.expv(0.6, op, b, m=m, ishermitian=False)).astype(T64)
+    assert "patch" in eu.expv.last_stats["path"], eu.expv.last_stats
+    close(w, ko.expv(0.6, A64, b64, m=m, ishermitian=False), tol, "band of 40 rows (%s), own ordering, patch form: expv vs oracle" % np.dtype(T).name)
+    Ks = eu.arnoldi(op, b, m=m, ishermitian=False)
+    close(np.asarray(Ks.getH()).astype(T64), ko.arnoldi(A64, b64, m=m, ishermitian=False).getH(), tol, "band of 40 rows (%s): H vs oracle" % np.dtype(T).name, mat=True)
+    close(np.asarray(eu.expv(0.6, op, b, m=m, iop=2, ishermitian=False)).astype(T64), ko.expv(0.6, A64, b64, m=m, iop=2, ishermitian=False), 10 * tol,
+          "band of 40 rows (%s): expv with iop = 2 vs oracle" % np.dtype(T).name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["schroedinger_c128", "complex_grid_c128", "complex_grid_c64", "complex_banded_c128", "complex_mesh_c128"])
 def test_patch_form_complex_element_types(eu, case):
     """The patch form for the complex element types (tiles of 256 ComplexF64 / 512 ComplexF32 rows = 16 x 16 / 16 x 32 patches): the
