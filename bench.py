@@ -587,6 +587,23 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
         sec[key10] = e
         del op10
     del A10
+    # (3b4') a band of 40 rows: a thin 2-D grid (rows of 40 cells, offsets -40, -1, 0, 1, 40).  Too wide for the halo form; up to round 3
+    # (and with patch = 0) the wave form; round 4: the patch form in the operator's own ordering (ring = the 80 rows around a tile)
+    A40 = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-40, -1, 0, 1, 40], shape=(n, n), format="csr")
+    for key40, patch40 in (("thin_grid_band40", 1), ("thin_grid_band40_wave_form", 0)):
+        ctx.set_option("patch", patch40)
+        op40 = eu.MIOperator(A40, ctx)
+        ctx.set_option("patch", 1)
+        f40 = lambda: eu.expv(T_FINAL, op40, b, m=m, ishermitian=False, out=w)
+        f40()
+        env.sync()
+        e = entry("expv, thin 2-D grid: offsets (-40,-1,0,1,40), a band of 40 rows, context option patch = %d: %s, n=%d m=%d"
+                  % (patch40, "patch form in the operator's own ordering" if patch40 else "wave form", n, m),
+                  timed(f40, max(5, args.steps // 2), 1, env.sync), m, alg_bytes_expv(n, A40.nnz, m))
+        e["path"] = list(eu.expv.last_stats["path"])
+        sec[key40] = e
+        del op40
+    del A40
     # (3b5) a Schroedinger-type problem: real symmetric 5-point grid operator + potential, COMPLEX vector, imaginary time -- the Krylov
     # quantities are ComplexF64 (T = promote(eltype A, eltype b), arnoldi.jl:163), the iteration is Lanczos with complex t
     # (krylov_phiv.jl:252-280).  Round 4: patch form for the complex element types (tiles of 256 rows = 16 x 16 patches); before (and
