@@ -932,6 +932,10 @@ static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, c
   //  cells, a block-banded system -- has a ring of <= a quarter of the tile; measured 0.556 (wave form) -> 0.65-0.68: tools/wide_band_ab.py)
   const int64_t band_max = wide_env >= 0 ? wide_env : banded_ring_max((int)sizeof(V));
   if (!P.sell_ok || P.overflow || P.bandwidth > band_max || (P.pipe_dia && !force)) return false;
+  // (the tile-local columns are laid out in ascending-column order of a row, the SELL values in the order the rows are STORED: the
+  //  same thing only for rows with strictly ascending columns -- anything else keeps the halo / wave form, whose columns follow the
+  //  stored order.  Reordered operators are rewritten with sorted rows, so the question does not arise for them.)
+  if (!P.sorted_unique) return false;
   PatchPlan pl;
   pl.perm.resize((size_t)n);
   std::iota(pl.perm.begin(), pl.perm.end(), 0);

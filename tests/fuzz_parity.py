@@ -19,7 +19,7 @@ eu = expv_mi_loader.load()
 
 
 def make_operator(rng, n, cplx):
-    kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense", "grid2d"])
+    kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense", "grid2d", "wide_band"])
     def vals(shape, scale):
         v = rng.standard_normal(shape) * scale
         return v + 1j * rng.standard_normal(shape) * scale if cplx else v
@@ -58,6 +58,17 @@ def make_operator(rng, n, cplx):
             q = rng.permutation(n)
             A = A[q][:, q].tocsr()
             A.sort_indices()
+    elif kind == "wide_band":
+        # a band of 9 .. 140 rows (thin grids, block-banded systems): up to an eighth of a tile the patch form in the operator's own ordering,
+        # beyond it the wave form / mesh patches / the two-kernel step
+        w = int(rng.integers(9, 141))
+        n = max(n, 3 * w + 5)
+        offs = sorted(set([0, -w if rng.random() < 0.8 else w] + [int(o) for o in rng.integers(-w, w + 1, size=int(rng.integers(1, 10)))]))
+        d = [vals(n - abs(o), 0.3 / np.sqrt(len(offs))) for o in offs]
+        A = sp.diags(d, offs, shape=(n, n), format="csr") - 0.5 * sp.identity(n, format="csr")
+        if rng.random() < 0.25:
+            A = ((A + A.conj().T) * 0.5).tocsr()
+            kind = "wide_band_symmetric"
     elif kind == "wide_diagonals":
         nd = int(rng.integers(2, 7))
         offs = sorted(set([0] + [int(o) for o in rng.integers(-(n - 1), n, size=nd)]))
@@ -137,7 +148,7 @@ def one_case(seed, index, verbose=False):
     tq = float(rng.choice([0.7, 0.7, 0.7, -0.4, 1e-8, 0.0, 3.0]))      # the time of the plain calls
     m = int(rng.integers(1, 41))
     iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
-    herm = kind in ("symmetric_banded", "hermitian_dense", "grid2d_symmetric") and bool(rng.integers(0, 2))
+    herm = kind in ("symmetric_banded", "hermitian_dense", "grid2d_symmetric", "wide_band_symmetric") and bool(rng.integers(0, 2))
     call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate",
                        "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct", "async_device", "caches"])
     ortho = str(rng.choice(["lowsync", "mgs"]))

@@ -1181,6 +1181,52 @@ def test_banded_operator_without_a_diagonal_form_runs_on_tile_local_columns(eu, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["ten_offsets", "band40", "grid"])
+def test_rows_stored_out_of_order_or_with_repeated_entries_through_the_c_abi(eu, pattern):
+    """expv_mi_op_create_csr takes rows as they are: columns in any order, an entry given twice (its values add up, as in
+    SparseArrays' mul!).  The Python front end always sorts, so this goes through the C ABI: the same matrix with every row's entries
+    reversed and one entry per row split in two must give the results of the tidy one -- whichever storage form and ordering creation
+    picks for it (tile-local columns are only built for rows with strictly ascending columns; reordered operators are rewritten)."""
+    import ctypes as C
+    from exponentialutilities_jl_amd import _lib as L
+    rng = np.random.default_rng(53)
+    k = 96
+    n = k * 700
+    offs = {"ten_offsets": [-8, -6, -5, -3, -1, 0, 1, 2, 4, 7], "band40": [-40, -1, 0, 1, 40], "grid": [-k, -1, 0, 1, k]}[pattern]
+    A = sp.diags([(0.2 + 0.1 * rng.random(n - abs(o))) * (-2.0 if o == 0 else 1.0) for o in offs], offs, shape=(n, n), format="csr")
+    A.sort_indices()
+    b = rng.standard_normal(n)
+    ctx = eu.Context()
+    want = np.asarray(eu.expv(0.5, eu.MIOperator(A, ctx), b, m=18, ishermitian=False))
+    close(want, ko.expv(0.5, A, b, m=18, ishermitian=False), TOL, "tidy rows (%s): expv vs oracle" % pattern)
+    # every row reversed; the row's first entry split into two halves at both ends of the row
+    ip, ix, vv = [0], [], []
+    for r in range(n):
+        c = A.indices[A.indptr[r]:A.indptr[r + 1]][::-1]
+        v = A.data[A.indptr[r]:A.indptr[r + 1]][::-1]
+        ix.extend([c[0]] + list(c[1:]) + [c[0]])
+        vv.extend([0.25 * v[0]] + list(v[1:]) + [0.75 * v[0]])
+        ip.append(len(ix))
+    ip, ix, vv = np.asarray(ip, dtype=np.int32), np.asarray(ix, dtype=np.int32), np.asarray(vv, dtype=np.float64)
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.expv_mi_op_create_csr(ctx._h, L.F64, n, ip.ctypes.data, ix.ctypes.data, vv.ctypes.data, 4, 0, C.byref(h)) == 0
+    try:
+        w = np.empty(n)
+        o = L.ArnoldiOpts()
+        lib.expv_mi_arnoldi_opts_default(C.byref(o))
+        o.m, o.ishermitian = 18, 0
+        st = L.ExpvStats()
+        assert lib.expv_mi_expv(ctx._h, h, 0.5, 0.0, b.ctypes.data, L.HOST, w.ctypes.data, L.HOST, L.F64, C.byref(o), C.byref(st)) == 0
+        close(w, want, 1e-13, "rows reversed + a repeated entry (%s): expv == the tidy matrix" % pattern)
+        y = np.empty(n)
+        assert lib.expv_mi_op_apply(h, b.ctypes.data, L.HOST, y.ctypes.data, L.HOST) == 0
+        close(y, A @ b, 1e-14, "rows reversed + a repeated entry (%s): mul!" % pattern)
+    finally:
+        lib.expv_mi_op_destroy(h)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("T", [np.float64, np.float32, np.complex128])
 def test_wide_band_operator_in_its_own_ordering_on_the_patch_form(eu, T):
     """A band wider than the halo form's 8 rows but within 64 -- a thin 2-D grid with rows of 40 cells, coefficients varying -- ran the
