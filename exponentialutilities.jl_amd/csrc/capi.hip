@@ -323,6 +323,21 @@ static PatternPlan analyze_pattern(int64_t n, const int32_t *rp, const int32_t *
   return P;
 }
 
+// The analysis of the CSR arrays an operator is being built from, computed once per state of the arrays (operator creation asks for it
+// in several places; the arrays only ever change by being swapped for reordered ones, so their addresses identify the state).
+struct PatternCache {
+  const int32_t *rp = nullptr, *ci = nullptr;
+  int64_t nnz = -1;
+  PatternPlan P;
+  const PatternPlan &get(int64_t n, const std::vector<int32_t> &rpv, const std::vector<int32_t> &civ, int value_bytes) {
+    if (rp != rpv.data() || ci != civ.data() || nnz != (int64_t)civ.size()) {
+      P = analyze_pattern(n, rpv.data(), civ.data(), (int64_t)civ.size(), value_bytes);
+      rp = rpv.data(); ci = civ.data(); nnz = (int64_t)civ.size();
+    }
+    return P;
+  }
+};
+
 // SELL-C-sigma (sigma = 1: no row sorting) with C = 128 rows (fp64) / 64 rows (complex): slot-major
 // inside a slice so one wave reads 1 KiB of values per slot.  Built only when padding stays small.
 template <class V>
@@ -633,11 +648,11 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
 // Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
 // On return rp / ci / va hold P A P' and op.perm the ordering; op.csc_pos maps the caller's entries to the reordered CSR arrays.
 template <class V>
-static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va) {
+static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, PatternCache &pc) {
   const int mode = op.ctx->opt.reorder;
   if (mode == 0 || n < 2 || ci.empty()) return;
   const auto t0 = std::chrono::steady_clock::now();
-  const PatternPlan P0 = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  const PatternPlan P0 = pc.get(n, rp, ci, (int)sizeof(V));
   const PatClass c0 = pattern_class_ex(P0, n, op.dtype);
   // worth a try: the two-kernel step, or the wave form on SELL slots whose columns reach far (every tile then waits for many
   // others).  Not: the halo form, diagonals of a structured grid in its natural ordering, irregular rows (an ordering does not
@@ -704,6 +719,10 @@ static bool detect_grid2d(const PatternPlan &P, int64_t n, int64_t *k_out) {
   if (k < 64 || n < 8 * k) return false;
   *k_out = k;
   return true;
+}
+static bool detect_grid2d_quick(const PatternPlan &P, int64_t n) {
+  int64_t k = 0;
+  return detect_grid2d(P, n, &k);
 }
 static std::vector<int32_t> patch_order(int64_t n, int64_t k, int64_t R, int64_t TR) {
   const int64_t grows = (n + k - 1) / k;
@@ -923,10 +942,9 @@ static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::ve
 // tile) and column indices that are positions in the tile -- equal for all interior slices, stored once, read from L2.  No
 // permutation: the plan is made for the operator as it is (natural ordering, or what reverse Cuthill-McKee left).
 template <class V>
-static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci) {
+static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, const PatternPlan &P) {
   static const bool force = std::getenv("EXPV_MI_RING_BANDED") != nullptr;      // developer A/B: also when a diagonal form exists
   if (!op.ctx->opt.patch || op.ring_pad > 0 || n < 2 || ci.empty()) return false;
-  const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
   static const int wide_env = std::getenv("EXPV_MI_RING_BAND_MAX") ? std::atoi(std::getenv("EXPV_MI_RING_BAND_MAX")) : -1;      // developer A/B
   // (beyond the halo form's 8 rows too: a band of up to an eighth of a tile -- 64 rows for fp64: a thin 2-D grid with rows of k < 64
   //  cells, a block-banded system -- has a ring of <= a quarter of the tile; measured 0.556 (wave form) -> 0.65-0.68: tools/wide_band_ab.py)
@@ -979,17 +997,18 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   op.nnz = (int64_t)ci.size();
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);      // (both invariant under a symmetric permutation)
   lap("ishermitian + opnorm");
-  maybe_reorder<V>(op, n, rp, ci, va);
+  PatternCache pc;
+  maybe_reorder<V>(op, n, rp, ci, va, pc);
   lap("reordering (RCM)");
-  (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
+  if (detect_grid2d_quick(pc.get(n, rp, ci, (int)sizeof(V)), n)) (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
   lap("grid-patch ordering");
-  (void)try_banded_ring<V>(op, n, rp, ci);
+  (void)try_banded_ring<V>(op, n, rp, ci, pc.get(n, rp, ci, (int)sizeof(V)));
   lap("tile-local columns of a banded operator");
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size(), ci.data());
   lap("SELL layout");
-  const PatternPlan P = analyze_pattern(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V));
+  const PatternPlan P = pc.get(n, rp, ci, (int)sizeof(V));
   op.rows_sorted_unique = P.sorted_unique;
   op.bandwidth = P.bandwidth;      // max |col - row|
   lap("pattern analysis");
