@@ -214,7 +214,12 @@ def one_case(seed, index, verbose=False):
         brk = md < min(m, n) or md == n      # happy breakdown: column md + 1 of V and H[md + 1, md] are rounding noise
         Hsub = np.abs(np.diag(np.asarray(Ko.getH()), -1))
         near_tol = Ks.m != Ko.m and min(Ks.m, Ko.m) - 1 < len(Hsub) and Hsub[min(Ks.m, Ko.m) - 1] < 1e-5
-        if not single and Ks.m != Ko.m and not near_tol:      # (a residual within 100x of the breakdown tolerance may fall either side of it)
+        if float(Ks.beta) == 0.0 or float(Ko.beta) == 0.0:
+            # zero starting vector: firststep! leaves V UNINITIALISED (arnoldi.jl:230-250) -- only beta and H == 0 are defined
+            # (seed 31337 case 11086: the basis of a recycled subspace held the previous call's columns)
+            err = 0.0 if (float(Ks.beta) == float(Ko.beta) == 0.0 and not np.any(np.asarray(Ks.getH()))) else float("inf")
+            extra["zero_starting_vector"] = True
+        elif not single and Ks.m != Ko.m and not near_tol:      # (a residual within 100x of the breakdown tolerance may fall either side of it)
             err = float("inf")
         elif Ks.m != Ko.m and not np.isfinite(np.asarray(Ks.getH())).all():
             err = float("inf")
