@@ -37,6 +37,107 @@ C2_VALS = (0.3, 1.2, -2.0, 0.8, -0.1)          # non-symmetric  -> Arnoldi path 
 C2_SYM_VALS = (0.5, 1.0, -3.0, 1.0, 0.5)       # symmetric      -> Lanczos path
 
 
+LINE_LIMIT = 4000     # the driver keeps the tail of stdout: the LAST line must fit (<= 4 KB)
+
+
+def _r(x, sig=9):
+    """floats to `sig` significant digits (value / ms_per_step stay consistent to 1e-8), containers recursively"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if np.isfinite(x) else None
+    if isinstance(x, (np.floating,)):
+        return _r(float(x), sig)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The one line the driver parses: headline keys, a flat config, a flat roofline, a flat cpu_baseline.  Everything else
+    (per-kernel tables, the secondary entries with their prose) goes to bench_full.json and to an earlier 'FULL ' line."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    c = {k: out[k] for k in head if k in out}
+    cfg = {}
+    for k, v in (out.get("config") or {}).items():
+        if isinstance(v, str):
+            cfg[k] = v if len(v) <= 240 else v[:237] + "..."
+        elif isinstance(v, (int, float, bool, type(None), np.integer, np.floating)):
+            cfg[k] = v
+        elif k == "path" and isinstance(v, (list, tuple)):
+            cfg[k] = list(v)
+        elif k == "split_api_sync_outputs" and isinstance(v, dict):
+            cfg[k] = {q: v.get(q) for q in ("value", "frac", "ms_per_call")}
+        elif k == "secondary_fracs" and isinstance(v, dict):
+            cfg[k] = {q: (float("%.3g" % z) if isinstance(z, float) else z) for q, z in v.items()}
+    c["config"] = cfg
+    for k in ("ranks_seen", "devices", "process_group", "standin"):
+        if k in out:
+            c[k] = out[k]
+    if "per_rank_ms_per_step" in out:
+        c["per_rank_ms_per_step"] = [float("%.5g" % v) for v in out["per_rank_ms_per_step"]]
+    for k in ("gather", "verified", "collectives_per_call", "applications_per_call"):      # (c5 / c3 lines: small dicts / scalars)
+        v = out.get(k)
+        if isinstance(v, dict):
+            c[k] = {q: z for q, z in v.items() if isinstance(z, (int, float, bool, type(None))) or (isinstance(z, str) and len(z) <= 80)}
+        elif v is not None:
+            c[k] = v
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms",
+                                    "alg_bytes_per_launch", "expv_frac") if k in r}
+        if isinstance(rr.get("traffic_source"), str) and len(rr["traffic_source"]) > 80:
+            rr["traffic_source"] = rr["traffic_source"][:77] + "..."
+        if isinstance(r.get("serial"), dict):
+            rr["serial"] = {k: r["serial"].get(k) for k in ("frac", "avg_launch_ms")}
+        c["roofline"] = rr
+    b = out.get("cpu_baseline")
+    if isinstance(b, dict):
+        bb = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "sample") if k in b}
+        if isinstance(bb.get("sample"), str) and len(bb["sample"]) > 120:
+            bb["sample"] = bb["sample"][:117] + "..."
+        if "parity_rel_err_w" in b:
+            bb["parity"] = b["parity_rel_err_w"]
+        if isinstance(b.get("one_thread"), dict):
+            bb["one_thread"] = {"value": b["one_thread"].get("value")}
+        if isinstance(b.get("by_threads"), dict):
+            bb["by_threads"] = {k: float("%.4g" % v) for k, v in b["by_threads"].items()}
+        c["cpu_baseline"] = bb
+    c["full"] = "bench_full.json"
+    c = _r(c)
+    line = json.dumps(c, separators=(",", ":"))
+    # belt and braces: shed the optional parts, least important first, until the line fits
+    for victim in (("config", "secondary_fracs_minmax"), ("per_rank_ms_per_step",), ("devices",), ("cpu_baseline", "by_threads"),
+                   ("config", "path"), ("config", "secondary_fracs")):
+        if len(line) <= LINE_LIMIT:
+            break
+        d = c
+        for k in victim[:-1]:
+            d = d.get(k, {})
+        d.pop(victim[-1], None)
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:
+        raise SystemExit("bench.py: the result line is %d characters (limit %d): the driver could not parse it" % (len(line), LINE_LIMIT))
+    return line
+
+
+def emit(out):
+    """full record -> bench_full.json (+ gpurun_out/ when present) and an earlier 'FULL ' stdout line; compact record LAST"""
+    full = json.dumps(_r(out, 12))
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    print("FULL " + full, flush=True)
+    print(compact_line(out), flush=True)
+
+
 def c2_operator(n, sym=False, dtype=np.float64):
     """constant diagonals at offsets (-2..2)."""
     import scipy.sparse as sp
@@ -249,7 +350,7 @@ def c3_rows(torch, device, n, lo, hi, chunk=4096):
     return rows
 
 
-def run_c3(args, eu, env, emit=True):
+def run_c3(args, eu, env, do_emit=True):
     """BASELINE configs[2]: phiv_timestep, adaptive, K = 4, dense fp64.  n = 2e5 (320 GB) does not fit one MI355X: with
     --gpus >= 2 the rows of A are sharded over the ranks (dist.RowShardedDense: local GEMV + one all-gather of the n-vector per
     operator application, the Krylov iteration replicated); at --gpus 1 the largest n that fits is used unless --n3 says
@@ -308,12 +409,12 @@ def run_c3(args, eu, env, emit=True):
         out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
     if not same:
         raise SystemExit("config 3: the replicated iteration differs between ranks")
-    if rank == 0 and emit:
-        print(json.dumps(out), flush=True)
+    if rank == 0 and do_emit:
+        emit(out)
     return out
 
 
-def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True, dtype=np.float64):
+def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, do_emit=True, dtype=np.float64):
     """BASELINE configs[4]: nprob independent expv problems (n = 1e5, C2 diagonals scaled per problem, m = 30), problems
     sharded over the ranks, one final gather of the results.  After the timed region two random columns
     of the gathered result are recomputed on this rank through the single-problem entry point and compared."""
@@ -388,8 +489,8 @@ def run_c5(args, eu, env, n=100_000, m=M_KRYLOV, emit=True, dtype=np.float64):
         out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
     if worst_all > bar:
         raise SystemExit("config 5: gathered result differs from the recomputed columns: %.3e" % worst_all)
-    if rank == 0 and emit:
-        print(json.dumps(out), flush=True)
+    if rank == 0 and do_emit:
+        emit(out)
     return out
 
 
@@ -735,14 +836,14 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     del opc, Ac, uc
     # (5) BASELINE configs[4] on ONE GPU: its 1/8 share of the 1024 problems
     a5 = argparse.Namespace(nprob=128, steps=max(2, args.steps // 5), warmup=1)
-    o5 = run_c5(a5, eu, env, emit=False)
+    o5 = run_c5(a5, eu, env, do_emit=False)
     sec["c5_one_gpu_share"] = {"what": "BASELINE configs[4], one GPU's share: 128 independent expv, n=1e5, m=30",
                                "value": o5["value"], "unit": "matvecs/s", "ms_per_call": o5["ms_per_step"],
                                "alg_GBps": o5["roofline"]["achieved"], "frac": o5["roofline"]["frac"],
                                "verified_max_rel_err": o5["verified"]["max_rel_err"]}
     # (5a) the same share in Float32 (BlasFloat, ExponentialUtilities.jl:19): batched single-pass step on 32-bit storage
     a5f = argparse.Namespace(nprob=128, steps=max(2, args.steps // 5), warmup=1)
-    o5f = run_c5(a5f, eu, env, emit=False, dtype=np.float32)
+    o5f = run_c5(a5f, eu, env, do_emit=False, dtype=np.float32)
     sec["c5_float32"] = {"what": "BASELINE configs[4] in Float32, one GPU's share: 128 independent expv, n=1e5, m=30; contract with s = 4",
                          "value": o5f["value"], "unit": "matvecs/s", "ms_per_call": o5f["ms_per_step"],
                          "alg_GBps": o5f["roofline"]["achieved"], "frac": o5f["roofline"]["frac"],
@@ -1108,7 +1209,7 @@ def run_c2(args, eu, env):
         out["standin"] = env.standin
         out["data"] = "stand-in solver on CPU (plumbing test of the launch / sharding / collective code: NOT a measurement)"
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     return out
 
 

@@ -118,7 +118,7 @@ def _c5_worker(rank, world, port, nprob, n, out_dir):
     try:
         env = bench.Env(torch, dist, world, rank, "cpu", None)
         args = argparse.Namespace(nprob=nprob, steps=2, warmup=1)
-        out = bench.run_c5(args, _StubEU, env, n=n, m=10, emit=False)
+        out = bench.run_c5(args, _StubEU, env, n=n, m=10, do_emit=False)
         json.dump(out, open(os.path.join(out_dir, f"c5_{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()
@@ -289,3 +289,38 @@ def test_bench_rank_check_rejects_ranks_sharing_a_device():
     with pytest.raises(SystemExit) as ei:
         _Env(torch, dist, 2, 0, "cpu", None).check_ranks(2)
     assert "distinct" in str(ei.value)
+
+
+def test_bench_result_line_stays_under_4k_for_the_driver():
+    """BENCH_r04.json had `parsed: null` because the one JSON line had grown to 21.7 KB.  The LAST stdout line is
+    now a compact record (headline keys, flat config / roofline / cpu_baseline); the full record goes to bench_full.json.  Checked
+    here on the very record that broke the driver (profiles/r04_bench_final.json) and on an 8-rank worst case."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_final.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert abs(d["value"] - full["value"]) <= 1e-8 * full["value"] and abs(d["value"] - 30 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert "kernels" not in d["roofline"] and "note" not in d["roofline"] and "secondary" not in d
+    assert set(d["config"]["secondary_fracs"]) >= {"lanczos", "c4_kiops_complex", "general_sparse_random"}
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert len(d["cpu_baseline"]["sample"]) <= 120 and len(d["roofline"]["traffic_source"]) <= 80
+    # 8 ranks, twice as many secondaries with long names: the line sheds optional parts instead of growing past the limit
+    big = dict(full, n_gpus=8, ranks_seen=8, devices=["runc/%032d/pci-0:%d.0" % (i, i) for i in range(8)],
+               per_rank_ms_per_step=[1.1153013 + 1e-3 * i for i in range(8)])
+    big["config"] = dict(full["config"])
+    big["config"]["secondary_fracs"] = {("a_rather_long_secondary_entry_name_%03d" % i): 0.123456 for i in range(120)}
+    line8 = bench.compact_line(big)
+    assert len(line8) < 4096
+    d8 = json.loads(line8)
+    assert d8["n_gpus"] == 8 and d8["roofline"]["frac"] == d["roofline"]["frac"] and "cpu_baseline" in d8

@@ -1328,16 +1328,24 @@ def test_bench_line_contract():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-secondary"],
-                       cwd=root, capture_output=True, text=True, timeout=900)
+    # the command the driver runs, secondaries ON: the LAST stdout line is the record and must stay < 4 KB
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       cwd=root, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    d = json.loads(lines[0])
+    out_lines = [l for l in p.stdout.splitlines() if l.strip()]
+    last = out_lines[-1]
+    assert len(last) < 4096, len(last)
+    lines = [l for l in out_lines if l.startswith("{")]
+    assert len(lines) == 1 and lines[0] is last, p.stdout[-2000:]
+    d = json.loads(last)
+    assert len(d["config"]["secondary_fracs"]) >= 30          # the flat {name: frac} map travels in the line ...
+    full = json.load(open(os.path.join(root, "bench_full.json")))
+    assert "secondary" in full and "kernels" in full["roofline"]          # ... the prose and the per-kernel tables in the side file
+    assert full["value"] == pytest.approx(d["value"], rel=1e-8)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f64" and d["unit"] == "matvecs/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["unit"] == "matvecs/s"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
     assert abs(d["value"] - 30 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
