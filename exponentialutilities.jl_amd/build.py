@@ -59,7 +59,27 @@ def build(force=False, verbose=True):
                 print(warn)
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    _prune(objdir, objs, srcs, headers, verbose)
     return LIB
+
+
+def _prune(objdir, objs, srcs, headers, verbose):
+    """Delete every object / library in the package directory that this build did not produce: experiment leftovers
+    (variant objects, A/B libraries) would otherwise travel to the GPU box and could be loaded by accident.  The trace
+    library (tools only) survives while it is newer than every source."""
+    keep = {os.path.abspath(o) for o in objs} | {os.path.abspath(LIB)}
+    trace_so, trace_o = os.path.join(HERE, "libexpv_mi_trace.so"), os.path.join(objdir, "pipe_trace.o")
+    deps = [os.path.join(CSRC, s) for s in srcs] + headers
+    if os.path.exists(trace_so) and not _stale(trace_so, deps):
+        keep |= {os.path.abspath(trace_so), os.path.abspath(trace_o)}
+    for d in (HERE, objdir):
+        for f in os.listdir(d):
+            path = os.path.abspath(os.path.join(d, f))
+            artefact = f.endswith((".o", ".so", ".a", ".hsaco", ".co")) or ".o." in f or ".so." in f
+            if os.path.isfile(path) and artefact and path not in keep:
+                if verbose:
+                    print("[build] removing stale artefact", os.path.relpath(path, HERE), flush=True)
+                os.remove(path)
 
 
 def build_trace(verbose=True):
