@@ -833,7 +833,58 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
               alg_bytes_kiops(n, nnz, spc, acc_r, j_acc_r, s=8), stats=list(st_r["st"]), krylov_steps_per_call=spc)
     e["unit"] = "Krylov steps/s"
     sec["kiops_real"] = e
+    # (4b) full Arnoldi on a COMPLEX operator at the default m = 30 (windows up to 29 + the closing pass's 30 columns): the C2
+    # pattern x (1 + 0.25i), complex b -- the shape of the reference's own GPU test (test/gpu/gputests.jl:41-58: ComplexF64 operator,
+    # expv(t, A_gpu, b) at default m).  Up to round 4 the single-pass step took complex windows <= 15, so this ran the two-kernel
+    # step throughout.  Contract with s = 16.
+    wc_ = torch.empty_like(uc)
+    fca = lambda: eu.expv(T_FINAL, opc, uc, m=m, ishermitian=False, out=wc_)
+    fca()
+    env.sync()
+    e = entry("expv(1.0, A, b), C2 pattern x (1+0.25i), ComplexF64, complex b, full Arnoldi m=%d, n=%d; contract with s = 16" % (m, n),
+              timed(fca, max(5, args.steps // 2), 1, env.sync), m, alg_bytes_expv(n, Ac.nnz, m, s=16))
+    e["path"] = list(eu.expv.last_stats["path"])
+    sec["c2_complex_full_arnoldi"] = e
+    del wc_
     del opc, Ac, uc
+    # (4c) the reference's GPU test operator itself, scaled up: A = triu(sprand(ComplexF64, n, n, 10/n), 1) + sprand(ComplexF64, n, n,
+    # 1/n), b = rand(ComplexF64, n), t = 0.1 (gputests.jl:41-52) -- uniformly random columns, no structure: the two-kernel step
+    rgp = np.random.default_rng(41)
+    nz1, nz2 = 10 * n, n
+    r1, c1_ = rgp.integers(0, n, nz1), rgp.integers(0, n, nz1)
+    keep = c1_ > r1
+    Agp = (sp.csr_matrix(((rgp.random(nz1) + 1j * rgp.random(nz1))[keep], (r1[keep], c1_[keep])), shape=(n, n))
+           + sp.csr_matrix((rgp.random(nz2) + 1j * rgp.random(nz2), (rgp.integers(0, n, nz2), rgp.integers(0, n, nz2))), shape=(n, n))).tocsr()
+    Agp.sum_duplicates()
+    opgp = eu.MIOperator(Agp, ctx)
+    bgp = torch.as_tensor(rgp.random(n) + 1j * rgp.random(n), device=env.device)
+    wgp = torch.empty_like(bgp)
+    fgp = lambda: eu.expv(0.1, opgp, bgp, m=m, ishermitian=False, out=wgp)
+    fgp()
+    env.sync()
+    e = entry("expv(0.1, A, b), the operator of the reference's GPU test (triu(sprand(ComplexF64, n, n, 10/n), 1) + sprand(ComplexF64, n, n, 1/n)) "
+              "at n=%d, nnz=%d, m=%d; contract with s = 16" % (n, Agp.nnz, m),
+              timed(fgp, max(3, args.steps // 4), 1, env.sync), m, alg_bytes_expv(n, Agp.nnz, m, s=16))
+    e["path"] = list(eu.expv.last_stats["path"])
+    sec["sprand_complex_gputests_shape"] = e
+    del opgp, Agp, bgp, wgp
+    # (4d) the reference's operator contract (docs/src/interfaces.md:7-36, basictests.jl:786-816): a matrix-free operator -- here a
+    # callback whose mul! is torch's CSR product of the C2 operator on the library's stream.  Modular step: the window is read twice,
+    # extra launches; contract = the stored operator's (the callback's own traffic is what a stored operator's would be)
+    Ac2_ = c2_operator(n)
+    At_ = torch.sparse_csr_tensor(torch.as_tensor(Ac2_.indptr, dtype=torch.int64), torch.as_tensor(Ac2_.indices, dtype=torch.int64),
+                                  torch.as_tensor(Ac2_.data), size=(n, n), device=env.device)
+    mf_ = eu.MIOperator(None, ctx, matvec=lambda x: At_ @ x, shape=(n, n), dtype=np.float64, ishermitian=False)
+    fmf = lambda: eu.expv(T_FINAL, mf_, b, m=m, ishermitian=False, out=w)
+    fmf()
+    env.sync()
+    e = entry("expv(1.0, A, b) through a matrix-free operator (callback: torch CSR product of the C2 operator), n=%d m=%d" % (n, m),
+              timed(fmf, max(5, args.steps // 2), 1, env.sync), m, b_alg)
+    e["path"] = list(eu.expv.last_stats["path"])
+    xm_ = torch.randn(n, dtype=torch.float64, device=env.device)
+    e["callback_matvec_alone_us"] = 1e6 * timed(lambda: At_ @ xm_, 30, 5, env.sync)
+    sec["matrix_free_callback"] = e
+    del mf_, At_, Ac2_
     # (5) BASELINE configs[4] on ONE GPU: its 1/8 share of the 1024 problems
     a5 = argparse.Namespace(nprob=128, steps=max(2, args.steps // 5), warmup=1)
     o5 = run_c5(a5, eu, env, do_emit=False)

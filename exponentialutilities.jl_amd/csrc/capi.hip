@@ -1134,6 +1134,20 @@ void ks_bind_row_order(Ks &ks, Op &op, int init) {
   if (init > 0) ks_set_row_order(ks, op.perm);
   else ks.vperm = op.perm;
 }
+// Scope of one factorisation call on a caller-owned subspace: whatever happens inside (a dimension mismatch, an element-type
+// mismatch, a failed resize -- anything the engine throws before or after touching the basis), the "b is in the caller's
+// ordering" request does not outlive the call, and a FRESH call that failed gives the subspace its previous row ordering back
+// (its rebind was a pointer assignment; the stored basis, if the failure came before the first step, is still in that ordering).
+struct FactorisationScope {
+  Ks &ks;
+  decltype(Ks::vperm) vperm_before;
+  bool fresh, done = false;
+  FactorisationScope(Ks &k, int init) : ks(k), vperm_before(k.vperm), fresh(init == 0) {}
+  ~FactorisationScope() {
+    ks.b_natural = false;
+    if (!done && fresh) ks.vperm = vperm_before;
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -1680,6 +1694,7 @@ int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     DevBuf tmp;
     const void *bd;
+    FactorisationScope scope(*ks, o.init);
     if (op->perm && op->n == ks->n && o.init == 0) {      // b stays in the caller's ordering: the engine gathers it in its first step
       bd = stage_in(ks->ctx, b, b_loc, (size_t)ks->n * dtype_size(ks->dtypeT), tmp);
       ks->b_natural = true;
@@ -1688,7 +1703,7 @@ int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     }
     ks_bind_row_order(*ks, *op, o.init);
     arnoldi_run(*ks, *op, bd, o, nullptr, false);
-    ks->b_natural = false;
+    scope.done = true;
   });
 }
 int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, const expv_mi_arnoldi_opts *opts) {
@@ -1696,9 +1711,11 @@ int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     expv_mi_arnoldi_opts o;
     if (opts) o = *opts; else expv_mi_arnoldi_opts_default(&o);
     DevBuf tmp;
+    FactorisationScope scope(*ks, o.init);
     const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
     ks_bind_row_order(*ks, *op, o.init);
     arnoldi_run(*ks, *op, bd, o, nullptr, true);
+    scope.done = true;
   });
 }
 int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t ldb, int p, int b_loc, const void *w,
@@ -1719,6 +1736,7 @@ int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t
       aug.B = stage_in_2d(ks->ctx, B, b_loc, ks->n, p, ldb, esz, bt, &ldbd);
       aug.w = stage_in(ks->ctx, w, w_loc, (size_t)ks->n * esz, wt);
     }
+    FactorisationScope scope(*ks, o.init);
     ks_bind_row_order(*ks, *op, o.init);
     aug.ldb = ldbd;
     aug.p = p;
@@ -1726,6 +1744,7 @@ int expv_mi_arnoldi_aug(expv_mi_ks_t ks, expv_mi_op_t op, const void *B, int64_t
     aug.t = t;
     aug.mu = mu;
     arnoldi_run(*ks, *op, nullptr, o, &aug, false);
+    scope.done = true;
   });
 }
 
@@ -1771,6 +1790,7 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     ks.skip_tail = true;
     DevBuf tmp;
     const void *bd;
+    FactorisationScope scope(ks, 0);
     if (op->perm) {      // b stays in the caller's ordering: the engine gathers it in its first step
       bd = stage_in(ctx, b, b_loc, (size_t)op->n * dtype_size(op->dtype), tmp);
       ks.b_natural = true;
@@ -1779,6 +1799,7 @@ int expv_mi_expv(expv_mi_ctx_t ctx, expv_mi_op_t op, double t_re, double t_im, c
     }
     ks.vperm = op->perm;      // (expv_eval puts the rows of w back in their natural places)
     const int mv = arnoldi_run(ks, *op, bd, o, nullptr, false);
+    scope.done = true;
     ks.b_natural = false;
     expv_eval(ks, t_re, t_im, w, w_loc, w_dtype);
     if (stats) {
@@ -1957,10 +1978,21 @@ int expv_mi_host_pattern_info(int64_t n, const int32_t *rowptr, const int32_t *c
     out[7] = P.sell_cut;                     // > 0: irregular rows, SELL slots up to this many per row + overflow pass
   });
 }
+// the host analysis entry points index with what the caller hands them: a pattern that op_create_csr would refuse is refused here too
+static void check_host_pattern(int64_t n, const int32_t *rowptr, const int32_t *colind, const char *who) {
+  if (n <= 0) return;
+  if (rowptr[0] != 0) fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": rowptr[0] must be 0 (0-based CSR)");
+  for (int64_t i = 0; i < n; ++i)
+    if (rowptr[i + 1] < rowptr[i]) fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": rowptr must be non-decreasing");
+  const int64_t nnz = rowptr[n];
+  for (int64_t k = 0; k < nnz; ++k)
+    if (colind[k] < 0 || colind[k] >= n) fail(EXPV_MI_ARGUMENT_ERROR, std::string(who) + ": column index outside [0, n)");
+}
 int expv_mi_host_rcm(int64_t n, const int32_t *rowptr, const int32_t *colind, int dtype, int32_t *perm, int64_t out[4]) {
   return guarded(nullptr, [&] {
     if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && !colind)) fail(EXPV_MI_ARGUMENT_ERROR, "host_rcm: bad arguments");
     check_device_dtype(dtype, "host_rcm");
+    check_host_pattern(n, rowptr, colind, "host_rcm");
     const int64_t nnz = n > 0 ? (int64_t)rowptr[n] : 0;
     const std::vector<int32_t> pv = reorder::rcm(n, rowptr, colind);
     if (perm) std::copy(pv.begin(), pv.end(), perm);
@@ -1983,6 +2015,7 @@ static int host_patch_order_impl(int64_t n, const int32_t *rowptr, const int32_t
   return guarded(nullptr, [&] {
     if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && !colind) || !out) fail(EXPV_MI_ARGUMENT_ERROR, "host_patch_order: bad arguments");
     check_device_dtype(dtype, "host_patch_order");
+    check_host_pattern(n, rowptr, colind, "host_patch_order");
     for (int q = 0; q < 8; ++q) out[q] = 0;
     PatchPlan pl;
     const int64_t nnz = n > 0 ? (int64_t)rowptr[n] : 0;

@@ -221,8 +221,8 @@ void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, cons
                    int nbatch = 1);
 
 // ---- single-pass step for narrow-banded operators (pipe.hip; fp64 and complex-fp64) ---------
-constexpr int PIPE_CH = 32;       // longest window + 1 (fp64); complex-fp64: 16
-constexpr int PIPE_CH_CPLX = 16;
+constexpr int PIPE_CH = 32;       // longest window + 1: every element type (the complex ones keep two running sums per lane beyond 16 columns)
+constexpr int PIPE_CH_CPLX = 32;
 constexpr int PIPE_WMAX = 8;      // largest half-bandwidth handled (halo = 2w rows per tile)
 constexpr int PIPE_DIA_MAX = 8;       // diagonals of the DIA form of a narrow-banded operator
 constexpr int PIPE_AUG_MAX = 8;       // widest augmentation (kiops: p extra rows / columns)

@@ -19,6 +19,9 @@
 //   K8  arnoldi.jl:195-202       aug_apply
 //   K10-K12 krylov_phiv.jl:229-244,641-649   combine
 //   K13-K14 krylov_phiv_adaptive.jl:353-362,425-443   lincomb
+#include <stdexcept>
+#include <string>
+#include <cstdint>
 #include <map>
 #include <mutex>
 
@@ -455,7 +458,7 @@ void spmv_ovf(hipStream_t s, const OvfView<T> &o, const T *x, const StepState *s
   if (o.nchunk <= 0) return;
   int64_t g = (o.nchunk + (BLOCK / 64) - 1) / (BLOCK / 64);
   if (o.ncb > 0) {      // column-blocked form: every workgroup takes consecutive chunks, dispatched in order = one block after the other
-    if (nbatch != 1) return;                               // (single problems only)
+    if (nbatch != 1) throw std::runtime_error("column-blocked operator form: single problems only (a batched apply would drop every entry)");
     hipLaunchKernelGGL(k_spmv_cbf<T>, dim3((unsigned)g), dim3(BLOCK), 0, s, o, x, st, step);
     if (o.nmulti > 0)
       hipLaunchKernelGGL(k_cbf_combine<T>, dim3((unsigned)std::min<int64_t>(MAX_GRID, (o.nmulti + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, o, st, step);
@@ -1243,6 +1246,7 @@ void op_update_forms(hipStream_t s, const OpUpdateArgs<T> &a) {
     hipLaunchKernelGGL(k_op_dia_const<T>, dim3(a.nd, (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, a.n / (4 * BLOCK)))), dim3(BLOCK), 0, s, a.dia,
                        a.dia_ld, a.dia_off, a.n, a.out);
 }
+struct ulonglong2_u { unsigned long long a, b; };      // a 16-byte element moved as two 8-byte words (8-byte aligned pointers)
 template <class W>
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(W *__restrict__ dst, int64_t ld_dst, const W *__restrict__ src, int64_t ld_src,
                                                        const int32_t *__restrict__ idx, int64_t n) {
@@ -1254,14 +1258,26 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(W *__restrict__ dst, int6
 void gather_rows(hipStream_t s, size_t esz, void *dst, int64_t ld_dst, const void *src, int64_t ld_src, const int32_t *idx, int64_t n,
                  int ncols) {
   if (n <= 0 || ncols <= 0) return;
-  const dim3 g((unsigned)grid_for(n, BLOCK * 2), (unsigned)ncols);
-  if (esz == 4)
-    hipLaunchKernelGGL(k_gather_rows<uint32_t>, g, dim3(BLOCK), 0, s, (uint32_t *)dst, ld_dst, (const uint32_t *)src, ld_src, idx, n);
-  else if (esz == 8)
-    hipLaunchKernelGGL(k_gather_rows<unsigned long long>, g, dim3(BLOCK), 0, s, (unsigned long long *)dst, ld_dst,
-                       (const unsigned long long *)src, ld_src, idx, n);
-  else
-    hipLaunchKernelGGL(k_gather_rows<uint4>, g, dim3(BLOCK), 0, s, (uint4 *)dst, ld_dst, (const uint4 *)src, ld_src, idx, n);
+  // 16-byte elements as uint4 only when both sides are 16-byte aligned (a caller's ComplexF64 device pointer need not be)
+  const bool al16 = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0 &&
+                    ((ld_dst * (int64_t)esz) & 15) == 0 && ((ld_src * (int64_t)esz) & 15) == 0;
+  for (int c0 = 0; c0 < ncols; c0 += 65535) {      // (gridDim.y <= 65535)
+    const int nc = std::min(ncols - c0, 65535);
+    char *d = static_cast<char *>(dst) + (size_t)c0 * (size_t)ld_dst * esz;
+    const char *sp = static_cast<const char *>(src) + (size_t)c0 * (size_t)ld_src * esz;
+    const dim3 g((unsigned)grid_for(n, BLOCK * 2), (unsigned)nc);
+    if (esz == 4)
+      hipLaunchKernelGGL(k_gather_rows<uint32_t>, g, dim3(BLOCK), 0, s, (uint32_t *)d, ld_dst, (const uint32_t *)sp, ld_src, idx, n);
+    else if (esz == 8)
+      hipLaunchKernelGGL(k_gather_rows<unsigned long long>, g, dim3(BLOCK), 0, s, (unsigned long long *)d, ld_dst,
+                         (const unsigned long long *)sp, ld_src, idx, n);
+    else if (al16)
+      hipLaunchKernelGGL(k_gather_rows<uint4>, g, dim3(BLOCK), 0, s, (uint4 *)d, ld_dst, (const uint4 *)sp, ld_src, idx, n);
+    else
+      hipLaunchKernelGGL(k_gather_rows<ulonglong2_u>, g, dim3(BLOCK), 0, s, (ulonglong2_u *)d, ld_dst, (const ulonglong2_u *)sp, ld_src, idx, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("gather_rows: ") + hipGetErrorString(e));
+  }
 }
 
 template void op_scatter_values<double>(hipStream_t, double *, const double *, const int32_t *, int64_t);

@@ -101,6 +101,17 @@ __device__ unsigned long long g_wave_trace[33][128][6][6];
 #define PIPE_STAMP(step, slot) do { } while (0)
 #define WAVE_STAMP(step, tl, slot) do { } while (0)
 #endif
+// overlapped patch form: ring positions of a tile whose older window columns are parked in LDS ahead of the step flag (16-byte
+// elements with 24 / 32 columns: 64, so that the staging area stays at 32 KB)
+template <class T, int CH> constexpr int pipe_ring_stage() { return (sizeof(T) == 16 && CH > 16) ? 64 : 128; }
+template <class T, int CH> constexpr int pipe_ring_stage_elems() {      // (the 16- and 24-column variants: the larger of the two, see k_pipe_live)
+  constexpr int own = (CH - 1) * pipe_ring_stage<T, CH>();
+  if constexpr (CH == 16 || CH == 24) {
+    constexpr int a = 15 * pipe_ring_stage<T, 16>(), b = 23 * pipe_ring_stage<T, 24>();
+    return a > b ? a : b;
+  }
+  return own;
+}
 template <class T, int EXTRA = 0>     // EXTRA: more room behind the tile rows of u_j (patch form: the ring of a tile + its partial sums)
 struct PipeSharedT {
   T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX + EXTRA];
@@ -108,8 +119,9 @@ struct PipeSharedT {
   T ut[PIPE_AUG_MAX];              // augmented operator: rows n_op.. of u_j
   int doff[PIPE_DIA_MAX];          // DIA offsets (a dynamically indexed kernel argument would be copied to scratch)
   double dcoef[PIPE_DIA_MAX];      // ... and the diagonal constants of a constant-coefficient operator
-  double red_s[BLOCK / 64][64];
-  double vals_s[64];
+  static constexpr int RW = ST<T>::is_complex ? 128 : 64;      // partial sums of a pass: 2 NR (CH-1) + NR + 1 words (complex, 31 columns: 127)
+  double red_s[BLOCK / 64][RW];
+  double vals_s[RW];
   double std_s[MAX_RED_VALUES];
   int flag_s;
   T gs_s[PIPE_CH * (PIPE_CH - 1) / 2];   // Gram entries of a window of <= PIPE_CH columns
@@ -227,15 +239,19 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   constexpr int K = (LSET <= 16) ? LSET : 16; // values per halving reduction
   constexpr int P = (LSET + K - 1) / K;       // parts per set
   constexpr int NSETS = 2 * P;                // d~ and g~ sets
-  static_assert(64 / K >= NSETS, "one lane per set among the copies of a value");
-  static_assert(2 * NR * (CH - 1) + NR + 1 <= 64, "partial sums of a workgroup fit one 64-word row");
+  constexpr int COPIES = 64 / K;              // lanes holding the same value index after a halving reduction
+  // one running sum per lane while the sets fit the copies of a value; the long complex windows (24 / 32 columns: 6 / 8 sets of
+  // 16 values) keep TWO -- the sums against y~ and those against u_j of the same part
+  constexpr bool TWO_ACC = NSETS > COPIES;
+  static_assert(COPIES >= (TWO_ACC ? P : NSETS), "one lane per set (or per part) among the copies of a value");
+  static_assert(2 * NR * (CH - 1) + NR + 1 <= SH::RW, "partial sums of a workgroup fit one row of red_s");
   static_assert(!WAVE || SELL_T, "the wave form: the real element types");
   static_assert(2 * PIPE_WMAX * 32 <= 2 * BLOCK, "the halo elements of a tile fit two rounds of the workgroup");
   static_assert(DIA || SELL_T || RING, "the complex element types use the DIA form and the patch form");
   auto &us = sh.us;
   T(&hs)[32] = sh.hs;
-  double(&red_s)[BLOCK / 64][64] = sh.red_s;
-  double(&vals_s)[64] = sh.vals_s;
+  double(&red_s)[BLOCK / 64][SH::RW] = sh.red_s;
+  double(&vals_s)[SH::RW] = sh.vals_s;
   double(&std_s)[MAX_RED_VALUES] = sh.std_s;
   int &flag_s = sh.flag_s;
   T(&gs_s)[PIPE_CH * (PIPE_CH - 1) / 2] = sh.gs_s;
@@ -321,6 +337,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   const int64_t cstep = (int64_t)pa.udir * a.ldv;       // element stride between consecutive window columns
   const int64_t nb = (a.n + 127) & ~(int64_t)127;        // library vectors are padded (zeros) up to here
   double acc = 0.0;                           // running total of one value of one set (see below)
+  [[maybe_unused]] double acc2 = 0.0;         // TWO_ACC: the same for the set against u_j
 
   const int64_t ntiles = (a.n + TR - 1) / TR;
   // patch form: the workgroups of one XCD (blockIdx.x % 8 on this chip) share a CONTIGUOUS eighth of the tiles and take them
@@ -440,7 +457,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     [[maybe_unused]] int64_t r_row = -1;
     [[maybe_unused]] bool r_staged = false;
     [[maybe_unused]] T r_new = ST<T>::zero(), r_y = ST<T>::zero();
-    constexpr int RSTAGE = 128;                       // ring positions whose raw window values fit the LDS staging area
+    constexpr int RSTAGE = pipe_ring_stage<T, CH>();  // ring positions whose raw window values fit the LDS staging area
     constexpr int RAW0 = N * BLOCK + 2 * BLOCK;       // ... which starts here in us[] (overlapped patch form only)
     if constexpr (RING) {
       if (!pa.final) {
@@ -646,7 +663,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         else arr[k] = 0.0;
       }
       wave_reduce_multi<K>(arr);
-      if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
+      if constexpr (TWO_ACC) {
+        if ((lane & (COPIES - 1)) == part) {
+          if (sidx < P) acc += arr[0];
+          else acc2 += arr[0];
+        }
+      } else {
+        if ((lane & (NSETS - 1)) == sidx) acc += arr[0];
+      }
     };
     if constexpr (WAVE) {
       // u_j of this tile goes to memory (write-through), then the tile's flag; the operator rows of this tile read
@@ -892,17 +916,24 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   // compact value layout: [0, NR und) d~ slots, [NR und, 2 NR und) g~ slots, NR words <u,y~>, then ||u||^2
   const int o_self = 2 * NR * und, o_nrm = 2 * NR * und + NR;
   {
-    constexpr int COPIES = 64 / K;             // lanes holding the same value index after the reduction
     const int idx = wave_multi_index<K>(lane);
-    const int sidx = lane & (NSETS - 1);
-    if ((lane & (COPIES - 1)) == sidx) {
-      const int part = sidx % P, t = sidx / P;
+    auto put_sum = [&](int part, int t, double v) {
       const int qq = part * K + idx;
       const int q = qq / NR, r = qq % NR;
       if (q == CH - 1) {
-        if (t == 0) red_s[wave][o_self + r] = acc;
-        else if (r == 0) red_s[wave][o_nrm] = acc;
-      } else if (q < und) red_s[wave][t * NR * und + NR * q + r] = acc;
+        if (t == 0) red_s[wave][o_self + r] = v;
+        else if (r == 0) red_s[wave][o_nrm] = v;
+      } else if (q < und) red_s[wave][t * NR * und + NR * q + r] = v;
+    };
+    if constexpr (TWO_ACC) {
+      const int part = lane & (COPIES - 1);
+      if (part < P) {
+        put_sum(part, 0, acc);
+        put_sum(part, 1, acc2);
+      }
+    } else {
+      const int sidx = lane & (NSETS - 1);
+      if ((lane & (COPIES - 1)) == sidx) put_sum(sidx % P, sidx / P, acc);
     }
   }
   __syncthreads();
@@ -1035,7 +1066,7 @@ void pipe_gate(hipStream_t s, const uint32_t *arrive, int expected, StepState *s
 }
 
 // tile rows + ring (<= BLOCK) + BLOCK partial sums; the overlapped form adds the staging area of its first tile (CH-1 columns x 128 positions)
-template <class T, int STAGE_COLS = 0> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX + STAGE_COLS * 128>;
+template <class T, int STAGE_ELEMS = 0> using PipeSharedRing = PipeSharedT<T, 2 * BLOCK - 2 * PIPE_WMAX + STAGE_ELEMS>;
 // ---- patch form: single-pass step for operators stored in a grid-patch ordering (capi.hip: a tile of rows is a patch of a 2-D
 // grid, its +-k neighbours are in the tile or in a ring of ~100 rows that is recomputed like the banded form's halo) ----
 template <class T, int CH, int WAVES, int PS, bool AUG = false>
@@ -1049,7 +1080,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
   // (the 16- and the 24-column variant run at the same 3 workgroups per CU and follow each other in a factorisation: the same LDS
   //  size for both, so that a workgroup of step 17 fits the hole a workgroup of step 16 leaves -- with different sizes the first
   //  24-column step waited ~25 us for two adjacent holes: profiles/r04_ab_variants.txt)
-  using SH = typename std::conditional<RING, PipeSharedRing<T, (CH == 16 ? 24 : CH) - 1>, PipeSharedT<T>>::type;
+  using SH = typename std::conditional<RING, PipeSharedRing<T, pipe_ring_stage_elems<T, CH>()>, PipeSharedT<T>>::type;
   __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
@@ -1417,6 +1448,14 @@ bool pipe_resident(hipStream_t s, const ResArgs &ra) {
 }
 
 template <class T> constexpr int pipe_tile_rows() { return Pack<T>::N * BLOCK; }
+// element types / windows with a non-temporal variant of the banded DIA step: fp64, and ComplexF64 from 16 columns on (at n = 1e6
+// a window of 20 complex columns is 320 MB: past the Infinity Cache like fp64 at n = 2e6)
+#ifndef PIPE_CPLX_NT
+#define PIPE_CPLX_NT 1
+#endif
+template <class T, int CH> constexpr bool pipe_has_nt() {
+  return std::is_same<T, double>::value || (PIPE_CPLX_NT && std::is_same<T, cplx>::value && CH >= 16);
+}
 
 // Non-temporal loads for the once-per-pass streams of this step?  nt_mode: 0 = by footprint (what the step touches: window
 // columns, operator diagonals, y~ in and out, u_j out -- for all problems of a batched launch), 1 = never, 2 = always.
@@ -1439,7 +1478,7 @@ static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int b
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && std::is_same<T, double>::value) {
+  if constexpr (DIA && !AUG && pipe_has_nt<T, CH>()) {
     if (pipe_nontemporal(pa, nbatch)) {
       hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, true>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
       return;
@@ -1481,7 +1520,15 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
     default: pipe_launch<double, 32, 2, 5, false>(s, pa, nbatch, batch_rounds); break;
   }
 }
-void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_rounds) {   // complex: DIA form, windows <= 15
+// complex windows of 16 .. 31 columns (full Arnoldi at the default m = 30 on a complex operator, arnoldi.jl:161-165): one row
+// per lane, so 31 columns are 124 VGPRs of window -- the budget the 32-column fp64 variant lives on, at the same 2 workgroups per CU
+#ifndef PIPE_C24_PS
+#define PIPE_C24_PS 4
+#endif
+#ifndef PIPE_C32_PS
+#define PIPE_C32_PS 2
+#endif
+void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_rounds) {   // complex: DIA form
   if (pa.aug_p > 0) {
     if (pa.und <= 3) pipe_launch<cplx, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
     else pipe_launch<cplx, 8, 3, 6, true, true>(s, pa, nbatch, batch_rounds);
@@ -1489,7 +1536,9 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_r
   }
   if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
-  else pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 1) pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 2) pipe_launch<cplx, 24, 2, PIPE_C24_PS, true>(s, pa, nbatch, batch_rounds);
+  else pipe_launch<cplx, 32, 2, PIPE_C32_PS, true>(s, pa, nbatch, batch_rounds);
 }
 
 // Float32 / ComplexF32: the DIA halo form (tiles of 1024 / 512 rows: 4 / 2 rows per 16-byte pack), same register budgets per
@@ -1514,7 +1563,9 @@ void pipe_step(hipStream_t s, const PipeArgsT<float> &pa, int nbatch, int batch_
 void pipe_step(hipStream_t s, const PipeArgsT<cplx32> &pa, int nbatch, int batch_rounds) {
   if (pipe_small(pa.und, nbatch)) pipe_launch<cplx32, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 0) pipe_launch<cplx32, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
-  else pipe_launch<cplx32, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 1) pipe_launch<cplx32, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 2) pipe_launch<cplx32, 24, 2, PIPE_C24_PS, true>(s, pa, nbatch, batch_rounds);
+  else pipe_launch<cplx32, 32, 2, PIPE_C32_PS, true>(s, pa, nbatch, batch_rounds);
 }
 
 template <class T, int CH, int WAVES, int PS, bool DIA>
@@ -1563,7 +1614,7 @@ static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && std::is_same<T, double>::value) {
+  if constexpr (DIA && !AUG && pipe_has_nt<T, CH>()) {
     if (pipe_nontemporal(pa, 1)) {
       hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
       return nb;
@@ -1640,12 +1691,14 @@ int pipe_step_ring(hipStream_t s, const PipeArgsT<double> &pa, bool live) {
   return pipe_step_ring_T<double>(s, pa, live);
 }
 int pipe_step_ring(hipStream_t s, const PipeArgsT<float> &pa, bool live) { return pipe_step_ring_T<float>(s, pa, live); }
-// complex element types: windows <= 15, the register budgets of their diagonal form
+// complex element types: the register budgets of their diagonal form
 template <class T>
 static int pipe_step_ring_C(hipStream_t s, const PipeArgsT<T> &pa, bool live) {
   if (pipe_small(pa.und, 1)) return pipe_ring_launch<T, 4, 4, 6>(s, pa, live);
   if (pipe_variant(pa.und) == 0) return pipe_ring_launch<T, 8, 3, 6>(s, pa, live);
-  return pipe_ring_launch<T, 16, 2, 6>(s, pa, live);
+  if (pipe_variant(pa.und) == 1) return pipe_ring_launch<T, 16, 2, 6>(s, pa, live);
+  if (pipe_variant(pa.und) == 2) return pipe_ring_launch<T, 24, 2, PIPE_C24_PS>(s, pa, live);
+  return pipe_ring_launch<T, 32, 2, PIPE_C32_PS>(s, pa, live);
 }
 int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx> &pa, bool live) {
   if (pa.aug_p > 0) {      // augmented operator (kiops with complex operands: this build's extension), windows <= 7
@@ -1684,7 +1737,9 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
   }
   if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx, 4, 4, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx, 8, 3, 6, true>(s, pa);
-  return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 1) return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 2) return pipe_live_launch<cplx, 24, 2, PIPE_C24_PS, true>(s, pa);
+  return pipe_live_launch<cplx, 32, 2, PIPE_C32_PS, true>(s, pa);
 }
 
 int pipe_step_live(hipStream_t s, const PipeArgsT<float> &pa) {
@@ -1706,7 +1761,9 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<float> &pa) {
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx32> &pa) {
   if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx32, 4, 4, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx32, 8, 3, 6, true>(s, pa);
-  return pipe_live_launch<cplx32, 16, 2, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 1) return pipe_live_launch<cplx32, 16, 2, 6, true>(s, pa);
+  if (pipe_variant(pa.und) == 2) return pipe_live_launch<cplx32, 24, 2, PIPE_C24_PS, true>(s, pa);
+  return pipe_live_launch<cplx32, 32, 2, PIPE_C32_PS, true>(s, pa);
 }
 
 // V[:, c] *= scales[c] for c < ncols: materialise the orthonormal basis after a pipelined factorisation

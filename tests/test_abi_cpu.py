@@ -597,3 +597,33 @@ def test_host_mesh_patches_of_meshes_in_any_numbering(eu):
     g3 = sp.diags([1.0] * 7, [-k3 * k3, -k3, -1, 0, 1, k3, k3 * k3], shape=(k3 ** 3, k3 ** 3), format="csr")
     assert eu.host_patch_order(g3, mesh=True)[0] is None                # levels of a 3-D grid are planes: far wider than 8 sqrt(n)
     assert eu.host_patch_order(sp.identity(100, format="csr"), mesh=True)[0] is None      # (too small to bother)
+
+
+def test_host_ordering_entry_points_refuse_malformed_patterns(eu):
+    """expv_mi_host_rcm / _host_patch_order / _host_mesh_patch_order index with the caller's rowptr / colind; a column
+    index outside [0, n), a decreasing rowptr or rowptr[0] != 0 is an ArgumentError like in expv_mi_op_create_csr, not a heap
+    overrun."""
+    from exponentialutilities_jl_amd import _lib
+    lib = _lib.load()
+    n = 6
+    good_rp = np.array([0, 2, 4, 6, 8, 10, 12], dtype=np.int32)
+    good_ci = np.array([0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 0], dtype=np.int32)
+    perm = np.zeros(n, dtype=np.int32)
+    cnt = np.zeros(4, dtype=np.int32)
+    out4, out8 = np.zeros(4, dtype=np.int64), np.zeros(8, dtype=np.int64)
+    F64, ARG = 0, 2      # EXPV_MI_F64, EXPV_MI_ARGUMENT_ERROR (include/expv_mi.h)
+    assert lib.expv_mi_host_rcm(n, good_rp.ctypes.data, good_ci.ctypes.data, F64, perm.ctypes.data, out4.ctypes.data) == 0
+    assert sorted(perm.tolist()) == list(range(n))
+    bad = []
+    ci = good_ci.copy(); ci[5] = n          # column == n
+    bad.append((good_rp, ci))
+    ci = good_ci.copy(); ci[0] = -1         # negative column
+    bad.append((good_rp, ci))
+    rp = good_rp.copy(); rp[3] = 3          # decreasing rowptr
+    bad.append((rp, good_ci))
+    rp = good_rp.copy(); rp[0] = 1          # 1-based rowptr
+    bad.append((rp, good_ci))
+    for rp, ci in bad:
+        assert lib.expv_mi_host_rcm(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, out4.ctypes.data) == ARG
+        assert lib.expv_mi_host_patch_order(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, cnt.ctypes.data, out8.ctypes.data) == ARG
+        assert lib.expv_mi_host_mesh_patch_order(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, cnt.ctypes.data, out8.ctypes.data) == ARG
