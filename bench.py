@@ -73,6 +73,8 @@ def compact_line(out):
             cfg[k] = {q: v.get(q) for q in ("value", "frac", "ms_per_call")}
         elif k == "secondary_fracs" and isinstance(v, dict):
             cfg[k] = {q: (float("%.3g" % z) if isinstance(z, float) else z) for q, z in v.items()}
+        elif k == "reordered_setup_s" and isinstance(v, dict):      # {entry: [first creation, the same pattern again]} in seconds
+            cfg[k] = v
     c["config"] = cfg
     for k in ("ranks_seen", "devices", "process_group", "standin"):
         if k in out:
@@ -768,9 +770,14 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
             Ag = sum(parts_).tocsr()[q_][:, q_].tocsr()
         else:
             Ag = general_sparse_operator(kind, n)
+        eu.plan_cache(clear=True)                      # (setup_s is the cost of a pattern never seen before)
         t0 = time.perf_counter()
         opx = eu.MIOperator(Ag, ctx)
         t_set = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        opx_again = eu.MIOperator(Ag, ctx)             # the same pattern again: ordering / patch plan from the plan cache
+        t_set_again = time.perf_counter() - t0
+        del opx_again
         fx = lambda: eu.expv(T_FINAL, opx, b, m=m, ishermitian=False, out=w)
         fx()
         env.sync()
@@ -785,7 +792,7 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
                    "shuffled_grid": "a 2-D 5-point grid operator under a random symmetric permutation (cut into patches at creation: patch form)",
                    "shuffled_trimesh": "a triangulated planar mesh numbered at random (cut into patches at creation: patch form)"}.get(kind, "uniformly random"), n, Ag.nnz, m),
                   tx, m, alg_bytes_expv(n, Ag.nnz, m),
-                  path=pathx, setup_s=t_set, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
+                  path=pathx, setup_s=t_set, setup_again_s=t_set_again, row_len_max=int(rl.max()), row_len_mean=float(rl.mean()),
                   storage=eu.host_pattern_info(Ag)["path"], reorder=opx.reorder_info, patch_info=opx.patch_info,
                   verified_vs_scipy_expm_multiply=float(np.linalg.norm(wx - truth) / np.linalg.norm(truth)))
         if e["verified_vs_scipy_expm_multiply"] > 1e-9:
@@ -1261,6 +1268,8 @@ def run_c2(args, eu, env):
             if isinstance(e_, dict) and "us_per_krylov_step" in e_:
                 summ["small_systems." + k_ + ".us_per_step"] = round(float(e_["us_per_krylov_step"]), 2)
         out["config"]["secondary_fracs"] = summ
+        out["config"]["reordered_setup_s"] = {k_: [round(float(sec[k_]["setup_s"]), 3), round(float(sec[k_]["setup_again_s"]), 3)]
+                                    for k_ in ("general_sparse_rcm", "general_sparse_rcm_grid", "general_sparse_mesh") if k_ in sec and "setup_again_s" in sec[k_]}
         out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline and ctx is not None:
         eu.expv(T_FINAL, op, b, m=m, ishermitian=False, ortho=args.ortho, out=w)

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "expv_mi_op_info": (_i, [_vp, _pi64, _pi64, _pi, _pd, _pi]),
     "expv_mi_op_reorder_info": (_i, [_vp, _vp]),
     "expv_mi_op_patch_info": (_i, [_vp, _vp]),
+    "expv_mi_plan_cache": (_i, [_i, _i64, _vp]),
     "expv_mi_host_patch_order": (_i, [C.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
     "expv_mi_host_mesh_patch_order": (_i, [C.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
     "expv_mi_op_apply": (_i, [_vp, _vp, _i, _vp, _i]),

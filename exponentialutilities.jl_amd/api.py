@@ -30,7 +30,7 @@ __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
     "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
-    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "host_patch_order", "clear_operator_cache",
+    "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "host_patch_order", "clear_operator_cache", "plan_cache",
 ]
 
 ExpvMIError = L.ExpvMIError
@@ -609,6 +609,20 @@ def _as_operator(A, want_dtype=None, ctx=None):
         if want != op.dtype:
             op = op.astype(want)
     return op
+
+
+def plan_cache(clear=False, capacity=None):
+    """Ordering plans by pattern (expv_mi_plan_cache): creating a sparse operator whose pattern was seen before reuses the row
+    ordering / patch plan worked out then.  Returns {"plans", "hits", "misses", "capacity"}; ``clear`` drops the stored plans,
+    ``capacity`` sets how many patterns are kept (0 = off)."""
+    out = (C.c_int64 * 4)()
+    lib = L.load()
+    if clear:
+        _check(lib.expv_mi_plan_cache(1, 0, out))
+    if capacity is not None:
+        _check(lib.expv_mi_plan_cache(2, int(capacity), out))
+    _check(lib.expv_mi_plan_cache(0, 0, out))
+    return {"plans": int(out[0]), "hits": int(out[1]), "misses": int(out[2]), "capacity": int(out[3])}
 
 
 def clear_operator_cache():

@@ -75,7 +75,7 @@ def _prune(objdir, objs, srcs, headers, verbose):
     for d in (HERE, objdir):
         for f in os.listdir(d):
             path = os.path.abspath(os.path.join(d, f))
-            artefact = f.endswith((".o", ".so", ".a", ".hsaco", ".co", ".s", ".bc", ".hipi", ".out")) or ".o." in f or ".so." in f
+            artefact = f.endswith((".o", ".so", ".a", ".hsaco", ".co", ".s", ".bc", ".hipi", ".out", ".hipfb")) or ".o." in f or ".so." in f
             if os.path.isfile(path) and artefact and path not in keep:
                 if verbose:
                     print("[build] removing stale artefact", os.path.relpath(path, HERE), flush=True)

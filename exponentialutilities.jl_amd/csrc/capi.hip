@@ -637,6 +637,78 @@ static PatClass pattern_class_ex(const PatternPlan &P, int64_t n, int dtype) {
 }
 static int pattern_class(const PatternPlan &P, int64_t n, int dtype) { return pattern_class_ex(P, n, dtype).cls; }
 
+// ---- ordering plans by pattern (round 5) ---------------------------------------------------------------------------------------
+// What operator creation works out from the PATTERN of a sparse operator -- the row ordering (reverse Cuthill-McKee / grid patches /
+// mesh patches), P A P' in CSR with the map back to the caller's entries, the per-tile rings and tile-local columns of the patch
+// form -- costs 0.4 .. 1.1 s at n = 1e6 (breadth-first searches over a randomly numbered graph: one cache miss per node), against
+// ~1.2 ms per expv.  A caller that creates an operator with the same pattern again (a Jacobian re-assembled per time step, every
+// rank of a batch) gets the stored plan: one hash + one comparison of the pattern (O(nnz) streaming), then only the value scatter and
+// the uploads.  Process-wide, the last EXPV_MI_PLAN_CACHE patterns (default 2, 0 = off; ~100 MB of host memory per entry at n = 1e6).
+// The reference has no counterpart: it applies A as stored (arnoldi.jl:185).
+struct PatchPlan;
+struct OrderPlan {
+  int64_t n = 0, nnz = 0;
+  int value_bytes = 0, reorder_mode = 0, patch_mode = 0;
+  uint64_t hash = 0;
+  std::vector<int32_t> rp0, ci0;                  // the pattern the plan was made for (compared on a hit: a hash is not an identity)
+  bool reordered = false;
+  std::vector<int32_t> perm, src, rp2, ci2;
+  int64_t bw0 = 0, bw1 = 0;
+  bool has_patch = false;
+  std::shared_ptr<PatchPlan> patch;               // rings + tile-local columns (its perm / src / rp2 / ci2 are emptied: kept above)
+};
+static uint64_t pattern_hash(const int32_t *rp, int64_t nrp, const int32_t *ci, int64_t nci) {
+  auto mix = [](uint64_t h, uint64_t v) { h ^= v * 0x9e3779b97f4a7c15ull; h = (h << 27) | (h >> 37); return h * 0xff51afd7ed558ccdull + 0x2545f4914f6cdd1dull; };
+  uint64_t h[4] = {1, 2, 3, 4};
+  auto run = [&](const int32_t *p, int64_t len) {
+    int64_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+      uint64_t w[4];
+      std::memcpy(w, p + i, 32);
+      for (int q = 0; q < 4; ++q) h[q] = mix(h[q], w[q]);
+    }
+    for (; i < len; ++i) h[0] = mix(h[0], (uint32_t)p[i]);
+  };
+  run(rp, nrp);
+  run(ci, nci);
+  return mix(mix(mix(h[0], h[1]), h[2]), h[3]) ^ (uint64_t)nci;
+}
+struct OrderPlanCache {
+  std::mutex mu;
+  std::vector<std::shared_ptr<OrderPlan>> entries;      // most recently used first
+  size_t capacity;
+  long hits = 0, misses = 0;
+  OrderPlanCache() {
+    const char *e = std::getenv("EXPV_MI_PLAN_CACHE");
+    capacity = e ? (size_t)std::max(0, std::atoi(e)) : 2;
+  }
+  std::shared_ptr<OrderPlan> find(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, int value_bytes, int rmode, int pmode, uint64_t h) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < entries.size(); ++i) {
+      const auto &e = entries[i];
+      if (e->hash != h || e->n != n || e->nnz != (int64_t)ci.size() || e->value_bytes != value_bytes || e->reorder_mode != rmode || e->patch_mode != pmode) continue;
+      if (std::memcmp(e->rp0.data(), rp.data(), sizeof(int32_t) * rp.size()) != 0 || std::memcmp(e->ci0.data(), ci.data(), sizeof(int32_t) * ci.size()) != 0) continue;
+      auto hit = e;
+      entries.erase(entries.begin() + (long)i);
+      entries.insert(entries.begin(), hit);
+      ++hits;
+      return hit;
+    }
+    ++misses;
+    return nullptr;
+  }
+  void put(const std::shared_ptr<OrderPlan> &pl) {
+    if (capacity == 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    entries.insert(entries.begin(), pl);
+    if (entries.size() > capacity) entries.resize(capacity);
+  }
+  void clear() { std::lock_guard<std::mutex> lk(mu); entries.clear(); }
+};
+static OrderPlanCache &plan_cache() { static OrderPlanCache c; return c; }
+// the plan being recorded by the creation in progress on this thread (install_row_order / upload_patch_plan write into it)
+static thread_local OrderPlan *g_plan_rec = nullptr;
+
 template <class V>
 static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &perm, const std::vector<int32_t> &src, std::vector<int32_t> &rp,
                               std::vector<int32_t> &ci, std::vector<V> &va, std::vector<int32_t> &rp2, std::vector<int32_t> &ci2, int64_t bw0, int64_t bw1,
@@ -795,6 +867,15 @@ static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &per
   pm->bandwidth_before = bw0;
   pm->bandwidth_after = bw1;
   pm->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (g_plan_rec) {      // (a patch plan in an operator's own ordering follows without a second ordering: one perm per plan)
+    g_plan_rec->reordered = true;
+    g_plan_rec->perm = perm;
+    g_plan_rec->src = src;
+    g_plan_rec->rp2 = rp2;
+    g_plan_rec->ci2 = ci2;
+    g_plan_rec->bw0 = bw0;
+    g_plan_rec->bw1 = bw1;
+  }
   rp.swap(rp2);
   ci.swap(ci2);
   va.swap(va2);
@@ -962,6 +1043,14 @@ static bool try_banded_ring(Op &op, int64_t n, const std::vector<int32_t> &rp, c
   return true;
 }
 static void upload_patch_plan(Op &op, PatchPlan &pl) {
+  if (g_plan_rec) {
+    auto keep = std::make_shared<PatchPlan>();
+    keep->k = pl.k; keep->nt = pl.nt; keep->bw0 = pl.bw0; keep->bw1 = pl.bw1;
+    keep->rows = pl.rows; keep->cnt = pl.cnt; keep->lcol = pl.lcol; keep->soff = pl.soff;
+    keep->RP = pl.RP; keep->maxring = pl.maxring; keep->ring_sum = pl.ring_sum; keep->over128 = pl.over128;
+    g_plan_rec->has_patch = true;
+    g_plan_rec->patch = keep;
+  }
   op.ring_col_unique = (int64_t)pl.lcol.size();
   pl.lcol.resize(pl.lcol.size() + 4, 0);
   op.ring_soff.alloc(sizeof(int64_t) * pl.soff.size());
@@ -998,12 +1087,48 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   csr_props<V>(n, rp, ci, va, &op.ishermitian, &op.opnorm_inf);      // (both invariant under a symmetric permutation)
   lap("ishermitian + opnorm");
   PatternCache pc;
-  maybe_reorder<V>(op, n, rp, ci, va, pc);
-  lap("reordering (RCM)");
-  if (detect_grid2d_quick(pc.get(n, rp, ci, (int)sizeof(V)), n)) (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
-  lap("grid-patch ordering");
-  (void)try_banded_ring<V>(op, n, rp, ci, pc.get(n, rp, ci, (int)sizeof(V)));
-  lap("tile-local columns of a banded operator");
+  // the ordering plan of this pattern: from the cache, or worked out now and kept
+  OrderPlanCache &cache = plan_cache();
+  std::shared_ptr<OrderPlan> plan;
+  uint64_t ph = 0;
+  const bool cacheable = cache.capacity > 0 && n >= 4096 && !ci.empty();
+  if (cacheable) {
+    ph = pattern_hash(rp.data(), (int64_t)rp.size(), ci.data(), (int64_t)ci.size());
+    plan = cache.find(n, rp, ci, (int)sizeof(V), op.ctx->opt.reorder, op.ctx->opt.patch, ph);
+    lap("pattern hash + plan lookup");
+  }
+  if (plan) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (plan->reordered) {
+      std::vector<int32_t> rp2 = plan->rp2, ci2 = plan->ci2;
+      install_row_order<V>(op, n, plan->perm, plan->src, rp, ci, va, rp2, ci2, plan->bw0, plan->bw1, t0);
+    }
+    if (plan->has_patch) {
+      PatchPlan pl = *plan->patch;      // (upload pads its arrays)
+      upload_patch_plan(op, pl);
+    }
+    op.plan_cached = true;
+    lap("ordering plan from the cache");
+  } else {
+    std::shared_ptr<OrderPlan> rec;
+    if (cacheable) {
+      rec = std::make_shared<OrderPlan>();
+      rec->n = n; rec->nnz = (int64_t)ci.size(); rec->value_bytes = (int)sizeof(V);
+      rec->reorder_mode = op.ctx->opt.reorder; rec->patch_mode = op.ctx->opt.patch; rec->hash = ph;
+      rec->rp0 = rp; rec->ci0 = ci;
+      g_plan_rec = rec.get();
+    }
+    struct RecOff { ~RecOff() { g_plan_rec = nullptr; } } rec_off;
+    maybe_reorder<V>(op, n, rp, ci, va, pc);
+    lap("reordering (RCM)");
+    if (detect_grid2d_quick(pc.get(n, rp, ci, (int)sizeof(V)), n)) (void)try_patch_order<V>(op, n, rp, ci, va, false, 0);
+    lap("grid-patch ordering");
+    (void)try_banded_ring<V>(op, n, rp, ci, pc.get(n, rp, ci, (int)sizeof(V)));
+    lap("tile-local columns of a banded operator");
+    g_plan_rec = nullptr;
+    // worth keeping: an ordering or a patch plan (a pattern that needed neither costs nothing to analyse again)
+    if (rec && (rec->reordered || rec->has_patch)) cache.put(rec);
+  }
   upload_csr<V>(op, rp, ci, va);
   lap("CSR upload");
   build_sell<V>(op, n, rp, (int64_t)ci.size(), ci.data());
@@ -1500,6 +1625,26 @@ int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]) {
   out[2] = op->perm ? op->perm->bandwidth_after : op->bandwidth;
   out[3] = op->perm ? (int64_t)(op->perm->setup_ms * 1000.0) : 0;
   return EXPV_MI_OK;
+}
+
+int expv_mi_plan_cache(int what, int64_t value, int64_t out[4]) {
+  return guarded(nullptr, [&] {
+    OrderPlanCache &c = plan_cache();
+    if (what == 1) c.clear();
+    else if (what == 2) {
+      if (value < 0 || value > 64) fail(EXPV_MI_ARGUMENT_ERROR, "plan_cache: capacity must be 0 .. 64");
+      std::lock_guard<std::mutex> lk(c.mu);
+      c.capacity = (size_t)value;
+      if (c.entries.size() > c.capacity) c.entries.resize(c.capacity);
+    } else if (what != 0) fail(EXPV_MI_ARGUMENT_ERROR, "plan_cache: what = 0 (statistics), 1 (clear) or 2 (set capacity)");
+    if (out) {
+      std::lock_guard<std::mutex> lk(c.mu);
+      out[0] = (int64_t)c.entries.size();
+      out[1] = c.hits;
+      out[2] = c.misses;
+      out[3] = (int64_t)c.capacity;
+    }
+  });
 }
 
 int expv_mi_op_patch_info(expv_mi_op_t op, int64_t out[8]) {

@@ -290,6 +290,7 @@ struct Op {
   // -1 = none) and the SELL column array restated as positions in the tile's LDS image (tile row, or tile rows + ring position)
   DevBuf ring_rows, ring_cnt, ring_col, ring_soff;
   int64_t ring_col_unique = 0;      // SELL column blocks kept after sharing equal ones (slices)
+  bool plan_cached = false;      // the ordering / patch plan came from the process-wide plan cache (capi.hip: OrderPlanCache)
   int64_t ring_sum = 0, ring_over128 = 0, ring_tiles = 0;      // sum of the ring lengths, tiles with a ring of more than 128 rows, tiles
   int ring_pad = 0;          // 0: no patch form
   int ring_max = 0;          // longest ring of a tile

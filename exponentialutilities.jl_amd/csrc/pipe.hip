@@ -112,19 +112,22 @@ template <class T, int CH> constexpr int pipe_ring_stage_elems() {      // (the 
   }
   return own;
 }
-template <class T, int EXTRA = 0>     // EXTRA: more room behind the tile rows of u_j (patch form: the ring of a tile + its partial sums)
+// EXTRA: more room behind the tile rows of u_j (patch form: the ring of a tile + its partial sums; PF: the park area of the next tile);
+// SMALL: a kernel whose windows have <= 7 columns (PF variants: the park area has to fit four workgroups per CU)
+template <class T, int EXTRA = 0, bool SMALL = false>
 struct PipeSharedT {
-  T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX + EXTRA];
+  alignas(16) T us[Pack<T>::N * BLOCK + 2 * PIPE_WMAX + EXTRA];
   T hs[32];                        // update coefficients (h_i s_i): LDS broadcast, no SGPRs
   T ut[PIPE_AUG_MAX];              // augmented operator: rows n_op.. of u_j
   int doff[PIPE_DIA_MAX];          // DIA offsets (a dynamically indexed kernel argument would be copied to scratch)
   double dcoef[PIPE_DIA_MAX];      // ... and the diagonal constants of a constant-coefficient operator
-  static constexpr int RW = ST<T>::is_complex ? 128 : 64;      // partial sums of a pass: 2 NR (CH-1) + NR + 1 words (complex, 31 columns: 127)
+  static constexpr int RW = (ST<T>::is_complex && !SMALL) ? 128 : 64;      // partial sums of a pass: 2 NR (CH-1) + NR + 1 words (complex, 31 columns: 127)
+  static constexpr int GS = SMALL ? 28 : PIPE_CH * (PIPE_CH - 1) / 2;
   double red_s[BLOCK / 64][RW];
   double vals_s[RW];
   double std_s[MAX_RED_VALUES];
   int flag_s;
-  T gs_s[PIPE_CH * (PIPE_CH - 1) / 2];   // Gram entries of a window of <= PIPE_CH columns
+  T gs_s[GS];                      // Gram entries of a window of <= PIPE_CH columns
   double cs_s[64];                 // per-slot factors folded into the next pass's coefficients
 };
 // The grid-wide flag of the overlapped form: PIPE_FLAG_COPIES words, 4 KB apart (different memory channels);
@@ -224,9 +227,25 @@ template <> struct ColPack<4> {
 template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(const int32_t *p) { c[0] = *p; } };
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
+#ifndef PIPE_XPF_MIN_CH
+#define PIPE_XPF_MIN_CH 99      // window capacity from which the in-place cross-tile prefetch of the window is compiled in (99: off = the product; measured neutral, profiles/r05_ab_variants.txt item 3)
+#endif
+// PF (windows of <= 2 columns, banded DIA form: Lanczos, iop = 2, kiops): what the NEXT tile of the workgroup needs from memory is
+// requested one tile ahead.  A short-window step is bound by its chain of dependent phases (flag -> first tile -> the tiles behind
+// it, loaded from scratch -> reduction), and in the overlapped form the memory system idles while a step's reduction and epilogue
+// run.  With PF the step-independent operands of the next tile (operator diagonals, the older window column) travel straight into
+// LDS (global_load_lds_dwordx4: no VGPR destination -- a second register set spilled at 4 workgroups per CU, profiles/r05_ab_variants.txt),
+// in the overlapped form BEFORE the wait on the previous step's flag; what the previous step wrote (its column of V, its y~) follows
+// into registers together with the first tile's, right behind the flag.
 template <class T, int CH, int PS, bool LIVE, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false,
-          class SH = PipeSharedT<T>>
+          class SH = PipeSharedT<T>, bool PF = false>
 __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_block, SH &sh) {
+  static_assert(!PF || (DIA && !WAVE && !RING && PS >= 1 && CH == 4 && !NT), "next-tile prefetch: the 4-column variants of the banded DIA halo form");
+  // XPF (long windows): a tile's products are reduced part by part (16 values at a time); once BOTH sets of a part are done its
+  // window columns are dead, and the same registers take the NEXT tile's values of those columns -- the loads fly during the
+  // remaining reductions, the barrier and the next tile's operator / halo phase instead of starting behind them.  A workgroup of a
+  // long-window variant shares its CU with one other (2 per CU): without this the CU's memory pipe idles whenever both compute.
+  constexpr bool XPF = (CH >= PIPE_XPF_MIN_CH) && !PF;
   static_assert(!AUG || ((DIA || RING) && !WAVE), "the augmented operator runs on the DIA halo form and on the patch form");
   static_assert(!RING || (!DIA && !WAVE), "the patch form: SELL slots with tile-local columns");
   constexpr bool IS_F64 = std::is_same<T, double>::value;      // constant diagonals: fp64 only
@@ -254,7 +273,8 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   double(&vals_s)[SH::RW] = sh.vals_s;
   double(&std_s)[MAX_RED_VALUES] = sh.std_s;
   int &flag_s = sh.flag_s;
-  T(&gs_s)[PIPE_CH * (PIPE_CH - 1) / 2] = sh.gs_s;
+  auto &gs_s = sh.gs_s;
+  static_assert(CH * (CH - 1) / 2 <= SH::GS, "Gram entries of the window fit gs_s");
   DotsArgs<T> a = pa.d;
   // per-problem arrays: the kernel arguments stay untouched (a modified copy of the whole argument block, with its
   // dynamically indexed dia_off[], would live in scratch); a batched launch moves these locals by blockIdx.y strides
@@ -361,6 +381,73 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   }
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
+  // ---- PF: the next tile's operands, requested one tile ahead ------------------------------------------------------------------
+  // park area (LDS, behind the tile + halo image of u_j): PS operator slots + one window column, a 16-byte pack per lane each
+  constexpr int PARK0 = Pack<T>::N * BLOCK + 2 * PIPE_WMAX;
+  static_assert(!PF || (PARK0 * sizeof(T)) % 16 == 0, "park area: 16-byte aligned");
+  [[maybe_unused]] Pack<T> nx_vnew, nx_y;      // the next tile's share of what the previous step wrote
+  [[maybe_unused]] T nx_h = ST<T>::zero();
+  [[maybe_unused]] bool nx_have = false;       // (workgroup-uniform)
+  const bool pf_on = PF && !(pa.step == 1 && !pa.cont) && !pa.final && !pa.dia_const && und <= 2;
+  auto park_slot = [&](int slot) -> T * { return &us[PARK0 + (slot * BLOCK + (int)threadIdx.x) * Pack<T>::N]; };
+  // pre: what does not depend on the previous step (operator diagonals, the older window column, its halo elements) -> LDS;
+  // post: what the previous step wrote (its column of V, its y~, their halo elements) -> registers
+  [[maybe_unused]] auto next_issue = [&](int64_t tileN, bool pre, bool post) {
+    if constexpr (PF) {
+      constexpr int NN = Pack<T>::N, TRN = NN * BLOCK;
+      const int64_t r0n = tileN * TRN, in = r0n + NN * (int64_t)threadIdx.x;
+      const int64_t nbn = (a.n + 127) & ~(int64_t)127;
+      const int64_t n_opn = AUG ? pa.n_op : a.n;
+      const bool actn = in < nbn;              // (whole waves)
+      const int kn = (a.jcol - 1 - pa.uc0) * pa.udir;
+      const int64_t cst = (int64_t)pa.udir * a.ldv;
+      const T *vpn = a.V + (int64_t)pa.uc0 * a.ldv + in;
+      if (pre) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this lane's reads of the park area for the CURRENT tile are done)
+        const int wbase = ((int)threadIdx.x >> 6) * 64 * NN;    // LDS destination of a wave: base + lane * 16 bytes
+        if (actn) {
+          if (!AUG || in < n_opn) {
+#pragma unroll
+            for (int sl = 0; sl < PS; ++sl)
+              if (sl < pa.ndiag)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dia_val + in + (int64_t)sl * pa.dia_ld),
+                                                 (__attribute__((address_space(3))) void *)&us[PARK0 + sl * BLOCK * NN + wbase], 16, 0, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k != kn && k < pa.und)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vpn + (int64_t)k * cst),
+                                               (__attribute__((address_space(3))) void *)&us[PARK0 + PS * BLOCK * NN + wbase], 16, 0, 0);
+        }
+        nx_h = ST<T>::zero();
+      }
+      if (post) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { nx_y.v[e] = ST<T>::zero(); nx_vnew.v[e] = ST<T>::zero(); }
+        if (actn) {
+          nx_y = ld_stream<false, T>(yprev + in);
+          if (kn >= 0 && kn < pa.und) nx_vnew = *reinterpret_cast<const Pack<T> *>(vpn + (int64_t)kn * cst);
+        }
+      }
+      if ((int)threadIdx.x < 2 * pa.w * 32) {      // first round of the halo loop (all of it for w <= 4)
+        const int hrow = (int)threadIdx.x >> 5, k = (int)threadIdx.x & 31;
+        const int64_t hr = (hrow < pa.w) ? r0n - pa.w + hrow : r0n + TRN + (hrow - pa.w);
+        if (hr >= 0 && hr < n_opn) {
+          if (k == 31) { if (post) nx_h = yprev[hr]; }
+          else if (k < pa.und && ((k == kn) ? post : pre)) nx_h = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+        }
+      }
+    }
+  };
+  [[maybe_unused]] bool park_pending = false;      // LDS transfers of the next tile in flight: drained where this tile waits for its own loads anyway
+  // window columns of the current tile (XPF: hoisted out of the tile loop -- they carry the next tile's values across the back edge)
+  Pack<T> vreg[CH - 1];
+  [[maybe_unused]] bool xp_have = false;           // vreg already holds (or is receiving) this tile's window values
+  auto tile_at = [&](int tl_) -> int64_t {         // tile number of the workgroup's tl_-th tile, -1: none
+    if (tl_ >= tiles_here) return -1;
+    const int64_t t_ = WAVE ? (int64_t)blockIdx.x + (int64_t)tl_ * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl_ : t0 + tl_;
+    return (t_ < (WAVE ? ntiles : rr_map ? rr_T1 : t1)) ? t_ : -1;
+  };
   for (int tl = 0; tl < tiles_here; ++tl) {
     // WAVE: tiles are dealt round-robin, so the tiles a tile waits for are in flight in neighbouring workgroups
     const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl : t0 + tl;
@@ -384,6 +471,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       if (act && (!AUG || i < n_op)) {      // (rows of the augmentation carry no operator entries)
         L = pa.ndiag;
         avp = dia_val + i;
+        if (PF && nx_have) {
+#pragma unroll
+          for (int sl = 0; sl < PS; ++sl)
+            if (sl < L) av[sl] = *reinterpret_cast<const Pack<T> *>(park_slot(sl));
+        } else
 #pragma unroll
         for (int sl = 0; sl < PS; ++sl)
           if (sl < L) {
@@ -413,14 +505,26 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
-    Pack<T> vreg[CH - 1];
+    if (!(XPF && xp_have)) {
 #pragma unroll
-    for (int k = 0; k < CH - 1; ++k)
+      for (int k = 0; k < CH - 1; ++k)
 #pragma unroll
-      for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
+        for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
+    }
     const bool wload = !first && act;
     const T *vp0 = a.V + (int64_t)pa.uc0 * a.ldv + i;    // window column k at vp0 + k * cstep
-    if (wload) {
+    if (XPF && xp_have) {
+      // (requested during the previous tile's reductions)
+    } else if (PF && nx_have) {
+      if (wload) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < und) {
+            if (k == knew) vreg[k] = nx_vnew;
+            else vreg[k] = *reinterpret_cast<const Pack<T> *>(park_slot(PS));
+          }
+      }
+    } else if (wload) {
       const T *vp = vp0;                                  // one running pointer, stepped per column
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k) {
@@ -432,6 +536,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
     for (int e = 0; e < N; ++e) u.v[e] = ST<T>::zero();
     bool have_ypre = false;
+    if (PF && nx_have && wload) { u = nx_y; have_ypre = true; }
     // halo rows of the first tile of an overlapped step: the elements of the older window columns are requested before the
     // wait, those the previous step wrote (its column and its y~) right behind the flag with everything else -- the halo
     // costs no memory round trip of its own between the flag and the first product
@@ -450,6 +555,15 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         int64_t hr;
         if (tid < 2 * w * 32 && halo_elem(tid, k, hr) && k < und && k != knew && k != 31)
           hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+      }
+    }
+    [[maybe_unused]] bool nx_post_due = false;
+    if constexpr (PF) {
+      if (nx_have) { hpre = nx_h; have_hpre = true; nx_have = false; }
+      if (pf_on && tile + 1 < t1) {
+        if (ready) { next_issue(tile + 1, true, true); nx_have = true; }
+        else { next_issue(tile + 1, true, false); nx_post_due = true; }      // (the rest right behind the step flag)
+        park_pending = true;
       }
     }
     // patch form: ring geometry of this tile (uniform per workgroup)
@@ -536,6 +650,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         T hc = ST<T>::zero();
         if (tid < und && tid < 32) hc = consume_T<T>(hcoef_in + tid);
         if (!prefetched) fetch_prev();
+        if constexpr (PF) {
+          if (nx_post_due) { next_issue(tile + 1, false, true); nx_have = true; }
+        }
         if (tid < 32) hs[tid] = hc;
         __syncthreads();
         PIPE_STAMP(pa.step, 6);
@@ -617,6 +734,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     have_hpre = false;
     }
     if (tl == 0) PIPE_STAMP(pa.step, 7);
+    if constexpr (PF) {
+      // the compiler does not order LDS-DMA against later ds_reads: drain here, where this tile's own loads (issued around the
+      // same time) are needed anyway -- loads return in order, so this costs nothing the next lines would not wait for
+      if (park_pending) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); park_pending = false; }
+    }
     if (first) {
       if (AUG) {
 #pragma unroll
@@ -637,7 +759,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         u = ld_pack_user(u0, i, a.n, is_al16(u0));
       }
     } else if (act) {
-      if (!(LIVE && have_ypre)) u = ld_stream<false, T>(yprev + i);
+      if (!have_ypre) u = ld_stream<false, T>(yprev + i);
 #pragma unroll
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
       // MGS axpy order.  fp64: slots k >= und hold h = +0 and v = +0, and fma(-0, 0, u) is u bit for bit (either zero sign
@@ -902,10 +1024,37 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     // recursive halving; afterwards a lane holds the wave total of value wave_multi_index<K>(lane) and
     // COPIES = 64/K lanes hold the same one, so lane (l & (NSETS-1)) == s keeps the running sum of
     // set s = part + P*t (t = 0: d~ against y~, t = 1: g~ against u): ONE accumulator per lane.
+    if constexpr (XPF) {
+      // part by part, both sets of a part, then the part's window columns for the NEXT tile into the same registers
+      const int64_t tnext = first ? -1 : tile_at(tl + 1);
+      const int64_t inext = tnext * TR + N * (int64_t)tid;
+      const bool actn = tnext >= 0 && inext < nb;             // (whole waves)
+      xp_have = tnext >= 0;
+      const T *vpn = a.V + (int64_t)pa.uc0 * a.ldv + inext;
+#pragma unroll
+      for (int part = 0; part < P; ++part) {
+        tile_set(part, y);
+        if constexpr (!WAVE) tile_set(P + part, u);           // (wave form: the sets against u_j were taken before the wait)
+        if (tnext >= 0) {
+#pragma unroll
+          for (int k = 0; k < CH - 1; ++k) {
+            // slot k belongs to part (NR k) / K .. (NR k + NR - 1) / K: requested behind the LAST part that reads it
+            if ((NR * k + NR - 1) / K == part && k < und) {
+              if (actn) vreg[k] = ld_stream<NT, T>(vpn + (int64_t)k * cstep);
+              else {
+#pragma unroll
+                for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
+              }
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int sidx = 0; sidx < NSETS; ++sidx) {
       if (WAVE && sidx >= P) break;                  // (wave form: the sets against u_j were taken before the wait)
       tile_set(sidx, sidx < P ? y : u);
+    }
     }
     if constexpr (!WAVE) __syncthreads();   // us is rewritten by the next tile
     if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 5);
@@ -1022,10 +1171,11 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   return 1;
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false, bool NT = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false, bool NT = false, bool PF = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe(const PipeArgsT<T> pa, int tiles_per_block) {
-  __shared__ PipeSharedT<T> sh;
-  (void)pipe_pass<T, CH, PS, false, DIA, false, AUG, NT>(pa, tiles_per_block, sh);
+  using SH = PipeSharedT<T, PF ? (PS + 1) * Pack<T>::N * BLOCK : 0, PF>;      // PF: the park area of the next tile behind us[]
+  __shared__ SH sh;
+  (void)pipe_pass<T, CH, PS, false, DIA, false, AUG, NT, false, SH, PF>(pa, tiles_per_block, sh);
 }
 
 // ---- wave form: single-pass step for operators made of a few diagonals with ARBITRARY offsets (structured grids) ----
@@ -1075,17 +1225,17 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> p
   (void)pipe_pass<T, CH, PS, false, false, false, AUG, false, true, PipeSharedRing<T>>(pa, tiles_per_block, sh);
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false, bool PF = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
   // (the 16- and the 24-column variant run at the same 3 workgroups per CU and follow each other in a factorisation: the same LDS
   //  size for both, so that a workgroup of step 17 fits the hole a workgroup of step 16 leaves -- with different sizes the first
   //  24-column step waited ~25 us for two adjacent holes: profiles/r04_ab_variants.txt)
-  using SH = typename std::conditional<RING, PipeSharedRing<T, pipe_ring_stage_elems<T, CH>()>, PipeSharedT<T>>::type;
+  using SH = typename std::conditional<RING, PipeSharedRing<T, pipe_ring_stage_elems<T, CH>()>, PipeSharedT<T, PF ? (PS + 1) * Pack<T>::N * BLOCK : 0, PF>>::type;
   __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG, NT, RING, SH>(pa, tiles_per_block, sh);
+  const int r = pipe_pass<T, CH, PS, true, DIA, WAVE, AUG, NT, RING, SH, PF>(pa, tiles_per_block, sh);
   if (r == 1 || r == 2) {   // last workgroup: publish the step (its results, stored through, first)
     PIPE_STAMP(pa.step, 5);
     EPI_STAMP(pa.step, 4);
@@ -1468,24 +1618,43 @@ static bool pipe_nontemporal(const PipeArgsT<T> &pa, int nbatch) {
   return (int64_t)nbatch * pa.d.n * (int64_t)sizeof(T) * streams > PIPE_NT_FOOTPRINT;
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false, bool PF = false>
 static void pipe_launch(hipStream_t s, const PipeArgsT<T> &pa, int nbatch, int batch_rounds = 2) {
   const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
-  const int maxb = resident_blocks((const void *)k_pipe<T, CH, WAVES, PS, DIA, AUG>);
+  const int maxb = resident_blocks((const void *)k_pipe<T, CH, WAVES, PS, DIA, AUG, false, PF>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   // batch: workgroups of all problems share the chip; a few resident rounds of fat workgroups instead of one tile each
   // (start-up round trips and the ticket are per workgroup)
   if (nbatch > 1) tpb = (ntiles * nbatch + (int64_t)batch_rounds * maxb - 1) / ((int64_t)batch_rounds * maxb);
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && pipe_has_nt<T, CH>()) {
+  if constexpr (DIA && !AUG && !PF && pipe_has_nt<T, CH>()) {
     if (pipe_nontemporal(pa, nbatch)) {
-      hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, true>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
+      hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, true, PF>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
       return;
     }
   }
-  hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe<T, CH, WAVES, PS, DIA, AUG, false, PF>), dim3(nb, nbatch), dim3(BLOCK), 0, s, pa, (int)tpb);
 }
+// short windows (<= 2 columns: Lanczos, iop = 2, kiops): the 4-column variants with the next tile requested one tile ahead (PF).
+// MEASURED AND NOT ADOPTED (profiles/r05_ab_variants.txt item 2): bit-identical results, Lanczos 19.6 -> 20.6 us per step, kiops 25.9
+// -> 26.9, complex kiops 41.6 -> 51.9 (register form at 3 workgroups per CU: 19.3 / 28.3 / 45.1).  The memory system is not idle
+// while a step's reduction runs -- the stragglers of that step are still streaming, and what the next step requests early competes
+// with them.  Compiled in with -DPIPE_PF=1 (then EXPV_MI_PIPE_PF=0 switches it off at run time); the product is built without it.
+#ifndef PIPE_PF
+#define PIPE_PF 0
+#endif
+static bool pipe_pf_enabled() {
+#if PIPE_PF
+  static const bool on = [] { const char *e = std::getenv("EXPV_MI_PIPE_PF"); return !(e && e[0] == '0'); }();
+  return on;
+#else
+  return false;
+#endif
+}
+#ifndef PIPE_PF_WAVES   // workgroups per CU of the short-window variants with the next tile prefetched (two sets of tile operands in registers)
+#define PIPE_PF_WAVES 4
+#endif
 #ifndef PIPE_V2_CH     // the 16..23-column step of a banded (DIA) operator: columns / workgroups per CU / operator slots in registers
 #define PIPE_V2_CH 24
 #define PIPE_V2_WAVES 3
@@ -1500,11 +1669,17 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
   // the register budget follows the window: short windows run with more workgroups per CU
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {   // augmented operator (kiops): DIA form, windows <= 7
+#if PIPE_PF
+    if (pa.und <= 2 && nbatch == 1 && pipe_pf_enabled()) { pipe_launch<double, 4, PIPE_PF_WAVES, 5, true, true, true>(s, pa, nbatch, batch_rounds); return; }
+#endif
     if (pa.und <= 3) pipe_launch<double, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
     else pipe_launch<double, 8, 4, 5, true, true>(s, pa, nbatch, batch_rounds);
     return;
   }
   if (pa.ndiag > 0) {
+#if PIPE_PF
+    if (pa.und <= 2 && nbatch == 1 && pipe_pf_enabled()) { pipe_launch<double, 4, PIPE_PF_WAVES, 5, true, false, true>(s, pa, nbatch, batch_rounds); return; }
+#endif
     switch (v) {
       case 0: pipe_launch<double, 8, 4, 5, true>(s, pa, nbatch, batch_rounds); break;
       case 1: pipe_launch<double, 16, 3, 6, true>(s, pa, nbatch, batch_rounds); break;
@@ -1530,10 +1705,16 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
 #endif
 void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_rounds) {   // complex: DIA form
   if (pa.aug_p > 0) {
+#if PIPE_PF
+    if (pa.und <= 2 && nbatch == 1 && pipe_pf_enabled()) { pipe_launch<cplx, 4, PIPE_PF_WAVES, 5, true, true, true>(s, pa, nbatch, batch_rounds); return; }
+#endif
     if (pa.und <= 3) pipe_launch<cplx, 4, 4, 6, true, true>(s, pa, nbatch, batch_rounds);
     else pipe_launch<cplx, 8, 3, 6, true, true>(s, pa, nbatch, batch_rounds);
     return;
   }
+#if PIPE_PF
+  if (pa.und <= 2 && nbatch == 1 && pipe_pf_enabled()) { pipe_launch<cplx, 4, PIPE_PF_WAVES, 5, true, false, true>(s, pa, nbatch, batch_rounds); return; }
+#endif
   if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 1) pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
@@ -1607,20 +1788,20 @@ bool pipe_step_wave(hipStream_t s, const PipeArgsT<float> &pa, int64_t max_abs_o
   }
 }
 
-template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false>
+template <class T, int CH, int WAVES, int PS, bool DIA, bool AUG = false, bool PF = false>
 static int pipe_live_launch(hipStream_t s, const PipeArgsT<T> &pa) {
   const int64_t ntiles = (pa.d.n + pipe_tile_rows<T>() - 1) / pipe_tile_rows<T>();
-  const int maxb = resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>);
+  const int maxb = resident_blocks((const void *)k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, false, false, PF>);
   int64_t tpb = (ntiles + maxb - 1) / maxb;
   if (tpb < 1) tpb = 1;
   const int nb = (int)((ntiles + tpb - 1) / tpb);
-  if constexpr (DIA && !AUG && pipe_has_nt<T, CH>()) {
+  if constexpr (DIA && !AUG && !PF && pipe_has_nt<T, CH>()) {
     if (pipe_nontemporal(pa, 1)) {
-      hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, true>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+      hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, true, false, PF>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
       return nb;
     }
   }
-  hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
+  hipLaunchKernelGGL((k_pipe_live<T, CH, WAVES, PS, DIA, false, AUG, false, false, PF>), dim3(nb), dim3(BLOCK), 0, s, pa, (int)tpb);
   return nb;
 }
 template <class T, int CH, int WAVES, int PS, bool DIA>
@@ -1712,10 +1893,16 @@ int pipe_step_ring(hipStream_t s, const PipeArgsT<cplx32> &pa, bool live) { retu
 int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns the number of workgroups launched
   const int v = pipe_variant(pa.und);
   if (pa.aug_p > 0) {
+#if PIPE_PF
+    if (pa.und <= 2 && pipe_pf_enabled()) return pipe_live_launch<double, 4, PIPE_PF_WAVES, 5, true, true, true>(s, pa);
+#endif
     if (pa.und <= 3) return pipe_live_launch<double, 4, 4, 6, true, true>(s, pa);
     return pipe_live_launch<double, 8, 4, 5, true, true>(s, pa);
   }
   if (pa.ndiag > 0) {
+#if PIPE_PF
+    if (pa.und <= 2 && pipe_pf_enabled()) return pipe_live_launch<double, 4, PIPE_PF_WAVES, 5, true, false, true>(s, pa);
+#endif
     switch (v) {
       case 0: return pipe_live_launch<double, 8, 4, 5, true>(s, pa);
       case 1: return pipe_live_launch<double, 16, 3, 6, true>(s, pa);
@@ -1732,9 +1919,15 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<double> &pa) {   // returns th
 }
 int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
   if (pa.aug_p > 0) {
+#if PIPE_PF
+    if (pa.und <= 2 && pipe_pf_enabled()) return pipe_live_launch<cplx, 4, PIPE_PF_WAVES, 5, true, true, true>(s, pa);
+#endif
     if (pa.und <= 3) return pipe_live_launch<cplx, 4, 4, 6, true, true>(s, pa);
     return pipe_live_launch<cplx, 8, 3, 6, true, true>(s, pa);
   }
+#if PIPE_PF
+  if (pa.und <= 2 && pipe_pf_enabled()) return pipe_live_launch<cplx, 4, PIPE_PF_WAVES, 5, true, false, true>(s, pa);
+#endif
   if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx, 4, 4, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx, 8, 3, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 1) return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);

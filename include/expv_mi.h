@@ -198,6 +198,14 @@ int expv_mi_op_reorder_info(expv_mi_op_t op, int64_t out[4]);
  * of the ring lengths, out[5] = tiles whose ring is longer than 128 rows, out[6] = column indices kept after sharing the equal
  * column blocks of slices, out[7] = ring entries stored per tile. */
 int expv_mi_op_patch_info(expv_mi_op_t op, int64_t out[8]);
+/* Ordering plans by pattern (no reference counterpart: the reference applies A as stored, arnoldi.jl:185).  What creation derives from
+ * the PATTERN of a sparse operator -- the row ordering, P A P' with the map back to the caller's entries, the rings and tile-local
+ * columns of the patch form -- is kept for the last few patterns (process-wide; default 2, environment EXPV_MI_PLAN_CACHE at load
+ * time, ~100 MB of host memory per entry at n = 1e6): creating an operator with a pattern seen before costs one hash and one comparison
+ * of the pattern plus the value scatter and the uploads (0.4 .. 1.1 s -> a few tens of ms at n = 1e6).  Patterns are compared entry by
+ * entry, never by hash alone.  what = 0: statistics only; 1: drop every stored plan; 2: set the capacity to `value` (0 .. 64; 0 = off).
+ * out (may be null) = {plans stored, hits, misses, capacity} after the call. */
+int expv_mi_plan_cache(int what, int64_t value, int64_t out[4]);
 /* The same analysis on the host, no device needed (tests; what expv_mi_op_create_csr would do with option patch = 1): CSR pattern with
  * 0-based int32 indices; perm (n entries, may be null): row i of the stored operator is row perm[i] of A; ring_count (one entry per
  * tile of 4096 / sizeof(element) rows, may be null); out as in expv_mi_op_patch_info (all zero when no 2-D grid is recognised). */

@@ -242,6 +242,14 @@ function reorder_info(op::MIOperator)
     check(ccall((:expv_mi_op_reorder_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), op.h, out), ctx().h)
     (reordered = out[1] != 0, bandwidth_before = out[2], bandwidth_after = out[3], setup_s = 1.0e-6 * out[4])
 end
+# ordering plans by pattern (process-wide): re-creating an operator with a pattern seen before reuses its row ordering / patch plan
+function plan_cache(; clear::Bool = false, capacity::Union{Nothing, Integer} = nothing)
+    out = zeros(Int64, 4)
+    clear && check(ccall((:expv_mi_plan_cache, lib), Cint, (Cint, Int64, Ptr{Int64}), 1, 0, out), C_NULL)
+    capacity === nothing || check(ccall((:expv_mi_plan_cache, lib), Cint, (Cint, Int64, Ptr{Int64}), 2, capacity, out), C_NULL)
+    check(ccall((:expv_mi_plan_cache, lib), Cint, (Cint, Int64, Ptr{Int64}), 0, 0, out), C_NULL)
+    (plans = out[1], hits = out[2], misses = out[3], capacity = out[4])
+end
 # 2-D grid stencils (context option "patch", default on): stored in a grid-patch ordering -- a special case of the reordering above,
 # equally invisible to the caller.  patch_form, the row length of the recognised grid, tiles, longest / mean ring of a tile.
 function patch_info(op::MIOperator)

@@ -1473,3 +1473,86 @@ def test_complex_windows_of_16_to_31_columns_on_the_single_pass_step(eu, form):
         ko.arnoldi_(Ko, A128, b128, m=22, ishermitian=False)
         ko.arnoldi_(Ko, A128, b128, m=30, init=22, ishermitian=False)
         close(np.asarray(Ks.getH()), Ko.getH(), tol, "%s: continuation init = 22 -> m = 30: H vs oracle" % form, mat=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["shuffled_band", "shuffled_grid", "banded_ten_offsets", "complex_shuffled_grid"])
+def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
+    """operator creation works the row ordering / patch plan out from the PATTERN (0.4 .. 1.1 s at n = 1e6); a second
+    operator with the same pattern takes the stored plan (expv_mi_plan_cache).  Same pattern + NEW values: a hit, identical storage
+    decisions, results against the oracle for the new values, and bit-identical to an operator built with the cache switched off;
+    a different pattern of the same size: a miss; capacity 0: never a hit."""
+    rng = np.random.default_rng(71)
+    cplx = kind.startswith("complex")
+    if kind == "shuffled_band":
+        n = 60_000
+        A0 = c2_operator(n)
+    elif kind in ("shuffled_grid", "complex_shuffled_grid"):
+        k = 200
+        n = k * 240
+        A0 = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+        if cplx:
+            A0 = (A0 * (1 + 0.25j)).tocsr()
+    else:
+        n = 40_000
+        offs = [-8, -6, -5, -3, -1, 0, 1, 2, 4, 7]
+        A0 = sp.diags([(0.1 + 0.05 * rng.random(n - abs(o))) * (1 if o else -6.0) for o in offs], offs, shape=(n, n), format="csr")
+    if kind != "banded_ten_offsets":
+        q = rng.permutation(n)
+        A0 = A0[q][:, q].tocsr()
+    A0.sort_indices()
+    b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0.0)
+    ctx = eu.Context()
+    eu.plan_cache(clear=True, capacity=2)
+    s0 = eu.plan_cache()
+    op1 = eu.MIOperator(A0, ctx)
+    s1 = eu.plan_cache()
+    assert s1["misses"] == s0["misses"] + 1 and s1["hits"] == s0["hits"] and s1["plans"] == 1, (s0, s1)
+    A1 = A0.copy()
+    A1.data = A1.data * (1.0 + 0.1 * rng.random(A1.nnz))                    # same pattern, new values
+    op2 = eu.MIOperator(A1, ctx)
+    s2 = eu.plan_cache()
+    assert s2["hits"] == s1["hits"] + 1 and s2["plans"] == 1, (s1, s2)
+    assert op2.reorder_info["reordered"] == op1.reorder_info["reordered"] and op2.patch_info == op1.patch_info
+    assert op2.reorder_info["bandwidth_after"] == op1.reorder_info["bandwidth_after"]
+    m = 20
+    w2 = np.asarray(eu.expv(0.5, op2, b, m=m, ishermitian=False)).copy()
+    path2 = list(eu.expv.last_stats["path"])
+    close(w2, ko.expv(0.5, A1.astype(np.complex128 if cplx else np.float64), b, m=m, ishermitian=False), TOL, "%s: operator from a cached plan vs oracle" % kind)
+    close(np.asarray(op2 @ b), A1 @ b, 1e-13, "%s: mul! through the cached plan" % kind)
+    # values-only update of an operator built from a cached plan scatters through the stored map
+    op2.update_values(A0)
+    close(np.asarray(eu.expv(0.5, op2, b, m=m, ishermitian=False)), ko.expv(0.5, A0.astype(np.complex128 if cplx else np.float64), b, m=m, ishermitian=False), TOL,
+          "%s: update_values on an operator from a cached plan" % kind)
+    # the same operator with the cache off: the same bits
+    eu.plan_cache(clear=True, capacity=0)
+    op3 = eu.MIOperator(A1, ctx)
+    s3 = eu.plan_cache()
+    assert s3["plans"] == 0 and s3["capacity"] == 0
+    w3 = np.asarray(eu.expv(0.5, op3, b, m=m, ishermitian=False)).copy()
+    assert list(eu.expv.last_stats["path"]) == path2
+    assert np.array_equal(w2, w3), "%s: cached plan and fresh plan differ" % kind
+    op4 = eu.MIOperator(A1, ctx)
+    assert eu.plan_cache()["hits"] == s3["hits"]                            # capacity 0: nothing stored, nothing found
+    # a different pattern of the same size and nnz count is a miss (compared entry by entry)
+    eu.plan_cache(clear=True, capacity=2)
+    op5 = eu.MIOperator(A1, ctx)
+    B = A1.copy().tolil()
+    r = n // 3
+    cols = B.rows[r]
+    old_c = cols[0]
+    new_c = (old_c + n // 2 + 11) % n
+    assert new_c not in cols
+    v = B[r, old_c]
+    B[r, old_c] = 0
+    B[r, new_c] = v
+    B = B.tocsr()
+    B.eliminate_zeros()
+    B.sort_indices()
+    assert B.nnz == A1.nnz and not np.array_equal(B.indices, A1.indices)
+    h0 = eu.plan_cache()["hits"]
+    op6 = eu.MIOperator(B, ctx)
+    assert eu.plan_cache()["hits"] == h0
+    close(np.asarray(op6 @ b), B @ b, 1e-13, "%s: a changed pattern is analysed afresh" % kind)
+    eu.plan_cache(clear=True, capacity=2)
+    del op1, op2, op3, op4, op5, op6
