@@ -716,7 +716,8 @@ static void install_row_order(Op &op, int64_t n, const std::vector<int32_t> &per
 // widest band (rows) an operator takes the patch form in its own ordering with: an eighth of a tile (ring <= a quarter of the tile's rows)
 static inline int64_t banded_ring_max(int value_bytes) { return (int64_t)(16 / value_bytes) * dev::BLOCK / 8; }
 template <class V>
-static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0);
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0,
+                            const reorder::Graph *G = nullptr);
 // Reverse Cuthill-McKee at creation (context option "reorder"; reorder.h): kept when it moves the operator to a better step form.
 // On return rp / ci / va hold P A P' and op.perm the ordering; op.csc_pos maps the caller's entries to the reordered CSR arrays.
 template <class V>
@@ -740,26 +741,43 @@ static void maybe_reorder(Op &op, int64_t n, std::vector<int32_t> &rp, std::vect
   // ordering that reaches the halo form (a banded operator) is better still -- but the bandwidth of a Cuthill-McKee ordering is at
   // least its widest level, so a first attempt that gives up beyond 4 x the halo width tells (one breadth-first search) whether to
   // bother; only when the patches do not work out either is the full ordering computed.
-  auto mesh = [&]() { return mode == 1 && !P0.overflow && try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth); };
+  static const bool tm = std::getenv("EXPV_MI_OP_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tm) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[op build]   reorder: %-32s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
+  lap("pattern class");
+  const reorder::Graph G(n, rp.data(), ci.data());      // the adjacency of A + A': built once, shared by every attempt below
+  lap("adjacency of A + A'");
+  auto mesh = [&]() { return mode == 1 && !P0.overflow && try_patch_order<V>(op, n, rp, ci, va, true, P0.bandwidth, &G); };
   std::vector<int32_t> perm;
   bool mesh_tried = false;
   if (mode == 1 && op.ctx->opt.patch && !P0.overflow) {
-    perm = reorder::rcm(n, rp.data(), ci.data(), 4 * dev::PIPE_WMAX);
+    perm = reorder::rcm(G, 4 * dev::PIPE_WMAX);
+    lap("RCM towards the halo form");
     if (perm.empty()) {
       mesh_tried = true;
-      if (mesh()) return;
+      const bool ok = mesh();
+      lap("mesh patches (all of it)");
+      if (ok) return;
     }
   }
-  if (perm.empty()) perm = reorder::rcm(n, rp.data(), ci.data(), mode == 1 ? useful : 0);
+  if (perm.empty()) { perm = reorder::rcm(G, mode == 1 ? useful : 0); lap("RCM"); }
   if (perm.empty()) return;
   std::vector<int32_t> rp2, ci2, src;
   reorder::permute_csr(n, rp.data(), ci.data(), perm, rp2, ci2, src);
+  lap("P A P'");
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), (int64_t)ci2.size(), (int)sizeof(V));
+  lap("pattern analysis of P A P'");
   const PatClass c1 = pattern_class_ex(P1, n, op.dtype);
   if (c1.cls < 3 && !mesh_tried && mesh()) return;
   const bool better = c1.cls > c0.cls || (c1.cls == c0.cls && c1.cls == 2 && 4 * c1.reach <= c0.reach);
   if (mode == 1 && !better) return;
   install_row_order<V>(op, n, perm, src, rp, ci, va, rp2, ci2, P0.bandwidth, P1.bandwidth, t0);
+  lap("values + maps + uploads");
 }
 
 // ---- grid-patch ordering (context option "patch"; round 4) ----------------------------------------------------------------------
@@ -903,12 +921,14 @@ static bool plan_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t 
 }
 // The same for a mesh in any numbering (reorder.h: mesh_patches): patches from two breadth-first distance fields.  Kept when every
 // tile's ring fits and the rings are short on average -- otherwise the caller goes on to reverse Cuthill-McKee.
-static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl) {
+static bool plan_mesh_patch(int64_t n, const int32_t *rp, const int32_t *ci, int64_t nnz, int value_bytes, int64_t bw0, PatchPlan &pl,
+                            const reorder::Graph *G = nullptr) {
   if (n < 8192 || nnz == 0 || (value_bytes != 16 && value_bytes != 8 && value_bytes != 4)) return false;
   const int64_t TR = (int64_t)(16 / value_bytes) * dev::BLOCK;
   const int64_t width = (int64_t)(8.0 * std::sqrt((double)n)) + 1024;      // a level of a planar-like mesh is O(sqrt n) wide
   const auto tm0 = std::chrono::steady_clock::now();
-  pl.perm = reorder::mesh_patches(n, rp, ci, TR, TR >= 1024 ? 24 : TR >= 512 ? 16 : 12, width);
+  pl.perm = G ? reorder::mesh_patches(*G, TR, TR >= 1024 ? 24 : TR >= 512 ? 16 : 12, width)
+              : reorder::mesh_patches(n, rp, ci, TR, TR >= 1024 ? 24 : TR >= 512 ? 16 : 12, width);
   const auto tm1 = std::chrono::steady_clock::now();
   if (pl.perm.empty()) return false;
   pl.k = 0;
@@ -931,16 +951,18 @@ static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci
   pl.nt = nt;
   std::vector<std::vector<int32_t>> ring((size_t)nt);
   pl.maxring = 0;
-  for (int64_t t = 0; t < nt; ++t) {
-    auto &g = ring[(size_t)t];
-    const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
-    for (int64_t r = r0; r < r1; ++r)
-      for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e)
-        if (ci2[(size_t)e] < r0 || ci2[(size_t)e] >= r1) g.push_back(ci2[(size_t)e]);
-    std::sort(g.begin(), g.end());
-    g.erase(std::unique(g.begin(), g.end()), g.end());
-    pl.maxring = std::max(pl.maxring, (int)g.size());
-  }
+  reorder::parallel_chunks(nt, [&](int64_t lo, int64_t hi) {
+    for (int64_t t = lo; t < hi; ++t) {
+      auto &g = ring[(size_t)t];
+      const int64_t r0 = t * TR, r1 = std::min<int64_t>(n, r0 + TR);
+      for (int64_t r = r0; r < r1; ++r)
+        for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e)
+          if (ci2[(size_t)e] < r0 || ci2[(size_t)e] >= r1) g.push_back(ci2[(size_t)e]);
+      std::sort(g.begin(), g.end());
+      g.erase(std::unique(g.begin(), g.end()), g.end());
+    }
+  }, 64);
+  for (int64_t t = 0; t < nt; ++t) pl.maxring = std::max(pl.maxring, (int)ring[(size_t)t].size());
   if (pl.maxring > dev::BLOCK) {
     for (int64_t t = 0; t < nt; ++t) { pl.ring_sum += (int64_t)ring[(size_t)t].size(); pl.over128 += ring[(size_t)t].size() > 128 ? 1 : 0; }
     return false;
@@ -965,15 +987,17 @@ static bool plan_patch_from_perm(int64_t n, const int32_t *rp, const int32_t *ci
     off[(size_t)sl + 1] = off[(size_t)sl] + (int64_t)L * SH;
   }
   std::vector<int32_t> lcol((size_t)std::max<int64_t>(off[(size_t)nsl], 1), 0);
-  for (int64_t r = 0; r < n; ++r) {
-    const int64_t t = r / TR, r0 = t * TR, sl = r / SH;
-    const auto &g = ring[(size_t)t];
-    for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e) {
-      const int64_t c = ci2[(size_t)e];
-      const int32_t loc = (c >= r0 && c < r0 + TR) ? (int32_t)(c - r0) : (int32_t)(TR + (std::lower_bound(g.begin(), g.end(), (int32_t)c) - g.begin()));
-      lcol[(size_t)(off[(size_t)sl] + (int64_t)(e - rp2[(size_t)r]) * SH + (r - sl * SH))] = loc;
+  reorder::parallel_chunks(n, [&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; ++r) {
+      const int64_t t = r / TR, r0 = t * TR, sl = r / SH;
+      const auto &g = ring[(size_t)t];
+      for (int32_t e = rp2[(size_t)r]; e < rp2[(size_t)r + 1]; ++e) {
+        const int64_t c = ci2[(size_t)e];
+        const int32_t loc = (c >= r0 && c < r0 + TR) ? (int32_t)(c - r0) : (int32_t)(TR + (std::lower_bound(g.begin(), g.end(), (int32_t)c) - g.begin()));
+        lcol[(size_t)(off[(size_t)sl] + (int64_t)(e - rp2[(size_t)r]) * SH + (r - sl * SH))] = loc;
+      }
     }
-  }
+  });
   const PatternPlan P1 = analyze_pattern(n, rp2.data(), ci2.data(), nnz, value_bytes);
   if (P1.overflow) return false;
   pl.bw0 = bw0;
@@ -1006,12 +1030,13 @@ static void upload_patch_plan(Op &op, PatchPlan &pl);
 // returns true when the operator was put into the patch ordering (rp / ci / va then hold P A P', op.perm the ordering, op.ring_* the
 // per-tile rings and the tile-local column array)
 template <class V>
-static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0) {
+static bool try_patch_order(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_t> &ci, std::vector<V> &va, bool mesh, int64_t bw0,
+                            const reorder::Graph *G) {
   if (!op.ctx->opt.patch || op.perm || n < 2 || ci.empty()) return false;
   // (every element type: V is double, float or their std::complex)
   const auto t0 = std::chrono::steady_clock::now();
   PatchPlan pl;
-  if (mesh ? !plan_mesh_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), bw0, pl)
+  if (mesh ? !plan_mesh_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), bw0, pl, G)
            : !plan_patch(n, rp.data(), ci.data(), (int64_t)ci.size(), (int)sizeof(V), pl)) return false;
   upload_patch_plan(op, pl);
   install_row_order<V>(op, n, pl.perm, pl.src, rp, ci, va, pl.rp2, pl.ci2, pl.bw0, pl.bw1, t0);

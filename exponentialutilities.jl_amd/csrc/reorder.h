@@ -15,46 +15,84 @@
 #include <climits>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 #include <utility>
 #include <vector>
 
 namespace expv_mi {
 namespace reorder {
 
-// perm[i] = the row of A that becomes row i of P A P'.  give_up_width > 0: return an EMPTY vector as soon as a level of the
-// rooted level structure of a component is wider than that -- the bandwidth of the Cuthill-McKee ordering is at least the widest
-// level, so an ordering that cannot get below the caller's useful reach (a random graph: levels of n/4 nodes) is not worth
-// finishing (operator creation: the adjacency + one breadth-first search instead of the whole ordering).
-inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t give_up_width = 0) {
-  std::vector<int32_t> perm((size_t)n);
-  if (n <= 0) return perm;
-  // --- symmetric adjacency without self loops: count, fill, sort + unique per node ---
-  std::vector<int64_t> ap((size_t)n + 1, 0);
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-      const int32_t c = ci[k];
-      if (c == r) continue;
-      ++ap[r + 1];
-      ++ap[c + 1];
-    }
-  for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
-  std::vector<int32_t> adj((size_t)ap[n]);
-  {
-    std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
+// run f(lo, hi) over [0, n) in contiguous chunks on up to `maxthreads` threads (host analysis loops whose iterations are independent)
+template <class F>
+inline void parallel_chunks(int64_t n, F f, int64_t min_chunk = 1 << 15) {
+  static const unsigned hw = [] {
+    unsigned h = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("EXPV_MI_HOST_THREADS")) h = (unsigned)std::max(1, std::atoi(e));
+    return std::max(1u, std::min(h, 16u));
+  }();
+  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(hw, n / std::max<int64_t>(1, min_chunk)));
+  if (nt <= 1) { f((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)nt - 1);
+  for (int64_t t = 1; t < nt; ++t) th.emplace_back([=, &f] { f(n * t / nt, n * (t + 1) / nt); });
+  f((int64_t)0, n / nt);
+  for (auto &x : th) x.join();
+}
+
+// symmetric adjacency of the pattern of A + A' without self loops: node i's neighbours are adj[ap[i] .. ap[i] + deg[i]), ascending.
+// Built once per operator creation and shared by every ordering attempt (rcm with a give-up width, mesh_patches, rcm again).
+struct Graph {
+  int64_t n = 0;
+  std::vector<int64_t> ap;
+  std::vector<int32_t> adj, deg;
+  Graph() {}
+  Graph(int64_t n_, const int32_t *rp, const int32_t *ci) { build(n_, rp, ci); }
+  void build(int64_t n_, const int32_t *rp, const int32_t *ci) {
+    n = n_;
+    ap.assign((size_t)n + 1, 0);
+    if (n <= 0) return;
     for (int64_t r = 0; r < n; ++r)
       for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
         const int32_t c = ci[k];
         if (c == r) continue;
-        adj[(size_t)fill[r]++] = c;
-        adj[(size_t)fill[c]++] = (int32_t)r;
+        ++ap[r + 1];
+        ++ap[c + 1];
       }
+    for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
+    adj.resize((size_t)ap[n]);
+    {
+      std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
+      for (int64_t r = 0; r < n; ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+          const int32_t c = ci[k];
+          if (c == r) continue;
+          adj[(size_t)fill[r]++] = c;
+          adj[(size_t)fill[c]++] = (int32_t)r;
+        }
+    }
+    deg.resize((size_t)n);
+    parallel_chunks(n, [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; ++i) {
+        int32_t *b = adj.data() + ap[i], *e = adj.data() + ap[i + 1];
+        std::sort(b, e);
+        deg[i] = (int32_t)(std::unique(b, e) - b);      // (entries beyond deg[i] of the node's range are unused)
+      }
+    });
   }
-  std::vector<int32_t> deg((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t *b = adj.data() + ap[i], *e = adj.data() + ap[i + 1];
-    std::sort(b, e);
-    deg[i] = (int32_t)(std::unique(b, e) - b);      // (entries beyond deg[i] of the node's range are unused)
-  }
+};
+
+// perm[i] = the row of A that becomes row i of P A P'.  give_up_width > 0: return an EMPTY vector as soon as a level of the
+// rooted level structure of a component is wider than that -- the bandwidth of the Cuthill-McKee ordering is at least the widest
+// level, so an ordering that cannot get below the caller's useful reach (a random graph: levels of n/4 nodes) is not worth
+// finishing (operator creation: one breadth-first search instead of the whole ordering).  A graph that HAS an ordering of bandwidth
+// w has no level wider than 2 w from any root, so a search that meets a level wider than 8 x give_up_width stops at once.
+inline std::vector<int32_t> rcm(const Graph &G, int64_t give_up_width = 0) {
+  const int64_t n = G.n;
+  std::vector<int32_t> perm((size_t)n);
+  if (n <= 0) return perm;
+  const std::vector<int64_t> &ap = G.ap;
+  const std::vector<int32_t> &deg = G.deg;
+  const int32_t *adj = G.adj.data();
   // (neighbours are put in ascending-degree order -- the Cuthill-McKee visiting order -- when a node is expanded, below: the
   //  level structures of the start-node search do not need it, and a hopeless pattern is given up before any of it)
   // nodes by ascending degree: candidates for the start of each component
@@ -65,6 +103,7 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci,
   std::vector<int32_t> stamp((size_t)n, 0), queue((size_t)n);
   std::vector<char> placed((size_t)n, 0);
   int32_t cur_stamp = 0;
+  bool hopeless = false;
   // breadth-first level structure rooted at s inside the not-yet-placed part; returns (eccentricity, last-level node of least degree)
   auto bfs_far = [&](int32_t s, int32_t *far, int64_t *width) {
     ++cur_stamp;
@@ -87,6 +126,7 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci,
         level_begin = level_end;
         level_end = tail;
         *width = std::max<int64_t>(*width, level_end - level_begin);
+        if (give_up_width > 0 && *width > 8 * give_up_width) { hopeless = true; break; }
       }
     }
     int32_t best = queue[(size_t)level_begin];
@@ -104,10 +144,12 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci,
     int32_t far = s;
     int64_t width = 0;
     int32_t ecc = bfs_far(s, &far, &width);
+    if (hopeless) return std::vector<int32_t>();
     for (int it = 0; it < 8; ++it) {
       int32_t far2 = far;
       int64_t w2 = 0;
       const int32_t ecc2 = bfs_far(far, &far2, &w2);
+      if (hopeless) return std::vector<int32_t>();
       if (ecc2 <= ecc) { if (w2 < width) s = far; break; }
       s = far;
       far = far2;
@@ -120,9 +162,11 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci,
     int64_t head = pos;
     order[(size_t)pos++] = s;
     placed[s] = 1;
+    std::vector<int32_t> nbuf;
     while (head < pos) {
       const int32_t u = order[(size_t)head++];
-      int32_t *nb = adj.data() + ap[u];
+      nbuf.assign(adj + ap[u], adj + ap[u] + deg[u]);      // (the shared adjacency stays in ascending order for the other attempts)
+      int32_t *nb = nbuf.data();
       if (deg[u] > 1) std::sort(nb, nb + deg[u], [&](int32_t x, int32_t y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
       for (int32_t k = 0; k < deg[u]; ++k) {
         const int32_t v = nb[k];
@@ -137,6 +181,10 @@ inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci,
   return perm;
 }
 
+inline std::vector<int32_t> rcm(int64_t n, const int32_t *rp, const int32_t *ci, int64_t give_up_width = 0) {
+  return rcm(Graph(n, rp, ci), give_up_width);
+}
+
 // P A P' in CSR with ascending columns per row; src[k] = index of entry k of the result in the original arrays
 inline void permute_csr(int64_t n, const int32_t *rp, const int32_t *ci, const std::vector<int32_t> &perm, std::vector<int32_t> &rp2,
                         std::vector<int32_t> &ci2, std::vector<int32_t> &src) {
@@ -147,15 +195,17 @@ inline void permute_csr(int64_t n, const int32_t *rp, const int32_t *ci, const s
   const size_t nnz = (size_t)rp2[(size_t)n];
   ci2.resize(nnz);
   src.resize(nnz);
-  std::vector<std::pair<int32_t, int32_t>> row;
-  for (int64_t i = 0; i < n; ++i) {
-    const int32_t r = perm[(size_t)i];
-    row.clear();
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) row.emplace_back(inv[(size_t)ci[k]], k);
-    std::sort(row.begin(), row.end());      // (duplicates of a column keep their original order: pairs compare by source index next)
-    int32_t o = rp2[(size_t)i];
-    for (const auto &e : row) { ci2[(size_t)o] = e.first; src[(size_t)o] = e.second; ++o; }
-  }
+  parallel_chunks(n, [&](int64_t lo, int64_t hi) {      // (rows are independent once the row pointers are known)
+    std::vector<std::pair<int32_t, int32_t>> row;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int32_t r = perm[(size_t)i];
+      row.clear();
+      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) row.emplace_back(inv[(size_t)ci[k]], k);
+      std::sort(row.begin(), row.end());      // (duplicates of a column keep their original order: pairs compare by source index next)
+      int32_t o = rp2[(size_t)i];
+      for (const auto &e : row) { ci2[(size_t)o] = e.first; src[(size_t)o] = e.second; ++o; }
+    }
+  });
 }
 
 // ---- patches of a planar-like mesh (round 4) --------------------------------------------------------------------------------------
@@ -168,35 +218,13 @@ inline void permute_csr(int64_t n, const int32_t *rp, const int32_t *ci, const s
 // tile, so each piece of a neighbour's ring is a contiguous run.  Connected components one after the other.  Returns an EMPTY vector
 // when a level is wider than give_up_width (not mesh-like: nothing to gain).  Whether the result is good enough is decided by the caller from the
 // rings it actually produces (a band that closes on itself -- a cylinder -- folds its length coordinate and fails that test).
-inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int32_t *ci, int64_t TR, int H, int64_t give_up_width) {
+inline std::vector<int32_t> mesh_patches(const Graph &G, int64_t TR, int H, int64_t give_up_width) {
   std::vector<int32_t> none;
+  const int64_t n = G.n;
   if (n <= 0) return none;
-  std::vector<int64_t> ap((size_t)n + 1, 0);
-  for (int64_t r = 0; r < n; ++r)
-    for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-      const int32_t c = ci[k];
-      if (c == r) continue;
-      ++ap[r + 1];
-      ++ap[c + 1];
-    }
-  for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
-  std::vector<int32_t> adj((size_t)ap[n]);
-  {
-    std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
-    for (int64_t r = 0; r < n; ++r)
-      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-        const int32_t c = ci[k];
-        if (c == r) continue;
-        adj[(size_t)fill[r]++] = c;
-        adj[(size_t)fill[c]++] = (int32_t)r;
-      }
-  }
-  std::vector<int32_t> deg((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t *b = adj.data() + ap[i], *e = adj.data() + ap[i + 1];
-    std::sort(b, e);
-    deg[i] = (int32_t)(std::unique(b, e) - b);
-  }
+  const std::vector<int64_t> &ap = G.ap;
+  const std::vector<int32_t> &deg = G.deg;
+  const int32_t *adj = G.adj.data();
   std::vector<int32_t> queue((size_t)n), stamp((size_t)n, 0), dist_a((size_t)n, 0), dist_b((size_t)n, 0);
   int32_t cur = 0;
   // distances from `root` inside its connected component (valid where stamp == the returned stamp); *count = nodes reached, *far = a
@@ -314,6 +342,10 @@ inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int
     std::copy(chunk.begin(), chunk.end(), order.begin() + t0);
   }
   return order;
+}
+
+inline std::vector<int32_t> mesh_patches(int64_t n, const int32_t *rp, const int32_t *ci, int64_t TR, int H, int64_t give_up_width) {
+  return mesh_patches(Graph(n, rp, ci), TR, H, give_up_width);
 }
 
 inline int64_t bandwidth(int64_t n, const int32_t *rp, const int32_t *ci) {
