@@ -86,6 +86,7 @@ struct Options {
   int patch = 1;           // 2-D grid stencils: 1 = store the operator in a grid-patch ordering at creation (a 512-row tile = a 16 x 32 patch of
                            // the grid; pipe.hip: patch form of the single-pass step, ring recomputed instead of per-tile flags: 11-18 %
                            // faster than the wave form at every size measured); 0 = natural ordering, wave form  (EXPV_MI_PATCH=0|1)
+  int matfree_fused = 1;   // matrix-free operators on the two-kernel step (their mul! feeds its first kernel); 0: the modular path of rounds 1-4
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();

@@ -406,6 +406,7 @@ int *Options::find(const char *name) {
   if (n == "pipeline_serial") return &pipeline_serial;
   if (n == "reorder") return &reorder;
   if (n == "patch") return &patch;
+  if (n == "matfree_fused") return &matfree_fused;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
   return nullptr;
@@ -529,7 +530,12 @@ struct ArnoldiCall {
     single_red = !c->opt.fused_two_reductions;
     // (the augmented operator of kiops runs the single-reduction step too: its p extra rows/columns are handled inside
     //  k_fused_a2; the two-reduction variant and the banded pipeline are for plain operators)
-    use_fused = !no_fused && (op.kind == OP_CSR) && op.sell_ok && (single_red || op.sell_cut == 0) && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
+    // (a matrix-free operator -- the reference's operator contract, docs/src/interfaces.md:7-36 -- takes the two-kernel step too: its
+    //  mul! is called on the un-normalised u_j, the step's first kernel takes y~ = A u_j from it instead of a stored form.  Like on
+    //  the modular path the callback runs m times whatever the device finds: a happy breakdown discards the later results.)
+    const bool stored = (op.kind == OP_CSR) && op.sell_ok && (single_red || op.sell_cut == 0);
+    const bool matfree = (op.kind == OP_CALLBACK) && single_red && c->opt.matfree_fused;
+    use_fused = !no_fused && (stored || matfree) && (!isaug || (single_red && p <= dev::FUSED_AUG_MAX)) &&
                 o.ortho != EXPV_MI_ORTHO_MGS && (lanczos || std::min(o.iop == 0 ? m : o.iop, m) <= dev::LOWSYNC_MAX);
     // single-pass banded pipeline (pipe.hip): default whenever it applies; EXPV_MI_NO_PIPE=1 switches it off (A/B)
     const bool no_pipe = !c->opt.pipeline;
@@ -935,6 +941,11 @@ struct ArnoldiCall {
       fa.step = j;
       fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
+      if (op.kind == OP_CALLBACK) {        // matrix-free: mul!(y~, A, u_j) by the caller, on this stream
+        T *ye = ks.ubuf.as<T>();
+        op_apply_T<T>(op, fa.u, ye, st, j);
+        fa.ext_y = ye;
+      }
       if (op.ovf_nseg > 0) {               // irregular rows: the entries beyond the SELL slot cut-off, from the CSR arrays
         ProfScope ps(c, EXPV_MI_K_MATVEC);
         if (op.cbf) {      // column-blocked form: the step's first kernel adds the blocks' partial vectors itself (no sum pass)

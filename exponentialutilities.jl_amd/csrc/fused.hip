@@ -328,6 +328,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
   if (step_skipped(a.st, fa.step)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool al = ((a.ldv * sizeof(T)) % 16 == 0) && is_al16(a.V) && is_al16(fa.ybuf) && is_al16(u);
+  const bool al_ext = fa.ext_y != nullptr && is_al16(fa.ext_y);
   double nrm = 0.0;
   for (int cb = 0; cb < a.nd; cb += CH) {
     using AT = typename ST<T>::acc_t;        // fp64 sums for the 32-bit element types
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
     }
     // augmented operator: the slices run over n_op + p rows; the last ones may lie beyond the operator's own
     const int p_aug = fa.aug_p;
-    const int64_t nsl = p_aug ? (a.n + SH - 1) / SH : fa.A.nslices;
+    const int64_t nsl = (p_aug || fa.ext_y) ? (a.n + SH - 1) / SH : fa.A.nslices;
     const int64_t s0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * spw;
     const int64_t s1 = (s0 + spw < nsl) ? s0 + spw : nsl;
     for (int64_t slice = s0; slice < s1; ++slice) {
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
       Pack<T> yv;
       const Pack<T> xv = ld_pack(u, i, a.n, al);
       if (cb == 0) {
-        if (fa.ndiag > 0 && i < fa.n_dia) dia_rows<T>(fa.dia_val, fa.dia_ld, fa.ndiag, fa.dia_off, i, fa.n_dia, u, yv.v);   // y~ = A u_j
+        if (fa.ext_y) yv = ld_pack(fa.ext_y, i, p_aug ? fa.n_op : a.n, al_ext);      // matrix-free: y~ = A u_j came from the caller's mul! (zeros beyond its rows)
+        else if (fa.ndiag > 0 && i < fa.n_dia) dia_rows<T>(fa.dia_val, fa.dia_ld, fa.ndiag, fa.dia_off, i, fa.n_dia, u, yv.v);   // y~ = A u_j
         else if (fa.ndiag == 0 && slice < fa.A.nslices) {
           sell_rows<T>(fa.A, slice, lane, u, yv.v);
           if (fa.ovf_y) {   // irregular rows: + what the overflow pass summed for these rows (spmv_ovf ran on the same u)
@@ -432,7 +434,7 @@ template <class T>
 void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
   constexpr int CH = DotChunk<T>::CH;
   constexpr int SHL = 64 * Pack<T>::N;
-  const int64_t nslices = a.aug_p ? (a.d.n + SHL - 1) / SHL : a.A.nslices;   // augmented: slices over n_op + p rows
+  const int64_t nslices = (a.aug_p || a.ext_y) ? (a.d.n + SHL - 1) / SHL : a.A.nslices;   // augmented / matrix-free: slices over all rows of the vectors
   // (a 2x-accumulator variant for windows of 17..32 columns measured slower -- 56 vs 48 us per launch, profiles/
   //  r01_ab_variants.txt -- and is not in the tree)
   int nb, spw;

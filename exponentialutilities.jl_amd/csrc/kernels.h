@@ -189,6 +189,7 @@ struct FusedAArgs {
   int ndiag;
   const int32_t *dia_off;   // device, ascending
   int64_t n_dia;            // operator rows (the DIA arrays cover rows < n_dia, padded to 512)
+  const T *ext_y;           // matrix-free operator: y~ = A u_j as the caller's mul! left it (nullptr: a stored operator); no SELL / DIA form is read
   const T *ovf_y;           // SELL with a slot cut-off: what the overflow pass left for these rows (nullptr: none)
   int ovf_ncb; int64_t ovf_pstride;      // > 0: ovf_y is the first of ovf_ncb partial vectors, ovf_pstride apart, to be added in order
 };

@@ -103,6 +103,9 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *                       single-pass step runs in its patch form (a tile = a 16 x 32 patch of the grid, the ring of rows around it
  *                       recomputed: no per-tile flags); 0 = natural ordering, wave form (expv_mi_op_patch_info; read when an
  *                       operator is created)
+ *   "matfree_fused" 1   matrix-free operators (expv_mi_op_create_callback) run the two-kernel step: the callback's y~ = A u_j goes
+ *                       straight into the step's first kernel (one reduction, two launches + the callback per step); 0 = the
+ *                       modular path (operator apply, projection, update, scale as separate launches)
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
