@@ -217,6 +217,7 @@ def one_case(seed, index, verbose=False):
         if float(Ks.beta) == 0.0 or float(Ko.beta) == 0.0:
             # zero starting vector: firststep! leaves V UNINITIALISED (arnoldi.jl:230-250) -- only beta and H == 0 are defined
             # (seed 31337 case 11086: the basis of a recycled subspace held the previous call's columns)
+            # (pinned by tests/test_gpu_configs.py::test_fuzz_pin_zero_start_vector_on_a_recycled_subspace)
             err = 0.0 if (float(Ks.beta) == float(Ko.beta) == 0.0 and not np.any(np.asarray(Ks.getH()))) else float("inf")
             extra["zero_starting_vector"] = True
         elif not single and Ks.m != Ko.m and not near_tol:      # (a residual within 100x of the breakdown tolerance may fall either side of it)
@@ -295,7 +296,7 @@ def one_case(seed, index, verbose=False):
             ok = bool(raised[0]) and bool(raised[1])
             if (n <= 2 or n <= m) and bool(raised[0]) != bool(raised[1]):
                 ok = True             # (an exhausted space, m >= n: whether its residual is exactly 0 or 1e-16 |A| decides, either is right;
-                                      #  seed 5151 case 459: n = 3)
+                                      #  seed 5151 case 459: n = 3 -- pinned by tests/test_gpu_configs.py::test_fuzz_pin_exhausted_krylov_space_m_not_below_n)
             if not raised[0] and raised[1] and "spins" in raised[1]:
                 ok = True             # (the Python oracle ran out of its time limit on a run the device finished: slow, not wrong)
             if not ok and single and raised[0] and not raised[1]:
@@ -305,7 +306,8 @@ def one_case(seed, index, verbose=False):
                 if not np.isfinite(grow) or grow > 1e10:
                     ok = True         # (exp(tA) amplifies by > 1e10: eps-level differences in the estimates decide the controller's path --
                                       #  seed 2027 case 22242: Hermitian A with eigenvalues up to +80, t = 1.3; estimates 10 % apart at
-                                      #  t = 0.4, the device's trajectory ends in the reference controller's fixed point tau_new = tau)
+                                      #  t = 0.4, the device's trajectory ends in the reference controller's fixed point tau_new = tau --
+                                      #  pinned by tests/test_gpu_configs.py::test_fuzz_pin_amplifying_hermitian_operator_controller_paths)
             return desc, (0.0 if ok else float("inf")), tol, {"raised_dev": raised[0], "raised_ref": raised[1], "skipped": "controller error"}
         U, Uo = outs
         extra = {"timestep": {k: v for k, v in tk.items()}}

@@ -1500,3 +1500,160 @@ def test_float32_sell_slot_forms_of_the_single_pass_step(eu, shape):
     rH = close(K32.getH().astype(np.float64), Ko.getH(), 1e-3, "  the oracle in float32 arithmetic vs the fp64 oracle: H (%s)" % shape, mat=True)
     eH = close(np.asarray(Ks.getH()).astype(np.float64), Ko.getH(), max(2e-5, 20 * rH), "Float32 SELL-slot form %s: H of 6 steps incl. H[7, 6] (fp32 bar)" % shape, mat=True)
     close(np.asarray(Ks.getV()).astype(np.float64), Ko.getV(), max(2e-5, 20 * rH), "Float32 SELL-slot form %s: V (max abs, fp32 bar)" % shape, absolute=True)
+
+
+def _fuzz_case_inputs(seed, index, call):
+    """Inputs of one case of tests/fuzz_parity.py (its generator is deterministic in (seed, index)): the case is run through the
+    harness with the device and oracle entry points replaced by recorders, so the test below sees exactly what the harness fed them."""
+    import tests.fuzz_parity as fz
+    rec = {}
+    saved = (getattr(fz.eu, call), getattr(fz.ko, call))
+
+    class _Captured(Exception):
+        pass
+
+    def cap_dev(*a, **kw):
+        rec["dev"] = (a, dict(kw))
+        raise ValueError("InexactError: captured")          # (a controller error: the harness goes on to the oracle side)
+
+    def cap_ref(*a, **kw):
+        rec["ref"] = (a, dict(kw))
+        raise ValueError("InexactError: captured")
+    setattr(fz.eu, call, cap_dev)
+    setattr(fz.ko, call, cap_ref)
+    try:
+        fz.one_case(seed, index)
+    finally:
+        setattr(fz.eu, call, saved[0])
+        setattr(fz.ko, call, saved[1])
+    assert "dev" in rec and "ref" in rec, "fuzz case %d/%d is not a %s case any more (generator changed?)" % (seed, index, call)
+    return rec
+
+
+@pytest.mark.gpu
+def test_fuzz_pin_amplifying_hermitian_operator_controller_paths(eu):
+    """seed 2027 case 22242 of the randomised hunt -- a dense Hermitian ComplexF64 operator with eigenvalues up to
+    +80, adaptive expv_timestep to t = 1.34: exp(tA) amplifies by ~1e45.  The harness classifies the run (device: controller error,
+    oracle: a result) as "not a parity question"; pinned here.  (a) On a horizon where rounding has not yet reached the error
+    estimates both controllers take the SAME path: equal sub-step counts, equal Krylov dimensions, U to 1e-10.  (b) On the full
+    horizon the device's failure is the reference controller's own fixed point (krylov_phiv_adaptive.jl:455-481: the proposal
+    tau_new equals tau, m does not move, omega stays above delta -- the reference loops there for ever, :390-423), reported after
+    1000 identical proposals as an ArgumentError -- not a device fault, not a wrong result."""
+    rec = _fuzz_case_inputs(2027, 22242, "expv_timestep")
+    (ts, A, b), kw = rec["dev"]
+    (ts_o, A_o, b_o), kw_o = rec["ref"]
+    assert kw["adaptive"] and np.iscomplexobj(A_o)
+    Ad = np.asarray(A_o.toarray() if hasattr(A_o, "toarray") else A_o)
+    ev = np.linalg.eigvalsh(Ad)
+    assert np.allclose(Ad, Ad.conj().T) and ev.max() > 40 and float(np.max(ts)) > 1.2      # the amplifying Hermitian case
+    # (a) a horizon both controllers agree on
+    t_small = np.array([0.1])
+    sd, so = {}, {}
+    U = np.asarray(eu.expv_timestep(t_small.copy(), A, b, **dict(kw, stats=sd)))
+    Uo = np.asarray(ko.expv_timestep(t_small.copy(), A_o, b_o, **dict(kw_o, stats=so)))
+    assert sd["num_timesteps"] == so["num_timesteps"] and sd["m"] == so["m"], (sd, so)
+    close(U, Uo, 1e-10, "amplifying Hermitian operator, t = 0.1: device vs oracle on the same controller path")
+    # (b) the full horizon: the device ends in the reference controller's fixed point and says so
+    log = []
+    with pytest.raises((ValueError, RuntimeError)) as ei:
+        eu.expv_timestep(np.asarray(ts).copy(), A, b, **dict(kw, verbose=True, out=log.append))
+    msg = str(ei.value)
+    assert "did not reach the tolerance in 1000 proposals" in msg, msg
+    import re
+    props = [ln for ln in log if "tau" in ln and "error estimate" in ln]
+    assert len(props) >= 500, (len(props), log[-5:])
+    tail = props[-400:]
+    taus = {re.search(r"tau = ([-+0-9.eE]+)", ln).group(1) for ln in tail}
+    ms = {re.search(r"m = (\d+)", ln).group(1) for ln in tail}
+    assert len(taus) == 1 and len(ms) == 1, (sorted(taus)[:4], sorted(ms), tail[-3:])      # tau_new == tau, m_new == m: the fixed point
+    # and the library is usable afterwards
+    close(np.asarray(eu.expv(0.01, A, b, m=10)), ko.expv(0.01, A_o, b_o, m=10), 1e-10, "expv after the controller error")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.complex128])
+def test_fuzz_pin_zero_start_vector_on_a_recycled_subspace(eu, T):
+    """seed 31337 case 11086 -- arnoldi! with a ZERO starting vector on a subspace that holds an earlier
+    factorisation.  firststep! zeroes H, finds beta == 0 and returns with V untouched (arnoldi.jl:230-250, :366): beta = 0 and
+    H = 0 EXACTLY, Ks.m as the reference leaves it, expv! = 0 exactly (krylov_phiv.jl:206-210), and the basis columns 2.. still hold
+    the previous call's vectors (column 1: those or the zero vector b itself) -- on the single-pass, the two-kernel and the modular path."""
+    rng = np.random.default_rng(91)
+    n, m = 3000, 12
+    cplx = np.dtype(T).kind == "c"
+    for kind in ("banded", "random", "dense"):
+        if kind == "banded":
+            A = c2_operator(n).astype(T)
+        elif kind == "random":
+            A = (sp.random(n, n, density=4.0 / n, random_state=5, format="csr") - 0.5 * sp.identity(n, format="csr")).astype(T)
+        else:
+            A = (rng.standard_normal((300, 300)) / np.sqrt(300)).astype(T)
+        nn = A.shape[0]
+        b = (rng.standard_normal(nn) + (1j * rng.standard_normal(nn) if cplx else 0)).astype(T)
+        Ks = eu.KrylovSubspace(T, T, nn, m)
+        eu.arnoldi_(Ks, A, b, m=m, ishermitian=False)
+        V_before = np.asarray(Ks.getV()).copy()
+        z = np.zeros(nn, dtype=T)
+        eu.arnoldi_(Ks, A, z, m=m, ishermitian=False)
+        Ko = ko.KrylovSubspace(T, T, nn, m)
+        ko.arnoldi_(Ko, A, b, m=m, ishermitian=False)
+        ko.arnoldi_(Ko, A, z, m=m, ishermitian=False)
+        assert Ks.beta == 0.0 and Ko.beta == 0.0
+        assert Ks.m == Ko.m and bool(Ks.wasbreakdown) == bool(Ko.wasbreakdown), (kind, Ks.m, Ko.m)
+        assert not np.any(np.asarray(Ks.getH())), "%s: H of a zero start vector must be exactly zero" % kind
+        w = np.asarray(eu.expv_(np.full(nn, 7.0, dtype=T), 0.3, Ks))
+        assert not np.any(w), "%s: expv! of a zero start vector must be exactly zero" % kind
+        # (the reference leaves V as it was -- formally uninitialised, arnoldi.jl:236-238; here the first pass stores u_1 = b = 0 in
+        #  column 1 before it knows beta, and nothing else is written)
+        V_after = np.asarray(Ks.getV())
+        assert np.array_equal(V_after[:, 1:], V_before[:, 1:]), "%s: a zero start vector must leave columns 2.. of the stored basis untouched" % kind
+        assert np.array_equal(V_after[:, 0], V_before[:, 0]) or not np.any(V_after[:, 0]), "%s: column 1 is the old v_1 or the zero vector" % kind
+        # the whole-call form too
+        assert not np.any(np.asarray(eu.expv(0.3, A, z, m=m, ishermitian=False)))
+
+
+@pytest.mark.gpu
+def test_fuzz_pin_exhausted_krylov_space_m_not_below_n(eu):
+    """seed 5151 case 459 -- n = 3 Hermitian dense, m = 35 > n, adaptive phiv_timestep.  The Krylov space is
+    exhausted after n steps; whether the residual that the error estimate is built from comes out as exactly 0 or as 1e-17 |A|
+    decides between Julia's InexactError at ceil(Int, log(omega / gamma) / log(kappa)) (krylov_phiv_adaptive.jl:470; kappa = 1: the
+    estimate does not move with m) and a finished run.  Both are the reference's behaviour; the harness accepts either for m >= n.
+    Pinned: the device's outcome is ONE OF THE TWO -- that InexactError (status ArgumentError, the :470 site in its text), or a result
+    that equals the dense truth -- and so is the oracle's; never a hang, never another error, never a wrong result."""
+    rec = _fuzz_case_inputs(5151, 459, "phiv_timestep")
+    (ts, A, B), kw = rec["dev"]
+    (ts_o, A_o, B_o), kw_o = rec["ref"]
+    Ad = np.asarray(A_o.toarray() if hasattr(A_o, "toarray") else A_o).astype(np.complex128)
+    n = Ad.shape[0]
+    assert n <= kw["m"] and kw["adaptive"], (n, kw)
+    ts = np.sort(np.asarray(ts, dtype=float))
+    Bd = np.asarray(B_o).astype(np.complex128)
+    p = Bd.shape[1] - 1
+    # dense truth: u(t) = sum_k t^k phi_k(tA) B[:, k]  (krylov_phiv_adaptive.jl:118-121) through the block-matrix identity
+    truth = []
+    for t in ts:
+        phis = dense_phis(t * Ad, p)
+        truth.append(sum((t ** k) * (phis[k] @ Bd[:, k]) for k in range(p + 1)))
+    truth = np.stack(truth, axis=1)
+    outcomes = []
+    for name, f in (("device", lambda: eu.phiv_timestep(ts.copy(), A, B, **kw)), ("oracle", lambda: ko.phiv_timestep(ts.copy(), A_o, B_o, **kw_o))):
+        try:
+            U = np.asarray(f()).astype(np.complex128)
+            close(U.reshape(truth.shape), truth, 1e-6 * max(1.0, kw["tol"] / 1e-8), "%s: exhausted Krylov space, finished run vs dense truth" % name)
+            outcomes.append("result")
+        except (ValueError, RuntimeError) as e:
+            assert "InexactError" in str(e) and ("470" in str(e) or "ceil" in str(e)), (name, str(e))
+            outcomes.append("InexactError")
+    assert set(outcomes) <= {"result", "InexactError"}
+    # exact exhaustion (a diagonal operator, a start vector in the span of three eigenvectors): both sides take the same branch
+    D = np.diag([-1.0, -2.0, -3.0]).astype(np.complex128)
+    Bx = np.ones((3, 2), dtype=np.complex128)
+    res = []
+    for f in (lambda: eu.phiv_timestep(np.array([0.5]), D, Bx, tol=1e-8, m=35, adaptive=True), lambda: ko.phiv_timestep(np.array([0.5]), D, Bx, tol=1e-8, m=35, adaptive=True)):
+        try:
+            res.append(np.asarray(f()))
+        except (ValueError, RuntimeError) as e:
+            assert "InexactError" in str(e), e
+            res.append(None)
+    assert (res[0] is None) == (res[1] is None), "exact exhaustion: device and oracle must take the same branch"
+    if res[0] is not None:
+        close(res[0], res[1], 1e-10, "exact exhaustion: device vs oracle")
