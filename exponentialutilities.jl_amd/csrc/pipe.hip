@@ -1697,6 +1697,9 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
 }
 // complex windows of 16 .. 31 columns (full Arnoldi at the default m = 30 on a complex operator, arnoldi.jl:161-165): one row
 // per lane, so 31 columns are 124 VGPRs of window -- the budget the 32-column fp64 variant lives on, at the same 2 workgroups per CU
+#ifndef PIPE_C24_WAVES
+#define PIPE_C24_WAVES 2
+#endif
 #ifndef PIPE_C24_PS
 #define PIPE_C24_PS 4
 #endif
@@ -1718,7 +1721,7 @@ void pipe_step(hipStream_t s, const PipeArgsT<cplx> &pa, int nbatch, int batch_r
   if (pipe_small(pa.und, nbatch)) pipe_launch<cplx, 4, 4, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 0) pipe_launch<cplx, 8, 3, 6, true>(s, pa, nbatch, batch_rounds);
   else if (pipe_variant(pa.und) == 1) pipe_launch<cplx, 16, 2, 6, true>(s, pa, nbatch, batch_rounds);
-  else if (pipe_variant(pa.und) == 2) pipe_launch<cplx, 24, 2, PIPE_C24_PS, true>(s, pa, nbatch, batch_rounds);
+  else if (pipe_variant(pa.und) == 2) pipe_launch<cplx, 24, PIPE_C24_WAVES, PIPE_C24_PS, true>(s, pa, nbatch, batch_rounds);
   else pipe_launch<cplx, 32, 2, PIPE_C32_PS, true>(s, pa, nbatch, batch_rounds);
 }
 
@@ -1931,7 +1934,7 @@ int pipe_step_live(hipStream_t s, const PipeArgsT<cplx> &pa) {
   if (pipe_small(pa.und, 1)) return pipe_live_launch<cplx, 4, 4, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 0) return pipe_live_launch<cplx, 8, 3, 6, true>(s, pa);
   if (pipe_variant(pa.und) == 1) return pipe_live_launch<cplx, 16, 2, 6, true>(s, pa);
-  if (pipe_variant(pa.und) == 2) return pipe_live_launch<cplx, 24, 2, PIPE_C24_PS, true>(s, pa);
+  if (pipe_variant(pa.und) == 2) return pipe_live_launch<cplx, 24, PIPE_C24_WAVES, PIPE_C24_PS, true>(s, pa);
   return pipe_live_launch<cplx, 32, 2, PIPE_C32_PS, true>(s, pa);
 }
 
