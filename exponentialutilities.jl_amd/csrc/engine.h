@@ -369,6 +369,8 @@ struct Ks {
   bool skip_tail = false;            // whole-call expv: v_{m+1} and H[m+1,m] are never used -> not computed
   int scale_cols = 0;
   DevBuf ubuf, ybuf;   // fused path: unnormalised u_{j+1} and y = A v_j (rows() elements each)
+  DevBuf extbuf;       // matrix-free operators on the two-kernel step: where the caller's mul! leaves y~ = A u_j.  Zero-filled when allocated:
+                       // the callback writes rows [0, n) only, the kernels read whole 16-byte packs up to the padded length
   // rows of V are in the ordering of the reordered operator that produced the basis (nullptr: natural).  Set / converted by the C
   // entry points (capi.hip: ks_bind_row_order); the evaluation entry points un-permute their results, the raw accessors of V
   // convert the basis back in place first.

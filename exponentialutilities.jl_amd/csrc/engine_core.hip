@@ -525,6 +525,28 @@ struct ArnoldiCall {
   }
 
   // ---- which step form runs ------------------------------------------------------------------
+  // THE decision table (storage is decided at operator creation, capi.hip: make_csr_op -> op.ndiag / op.ring_pad / op.gndiag /
+  // op.tile_reach / op.sell_cut / op.cbf; the call adds its window w = min(m - 1, iop) and the orthogonalisation mode):
+  //
+  //   operator as stored                                   call                          form                       flags set here
+  //   ---------------------------------------------------  ----------------------------  -------------------------  ---------------------
+  //   CSR, |col - row| <= 8, <= 8 full diagonals (DIA)     w <= 31, any element type     single-pass, halo, DIA     use_pipe
+  //   CSR, |col - row| <= 8, no diagonal form, patch = 0   w <= 31, Float64 / Float32    single-pass, halo, SELL    use_pipe
+  //   tile-local columns + ring lists (op.ring_pad > 0:    w <= 31, any element type     single-pass, patch form    use_pipe + use_ring
+  //     2-D grid patches, mesh patches, a band of <= an     (augmented: w <= 7, p <= 8,
+  //     eighth of a tile in its own ordering)                64-bit types)
+  //   <= 32 diagonals with any offsets (op.gndiag > 0)     m <= 32, fresh, not augmented  single-pass, wave, DIA     use_pipe + use_wave
+  //     or regular rows with bounded reach (tile_reach)     Float64 / Float32              single-pass, wave, SELL
+  //   any other CSR with SELL slots (regular rows; or      w <= 64, not strict MGS        two-kernel step            use_fused (+ overflow /
+  //     irregular: slots up to sell_cut + overflow pass /                                                             column-blocked pass)
+  //     column-blocked form)
+  //   matrix-free callback (option matfree_fused = 1)      w <= 64, not strict MGS        two-kernel step fed by     use_fused, fa.ext_y
+  //                                                                                       the callback's y~
+  //   dense; strict MGS (ortho = mgs); w > 64;             --                             modular launches           none
+  //     matfree_fused = 0; fused = 0
+  //   a continuation (init > 0) keeps the form of the table when the Gram rows of its window exist, else the modular launches.
+  // A bounded wait that expires (device shared with other work) redoes the call one launch after the other (pipe_serial) or, for the
+  // wave form, on the two-kernel step (wave_off): read_back().
   void choose_step_form() {
     const bool no_fused = !c->opt.fused;
     single_red = !c->opt.fused_two_reductions;
@@ -942,7 +964,11 @@ struct ArnoldiCall {
       fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       if (op.kind == OP_CALLBACK) {        // matrix-free: mul!(y~, A, u_j) by the caller, on this stream
-        T *ye = ks.ubuf.as<T>();
+        if (ks.extbuf.bytes < vbytes) {
+          ks.extbuf.alloc(vbytes);
+          HIPCHECK(hipMemsetAsync(ks.extbuf.p, 0, vbytes, s));      // (the rows beyond n stay zero: the callback never writes them)
+        }
+        T *ye = ks.extbuf.as<T>();
         op_apply_T<T>(op, fa.u, ye, st, j);
         fa.ext_y = ye;
       }

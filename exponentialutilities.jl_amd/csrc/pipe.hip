@@ -1697,11 +1697,13 @@ void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch, int batch
 }
 // complex windows of 16 .. 31 columns (full Arnoldi at the default m = 30 on a complex operator, arnoldi.jl:161-165): one row
 // per lane, so 31 columns are 124 VGPRs of window -- the budget the 32-column fp64 variant lives on, at the same 2 workgroups per CU
+// (the 24-column ComplexF64 DIA variant without operator slots in registers fits 168 VGPRs = 3 workgroups per CU: steps 17..24
+//  111.5 / 122.5 -> 107.8 / 116.1 us at n = 1e6, profiles/r05_ab_variants.txt item 4)
 #ifndef PIPE_C24_WAVES
-#define PIPE_C24_WAVES 2
+#define PIPE_C24_WAVES 3
 #endif
 #ifndef PIPE_C24_PS
-#define PIPE_C24_PS 4
+#define PIPE_C24_PS 0
 #endif
 #ifndef PIPE_C32_PS
 #define PIPE_C32_PS 2

@@ -1556,3 +1556,38 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
     close(np.asarray(op6 @ b), B @ b, 1e-13, "%s: a changed pattern is analysed afresh" % kind)
     eu.plan_cache(clear=True, capacity=2)
     del op1, op2, op3, op4, op5, op6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,iop,herm", [(1, 22, 0, False), (17, 2, 7, False), (129, 6, 7, True), (130, 30, 0, False), (257, 12, 2, False), (1001, 30, 0, True)])
+def test_matrix_free_operator_on_the_two_kernel_step_odd_sizes(eu, n, m, iop, herm):
+    """Round 5: matrix-free operators (docs/src/interfaces.md:7-36, basictests.jl:786-816) run the two-kernel step, their mul! feeding its
+    first kernel.  Found by tests/fuzz_parity.py (seed 5055 cases 8940 / 9732 / 13542: n = 1, 129, 17): the kernel reads y~ in whole
+    16-byte packs, the callback writes n elements -- for odd n the pack's last element was whatever the buffer held.  The buffer is now
+    the library's own, zero-filled.  Odd and even n, m > n (happy breakdown on the first step), Lanczos, an incomplete window, and the
+    modular path (option matfree_fused = 0) beside it."""
+    import torch
+    rng = np.random.default_rng([5055, n])
+    A = rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)
+    if herm:
+        A = (A + A.T) * 0.5
+    b = rng.standard_normal(n)
+    Ad = torch.as_tensor(A, device="cuda")
+    want = ko.expv(0.7, A, b, m=m, iop=iop, ishermitian=herm)
+    for fused in (1, 0):
+        ctx = eu.Context()
+        ctx.set_option("matfree_fused", fused)
+        # (poison the allocator's free blocks: a stale buffer must not be able to help)
+        junk = torch.full((4 * (n + 512),), float("nan"), dtype=torch.float64, device="cuda")
+        del junk
+        op = eu.MIOperator(None, ctx, matvec=lambda x: Ad @ x, shape=(n, n), dtype=np.float64, ishermitian=herm)
+        for rep in range(2):
+            w = np.asarray(eu.expv(0.7, op, b, m=m, iop=iop, ishermitian=herm))
+            path = list(eu.expv.last_stats["path"])
+            assert ("two_kernel" in path) == bool(fused) or "modular" in path, path
+            close(w, want, 1e-10, "matrix-free n=%d m=%d iop=%d herm=%d fused=%d rep %d: expv vs oracle" % (n, m, iop, herm, fused, rep))
+        Ks = eu.arnoldi(op, b, m=min(m, 30), iop=iop, ishermitian=herm)
+        Ko = ko.arnoldi(A, b, m=min(m, 30), iop=iop, ishermitian=herm)
+        assert Ks.m == Ko.m and bool(Ks.wasbreakdown) == bool(Ko.wasbreakdown), (Ks.m, Ko.m)
+        k = Ks.m
+        close(np.asarray(Ks.getH())[:k, :k], np.asarray(Ko.getH())[:k, :k], 1e-10, "matrix-free n=%d fused=%d: H vs oracle" % (n, fused), mat=True)
