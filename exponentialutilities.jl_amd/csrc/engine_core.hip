@@ -412,6 +412,7 @@ int *Options::find(const char *name) {
   return nullptr;
 }
 
+static const bool g_pipe_deal_rr = std::getenv("EXPV_MI_PIPE_DEAL_RR") != nullptr;      // developer A/B: halo forms deal their tiles round-robin
 static const int g_patch_xcd = std::getenv("EXPV_MI_PATCH_NO_XCD") ? 0 : 1;      // developer A/B of the patch form's tile mapping
 static const bool g_perm_fused = std::getenv("EXPV_MI_NO_PERM_FUSION") == nullptr;      // developer A/B: permutations of b / w inside the first step / the combine
 // host-side phase timing is a developer diagnostic (process-wide, printed when a context is destroyed), not library behaviour
@@ -848,6 +849,7 @@ struct ArnoldiCall {
         }
       }
       pa.w = use_ring ? 0 : (int)op.bandwidth;
+      if (!use_ring && !use_wave) pa.xcd_map = g_pipe_deal_rr ? 2 : 0;      // halo forms: tiles dealt round-robin (developer A/B)
       if (use_ring) { pa.ring_rows = op.ring_rows.as<int32_t>(); pa.ring_cnt = op.ring_cnt.as<int32_t>(); pa.ring_soff = op.ring_soff.as<int64_t>(); pa.ring_pad = op.ring_pad; pa.xcd_map = g_patch_xcd; }
       pa.yprev = cont ? V + (size_t)(j - 1) * ks.ldv : ((j & 1) ? yb2 : ya);
       pa.ybuf = (j & 1) ? ya : yb2;

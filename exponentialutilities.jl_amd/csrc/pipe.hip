@@ -381,6 +381,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   }
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
   const int64_t t1 = (t0 + tiles_per_block < ntiles) ? t0 + tiles_per_block : ntiles;
+  // halo forms: tiles dealt round-robin over the workgroups instead of in contiguous blocks (pa.xcd_map == 2): at any time the chip
+  // streams ONE moving window of every column instead of gridDim.x separate ones (DRAM page locality once the columns come from HBM)
+  const bool deal_rr = !WAVE && !RING && !PF && pa.xcd_map == 2 && !(!LIVE && gridDim.y > 1);
   // ---- PF: the next tile's operands, requested one tile ahead ------------------------------------------------------------------
   // park area (LDS, behind the tile + halo image of u_j): PS operator slots + one window column, a 16-byte pack per lane each
   constexpr int PARK0 = Pack<T>::N * BLOCK + 2 * PIPE_WMAX;
@@ -445,13 +448,13 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   [[maybe_unused]] bool xp_have = false;           // vreg already holds (or is receiving) this tile's window values
   auto tile_at = [&](int tl_) -> int64_t {         // tile number of the workgroup's tl_-th tile, -1: none
     if (tl_ >= tiles_here) return -1;
-    const int64_t t_ = WAVE ? (int64_t)blockIdx.x + (int64_t)tl_ * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl_ : t0 + tl_;
-    return (t_ < (WAVE ? ntiles : rr_map ? rr_T1 : t1)) ? t_ : -1;
+    const int64_t t_ = (WAVE || deal_rr) ? (int64_t)blockIdx.x + (int64_t)tl_ * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl_ : t0 + tl_;
+    return (t_ < ((WAVE || deal_rr) ? ntiles : rr_map ? rr_T1 : t1)) ? t_ : -1;
   };
   for (int tl = 0; tl < tiles_here; ++tl) {
     // WAVE: tiles are dealt round-robin, so the tiles a tile waits for are in flight in neighbouring workgroups
-    const int64_t tile = WAVE ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl : t0 + tl;
-    if (tile >= (WAVE ? ntiles : rr_map ? rr_T1 : t1)) break;
+    const int64_t tile = (WAVE || deal_rr) ? (int64_t)blockIdx.x + (int64_t)tl * gridDim.x : rr_map ? rr_T0 + rr_q + rr_W * tl : t0 + tl;
+    if (tile >= ((WAVE || deal_rr) ? ntiles : rr_map ? rr_T1 : t1)) break;
     const int64_t r0 = tile * TR, i = r0 + N * (int64_t)tid;
     const bool act = i < nb;   // whole waves: nb is a multiple of the rows a wave owns
     if constexpr (WAVE) WAVE_STAMP(pa.step, tl, 0);
@@ -1104,8 +1107,14 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
   if constexpr (LIVE && !WAVE) {
     // behind the ticket every store of this workgroup's tiles is acknowledged: the tiles are ready for the next step
     if (pa.tile_flags != nullptr && !pa.final)
+    {
+      if (deal_rr) {
+        for (int64_t t = (int64_t)blockIdx.x + (int64_t)tid * gridDim.x; t < ntiles && tid < tiles_per_block; t += (int64_t)BLOCK * gridDim.x)
+          __hip_atomic_store(pa.tile_flags + t, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else
       for (int64_t t = t0 + tid; t < t1; t += BLOCK)
         __hip_atomic_store(pa.tile_flags + t, pa.tile_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (!reducer) return 0;
   PIPE_STAMP(pa.step, 2);
