@@ -1476,7 +1476,7 @@ def test_complex_windows_of_16_to_31_columns_on_the_single_pass_step(eu, form):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["shuffled_band", "shuffled_grid", "banded_ten_offsets", "complex_shuffled_grid"])
+@pytest.mark.parametrize("kind", ["shuffled_band", "shuffled_grid", "banded_ten_offsets", "complex_shuffled_grid", "shuffled_band_csc"])
 def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
     """operator creation works the row ordering / patch plan out from the PATTERN (0.4 .. 1.1 s at n = 1e6); a second
     operator with the same pattern takes the stored plan (expv_mi_plan_cache).  Same pattern + NEW values: a hit, identical storage
@@ -1484,7 +1484,8 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
     a different pattern of the same size: a miss; capacity 0: never a hit."""
     rng = np.random.default_rng(71)
     cplx = kind.startswith("complex")
-    if kind == "shuffled_band":
+    csc = kind.endswith("_csc")          # (Julia's SparseMatrixCSC: the plan is made for the CSR form the library converts to, the value map composed)
+    if kind in ("shuffled_band", "shuffled_band_csc"):
         n = 60_000
         A0 = c2_operator(n)
     elif kind in ("shuffled_grid", "complex_shuffled_grid"):
@@ -1501,6 +1502,9 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
         q = rng.permutation(n)
         A0 = A0[q][:, q].tocsr()
     A0.sort_indices()
+    if csc:
+        A0 = A0.tocsc()
+        A0.sort_indices()
     b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0.0)
     ctx = eu.Context()
     eu.plan_cache(clear=True, capacity=2)
@@ -1537,7 +1541,7 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
     # a different pattern of the same size and nnz count is a miss (compared entry by entry)
     eu.plan_cache(clear=True, capacity=2)
     op5 = eu.MIOperator(A1, ctx)
-    B = A1.copy().tolil()
+    B = A1.tocsr().copy().tolil()
     r = n // 3
     cols = B.rows[r]
     old_c = cols[0]
@@ -1549,7 +1553,7 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
     B = B.tocsr()
     B.eliminate_zeros()
     B.sort_indices()
-    assert B.nnz == A1.nnz and not np.array_equal(B.indices, A1.indices)
+    assert B.nnz == A1.nnz and not np.array_equal(B.indices, A1.tocsr().indices)
     h0 = eu.plan_cache()["hits"]
     op6 = eu.MIOperator(B, ctx)
     assert eu.plan_cache()["hits"] == h0
