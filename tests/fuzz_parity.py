@@ -398,10 +398,12 @@ def one_case(seed, index, verbose=False):
         Bm = np.asfortranarray((rng.standard_normal((n, nprob)) + (1j * rng.standard_normal((n, nprob)) if cplx else 0)).astype(T))
         mb = min(m, 30)
         W = np.asarray(eu.expv_batch(0.7, P, vals, Bm, m=mb, iop=iop))
+        extra["batch_problems"] = []
         for q in range(nprob):
             Aq = P.copy()
             Aq.data = vals[q].copy()
             err = max(err, rel(W[:, q], ko.expv(0.7, Aq.astype(T64), Bm[:, q].astype(T64), m=mb, iop=iop, ishermitian=False)))
+            extra["batch_problems"].append((Aq.astype(T64), Bm[:, q].astype(T64), mb))
     elif call == "async_device":
         # the mode the headline runs in: a context with stream-ordered outputs, operands and results resident on the device,
         # several calls in flight before one synchronisation
@@ -467,6 +469,22 @@ def one_case(seed, index, verbose=False):
     # orthogonality by `loss`, two correct implementations that add their dot products in a different order differ by a multiple
     # of it (the fixed-size suites scale their bars the same way).  Evaluated only for flagged cases.
     A2x = extra.pop("second_operator", None)
+    batch_problems = extra.pop("batch_problems", None)
+    if not single and np.isfinite(err) and err > tol and call == "batch" and batch_problems and iop == 0:
+        # (seed 8088 case 4782: three ComplexF64 banded problems scaled to |A| ~ 45, m = 14 -- the oracle's own bases are orthogonal to
+        #  6e-10 .. 3e-9 only, the device's to 6e-10 .. 8e-10; batch and single-problem calls agree with each other to 1e-12 .. 3e-10:
+        #  tools/fuzz_repro_8088.py)
+        loss = 0.0
+        for Aq, bq, mq in batch_problems:
+            try:
+                Kq = ko.arnoldi(Aq, bq, m=mq, iop=0, ishermitian=False)
+                Vq = Kq.getV()[:, : Kq.m + 1]
+                loss = max(loss, float(np.max(np.abs(Vq.conj().T @ Vq - np.eye(Vq.shape[1])))))
+            except Exception:
+                pass
+        if loss > 0.0:
+            extra["oracle_loss_of_orthogonality"] = loss
+            tol = max(tol, 10.0 * loss)
     if not single and np.isfinite(err) and err > tol and call in ("expv", "arnoldi", "update_values", "subspace_reuse", "continuation",
                                                                   "async_device", "phiv", "phiv_correct", "expv_complex_t", "caches"):
         loss = 0.0

@@ -627,3 +627,54 @@ def test_host_ordering_entry_points_refuse_malformed_patterns(eu):
         assert lib.expv_mi_host_rcm(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, out4.ctypes.data) == ARG
         assert lib.expv_mi_host_patch_order(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, cnt.ctypes.data, out8.ctypes.data) == ARG
         assert lib.expv_mi_host_mesh_patch_order(n, rp.ctypes.data, ci.ctypes.data, F64, perm.ctypes.data, cnt.ctypes.data, out8.ctypes.data) == ARG
+
+
+def test_orderings_do_not_depend_on_the_locality_relabelling(eu):
+    """Round 5: the breadth-first searches of operator creation (reverse Cuthill-McKee, mesh patches) run on a copy of the graph
+    renumbered in breadth-first order (reorder.h: Graph::local -- cache-local arrays instead of a miss per node); visiting orders and
+    ties follow the ORIGINAL numbering, so every ordering must come out bit for bit as without the copy (EXPV_MI_NO_RELABEL=1):
+    shuffled band, shuffled 2-D grid, a shuffled triangulated mesh, two components + isolated nodes, a random graph (given up)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+
+    def shuffled(A, seed):
+        q = np.random.default_rng(seed).permutation(A.shape[0])
+        return A[q][:, q].tocsr()
+    n = 150_000
+    band = shuffled(sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-2, -1, 0, 1, 2], shape=(n, n), format="csr"), 1)
+    k = 400
+    grid0 = sp.diags([1.0, 1.0, -4.0, 1.0, 1.0], [-k, -1, 0, 1, k], shape=(k * k, k * k), format="csr")
+    grid = shuffled(grid0, 2)
+    ii = np.arange(k * k)
+    parts = []
+    for dr, dc in ((0, 0), (0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (-1, -1)):
+        r, c = ii // k + dr, ii % k + dc
+        ok = (r >= 0) & (r < k) & (c >= 0) & (c < k)
+        parts.append(sp.csr_matrix((np.ones(ok.sum()), (ii[ok], (r * k + c)[ok])), shape=(k * k, k * k)))
+    mesh = shuffled(sum(parts).tocsr(), 3)
+    two = shuffled(sp.block_diag([grid0[:80_000, :80_000], sp.identity(7, format="csr"), grid0[:70_000, :70_000]], format="csr"), 4)
+    nr = 140_000
+    rnd = (sp.csr_matrix((np.ones(4 * nr), (rng.integers(0, nr, 4 * nr), rng.integers(0, nr, 4 * nr))), shape=(nr, nr)) + sp.identity(nr, format="csr")).tocsr()
+    rnd.sum_duplicates()
+    for name, A in (("band", band), ("grid", grid), ("mesh", mesh), ("two components", two), ("random", rnd)):
+        A.sort_indices()
+        res = {}
+        for mode in ("relabelled", "plain"):
+            if mode == "plain":
+                os.environ["EXPV_MI_NO_RELABEL"] = "1"
+            else:
+                os.environ.pop("EXPV_MI_NO_RELABEL", None)
+            try:
+                perm, info = eu.host_rcm(A)
+                pperm, cnt, pinfo = eu.host_patch_order(A, mesh=True)
+            finally:
+                os.environ.pop("EXPV_MI_NO_RELABEL", None)
+            res[mode] = (perm.copy(), info, None if pperm is None else pperm.copy(), cnt.copy(), pinfo)
+        a, b = res["relabelled"], res["plain"]
+        assert sorted(a[0].tolist()) == list(range(A.shape[0])), name
+        assert np.array_equal(a[0], b[0]), "%s: reverse Cuthill-McKee differs with the local copy" % name
+        assert a[1] == b[1], name
+        assert (a[2] is None) == (b[2] is None), name
+        if a[2] is not None:
+            assert np.array_equal(a[2], b[2]), "%s: mesh patches differ with the local copy" % name
+            assert np.array_equal(a[3], b[3]) and a[4] == b[4], name
