@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <climits>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <numeric>
@@ -105,24 +107,33 @@ struct Graph {
     n = n_;
     ap.assign((size_t)n + 1, 0);
     if (n <= 0) return;
-    for (int64_t r = 0; r < n; ++r)
-      for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-        const int32_t c = ci[k];
-        if (c == r) continue;
-        ++ap[r + 1];
-        ++ap[c + 1];
-      }
+    // Every thread owns a range of NODES: it takes the entries (r, c) of its own rows for the r side and scans the whole pattern for the
+    // columns that fall into its range (sequential reads; the random writes of a thread stay inside its slice).  The lists are sorted
+    // afterwards, so the order in which they are filled does not matter.
+    parallel_chunks(n, [&](int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k)
+          if (ci[k] != r) ++ap[(size_t)r + 1];
+      for (int64_t r = 0; r < n; ++r)
+        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+          const int32_t c = ci[k];
+          if (c >= lo && c < hi && c != r) ++ap[(size_t)c + 1];
+        }
+    }, 1 << 16);
     for (int64_t i = 0; i < n; ++i) ap[i + 1] += ap[i];
     adj.resize((size_t)ap[n]);
     {
       std::vector<int64_t> fill(ap.begin(), ap.end() - 1);
-      for (int64_t r = 0; r < n; ++r)
-        for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
-          const int32_t c = ci[k];
-          if (c == r) continue;
-          adj[(size_t)fill[r]++] = c;
-          adj[(size_t)fill[c]++] = (int32_t)r;
-        }
+      parallel_chunks(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; ++r)
+          for (int32_t k = rp[r]; k < rp[r + 1]; ++k)
+            if (ci[k] != r) adj[(size_t)fill[(size_t)r]++] = ci[k];
+        for (int64_t r = 0; r < n; ++r)
+          for (int32_t k = rp[r]; k < rp[r + 1]; ++k) {
+            const int32_t c = ci[k];
+            if (c >= lo && c < hi && c != r) adj[(size_t)fill[(size_t)c]++] = (int32_t)r;
+          }
+      }, 1 << 16);
     }
     deg.resize((size_t)n);
     parallel_chunks(n, [&](int64_t lo, int64_t hi) {
@@ -175,9 +186,27 @@ inline std::vector<int32_t> rcm(const Graph &G0, int64_t give_up_width = 0) {
   //  level structures of the start-node search do not need it, and a hopeless pattern is given up before any of it)
   // nodes by ascending degree: candidates for the start of each component
   std::vector<int32_t> bydeg((size_t)n);
-  for (int64_t o = 0; o < n; ++o) bydeg[(size_t)o] = G.by_orig(o);      // (ties in ascending ORIGINAL number)
-  std::stable_sort(bydeg.begin(), bydeg.end(), [&](int32_t x, int32_t y) { return deg[x] < deg[y]; });
+  {   // stable counting sort by degree over the nodes in ascending ORIGINAL number (= a stable sort of that sequence by degree)
+    int32_t dmax = 0;
+    for (int64_t i = 0; i < n; ++i) dmax = std::max(dmax, deg[(size_t)i]);
+    std::vector<int64_t> start((size_t)dmax + 2, 0);
+    for (int64_t i = 0; i < n; ++i) ++start[(size_t)deg[(size_t)i] + 1];
+    for (int32_t d = 0; d <= dmax; ++d) start[(size_t)d + 1] += start[(size_t)d];
+    for (int64_t o = 0; o < n; ++o) {
+      const int32_t x = G.by_orig(o);
+      bydeg[(size_t)start[(size_t)deg[(size_t)x]]++] = x;
+    }
+  }
 
+  static const bool tm = std::getenv("EXPV_MI_OP_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tm) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[op build]     rcm: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
+  lap("local copy + degree order");
   std::vector<int32_t> stamp((size_t)n, 0), queue((size_t)n);
   std::vector<char> placed((size_t)n, 0);
   int32_t cur_stamp = 0;
@@ -235,6 +264,7 @@ inline std::vector<int32_t> rcm(const Graph &G0, int64_t give_up_width = 0) {
       width = w2;
     }
     if (give_up_width > 0 && width > give_up_width) return std::vector<int32_t>();
+    if (cand == 0) lap("start node (searches)");
     // Cuthill-McKee from s
     const int64_t first = pos;
     int64_t head = pos;
@@ -256,6 +286,7 @@ inline std::vector<int32_t> rcm(const Graph &G0, int64_t give_up_width = 0) {
     std::reverse(order.begin() + first, order.begin() + pos);      // reverse Cuthill-McKee, component by component
   }
   for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = G.tie(order[(size_t)i]);
+  lap("Cuthill-McKee passes");
   return perm;
 }
 
