@@ -57,7 +57,7 @@ def _r(x, sig=9):
 
 def compact_line(out):
     """The one line the driver parses: headline keys, a flat config, a flat roofline, a flat cpu_baseline.  Everything else
-    (per-kernel tables, the secondary entries with their prose) goes to bench_full.json and to an earlier 'FULL ' line."""
+    (per-kernel tables, the secondary entries with their prose) goes to bench_full.json and, in pieces, to stderr."""
     head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
     c = {k: out[k] for k in head if k in out}
@@ -129,7 +129,8 @@ def compact_line(out):
 
 
 def emit(out):
-    """full record -> bench_full.json (+ gpurun_out/ when present) and an earlier 'FULL ' stdout line; compact record LAST"""
+    """full record -> bench_full.json (+ gpurun_out/ when present) and 'FULL[i] ' pieces on stderr; the compact record is the LAST (and only
+    large) stdout line"""
     full = json.dumps(_r(out, 12))
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         try:
@@ -138,7 +139,9 @@ def emit(out):
                     f.write(full + "\n")
         except OSError:
             pass
-    print("FULL " + full, flush=True)
+    # (stdout carries the compact line and nothing else of this size: the full record goes to stderr, in pieces no reader chokes on)
+    for i in range(0, len(full), 3000):
+        print("FULL[%d] %s" % (i // 3000, full[i:i + 3000]), file=sys.stderr, flush=True)
     print(compact_line(out), flush=True)
 
 
