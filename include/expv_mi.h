@@ -169,7 +169,10 @@ int expv_mi_op_create_csr(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *r
 int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void *A, int64_t lda, int loc,
                             expv_mi_op_t *op);
 /* Matrix-free operator: `matvec(user, x_dev, y_dev, hip_stream)` must enqueue y = A*x on the stream
- * (basictests.jl:786-816 interface contract). */
+ * (basictests.jl:786-816 interface contract).  What the callback may rely on: x and y are device vectors of n elements, 16-byte
+ * aligned, valid for the duration of the call, y does not alias x; A must be LINEAR in x -- inside a factorisation the library
+ * applies it to the un-normalised u_j = beta_j v_j (the result is rescaled), and it calls it once per step up to m even when the
+ * device finds a happy breakdown earlier (the later results are discarded: the reference stops calling mul! there, arnoldi.jl:370). */
 typedef int (*expv_mi_matvec_fn)(void *user, const void *x_dev, void *y_dev, void *hip_stream);
 int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_matvec_fn fn, void *user,
                                int ishermitian, int64_t nnz_hint, expv_mi_op_t *op);
