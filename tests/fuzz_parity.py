@@ -18,8 +18,13 @@ from oracle import krylov_oracle as ko
 eu = expv_mi_loader.load()
 
 
+FOCUS = __import__("os").environ.get("FUZZ_FOCUS", "")      # "complex_windows": complex element types, banded / grid / wide-band operators, m in 16..40 (round 5's new kernels)
+
+
 def make_operator(rng, n, cplx):
     kind = rng.choice(["banded", "banded", "wide_diagonals", "regular_rows", "irregular_rows", "dense", "symmetric_banded", "hermitian_dense", "grid2d", "wide_band"])
+    if FOCUS == "complex_windows":
+        kind = rng.choice(["banded", "banded", "grid2d", "wide_band", "symmetric_banded"])
     def vals(shape, scale):
         v = rng.standard_normal(shape) * scale
         return v + 1j * rng.standard_normal(shape) * scale if cplx else v
@@ -126,6 +131,8 @@ def _np(x):
 def one_case(seed, index, verbose=False):
     rng = np.random.default_rng([seed, index])
     T = np.dtype(rng.choice(["float64", "float64", "complex128", "float32", "complex64"]))
+    if FOCUS == "complex_windows":
+        T = np.dtype(rng.choice(["complex128", "complex128", "complex64"]))
     cplx = T.kind == "c"
     T64 = np.dtype(np.complex128 if cplx else np.float64)
     single = T.itemsize == (8 if cplx else 4)
@@ -148,6 +155,9 @@ def one_case(seed, index, verbose=False):
     tq = float(rng.choice([0.7, 0.7, 0.7, -0.4, 1e-8, 0.0, 3.0]))      # the time of the plain calls
     m = int(rng.integers(1, 41))
     iop = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
+    if FOCUS == "complex_windows":
+        m = int(rng.integers(16, 41))
+        iop = int(rng.choice([0, 0, 0, 17, 24, 31]))
     herm = kind in ("symmetric_banded", "hermitian_dense", "grid2d_symmetric", "wide_band_symmetric") and bool(rng.integers(0, 2))
     call = rng.choice(["expv", "expv", "arnoldi", "phiv", "expv_timestep", "phiv_timestep", "expv_complex_t", "kiops", "error_estimate",
                        "subspace_reuse", "continuation", "update_values", "matrix_free", "batch", "phiv_correct", "async_device", "caches"])
