@@ -56,6 +56,17 @@ inline auto dispatch_dtype(int dt, F &&f) {
 // printed when the context is destroyed
 void ht_mark(int id);
 void ht_report();
+// sequence trace of ONE driver call (EXPV_MI_CALL_TRACE=1): host wall-clock stamps in call order, printed to stderr when the call
+// ends -- where a kiops / phiv_timestep! call spends its time between the device's factorisations (tools/kiops_trace.py)
+struct CallTrace {
+  static bool enabled();
+  bool on = enabled();
+  std::vector<std::pair<const char *, double>> ev;
+  void mark(const char *what);
+  void dump(const char *title);
+};
+extern thread_local CallTrace *t_call_trace;      // the driver call in progress on this thread (nullptr: none, or tracing off)
+inline void ct_mark(const char *what) { if (t_call_trace) t_call_trace->mark(what); }
 
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

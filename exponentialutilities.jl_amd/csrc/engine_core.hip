@@ -433,6 +433,22 @@ void ht_report() {
   for (int i = 1; i < 16; ++i)
     if (g_ht_cnt[i]) std::fprintf(stderr, "[host timing] %-28s %8.2f us avg over %ld\n", names[i], g_ht_sum[i] / g_ht_cnt[i], g_ht_cnt[i]);
 }
+thread_local CallTrace *t_call_trace = nullptr;
+bool CallTrace::enabled() {
+  static const bool e = std::getenv("EXPV_MI_CALL_TRACE") != nullptr;
+  return e;
+}
+void CallTrace::mark(const char *what) {
+  if (!on) return;
+  ev.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+void CallTrace::dump(const char *title) {
+  if (!on || ev.empty()) return;
+  std::fprintf(stderr, "[call trace] %s\n", title);
+  for (size_t i = 0; i < ev.size(); ++i)
+    std::fprintf(stderr, "[call trace] %9.1f us  +%7.1f  %s\n", ev[i].second - ev[0].second, i ? ev[i].second - ev[i - 1].second : 0.0, ev[i].first);
+  ev.clear();
+}
 template <class T>
 static int arnoldi_T(Ks &ks, Op &op, const T *b, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug, bool lanczos);
 // the single-pass step (pipe.hip): fp64 in every form, the other element types on the diagonal (DIA) halo form
@@ -514,7 +530,9 @@ struct ArnoldiCall {
     // mode) asks for a true continuation through Ks::lanczos_continue
     jstart = (lanczos && !ks.lanczos_continue) ? 1 : init;
     if (jstart > m) return 0;
+    ct_mark("  arnoldi!: form chosen, first step set up");
     reset_device_state();
+    ct_mark("  arnoldi!: device state reset enqueued");
     if (use_pipe) {
       if constexpr (kPipeType<T>) steps_single_pass();
       else fail(EXPV_MI_HIP_ERROR, "single-pass step chosen for a 32-bit element type");
@@ -522,6 +540,7 @@ struct ArnoldiCall {
     else if (use_fused && single_red) steps_two_kernel();
     else if (use_fused) steps_two_kernel_two_reductions();
     else steps_modular();
+    ct_mark("  arnoldi!: all step launches enqueued");
     return read_back();
   }
 

@@ -478,6 +478,9 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   if (numSteps != 1)
     fail(EXPV_MI_DIMENSION_MISMATCH, "kiops: size(tau_out,2) > 1 fails checkdims in the reference (arnoldi.jl:217)");
   std::vector<double> w_aug(p, 0.0);
+  CallTrace tr;
+  struct TraceScope { CallTrace *prev; TraceScope(CallTrace *t) : prev(t_call_trace) { t_call_trace = t->on ? t : nullptr; } ~TraceScope() { t_call_trace = prev; } } trace_scope(&tr);
+  tr.mark("kiops_T entered");
   HIPCHECK(hipMemcpyAsync(wdev, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));   // w[:,1] = u[:,1]
   const double normU = *u_host_abs1;                               // norm(u[:, 2:end], 1), entrywise
   double nu = 1, mu = 1;
@@ -521,6 +524,7 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   aug.w = wdev;
   aug.w_aug_host = w_aug.data();
   aug.mu = mu;
+  tr.mark("prologue enqueued (w = u, u_flip)");
   while (tau_now < tau_end) {
     const int oldj = ks.m;
     ao.m = m;
@@ -532,6 +536,7 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
     struct DeferOff { Ks &k; ~DeferOff() { k.defer_tail_req = false; } } defer_off{ks};
     arnoldi_run(ks, op, nullptr, ao, &aug, false);
     ks.defer_tail_req = false;
+    tr.mark("arnoldi! returned (early flag of step m: H[1:m, 1:m] on the host)");
     j = ks.m;
     bool happy = j < oldj;
     const double beta = ks.beta;
@@ -541,12 +546,14 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
     Mat<S> F = hblock<S>(ks, j + 1, sgn * tau);    // exp(sgn*tau*H[1:j+1, 1:j+1])
     dense::expm_higham2005base(F);
     ++exps;
+    tr.mark("host exp(tau H) done");
     if (ks.tail.pending) {
       ks_finish_tail(ks);
       nrm = getH(ks, j, j - 1);
     } else {
       setH(ks, j, j - 1, nrm);
     }
+    tr.mark("closing pass arrived (H[m+1, m])");
     double tau_new;
     int m_new;
     if (happy) {
@@ -614,11 +621,13 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
       tau_now += tau;
       j = 0;
       ireject = 0;
+      tr.mark("accepted: solution update enqueued");
     } else {
       ++ireject;
       if (ireject > 1000)      // (the reference has no bound, kiops.jl:170-281; see phiv_timestep_T)
         fail(EXPV_MI_ARGUMENT_ERROR, "kiops: 1000 rejected steps in a row (tol below the resolution of the arithmetic?)");
       setH(ks, 0, j, cd(0.0, 0.0));
+      tr.mark("rejected");
     }
     oldtau = tau;
     tau = tau_new;
@@ -634,7 +643,10 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
       fail(EXPV_MI_UNSUPPORTED, "kiops task1 with several outputs is flagged FIXME in kiops.jl:255");
     }
   }
+  tr.mark("loop left");
   HIPCHECK(hipStreamSynchronize(s));
+  tr.mark("stream drained");
+  tr.dump("kiops");
   stats[0] = step; stats[1] = reject; stats[2] = krystep; stats[3] = exps; stats[4] = m;
 }
 

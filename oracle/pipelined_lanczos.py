@@ -1,0 +1,148 @@
+"""Pipelined (communication-hiding) restatements of ``lanczos_step!`` -- numpy, TEST INFRASTRUCTURE.
+
+Only ``tests/`` and ``tools/pipelined_lanczos_accuracy.py`` may import this file; the product
+(``exponentialutilities.jl_amd``) never does.  It exists to MEASURE what a pipelined recurrence would cost
+in accuracy against the reference recurrence before anything like it is built on the device
+(VERDICT round 5, item 4).
+
+Reference recurrence (``/root/reference/src/arnoldi.jl:388-403``), one global reduction after the other:
+
+    y = A v_j;  alpha_j = <v_j, y>;  y -= alpha_j v_j + beta_{j-1} v_{j-1};  beta_j = ||y||;  v_{j+1} = y / beta_j
+
+Two restatements, both Hermitian-only like ``lanczos!`` itself:
+
+``lanczos_p1``  Ghysels-Vanroose one-reduction form (the Lanczos analogue of their pipelined CG, "Hiding global
+                synchronization latency in the preconditioned Conjugate Gradient algorithm", Parallel Computing 40, 2014):
+                an auxiliary basis z_j = A v_j is carried by recurrence, the step's ONE reduction returns
+                <v_j, z_j> and <z_j, z_j>, and beta_j follows from ||z_j||^2 = alpha_j^2 + beta_{j-1}^2 + beta_j^2
+                (orthonormality of v_{j-1}, v_j, v_{j+1}).  The operator is applied to z_j (q_j = A z_j), which does not
+                need the reduction's result: that product is what overlaps the reduction.
+
+``lanczos_p2``  the same with the scalars arriving ONE PASS LATE (what a device pass that must not wait for the
+                previous pass' reduction would need): pass j+1 applies A to q_j before alpha_j / beta_j exist and takes
+                all inner products from the Gram matrix of the vectors it streams, i.e. "inner products by expansion".
+                v_{j+1}, z_{j+1}, q_{j+1} are formed from the expanded scalars.
+
+Both return (alpha[1..m], beta[1..m], V[:, 0..m]) with H = tridiag(beta, alpha, beta), like ``lanczos_`` of
+``oracle/krylov_oracle.py``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _mul(A, x):
+    return A @ x
+
+
+def lanczos_ref(A, b, m):
+    """arnoldi.jl:388-403, 456-490 (no breakdown test: the accuracy study runs all m steps)."""
+    n = b.shape[0]
+    T = np.result_type(A.dtype, b.dtype, np.float64)
+    V = np.zeros((n, m + 1), dtype=T)
+    alpha = np.zeros(m)
+    beta = np.zeros(m)
+    beta0 = float(np.linalg.norm(b))
+    V[:, 0] = b / beta0
+    for j in range(1, m + 1):
+        y = _mul(A, V[:, j - 1])
+        a = np.vdot(V[:, j - 1], y).real
+        alpha[j - 1] = a
+        y = y - a * V[:, j - 1]
+        if j > 1:
+            y = y - beta[j - 2] * V[:, j - 2]
+        beta[j - 1] = float(np.linalg.norm(y))
+        V[:, j] = y / beta[j - 1]
+    return beta0, alpha, beta, V
+
+
+def lanczos_p1(A, b, m):
+    """Ghysels-Vanroose one-reduction Lanczos: ONE reduction {<v_j,z_j>, <z_j,z_j>} per step, q_j = A z_j beside it."""
+    n = b.shape[0]
+    T = np.result_type(A.dtype, b.dtype, np.float64)
+    V = np.zeros((n, m + 1), dtype=T)
+    alpha = np.zeros(m)
+    beta = np.zeros(m)
+    beta0 = float(np.linalg.norm(b))
+    V[:, 0] = b / beta0
+    z = _mul(A, V[:, 0])                 # z_1 = A v_1
+    z_old = np.zeros_like(z)
+    b_old = 0.0
+    for j in range(1, m + 1):
+        v = V[:, j - 1]
+        # --- the step's single reduction ---
+        a = np.vdot(v, z).real
+        zz = np.vdot(z, z).real
+        # --- beside it: the operator on z_j ---
+        q = _mul(A, z)
+        alpha[j - 1] = a
+        b2 = zz - a * a - b_old * b_old
+        bj = np.sqrt(b2) if b2 > 0 else 0.0
+        beta[j - 1] = bj
+        v_old = V[:, j - 2] if j > 1 else 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            V[:, j] = (z - a * v - b_old * v_old) / bj
+            z_new = (q - a * z - b_old * z_old) / bj
+        z_old, z = z, z_new
+        b_old = bj
+    return beta0, alpha, beta, V
+
+
+def lanczos_p2(A, b, m):
+    """Scalars one pass late: pass j+1 streams {v_j, v_{j-1}, z_j, z_{j-1}, q_j, q_{j-1}}, applies A to q_j and reduces their
+    Gram matrix; alpha_{j+1}, beta_{j+1} are EXPANDED from that Gram matrix and the (by then known) alpha_j, beta_j:
+
+        v_{j+1} = (z_j - a v_j - b' v_{j-1}) / b        z_{j+1} = (q_j - a z_j - b' z_{j-1}) / b
+        alpha_{j+1} = <v_{j+1}, z_{j+1}>,  ||z_{j+1}||^2  -- both quadratic forms in the six streamed vectors.
+    """
+    n = b.shape[0]
+    T = np.result_type(A.dtype, b.dtype, np.float64)
+    V = np.zeros((n, m + 1), dtype=T)
+    alpha = np.zeros(m)
+    beta = np.zeros(m)
+    beta0 = float(np.linalg.norm(b))
+    V[:, 0] = b / beta0
+    v = V[:, 0].copy()
+    z = _mul(A, v)
+    q = _mul(A, z)
+    zero = np.zeros_like(v)
+    v_o, z_o, q_o = zero, zero.copy(), zero.copy()
+    a = np.vdot(v, z).real                      # start-up: the first step's scalars by direct products
+    zz = np.vdot(z, z).real
+    b_o = 0.0
+    for j in range(1, m + 1):
+        alpha[j - 1] = a
+        b2 = zz - a * a - b_o * b_o
+        bj = np.sqrt(b2) if b2 > 0 else 0.0
+        beta[j - 1] = bj
+        # --- pass j+1, before a / bj "exist": stream the six vectors, r = A q_j, Gram matrix of S = [z q v | z_o q_o v_o]
+        r = _mul(A, q)
+        S = np.stack([v, z, q, v_o, z_o, q_o], axis=1)
+        G = (S.conj().T @ S).real
+        # coefficient vectors (in the basis S) of v_{j+1} and z_{j+1}
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cv = np.array([-a, 1.0, 0.0, -b_o, 0.0, 0.0]) / bj
+            cz = np.array([0.0, -a, 1.0, 0.0, -b_o, 0.0]) / bj
+            a_next = cv @ G @ cz
+            zz_next = cz @ G @ cz
+            # --- the lagged update (start of pass j+2 on the device) ---
+            v_n = (z - a * v - b_o * v_o) / bj
+            z_n = (q - a * z - b_o * z_o) / bj
+            q_n = (r - a * q - b_o * q_o) / bj
+        V[:, j] = v_n
+        v_o, z_o, q_o = v, z, q
+        v, z, q = v_n, z_n, q_n
+        b_o = bj
+        a, zz = a_next, zz_next
+    return beta0, alpha, beta, V
+
+
+def expv_from_lanczos(t, beta0, alpha, beta, V, m):
+    """krylov_phiv.jl:200-247 on the tridiagonal: w = beta0 V[:, :m] exp(t T_m) e_1 (eigen-decomposition, like the reference)."""
+    from scipy.linalg import eigh_tridiagonal
+    if m == 1:
+        lam, Z = alpha[:1].copy(), np.ones((1, 1))
+    else:
+        lam, Z = eigh_tridiagonal(alpha[:m], beta[:m - 1])
+    e = Z @ (np.exp(t * lam) * Z[0, :])
+    return beta0 * (V[:, :m] @ e)
