@@ -899,6 +899,9 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
             elif off > 0:
                 y[:-off].add_(x[off:], alpha=cv)
         return y
+    # (the callback is LINEAR: it opts in to the two-kernel step, context option matfree_fused = 1; the default since round 6 is the
+    #  reference's contract -- mul! on the normalised column, modular launches)
+    ctx.set_option("matfree_fused", 1)
     mf_ = eu.MIOperator(None, ctx, matvec=stencil_mul, shape=(n, n), dtype=np.float64, ishermitian=False)
     fmf = lambda: eu.expv(T_FINAL, mf_, b, m=m, ishermitian=False, out=w)
     eu.expv(T_FINAL, op, b, m=m, ishermitian=False, out=w)
@@ -912,8 +915,44 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     e["rel_diff_to_stored_operator_result"] = float(torch.linalg.norm(w - w_stored) / torch.linalg.norm(w_stored))
     xm_ = torch.randn(n, dtype=torch.float64, device=env.device)
     e["callback_matvec_alone_us"] = 1e6 * timed(lambda: stencil_mul(xm_), 30, 5, env.sync)
+    e["option"] = "matfree_fused = 1 (linear callback)"
     sec["matrix_free_callback"] = e
-    del mf_, w_stored, xm_
+    env.sync()
+    del mf_
+    # (4e) the same operator as a COMPILED callback: one hand-written HIP kernel behind expv_mi_matvec_fn (tests/c_harness/stencil_callback.hip,
+    # what a Julia host passes as a @cfunction) -- the library's own share of a matrix-free step, no Python inside the factorisation
+    cb_so = os.path.join(ROOT, "tests", "c_harness", "libstencil_cb.so")
+    if os.path.exists(cb_so):
+        import ctypes as C_
+
+        class StencilOp(C_.Structure):
+            _fields_ = [("n", C_.c_int64), ("ndiag", C_.c_int), ("off", C_.c_int * 8), ("coef", C_.c_double * 8)]
+        cbl = C_.CDLL(cb_so)
+        cbl.stencil_matvec.argtypes = [C_.c_void_p] * 4
+        cbl.stencil_matvec.restype = C_.c_int
+        assert cbl.stencil_op_sizeof() == C_.sizeof(StencilOp)
+        sop = StencilOp(n, len(C2_OFFSETS), (C_.c_int * 8)(*C2_OFFSETS), (C_.c_double * 8)(*C2_VALS))
+        for fused_opt, key in ((1, "matrix_free_compiled"), (0, "matrix_free_compiled_default_path")):
+            ctx.set_option("matfree_fused", fused_opt)
+            mfc = eu.MIOperator(None, ctx, matvec_c=(cbl.stencil_matvec, C_.addressof(sop)), shape=(n, n), dtype=np.float64, ishermitian=False)
+            fmc = lambda: eu.expv(T_FINAL, mfc, b, m=m, ishermitian=False, out=w)
+            fmc()
+            env.sync()
+            e = entry("expv(1.0, A, b) through a COMPILED matrix-free operator (callback = one HIP kernel, tests/c_harness/stencil_callback.hip), "
+                      "n=%d m=%d, option matfree_fused = %d%s" % (n, m, fused_opt, "" if fused_opt else " (the default: mul! on the normalised column, modular launches)"),
+                      timed(fmc, max(5, args.steps // 2), 1, env.sync), m, b_alg)
+            e["path"] = list(eu.expv.last_stats["path"])
+            e["rel_diff_to_stored_operator_result"] = float(torch.linalg.norm(w - w_stored) / torch.linalg.norm(w_stored))
+            if e["rel_diff_to_stored_operator_result"] > 1e-10:
+                raise SystemExit("%s: result differs from the stored operator's: %.3e" % (key, e["rel_diff_to_stored_operator_result"]))
+            ym_ = torch.empty_like(xm_)
+            st_ = torch.cuda.current_stream().cuda_stream
+            e["callback_matvec_alone_us"] = 1e6 * timed(lambda: cbl.stencil_matvec(C_.addressof(sop), C_.c_void_p(xm_.data_ptr()), C_.c_void_p(ym_.data_ptr()), C_.c_void_p(st_)), 30, 5, env.sync)
+            sec[key] = e
+            env.sync()
+            del mfc
+    ctx.set_option("matfree_fused", 0)
+    del w_stored, xm_
     # (5) BASELINE configs[4] on ONE GPU: its 1/8 share of the 1024 problems
     a5 = argparse.Namespace(nprob=128, steps=max(2, args.steps // 5), warmup=1)
     o5s = sorted((run_c5(a5, eu, env, do_emit=False) for _ in range(5)), key=lambda o_: o_["roofline"]["frac"])      # five runs: median, spread
@@ -953,40 +992,43 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
                     "stats": {k: stx.get(k) for k in ("num_timesteps", "matvecs", "m", "arnoldi_calls", "arnoldi_reused")}}
     # (6) BASELINE configs[2] on one GPU at a size that costs a few seconds: adaptive phiv_timestep, K = 4, dense fp64 operator
     # generated on the device (n = 65 536: 34 GB); the step is operator applications (mul!), the kernel the library's dense GEMV
-    n3 = 65_536
-    try:
-        A3 = c3_rows(torch, env.device, n3, 0, n3)
-        op3 = eu.MIOperator(A3, ctx)                      # device-resident, column-major: no copy
-        g3 = torch.Generator(device=env.device)
-        g3.manual_seed(5)
-        B3 = torch.randn((5, n3), dtype=torch.float64, device=env.device, generator=g3).t()
-        st3 = {}
-        f3 = lambda: eu.phiv_timestep(1.0, op3, B3, adaptive=True, tol=1e-7, m=10, stats=st3)
-        f3()
-        env.sync()
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-        c0 = ctx.counters()
-        reps3 = 3
-        t3 = timed(f3, reps3, 0, env.sync)
-        c1 = ctx.counters()
-        pr3 = ctx.prof_get()
-        ctx.prof_enable(False)
-        apps = ((c1["op_applies"] - c0["op_applies"]) + (c1["krylov_steps"] - c0["krylov_steps"])) / reps3
-        mv = pr3.get("matvec", {"launches": 0, "total_ms": 0.0})
-        gemv_ms = mv["total_ms"] / max(mv["launches"], 1)
-        sec["c3_dense_phiv_timestep"] = {
-            "what": "BASELINE configs[2] at n=%d (%.1f GB, one GPU): phiv_timestep(1.0, A, B; adaptive, K=4, tol=1e-7, m0=10), dense fp64 A "
-                    "generated on the device; unit = operator applications (all mul! calls)" % (n3, 8e-9 * n3 * n3),
-            "value": apps / t3, "unit": "matvecs/s", "ms_per_call": 1e3 * t3, "applications_per_call": apps,
-            "stats": {k: st3.get(k) for k in ("num_timesteps", "matvecs", "m")},
-            "gemv_avg_ms": gemv_ms, "gemv_launches_profiled": mv["launches"],
-            "gemv_alg_GBps": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9) if gemv_ms > 0 else None,
-            "frac": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gemv_ms > 0 else None,
-            "whole_call_alg_GBps": 8.0 * n3 * n3 * apps / t3 / 1e9}
-        del op3, A3, B3
-    except torch.cuda.OutOfMemoryError as ex:      # (a smaller card: say so instead of dropping the line silently)
-        sec["c3_dense_phiv_timestep"] = {"error": "out of memory for the %d x %d operator: %s" % (n3, n3, str(ex)[:80])}
+    for n3, key3, reps3 in ((65_536, "c3_dense_phiv_timestep", 3), (163_840, "c3_dense_phiv_timestep_n163840", 2)):
+        # (the second size is the LARGEST single-GPU configuration of BASELINE configs[2]: 214.7 GB of the 288 GB; generation ~15 s)
+        if n3 > 65_536 and args.no_c3_full:
+            continue
+        try:
+            A3 = c3_rows(torch, env.device, n3, 0, n3)
+            op3 = eu.MIOperator(A3, ctx)                      # device-resident, column-major: no copy
+            g3 = torch.Generator(device=env.device)
+            g3.manual_seed(5)
+            B3 = torch.randn((5, n3), dtype=torch.float64, device=env.device, generator=g3).t()
+            st3 = {}
+            f3 = lambda: eu.phiv_timestep(1.0, op3, B3, adaptive=True, tol=1e-7, m=10, stats=st3)
+            f3()
+            env.sync()
+            ctx.prof_reset()
+            ctx.prof_enable(True)
+            c0 = ctx.counters()
+            t3 = timed(f3, reps3, 0, env.sync)
+            c1 = ctx.counters()
+            pr3 = ctx.prof_get()
+            ctx.prof_enable(False)
+            apps = ((c1["op_applies"] - c0["op_applies"]) + (c1["krylov_steps"] - c0["krylov_steps"])) / reps3
+            mv = pr3.get("matvec", {"launches": 0, "total_ms": 0.0})
+            gemv_ms = mv["total_ms"] / max(mv["launches"], 1)
+            sec[key3] = {
+                "what": "BASELINE configs[2] at n=%d (%.1f GB, one GPU): phiv_timestep(1.0, A, B; adaptive, K=4, tol=1e-7, m0=10), dense fp64 A "
+                        "generated on the device; unit = operator applications (all mul! calls)" % (n3, 8e-9 * n3 * n3),
+                "value": apps / t3, "unit": "matvecs/s", "ms_per_call": 1e3 * t3, "applications_per_call": apps,
+                "stats": {k: st3.get(k) for k in ("num_timesteps", "matvecs", "m")},
+                "gemv_avg_ms": gemv_ms, "gemv_launches_profiled": mv["launches"],
+                "gemv_alg_GBps": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9) if gemv_ms > 0 else None,
+                "frac": (8.0 * n3 * n3 / (gemv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if gemv_ms > 0 else None,
+                "whole_call_alg_GBps": 8.0 * n3 * n3 * apps / t3 / 1e9}
+            del op3, A3, B3
+            torch.cuda.empty_cache()
+        except torch.cuda.OutOfMemoryError as ex:      # (a smaller card: say so instead of dropping the line silently)
+            sec[key3] = {"error": "out of memory for the %d x %d operator: %s" % (n3, n3, str(ex)[:80])}
     return sec
 
 
@@ -1072,6 +1114,7 @@ def main(argv=None):
     ap.add_argument("--spinup", type=float, default=0.6, help="seconds of untimed calls before the warm-up steps (device clocks; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (split API, Lanczos, C4, C5)")
+    ap.add_argument("--no-c3-full", action="store_true", help="secondary block: skip BASELINE configs[2] at its largest single-GPU size (n = 163 840, 214.7 GB)")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra non-overlapped profiling pass")
     ap.add_argument("--sync-outputs", action="store_true", help="every call returns only when its device result is complete")
     ap.add_argument("--split-api", action="store_true", help="time arnoldi!(Ks,A,b) + expv!(w,t,Ks) instead of expv(t,A,b)")
@@ -1163,6 +1206,20 @@ def run_c2(args, eu, env):
 
     # device spin-up (untimed, before the W warm-up steps of the contract): a box that has just been handed over clocks up during
     # its first few hundred milliseconds of work -- the first run on a fresh box measured 3 % below the second (26.1 k vs 26.9 k)
+    # ... and the figure WITHOUT that spin-up, measured first in the process (VERDICT r5 / ADVICE r5): the contract's W warm-up steps,
+    # then the same K steps -- what the first calls of an ODE integrator see on a box that has been idle (`value_cold` in the line)
+    cold = None
+    if env.ctx is not None and args.spinup > 0:
+        for _ in range(args.warmup):
+            one_expv()
+        env.barrier()
+        tc0 = time.perf_counter()
+        cu = 0
+        for _ in range(args.steps):
+            cu += one_expv()
+        env.barrier()
+        tc = max(env.per_rank(time.perf_counter() - tc0))
+        cold = {"value": float(sum(env.per_rank(cu))) / tc, "ms_per_step": 1e3 * tc / args.steps}
     spin_t0, spin_calls = time.perf_counter(), 0
     while env.ctx is not None and time.perf_counter() - spin_t0 < args.spinup:
         one_expv()
@@ -1271,7 +1328,8 @@ def run_c2(args, eu, env):
                    "n": n, "m": m, "nnz": int(nnz), "ortho": args.ortho, "setup_s": t_setup,
                    "entry": "arnoldi!+expv!" if args.split_api else "expv(t,A,b)", "path": path,
                    "outputs": "complete on return" if args.sync_outputs else "stream-ordered",
-                   "spinup_calls": spin_calls},
+                   "spinup_calls": spin_calls,
+                   "value_cold": cold["value"] if cold else None, "ms_per_step_cold": cold["ms_per_step"] if cold else None},
         "ranks_seen": seen, "devices": ids, "per_rank_ms_per_step": per_rank_ms, "process_group": env.backend,
         "counters": ctx.counters() if ctx is not None else None,
         "roofline": roofline,

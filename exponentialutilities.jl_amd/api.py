@@ -354,13 +354,22 @@ class MIOperator:
     ``shape``, ``dtype``, ``ishermitian`` (LinearAlgebra.ishermitian), ``nnz`` and ``opnorm_inf``.
     """
 
-    def __init__(self, A, ctx=None, dtype=None, ishermitian=None, matvec=None, shape=None):
+    def __init__(self, A, ctx=None, dtype=None, ishermitian=None, matvec=None, shape=None, matvec_c=None):
         lib = L.load()
         self.ctx = ctx or default_context()
         self.src = A
         h = C.c_void_p()
         self._cb = None
-        if matvec is not None:          # matrix-free: matvec(x_dev_tensor) -> y_dev_tensor (torch, on the stream)
+        if matvec_c is not None:        # matrix-free, compiled: (function pointer of type expv_mi_matvec_fn, user pointer) -- what a Julia
+            fn, user = matvec_c         # host passes as a @cfunction; nothing of Python runs inside the factorisation
+            n = int(shape[0])
+            dt = np.dtype(dtype or np.float64)
+            self._matvec = None
+            self._cb = (fn, user)       # (keeps the caller's objects alive)
+            _check(lib.expv_mi_op_create_callback(self.ctx._h, _code(dt), n, C.cast(fn, L.MATVEC_FN),
+                                                  C.cast(user, C.c_void_p) if not isinstance(user, (int, type(None))) else C.c_void_p(user),
+                                                  int(bool(ishermitian)), 0, C.byref(h)), self.ctx._h)
+        elif matvec is not None:        # matrix-free: matvec(x_dev_tensor) -> y_dev_tensor (torch, on the stream)
             n = int(shape[0])
             dt = np.dtype(dtype or np.float64)
             self._matvec = matvec

@@ -64,22 +64,45 @@ def build(force=False, verbose=True):
 
 
 def _prune(objdir, objs, srcs, headers, verbose):
-    """Delete every object / library in the package directory that this build did not produce: experiment leftovers
-    (variant objects, A/B libraries) would otherwise travel to the GPU box and could be loaded by accident.  The trace
-    library (tools only) survives while it is newer than every source."""
+    """Delete the artefacts of earlier experiments that this build did not produce, so that they cannot travel to the GPU box and be
+    loaded by accident: everything compiled in build/ (this package's own object directory) and the A/B libraries tools/build_variant.py
+    writes next to the product library (libexpv_mi_<TAG>.so).  Nothing else in the package directory is touched (a
+    build must not delete files it does not own by extension match).  EXPV_MI_NO_PRUNE=1 keeps everything.  The trace library (tools
+    only) survives while it is newer than every source."""
+    if os.environ.get("EXPV_MI_NO_PRUNE"):
+        return
     keep = {os.path.abspath(o) for o in objs} | {os.path.abspath(LIB)}
     trace_so, trace_o = os.path.join(HERE, "libexpv_mi_trace.so"), os.path.join(objdir, "pipe_trace.o")
     deps = [os.path.join(CSRC, s) for s in srcs] + headers
     if os.path.exists(trace_so) and not _stale(trace_so, deps):
         keep |= {os.path.abspath(trace_so), os.path.abspath(trace_o)}
-    for d in (HERE, objdir):
-        for f in os.listdir(d):
-            path = os.path.abspath(os.path.join(d, f))
-            artefact = f.endswith((".o", ".so", ".a", ".hsaco", ".co", ".s", ".bc", ".hipi", ".out", ".hipfb")) or ".o." in f or ".so." in f
-            if os.path.isfile(path) and artefact and path not in keep:
-                if verbose:
-                    print("[build] removing stale artefact", os.path.relpath(path, HERE), flush=True)
-                os.remove(path)
+    doomed = []
+    for f in os.listdir(objdir):      # our own object directory: compiler outputs only
+        if f.endswith((".o", ".so", ".a", ".hsaco", ".co", ".s", ".bc", ".hipi", ".out", ".hipfb")) or ".o." in f:
+            doomed.append(os.path.join(objdir, f))
+    for f in os.listdir(HERE):        # the package directory: variant libraries of the product only
+        if f.startswith("libexpv_mi_") and f.endswith(".so"):
+            doomed.append(os.path.join(HERE, f))
+    for path in map(os.path.abspath, doomed):
+        if os.path.isfile(path) and path not in keep:
+            if verbose:
+                print("[build] removing stale artefact", os.path.relpath(path, HERE), flush=True)
+            os.remove(path)
+
+
+def build_callback_example(verbose=True):
+    """tests/c_harness/libstencil_cb.so: a compiled matrix-free operator (one HIP kernel behind the expv_mi_matvec_fn contract) for the
+    GPU tests and bench.py's `matrix_free_compiled` entry.  Test infrastructure -- the product never loads it."""
+    src = os.path.join(HERE, "..", "tests", "c_harness", "stencil_callback.hip")
+    out = os.path.join(HERE, "..", "tests", "c_harness", "libstencil_cb.so")
+    if os.path.exists(src) and _stale(out, [src]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", out]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return os.path.abspath(out)
 
 
 def build_trace(verbose=True):

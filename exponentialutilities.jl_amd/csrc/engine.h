@@ -97,7 +97,11 @@ struct Options {
   int patch = 1;           // 2-D grid stencils: 1 = store the operator in a grid-patch ordering at creation (a 512-row tile = a 16 x 32 patch of
                            // the grid; pipe.hip: patch form of the single-pass step, ring recomputed instead of per-tile flags: 11-18 %
                            // faster than the wave form at every size measured); 0 = natural ordering, wave form  (EXPV_MI_PATCH=0|1)
-  int matfree_fused = 1;   // matrix-free operators on the two-kernel step (their mul! feeds its first kernel); 0: the modular path of rounds 1-4
+  int matfree_fused = 0;   // 1: matrix-free operators on the two-kernel step (their mul! feeds its first kernel, called on the UN-NORMALISED u_j =
+                           // beta_{j-1} v_j: for LINEAR callbacks only); 0 (default since round 6): the modular path, mul!(y, A, v_j) with |v_j| = 1
+                           // like the reference (arnoldi.jl:185) -- a finite-difference Jacobian-vector product tuned for unit vectors stays accurate
+  int kiops_skip_redo = 1; // kiops after a rejected sub-step: continue behind the closing pass (init = j + 1) instead of recomputing step j like
+                           // the reference's `for j in init:m` does (arnoldi.jl:368: same H[:, j], same v_{j+1} again); 0: the reference's loop
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the
                            // overlapped step-wise form, kept selectable for A/B              (EXPV_MI_RESIDENT=1 -> 1)
   static Options from_env();

@@ -407,6 +407,7 @@ int *Options::find(const char *name) {
   if (n == "reorder") return &reorder;
   if (n == "patch") return &patch;
   if (n == "matfree_fused") return &matfree_fused;
+  if (n == "kiops_skip_redo") return &kiops_skip_redo;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
   return nullptr;

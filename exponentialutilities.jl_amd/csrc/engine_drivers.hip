@@ -433,7 +433,7 @@ static Mat<S> hblock(const Ks &ks, int r, double scale) {   // scale * H[1:r, 1:
 
 template <class T>
 static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols, const T *u, int64_t ldu, int ppo,
-                    const double *u_host_abs1, T *wdev, const expv_mi_kiops_opts &o, int64_t stats[5]) {
+                    const double *u_host_abs1, T *wdev, const expv_mi_kiops_opts &o, int64_t stats[5], bool must_drain) {
   using S = typename std::conditional<ST<T>::is_complex, cd, double>::type;
   const int64_t n = op.n;
   const int dt = op.dtype;
@@ -447,7 +447,7 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   int herm = o.ishermitian < 0 ? op.ishermitian : o.ishermitian;
   // KrylovSubspace{T, U}(n, m, p)  (:74).  The subspace and the flipped-input scratch are private to the call, and
   // allocating ~n*(m+p)*sizeof(T) bytes costs more than a whole kiops step: keep them in the context between calls.
-  struct KiopsWs { expv_mi_ks_s ks; DevBuf uflip; };
+  struct KiopsWs { expv_mi_ks_s ks; DevBuf uflip; size_t uflip_zero_bytes = 0; };   // (uflip_zero_bytes: this much of uflip is known to hold zeros)
   KiopsWs *wsp = reinterpret_cast<KiopsWs *>(ctx->ws_kiops);
   const int dtU = herm ? EXPV_MI_F64 : dt;
   if (!wsp || wsp->ks.dtypeT != dt || wsp->ks.dtypeU != dtU || wsp->ks.n != n || wsp->ks.augmented != p || wsp->ks.maxiter < m) {
@@ -481,7 +481,9 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   CallTrace tr;
   struct TraceScope { CallTrace *prev; TraceScope(CallTrace *t) : prev(t_call_trace) { t_call_trace = t->on ? t : nullptr; } ~TraceScope() { t_call_trace = prev; } } trace_scope(&tr);
   tr.mark("kiops_T entered");
-  HIPCHECK(hipMemcpyAsync(wdev, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));   // w[:,1] = u[:,1]
+  // w[:,1] = u[:,1]  (:92): the first sub-step's factorisations read u itself -- w only has to exist once a sub-step has been
+  // accepted, and the solution update writes all of it (round 6: one 2 s n copy + its launch off the head of every call)
+  bool w_is_u = true;
   const double normU = *u_host_abs1;                               // norm(u[:, 2:end], 1), entrywise
   double nu = 1, mu = 1;
   if (ppo > 1 && normU > 0) {
@@ -491,11 +493,15 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   }
   // u_flip = reverse(u[:, 2:end], dims = 2) * nu   (:105-106)
   DevBuf &uflip = wsp->uflip;
-  if (uflip.bytes < sizeof(T) * (size_t)n * p + 16) uflip.alloc(sizeof(T) * (size_t)n * p + 16);
+  if (uflip.bytes < sizeof(T) * (size_t)n * p + 16) { uflip.alloc(sizeof(T) * (size_t)n * p + 16); wsp->uflip_zero_bytes = 0; }
   T *uf = uflip.as<T>();
-  if (padded) {
-    HIPCHECK(hipMemsetAsync(uf, 0, sizeof(T) * n * p, s));
+  if (padded) {      // the zero column stays zero from call to call: filled once
+    if (wsp->uflip_zero_bytes < sizeof(T) * (size_t)n * p) {
+      HIPCHECK(hipMemsetAsync(uf, 0, sizeof(T) * n * p, s));
+      wsp->uflip_zero_bytes = sizeof(T) * (size_t)n * p;
+    }
   } else {
+    wsp->uflip_zero_bytes = 0;
     for (int k = 0; k < p; ++k) {
       std::vector<const T *> in{u + (size_t)(p - k) * ldu};
       std::vector<double> cf{nu};
@@ -512,6 +518,7 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   bool orderold = true, kestold = true;
   double order = 0.0, kest = 2;
   int l = 1;
+  bool redo_skipped = false;
   expv_mi_arnoldi_opts ao;
   expv_mi_arnoldi_opts_default(&ao);   // tol stays at arnoldi!'s own default 1e-7 (kiops.jl:138-141 passes none)
   ao.iop = o.iop;
@@ -521,15 +528,17 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   aug.B = uf;
   aug.ldb = n;
   aug.p = p;
-  aug.w = wdev;
+  aug.w = u;
   aug.w_aug_host = w_aug.data();
   aug.mu = mu;
   tr.mark("prologue enqueued (w = u, u_flip)");
   while (tau_now < tau_end) {
     const int oldj = ks.m;
     ao.m = m;
-    ao.init = j;
+    ao.init = (redo_skipped && j > 0) ? j + 1 : j;
+    redo_skipped = false;
     aug.t = tau_now;
+    aug.w = w_is_u ? u : wdev;
     // the exponential below needs H[1:j, 1:j] only (H[j+1, j] is zeroed for it): let arnoldi return before the closing pass
     // (v_{j+1}, H[j+1, j]) has finished -- it runs on the device while the host exponentiates
     ks.defer_tail_req = true;
@@ -621,12 +630,17 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
       tau_now += tau;
       j = 0;
       ireject = 0;
+      w_is_u = false;
       tr.mark("accepted: solution update enqueued");
     } else {
       ++ireject;
       if (ireject > 1000)      // (the reference has no bound, kiops.jl:170-281; see phiv_timestep_T)
         fail(EXPV_MI_ARGUMENT_ERROR, "kiops: 1000 rejected steps in a row (tol below the resolution of the arithmetic?)");
       setH(ks, 0, j, cd(0.0, 0.0));
+      // The reference continues with arnoldi!(...; init = j), whose loop `for j in init:m` (arnoldi.jl:368) recomputes step j: the same
+      // H[:, j] and v_{j+1} again, from the same inputs.  v_{j+1} and H[j+1, j] are there (the closing pass): continue behind them.
+      // (lanczos! restarts at 1 whatever init is -- arnoldi.jl:480 -- and a breakdown ended the basis: those keep the reference's init)
+      if (ctx->opt.kiops_skip_redo && !herm && !ks.wasbreakdown && ks.m == j && j + 1 <= ks.maxiter) redo_skipped = true;
       tr.mark("rejected");
     }
     oldtau = tau;
@@ -643,8 +657,11 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
       fail(EXPV_MI_UNSUPPORTED, "kiops task1 with several outputs is flagged FIXME in kiops.jl:255");
     }
   }
+  if (w_is_u) HIPCHECK(hipMemcpyAsync(wdev, u, sizeof(T) * n, hipMemcpyDeviceToDevice, s));   // (no sub-step at all: tau_out == 0)
   tr.mark("loop left");
-  HIPCHECK(hipStreamSynchronize(s));
+  // results complete on return -- unless the context's outputs are stream-ordered and nothing staged by kiops_run has to outlive the
+  // queue (round 6: back-to-back calls of an integrator then overlap this call's solution update with the next call's first launches)
+  if (!ctx->async_out || must_drain) HIPCHECK(hipStreamSynchronize(s));
   tr.mark("stream drained");
   tr.dump("kiops");
   stats[0] = step; stats[1] = reject; stats[2] = krystep; stats[3] = exps; stats[4] = m;
@@ -670,10 +687,11 @@ void kiops_run(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_ncols,
     wtmp.alloc((size_t)n * esz + 16);
     wd = wtmp.p;
   }
+  const bool must_drain = utmp.p != nullptr || wtmp.p != nullptr;      // staged copies of u / w live in this frame
   if (op.dtype == EXPV_MI_C64)
-    kiops_T<cplx>(ctx, op, tau_out, ntau, tau_ncols, (const cplx *)ud, ldud, ncols_u, &normU, (cplx *)wd, o, stats);
+    kiops_T<cplx>(ctx, op, tau_out, ntau, tau_ncols, (const cplx *)ud, ldud, ncols_u, &normU, (cplx *)wd, o, stats, must_drain);
   else
-    kiops_T<double>(ctx, op, tau_out, ntau, tau_ncols, (const double *)ud, ldud, ncols_u, &normU, (double *)wd, o, stats);
+    kiops_T<double>(ctx, op, tau_out, ntau, tau_ncols, (const double *)ud, ldud, ncols_u, &normU, (double *)wd, o, stats, must_drain);
   if (op.perm) permute_out(ctx, *op.perm, wd, n, w, w_loc, n, 1, esz);
   else if (w_loc == EXPV_MI_HOST) copy_out_2d(ctx, w, EXPV_MI_HOST, n, wd, n, n, 1, esz);
 }

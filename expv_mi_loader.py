@@ -28,4 +28,6 @@ def build(force=False):
     spec = importlib.util.spec_from_file_location(NAME + "_build", os.path.join(PKG_DIR, "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.build(force=force)
+    lib = mod.build(force=force)
+    mod.build_callback_example()                 # tests/c_harness/libstencil_cb.so (compiled matrix-free operator: tests / bench only)
+    return lib

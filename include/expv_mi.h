@@ -103,9 +103,15 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *                       single-pass step runs in its patch form (a tile = a 16 x 32 patch of the grid, the ring of rows around it
  *                       recomputed: no per-tile flags); 0 = natural ordering, wave form (expv_mi_op_patch_info; read when an
  *                       operator is created)
- *   "matfree_fused" 1   matrix-free operators (expv_mi_op_create_callback) run the two-kernel step: the callback's y~ = A u_j goes
- *                       straight into the step's first kernel (one reduction, two launches + the callback per step); 0 = the
- *                       modular path (operator apply, projection, update, scale as separate launches)
+ *   "matfree_fused" 0   matrix-free operators (expv_mi_op_create_callback): 0 (default since round 6) = the modular path -- mul!(y, A, v_j) on
+ *                       the NORMALISED column like the reference (arnoldi.jl:185), then projection, update, scale as separate launches;
+ *                       1 = the two-kernel step: the callback is applied to the un-normalised u_j = beta_{j-1} v_j and its y~ goes straight
+ *                       into the step's first kernel (one reduction, two launches + the callback per step).  1 is for LINEAR callbacks
+ *                       only: a finite-difference Jacobian-vector product (f(u + eps v) - f(u)) / eps with eps tuned for |v| = 1 loses
+ *                       accuracy on a scaled argument
+ *   "kiops_skip_redo" 1 kiops after a rejected sub-step continues behind the closing pass of the factorisation it rejected (init = j + 1)
+ *                       instead of recomputing step j as the reference's loop `for j in init:m` does (arnoldi.jl:368 -- the same H[:, j]
+ *                       and v_{j+1} again); the statistics tuple is the reference's; 0 = recompute
  *   "resident" 0        whole factorisation as ONE cooperative kernel with part of the operand kept in LDS (experimental:
  *                       correct, slower than the default on every shape measured; kept for A/B)
  * A new context takes its defaults from the environment variables EXPV_MI_NO_PIPE, _NO_WAVE, _NO_FUSED, _FUSED_V1, _NO_DIA,
@@ -170,9 +176,12 @@ int expv_mi_op_create_dense(expv_mi_ctx_t ctx, int dtype, int64_t n, const void 
                             expv_mi_op_t *op);
 /* Matrix-free operator: `matvec(user, x_dev, y_dev, hip_stream)` must enqueue y = A*x on the stream
  * (basictests.jl:786-816 interface contract).  What the callback may rely on: x and y are device vectors of n elements, 16-byte
- * aligned, valid for the duration of the call, y does not alias x; A must be LINEAR in x -- inside a factorisation the library
- * applies it to the un-normalised u_j = beta_j v_j (the result is rescaled), and it calls it once per step up to m even when the
- * device finds a happy breakdown earlier (the later results are discarded: the reference stops calling mul! there, arnoldi.jl:370). */
+ * aligned, valid for the duration of the call, y does not alias x.  By default (context option "matfree_fused" = 0) x is the
+ * NORMALISED basis column v_j, |v_j| = 1, exactly what the reference hands to mul! (arnoldi.jl:185) -- a callback that is only
+ * approximately linear (a finite-difference Jacobian-vector product) sees the arguments it was tuned for.  With "matfree_fused" = 1
+ * (LINEAR callbacks: one reduction and two launches less per step) the library applies it to the un-normalised u_j = beta_j v_j and
+ * rescales the result.  Either way it is called once per step up to m even when the device finds a happy breakdown earlier (the
+ * host does not synchronise inside the loop; the later results are discarded -- the reference stops calling mul! there, arnoldi.jl:370). */
 typedef int (*expv_mi_matvec_fn)(void *user, const void *x_dev, void *y_dev, void *hip_stream);
 int expv_mi_op_create_callback(expv_mi_ctx_t ctx, int dtype, int64_t n, expv_mi_matvec_fn fn, void *user,
                                int ishermitian, int64_t nnz_hint, expv_mi_op_t *op);

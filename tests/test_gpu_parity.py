@@ -1563,6 +1563,53 @@ def test_ordering_plan_cache_reuses_the_plan_of_a_pattern_seen_before(eu, kind):
 
 
 @pytest.mark.gpu
+def test_matrix_free_callback_sees_normalised_columns_by_default(eu):
+    """the reference calls mul!(y, A, v_j) with |v_j| = 1 (arnoldi.jl:185, :306).  A callback that is only
+    approximately linear -- a finite-difference Jacobian-vector product (f(u0 + eps v) - f(u0)) / eps with eps tuned for unit vectors, the
+    usual matrix-free operator of an exponential integrator -- must see exactly that: the default (option matfree_fused = 0) hands it the
+    normalised column and agrees with the oracle driving the SAME function; the two-kernel step (matfree_fused = 1, linear callbacks
+    only) hands it beta_{j-1} v_j, and with |b| = 1e3 the truncation error of the difference quotient is 1e3 x larger: measurably worse."""
+    import torch
+    n, m = 600, 12
+    rng = np.random.default_rng(606)
+    A = rng.standard_normal((n, n)) / np.sqrt(n) - 0.5 * np.eye(n)
+    u0 = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    b *= 1.0e3 / np.linalg.norm(b)
+    eps = 1.0e-7
+    f_np = lambda u: A @ u + 0.5 * u * u * u
+    J = A + np.diag(1.5 * u0 * u0)                      # the exact Jacobian at u0
+    jv_np = lambda v: (f_np(u0 + eps * v) - f_np(u0)) / eps
+    Ad, u0d = torch.as_tensor(A, device="cuda"), torch.as_tensor(u0, device="cuda")
+    f_t = lambda u: Ad @ u + 0.5 * u * u * u
+    f0 = f_t(u0d)
+    jv_t = lambda v: (f_t(u0d + eps * v) - f0) / eps
+
+    class FD:                                         # the oracle's operator: the same difference quotient on the host
+        shape, dtype = (n, n), np.dtype(np.float64)
+        def __matmul__(self, v): return jv_np(v)
+    want = ko.expv(0.3, FD(), b, m=m, ishermitian=False)
+    exact = ko.expv(0.3, J, b, m=m, ishermitian=False)
+    errs = {}
+    for fused in (0, 1):
+        ctx = eu.Context()
+        if fused:
+            ctx.set_option("matfree_fused", 1)
+        else:
+            assert ctx.get_option("matfree_fused") == 0, "the default must be the reference's contract"
+        op = eu.MIOperator(None, ctx, matvec=jv_t, shape=(n, n), dtype=np.float64, ishermitian=False)
+        w = np.asarray(eu.expv(0.3, op, b, m=m, ishermitian=False))
+        path = list(eu.expv.last_stats["path"])
+        assert ("two_kernel" in path) == bool(fused), path
+        errs[fused] = float(np.linalg.norm(w - exact) / np.linalg.norm(exact))
+        if not fused:
+            close(w, want, 1e-6, "finite-difference J*v callback, default path: expv vs the oracle driving the same callback")
+    # the difference quotient's truncation error is O(eps |v|^2): unit columns 1e-7-ish, beta-scaled columns 1e3 x that and more
+    assert errs[0] < 1e-5, errs
+    assert errs[1] > 3 * errs[0], "scaled arguments should be visibly worse for this callback: %r" % (errs,)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,m,iop,herm", [(1, 22, 0, False), (17, 2, 7, False), (129, 6, 7, True), (130, 30, 0, False), (257, 12, 2, False), (1001, 30, 0, True)])
 def test_matrix_free_operator_on_the_two_kernel_step_odd_sizes(eu, n, m, iop, herm):
     """Round 5: matrix-free operators (docs/src/interfaces.md:7-36, basictests.jl:786-816) run the two-kernel step, their mul! feeding its
