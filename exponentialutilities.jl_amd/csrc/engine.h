@@ -100,6 +100,8 @@ struct Options {
   int matfree_fused = 0;   // 1: matrix-free operators on the two-kernel step (their mul! feeds its first kernel, called on the UN-NORMALISED u_j =
                            // beta_{j-1} v_j: for LINEAR callbacks only); 0 (default since round 6): the modular path, mul!(y, A, v_j) with |v_j| = 1
                            // like the reference (arnoldi.jl:185) -- a finite-difference Jacobian-vector product tuned for unit vectors stays accurate
+  int fa2_pipelined = 1;   // two-kernel step on SELL slots: a slice's independent requests (slots, u_j pack, first window columns) issued up front,
+                           // three dependent round trips per slice instead of seven (fused.hip; real element types); 0: the round-1..5 loop (A/B)
   int kiops_skip_redo = 1; // kiops after a rejected sub-step: continue behind the closing pass (init = j + 1) instead of recomputing step j like
                            // the reference's `for j in init:m` does (arnoldi.jl:368: same H[:, j], same v_{j+1} again); 0: the reference's loop
   int resident = 0;        // whole factorisation in ONE resident kernel (operator kept in LDS); measured slower than the

@@ -408,6 +408,7 @@ int *Options::find(const char *name) {
   if (n == "patch") return &patch;
   if (n == "matfree_fused") return &matfree_fused;
   if (n == "kiops_skip_redo") return &kiops_skip_redo;
+  if (n == "fa2_pipelined") return &fa2_pipelined;
   if (n == "spin_limit") return &spin_limit;
   if (n == "batch_rounds") return &batch_rounds;
   return nullptr;
@@ -984,6 +985,7 @@ struct ArnoldiCall {
       fa.ybuf = yb;
       fa.step = j;
       fa.cont = (!fresh && j == jstart) ? 1 : 0;   // v_j is already normalised and H[j, j-1] already known
+      fa.pipelined = c->opt.fa2_pipelined;
       if (isaug) { fa.aug_p = p; fa.n_op = ks.n; fa.B = reinterpret_cast<const T *>(aug->B); fa.ldb = aug->ldb; }
       if (op.kind == OP_CALLBACK) {        // matrix-free: mul!(y~, A, u_j) by the caller, on this stream
         if (ks.extbuf.bytes < vbytes) {

@@ -302,8 +302,147 @@ void finalize_last(hipStream_t s, T *V, int64_t ldv, int64_t n, const T *u, cons
   hipLaunchKernelGGL(k_finalize_last<T>, dim3(g, nbatch), dim3(BLOCK), 0, s, V, ldv, n, u, st, strideV);
 }
 
+// ---- first window chunk of a slice, SELL slots with far columns (round 6) -----------------------------------------------------------
+// The plain loop of k_fused_a2 walks a slice as a chain of DEPENDENT round trips: slots 0-3 (values + indices) -> their gathers ->
+// slot 4 -> its gathers -> y~ stored -> 8 window columns -> 8 more.  With ~3 waves per SIMD and 1.5-3 us per trip under load the
+// kernel is latency-bound long before the gathers reach the chip's request rate (profiles/r05_trace_two_kernel_random.txt: 61 us at a
+// window of ONE column, +2.3 us per further column where streaming it costs 1.3).  Here everything that does not depend on another
+// load is requested up front -- all slots' values and indices (<= FA2_SLOTS), this row pack of u_j, the first 8 window columns --,
+// the gathers follow as soon as the indices land, and the second half of the window is requested before the first half is consumed:
+// three round trips per slice instead of seven.  Per row the arithmetic and its order are those of the plain loop; the variant runs two
+// workgroups per CU instead of three (all slots, gathers and 16 window columns of a slice are live at once: 193 VGPRs), so the grid and
+// with it the order of the cross-workgroup sums differ -- results agree to the last bits, not bit for bit.
+// Measured (profiles/r06_fa2_ab.txt, r06_trace_two_kernel_random.txt; n = 1e6, 5 random columns per row, m = 30): the kernel 60 -> 60 us at a
+// window of one column, 85 -> 78 at 16, 107 -> 98 at 30 (sum over a factorisation 2590 -> 2353 us), whole call 3.40 -> 3.15 ms.  What
+// stays is the floor at one column: 5e6 gathers = 316 MB of line fills through the fabric (x is 8 MB, an XCD's L2 4 MB) beside 76 MB of
+// operator stream -- fabric traffic, which the window's bytes add to at the streaming rate (1.45 us per 8 MB column) however early
+// they are requested.
+template <class T> struct Fa2Slots { static constexpr int value = 6; };      // slots of a slice requested up front
+template <> struct Fa2Slots<cplx> { static constexpr int value = 4; };            // (ComplexF64: 16 bytes per value -- six spill at 256 VGPRs)
+#ifndef FA2_PIPELINED
+#define FA2_PIPELINED 1
+#endif
+#ifndef FA2_WAVES
+#define FA2_WAVES 2
+#endif
+template <class T, bool GRAM, int CH>
+__device__ __forceinline__ void fused_a2_slice_pipelined(const FusedAArgs<T> &fa, const DotsArgs<T> &a, const T *__restrict__ u, int64_t slice,
+                                                         int lane, int64_t i, bool al, Pack<T> &yv, const Pack<T> &xv,
+                                                         typename ST<T>::acc_t *accd, typename ST<T>::acc_t *accg) {
+  constexpr int N = Pack<T>::N;
+  constexpr int SH = 64 * N;
+  constexpr int LB = 8;
+  constexpr int FA2_SLOTS = Fa2Slots<T>::value;
+  static_assert(CH % LB == 0 && CH / LB <= 2, "window chunk = one or two groups of 8 columns");
+  const int64_t off = fa.A.slice_off[slice];
+  const int L = (int)((fa.A.slice_off[slice + 1] - off) / SH);
+  const T *vp = fa.A.val + off + (int64_t)lane * N;
+  const int32_t *cp = fa.A.col + off + (int64_t)lane * N;
+  const int L1 = L < FA2_SLOTS ? L : FA2_SLOTS;
+  // ---- round trip 1: operator slots + the first window columns ----
+  Pack<T> v[FA2_SLOTS];
+  int32_t c[FA2_SLOTS][N];
+#pragma unroll
+  for (int q = 0; q < FA2_SLOTS; ++q)
+    if (q < L1) {
+      v[q] = *reinterpret_cast<const Pack<T> *>(vp + (int64_t)q * SH);
+      load_cols<T>(cp + (int64_t)q * SH, c[q]);
+    }
+  const bool rows_in = i < a.n;
+  Pack<T> vv[LB];
+#pragma unroll
+  for (int k = 0; k < LB; ++k)
+    if (rows_in && k < a.nd) vv[k] = ld_pack(a.V + (int64_t)(a.c0 + a.dir * k) * a.ldv, i, a.n, al);
+  // ---- round trip 2: the gathers; the second half of the window behind them ----
+  T xg[FA2_SLOTS][N];
+#pragma unroll
+  for (int q = 0; q < FA2_SLOTS; ++q)
+    if (q < L1) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) xg[q][k] = u[c[q][k]];
+    }
+#pragma unroll
+  for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::zero();
+#pragma unroll
+  for (int q = 0; q < FA2_SLOTS; ++q)
+    if (q < L1) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::fma_(yv.v[k], v[q].v[k], xg[q][k]);
+    }
+  {      // rows longer than the pipelined slots: four slots in flight at a time behind them (same order of the sum)
+    int sl = L1;
+    for (; sl + 4 <= L; sl += 4) {
+      Pack<T> vs[4];
+      int32_t cs[4][N];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        vs[q] = *reinterpret_cast<const Pack<T> *>(vp + (int64_t)(sl + q) * SH);
+        load_cols<T>(cp + (int64_t)(sl + q) * SH, cs[q]);
+      }
+      T xs[4][N];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < N; ++k) xs[q][k] = u[cs[q][k]];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < N; ++k) ST<T>::fma_(yv.v[k], vs[q].v[k], xs[q][k]);
+    }
+    for (; sl < L; ++sl) {
+      const Pack<T> vs = *reinterpret_cast<const Pack<T> *>(vp + (int64_t)sl * SH);
+      int32_t cs[N];
+      load_cols<T>(cp + (int64_t)sl * SH, cs);
+#pragma unroll
+      for (int k = 0; k < N; ++k) ST<T>::fma_(yv.v[k], vs.v[k], u[cs[k]]);
+    }
+  }
+  if (fa.ovf_y) {   // irregular rows: + what the overflow pass summed for these rows
+    Pack<T> o = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + i);
+    for (int cb2 = 1; cb2 < fa.ovf_ncb; ++cb2) {
+      const Pack<T> p2 = *reinterpret_cast<const Pack<T> *>(fa.ovf_y + (int64_t)cb2 * fa.ovf_pstride + i);
+#pragma unroll
+      for (int k = 0; k < N; ++k) o.v[k] = ST<T>::add(o.v[k], p2.v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) yv.v[k] = ST<T>::add(yv.v[k], o.v[k]);
+  }
+  st_pack(fa.ybuf, i, a.n, al, yv);
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (i + k >= a.n) yv.v[k] = ST<T>::zero();
+  if (!rows_in) return;
+  Pack<T> vw[LB];
+  if (CH > LB) {
+#pragma unroll
+    for (int k = 0; k < LB; ++k)
+      if (LB + k < a.nd) vw[k] = ld_pack(a.V + (int64_t)(a.c0 + a.dir * (LB + k)) * a.ldv, i, a.n, al);
+  }
+#pragma unroll
+  for (int k = 0; k < LB; ++k)
+    if (k < a.nd) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        ST<T>::cfma(accd[k], vv[k].v[e], yv.v[e]);
+        if (GRAM) ST<T>::cfma(accg[k], vv[k].v[e], xv.v[e]);
+      }
+    }
+  if (CH > LB) {
+#pragma unroll
+    for (int k = 0; k < LB; ++k)
+      if (LB + k < a.nd) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          ST<T>::cfma(accd[LB + k], vw[k].v[e], yv.v[e]);
+          if (GRAM) ST<T>::cfma(accg[LB + k], vw[k].v[e], xv.v[e]);
+        }
+      }
+  }
+}
+
 // ---- single-reduction step --------------------------------------------------------------------
-template <class T, bool GRAM, int CH, int WAVES>
+// PL: the pipelined slice form for the first window chunk (plain operator on SELL slots only: the host picks the instantiation)
+template <class T, bool GRAM, int CH, int WAVES, bool PL = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int spw, double tol) {
   constexpr int N = Pack<T>::N;
   constexpr int SH = 64 * N;
@@ -348,7 +487,15 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_fused_a2(FusedAArgs<T> fa, int
       const int64_t i = slice * SH + (int64_t)lane * N;
       Pack<T> yv;
       const Pack<T> xv = ld_pack(u, i, a.n, al);
-      if (cb == 0) {
+      if constexpr (PL) {
+        if (cb == 0) {      // SELL slots, plain operator: requests up front
+          fused_a2_slice_pipelined<T, GRAM, CH>(fa, a, u, slice, lane, i, al, yv, xv, accd, accg);
+#pragma unroll
+          for (int k = 0; k < N; ++k) nrm += ST<T>::abs2(xv.v[k]);
+          continue;
+        }
+      }
+      if (!PL && cb == 0) {
         if (fa.ext_y) yv = ld_pack(fa.ext_y, i, p_aug ? fa.n_op : a.n, al_ext);      // matrix-free: y~ = A u_j came from the caller's mul! (zeros beyond its rows)
         else if (fa.ndiag > 0 && i < fa.n_dia) dia_rows<T>(fa.dia_val, fa.dia_ld, fa.ndiag, fa.dia_off, i, fa.n_dia, u, yv.v);   // y~ = A u_j
         else if (fa.ndiag == 0 && slice < fa.A.nslices) {
@@ -438,6 +585,22 @@ void fused_a2(hipStream_t s, const FusedAArgs<T> &a, double tol, int nbatch) {
   // (a 2x-accumulator variant for windows of 17..32 columns measured slower -- 56 vs 48 us per launch, profiles/
   //  r01_ab_variants.txt -- and is not in the tree)
   int nb, spw;
+  // plain operator on SELL slots with the pipelined option on: the instantiation whose first window chunk issues its requests up front
+  // (its register need -- all slots, gathers and 16 window columns of a slice live at once -- costs one wave per SIMD: FA2_WAVES)
+  // (the real element types: on the ComplexF64 GPU-test operator the two forms measure the same, 6.81 / 6.86 ms per call -- profiles/r06_fa2_ab.txt)
+  const bool pl = FA2_PIPELINED && a.pipelined && !ST<T>::is_complex && !a.ext_y && a.ndiag == 0 && !a.aug_p && nbatch == 1;
+  if (pl) {
+    if (a.d.mode == DOTS_LOWSYNC) {
+      auto k = k_fused_a2<T, true, CH, FA2_WAVES, true>;
+      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k)), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb, 1), dim3(BLOCK), 0, s, a, spw, tol);
+    } else {
+      auto k = k_fused_a2<T, false, CH, FA2_WAVES, true>;
+      plan_slices2(nslices, std::max(1, resident_blocks((const void *)k)), &nb, &spw);
+      hipLaunchKernelGGL(k, dim3(nb, 1), dim3(BLOCK), 0, s, a, spw, tol);
+    }
+    return;
+  }
   if (a.d.mode == DOTS_LOWSYNC) {
     auto k = k_fused_a2<T, true, CH, DOTS_WAVES>;
     plan_slices2(nslices, std::max(1, resident_blocks((const void *)k) / nbatch), &nb, &spw);

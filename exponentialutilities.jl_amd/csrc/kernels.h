@@ -192,6 +192,7 @@ struct FusedAArgs {
   const T *ext_y;           // matrix-free operator: y~ = A u_j as the caller's mul! left it (nullptr: a stored operator); no SELL / DIA form is read
   const T *ovf_y;           // SELL with a slot cut-off: what the overflow pass left for these rows (nullptr: none)
   int ovf_ncb; int64_t ovf_pstride;      // > 0: ovf_y is the first of ovf_ncb partial vectors, ovf_pstride apart, to be added in order
+  int pipelined;            // SELL slots of a plain operator: all independent requests of a slice up front (fused.hip: fused_a2_slice_pipelined)
 };
 constexpr int FUSED_AUG_MAX = 8;
 constexpr int GDIA_MAX = 32;       // most diagonals of the general DIA form   // widest augmentation the fused step handles (kiops: p = number of extra columns)

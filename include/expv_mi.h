@@ -109,6 +109,9 @@ int expv_mi_ctx_set_pipeline_overlap(expv_mi_ctx_t ctx, int on);
  *                       into the step's first kernel (one reduction, two launches + the callback per step).  1 is for LINEAR callbacks
  *                       only: a finite-difference Jacobian-vector product (f(u + eps v) - f(u)) / eps with eps tuned for |v| = 1 loses
  *                       accuracy on a scaled argument
+ *   "fa2_pipelined" 1   two-kernel step on SELL slots: every independent request of a slice (operator slots, this row pack of u_j, the first
+ *                       window columns) is issued up front: three dependent round trips per slice instead of seven (real element types;
+ *                       random columns at n = 1e6: 3.40 -> 3.15 ms per expv); 0 = the earlier loop.  Results agree to rounding
  *   "kiops_skip_redo" 1 kiops after a rejected sub-step continues behind the closing pass of the factorisation it rejected (init = j + 1)
  *                       instead of recomputing step j as the reference's loop `for j in init:m` does (arnoldi.jl:368 -- the same H[:, j]
  *                       and v_{j+1} again); the statistics tuple is the reference's; 0 = recompute

@@ -9,6 +9,8 @@ eu = expv_mi_loader.load()
 n = 1_000_000
 kind = sys.argv[2] if len(sys.argv) > 2 else "random"
 ctx = eu.Context(async_outputs=True)
+if len(sys.argv) > 3:
+    ctx.set_option("fa2_pipelined", int(sys.argv[3]))      # round 6: A/B of the two-kernel step's first kernel
 op = eu.MIOperator(general_sparse_operator(kind, n), ctx)
 b = torch.randn(n, dtype=torch.float64, device="cuda")
 w = torch.empty_like(b)
