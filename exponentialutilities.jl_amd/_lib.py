@@ -125,6 +125,11 @@ PROTOTYPES = {
                                 C.POINTER(ArnoldiOpts), C.POINTER(C.c_int32)]),
     "expv_mi_expv_batch_multi": (_i, [_pvp, _i, _i, _i64, _i, _vp, _vp, _vp, _i64, _pd, _vp, _i64, _vp, _i64, _i,
                                       C.POINTER(ArnoldiOpts), C.POINTER(C.c_int32)]),
+    "expv_mi_rccl_available": (_i, []),
+    "expv_mi_rccl_unique_id": (_i, [_vp]),
+    "expv_mi_comm_create": (_i, [_vp, _vp, _i, _i, _pvp]),
+    "expv_mi_gather_rccl": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "expv_mi_comm_destroy": (_i, [_vp]),
     "expv_mi_abi_sizeof": (C.c_size_t, [_i]),
     "expv_mi_abi_layout": (C.c_char_p, [_i]),
     "expv_mi_host_pattern_info": (_i, [C.c_int64, _vp, _vp, _i, _vp]),

@@ -29,7 +29,7 @@ from . import _lib as L
 __all__ = [
     "Context", "default_context", "MIOperator", "DeviceArray", "KrylovSubspace", "arnoldi", "arnoldi_",
     "lanczos_", "expv", "expv_", "phiv", "phiv_", "expv_timestep", "expv_timestep_", "phiv_timestep",
-    "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "ExpvMIError", "DimensionMismatch", "host_expm",
+    "phiv_timestep_", "kiops", "timestep_caches", "expv_batch", "expv_batch_multi", "RcclComm", "rccl_available", "rccl_unique_id", "ExpvMIError", "DimensionMismatch", "host_expm",
     "host_phiv_dense", "host_symtridiag_expcol", "host_symtridiag_exp_last", "host_pattern_info", "host_rcm", "host_patch_order", "clear_operator_cache", "plan_cache",
 ]
 
@@ -1100,6 +1100,55 @@ def expv_batch_multi(ts, pattern, vals, B, ctxs, *, m=None, tol=1e-7, iop=0, ish
 # ---------------------------------------------------------------------------------------------
 _HOST_CODES = {np.dtype(np.float64): L.F64, np.dtype(np.complex128): L.C64, np.dtype(np.float32): L.F32,
                np.dtype(np.complex64): L.C32}
+
+
+# ------------------------------------------------------------------------------------------
+# final gather over RCCL through the C ABI (include/expv_mi.h: expv_mi_comm_create / expv_mi_gather_rccl) -- the form a host
+# without torch.distributed uses; dist.py keeps the torch.distributed form beside it
+# ------------------------------------------------------------------------------------------
+def rccl_available():
+    return bool(L.load().expv_mi_rccl_available())
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId: rank 0 makes them, the host hands them to the other ranks."""
+    buf = C.create_string_buffer(128)
+    _check(L.load().expv_mi_rccl_unique_id(buf))
+    return buf.raw
+
+
+class RcclComm:
+    """An RCCL communicator bound to a context (collective constructor: every rank calls it with the same id)."""
+
+    def __init__(self, ctx, unique_id, nranks, rank):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: 128 bytes (rccl_unique_id())")
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        h = C.c_void_p()
+        idb = C.create_string_buffer(bytes(unique_id), 128)
+        _check(L.load().expv_mi_comm_create(ctx._h, idb, self.nranks, self.rank, C.byref(h)), ctx._h)
+        self._h = h
+        self._finalizer = weakref.finalize(self, L.load().expv_mi_comm_destroy, h)
+
+    def all_gather(self, send, out=None):
+        """recv[r * count : (r + 1) * count] = rank r's `send` (device tensors; enqueued on the context's stream)."""
+        import torch
+        dt = _np_dtype_of(send)
+        if not send.is_contiguous():
+            raise ValueError("all_gather: contiguous send block")
+        count = send.numel()
+        if out is None:
+            out = torch.empty(self.nranks * count, dtype=send.dtype, device=send.device)
+        _check(L.load().expv_mi_gather_rccl(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(out.data_ptr()), count, _code(dt)), self.ctx._h)
+        return out
+
+    def all_gather_raw(self, send_ptr, recv_ptr, count, dtype):
+        """The same on raw device pointers (DeviceArray.ptr): `count` elements of `dtype` per rank."""
+        _check(L.load().expv_mi_gather_rccl(self._h, C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr)), int(count), _code(np.dtype(dtype))), self.ctx._h)
+
+    def destroy(self):
+        if self._finalizer.alive:
+            self._finalizer()
 
 
 def _host_dtype(*dts):

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <type_traits>
 #include <cstring>
+#include <dlfcn.h>
 #include <unordered_map>
 
 #include "engine.h"
@@ -2355,6 +2356,102 @@ int expv_mi_expv_batch_multi(expv_mi_ctx_t *ctxs, int nctx, int dtype, int64_t n
   for (int k = 0; k < nctx; ++k)
     if (rc[k] != EXPV_MI_OK) return rc[k];
   return EXPV_MI_OK;
+}
+
+// ------------------------------------------------------------------ final gather over RCCL, one process per GPU ---------
+// north_star: "batched independent (A, v) pairs shard across the 8 GPUs of one node with RCCL over xGMI for the final gather only".
+// The Python harness does that gather through torch.distributed (dist.py); a Julia host has no torch.distributed, so the C ABI carries
+// its own: librccl.so is opened at first use (dlopen -- the library itself links nothing of RCCL and loads on a box without it), the
+// communicator is bound to a context, and the all-gather is enqueued on the CONTEXT's stream behind the shard's own work.
+extern "C++" {
+namespace {
+struct RcclApi {
+  void *h = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  void *CommInitRank = nullptr;                          // (ncclUniqueId by value: called through CommInitRankFn below)
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+struct UniqueId128 { char b[128]; };      // ncclUniqueId: NCCL_UNIQUE_ID_BYTES = 128 (rccl.h:40-43)
+typedef int (*CommInitRankFn)(void **, int, UniqueId128, int);
+RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *nm : names) {
+      api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (api.h) break;
+    }
+    if (!api.h) { api.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+    api.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(api.h, "ncclGetUniqueId"));
+    api.CommInitRank = dlsym(api.h, "ncclCommInitRank");
+    api.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(api.h, "ncclAllGather"));
+    api.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(api.h, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(api.h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) api.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+  });
+  return api;
+}
+void rccl_check(int rc, const char *what) {
+  if (rc == 0) return;
+  RcclApi &r = rccl();
+  fail(EXPV_MI_HIP_ERROR, std::string("RCCL: ") + what + " failed: " + (r.GetErrorString ? r.GetErrorString(rc) : "error " + std::to_string(rc)));
+}
+}  // namespace
+}  // extern "C++"
+struct expv_mi_comm_s {
+  Ctx *ctx = nullptr;
+  void *comm = nullptr;
+  int nranks = 0, rank = 0;
+};
+
+int expv_mi_rccl_available(void) {
+  RcclApi &r = rccl();
+  return (r.h && r.err.empty()) ? 1 : 0;
+}
+int expv_mi_rccl_unique_id(void *id128) {
+  if (!id128) return EXPV_MI_ARGUMENT_ERROR;
+  RcclApi &r = rccl();
+  if (!r.h || !r.err.empty()) return EXPV_MI_UNSUPPORTED;
+  return r.GetUniqueId(id128) == 0 ? EXPV_MI_OK : EXPV_MI_HIP_ERROR;
+}
+int expv_mi_comm_create(expv_mi_ctx_t ctx, const void *id128, int nranks, int rank, expv_mi_comm_t *comm) {
+  if (!ctx || !id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks) return EXPV_MI_ARGUMENT_ERROR;
+  return guarded(ctx, [&] {
+    RcclApi &r = rccl();
+    if (!r.h || !r.err.empty()) fail(EXPV_MI_UNSUPPORTED, r.err.empty() ? "librccl.so not available" : r.err);
+    ctx->use();      // (ncclCommInitRank binds the communicator to the CURRENT device)
+    UniqueId128 id;
+    std::memcpy(id.b, id128, sizeof(id.b));
+    std::unique_ptr<expv_mi_comm_s> c(new expv_mi_comm_s());
+    c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    rccl_check(reinterpret_cast<CommInitRankFn>(r.CommInitRank)(&c->comm, nranks, id, rank), "ncclCommInitRank");
+    *comm = c.release();
+  });
+}
+int expv_mi_comm_destroy(expv_mi_comm_t comm) {
+  if (!comm) return EXPV_MI_OK;
+  RcclApi &r = rccl();
+  int rc = EXPV_MI_OK;
+  if (comm->comm && r.CommDestroy) rc = r.CommDestroy(comm->comm) == 0 ? EXPV_MI_OK : EXPV_MI_HIP_ERROR;
+  delete comm;
+  return rc;
+}
+int expv_mi_gather_rccl(expv_mi_comm_t comm, const void *send_dev, void *recv_dev, int64_t count, int dtype) {
+  if (!comm || !comm->ctx) return EXPV_MI_ARGUMENT_ERROR;
+  Ctx *ctx = comm->ctx;
+  return guarded(ctx, [&] {
+    if (count < 0 || (count > 0 && (!send_dev || !recv_dev))) fail(EXPV_MI_ARGUMENT_ERROR, "gather: null buffer");
+    if (count == 0) return;
+    ctx->use();
+    // every element type travels as bytes: the gather moves result columns, it never adds them (ncclInt8 = 0, rccl.h)
+    const size_t bytes = (size_t)count * dtype_size(dtype);
+    rccl_check(rccl().AllGather(send_dev, recv_dev, bytes, /*ncclInt8*/ 0, comm->comm, ctx->stream), "ncclAllGather");
+    if (!ctx->async_out) HIPCHECK(hipStreamSynchronize(ctx->stream));
+  });
 }
 
 }  // extern "C"

@@ -30,6 +30,7 @@ extern "C" {
 typedef struct expv_mi_ctx_s *expv_mi_ctx_t;
 typedef struct expv_mi_op_s *expv_mi_op_t;
 typedef struct expv_mi_ks_s *expv_mi_ks_t;
+typedef struct expv_mi_comm_s *expv_mi_comm_t;      /* an RCCL communicator bound to a context (final gather of a sharded batch) */
 typedef struct expv_mi_tscache_s *expv_mi_tscache_t;
 
 typedef enum {
@@ -409,6 +410,28 @@ int expv_mi_expv_batch_multi(expv_mi_ctx_t *ctxs, int nctx, int dtype, int64_t n
                              const int32_t *colind, const void *vals, int64_t nnz_per_prob, const double *t,
                              const void *b, int64_t ldb, void *w, int64_t ldw, int w_loc,
                              const expv_mi_arnoldi_opts *opts, int32_t *m_used);
+
+/* ------------------------------------------------------------------ final gather over RCCL ---------- */
+/* BASELINE configs[4] in the one-process-per-GPU form: every rank solves its block of the independent problems with
+ * expv_mi_expv_batch on its own context (nothing is exchanged while they run) and the result blocks meet in
+ * ONE all-gather over xGMI.  The reference has no counterpart ("Distributed: none"); the Python harness does
+ * the same gather through torch.distributed (exponentialutilities.jl_amd/dist.py), a Julia host -- which has no torch.distributed --
+ * through these four calls.  librccl.so is opened at first use (dlopen): the library links nothing of RCCL.
+ *   expv_mi_rccl_available()        1 when librccl.so and its four entry points were found
+ *   expv_mi_rccl_unique_id(id128)   rank 0 fills 128 bytes (ncclGetUniqueId); the host hands them to the other ranks by its own means
+ *                                   (MPI.jl, Distributed.jl, a file)
+ *   expv_mi_comm_create(ctx, id128, nranks, rank, &comm)   collective over the nranks processes (ncclCommInitRank on ctx's device)
+ *   expv_mi_gather_rccl(comm, send, recv, count, dtype)    ncclAllGather of `count` elements per rank on the CONTEXT's stream, behind
+ *                                   whatever the context has queued: recv (device, nranks * count elements) holds rank r's block at
+ *                                   r * count.  Complete on return unless the context's outputs are stream-ordered.  With contiguous
+ *                                   shards of n-row columns, count = n * columns_per_rank gives the n x nprob result matrix on every rank
+ *   expv_mi_comm_destroy(comm)
+ * Status EXPV_MI_UNSUPPORTED when librccl.so is missing, EXPV_MI_HIP_ERROR with the RCCL message in expv_mi_last_error otherwise. */
+int expv_mi_rccl_available(void);
+int expv_mi_rccl_unique_id(void *id128);
+int expv_mi_comm_create(expv_mi_ctx_t ctx, const void *id128, int nranks, int rank, expv_mi_comm_t *comm);
+int expv_mi_gather_rccl(expv_mi_comm_t comm, const void *send_dev, void *recv_dev, int64_t count, int dtype);
+int expv_mi_comm_destroy(expv_mi_comm_t comm);
 
 /* ------------------------------------------------------------------ ABI self-description -- */
 /* sizeof and field layout of the option / result structs as THIS library was compiled, so a host language that restates

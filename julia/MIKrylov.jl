@@ -579,4 +579,35 @@ function expv_batch(ts::Vector{Float64}, pattern::SparseMatrixCSC, vals::Matrix{
     W, mused
 end
 
+# ---- the same batch with ONE Julia process per GPU: the final gather over RCCL (north_star: "RCCL over xGMI for the final gather only") ----
+# Each process solves its contiguous block with `expv_batch(...; devices = [local_gpu])`-style calls or its own loop, leaves the block in an
+# MIArray, and `allgather_columns!` brings the n x nprob result to every rank: one ncclAllGather on the context's stream.  The 128-byte id comes
+# from rank 0 (`rccl_unique_id()`) and reaches the other ranks by the host's own means (MPI.jl bcast, Distributed.jl, a file).
+rccl_available() = ccall((:expv_mi_rccl_available, lib), Cint, ()) == 1
+function rccl_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:expv_mi_rccl_unique_id, lib), Cint, (Ptr{UInt8},), id), C_NULL)
+    id
+end
+mutable struct RcclComm
+    h::Ptr{Cvoid}
+    nranks::Int
+    rank::Int
+    function RcclComm(id::Vector{UInt8}, nranks::Integer, rank::Integer)
+        length(id) == 128 || throw(ArgumentError("unique id: 128 bytes"))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:expv_mi_comm_create, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ptr{Ptr{Cvoid}}), ctx().h, id, nranks, rank, h), ctx().h)
+        c = new(h[], nranks, rank)
+        finalizer(x -> ccall((:expv_mi_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.h), c)
+        c
+    end
+end
+# recv[:, r * cols + 1 : (r + 1) * cols] = rank r's `send` (n x cols, contiguous): the blocks of `dist.shard_range` with equal shares
+function allgather_columns!(recv::MIArray{T}, send::MIArray{T}, comm::RcclComm) where {T}
+    length(recv) == comm.nranks * length(send) || throw(DimensionMismatch("recv must hold nranks blocks of send's size"))
+    check(ccall((:expv_mi_gather_rccl, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint),
+                comm.h, send.ptr, recv.ptr, length(send), dtype(T)), ctx().h)
+    recv
+end
+
 end # module

@@ -390,6 +390,44 @@ def test_batch_over_several_contexts_from_one_process(eu):
         eu.expv_batch_multi(ts, A0, vals[:, :-1], B, [eu.Context()], m=m)
 
 
+def test_c_abi_rccl_gather_world_size_one(eu):
+    """north_star: "RCCL over xGMI for the final gather only".  The C ABI's own gather (expv_mi_comm_create / expv_mi_gather_rccl:
+    librccl.so through dlopen, ncclAllGather on the context's stream) -- what a Julia host with one process per GPU calls, without
+    torch.distributed.  RCCL refuses two ranks on ONE device, so a 1-GPU box can only run world size 1: communicator creation from a
+    unique id, the gather of a batch's result block enqueued BEHIND the batch on the same stream (stream-ordered outputs: no host
+    synchronisation in between), every element type as bytes, destroy.  The 2-rank form is the same call with nranks = 2."""
+    import torch
+    assert eu.rccl_available(), "librccl.so must load on the GPU box"
+    ctx = eu.Context(async_outputs=True)
+    uid = eu.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = eu.RcclComm(ctx, uid, 1, 0)
+    rng = np.random.default_rng(23)
+    n, nprob, m = 20_000, 5, 30
+    A0 = c2_operator(n).tocsr()
+    A0.sort_indices()
+    vals = np.stack([A0.data * s for s in 1 + 0.1 * rng.random(nprob)])
+    B = np.asfortranarray(rng.standard_normal((n, nprob)))
+    ts = np.linspace(0.5, 1.0, nprob)
+    ref = eu.expv_batch(ts, A0, vals, B, m=m, ctx=eu.Context())
+    Wd = eu.DeviceArray((n, nprob), np.float64, ctx)
+    eu.expv_batch_multi(ts, A0, vals, B, [ctx], m=m, out=Wd)                 # this rank's block, left on its device
+    recv = eu.DeviceArray((n, nprob), np.float64, ctx)
+    comm.all_gather_raw(Wd.ptr, recv.ptr, n * nprob, np.float64)            # (no ctx.sync() in between)
+    ctx.sync()
+    got = recv.to_host()
+    close(got, np.asarray(ref), 1e-15, "C-ABI RCCL all-gather of a batch's result block (world size 1) vs the single-context batch")
+    for dt in (torch.float32, torch.complex64, torch.complex128):
+        x = torch.randn(3001, dtype=dt, device="cuda")
+        torch.cuda.synchronize()
+        y = comm.all_gather(x)
+        ctx.sync()
+        assert torch.equal(x, y), dt
+    comm.destroy()
+    with pytest.raises(ValueError):
+        eu.RcclComm(ctx, b"short", 1, 0)
+
+
 def test_basis_reuse_across_tau_only_retries_is_bit_identical(eu):
     """phiv_timestep! rebuilds the Krylov basis on every adaptation retry
     (krylov_phiv_adaptive.jl:417) even when only tau changed; the basis does not depend on tau, so the build keeps it.
