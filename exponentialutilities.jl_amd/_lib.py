@@ -26,7 +26,7 @@ KERNEL_IDS = {"firststep": 0, "matvec": 1, "dots": 2, "update": 3, "scale": 4, "
 
 class ArnoldiOpts(C.Structure):
     _fields_ = [("m", C.c_int32), ("iop", C.c_int32), ("init", C.c_int32), ("ishermitian", C.c_int32),
-                ("ortho", C.c_int32), ("reserved", C.c_int32), ("tol", C.c_double)]
+                ("ortho", C.c_int32), ("flags", C.c_int32), ("tol", C.c_double)]
 
 
 class ExpvStats(C.Structure):

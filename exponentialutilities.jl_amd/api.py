@@ -701,9 +701,10 @@ class KrylovSubspace:
         return self
 
 
-def _opts(m=None, tol=1e-7, iop=0, init=0, ishermitian=None, ortho="auto"):
+def _opts(m=None, tol=1e-7, iop=0, init=0, ishermitian=None, ortho="auto", flags=0):
     o = L.ArnoldiOpts()
     L.load().expv_mi_arnoldi_opts_default(C.byref(o))
+    o.flags = int(flags)
     o.m = int(m) if m is not None else 0
     o.tol = float(tol)
     o.iop = int(iop)
@@ -725,7 +726,8 @@ def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0
         raise DimensionMismatch(f"length(b) [{int(np.prod(ba.shape))}] == size(A,1) [{op.shape[0]}] doesn't hold")
     if ishermitian is None:
         ishermitian = op.ishermitian
-    o = _opts(m, tol, iop, init, ishermitian, ortho)
+    # (EXPV_MI_ARNOLDI_DEFER_TAIL: the closing pass is collected by whatever touches Ks next -- every accessor here is a library call)
+    o = _opts(m, tol, iop, init, ishermitian, ortho, flags=1)
     _check(L.load().expv_mi_arnoldi(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
     return Ks
 
@@ -736,7 +738,7 @@ def lanczos_(Ks, A, b, *, tol=1e-7, m=None, opnorm=None, init=0):
     ba = _Arg(b, Ks.T)
     if int(np.prod(ba.shape)) != op.shape[0]:
         raise DimensionMismatch("length(b) == size(A,1) doesn't hold")
-    o = _opts(m, tol, 0, init, True, "auto")
+    o = _opts(m, tol, 0, init, True, "auto", flags=1)
     _check(L.load().expv_mi_lanczos(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
     return Ks
 

@@ -1781,6 +1781,7 @@ int expv_mi_ks_destroy(expv_mi_ks_t ks) {
       } catch (...) {
       }
     }
+    try { ks_finish_tail(*ks); } catch (...) { (void)hipStreamSynchronize(ctx->stream); }      // (a deferred closing pass still writes into this storage)
     ctx->release(&ks->ctx);
     delete ks;
   }
@@ -1789,11 +1790,16 @@ int expv_mi_ks_destroy(expv_mi_ks_t ks) {
 int expv_mi_ks_resize(expv_mi_ks_t ks, int maxiter) {
   return guarded(ks->ctx, [&] {
     if (maxiter < 1) fail(EXPV_MI_ARGUMENT_ERROR, "resize!: maxiter >= 1 required");
+    ks_finish_tail(*ks);
     ks_resize(*ks, maxiter);
   });
 }
 int expv_mi_ks_get(expv_mi_ks_t ks, int *m, int *maxiter, int *augmented, double *beta, int *wasbreakdown) {
   if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  if (ks->tail.pending) {      // (a deferred closing pass: H[m+1, m] and the breakdown test of step m arrive here)
+    const int rc = guarded(ks->ctx, [&] { ks_finish_tail(*ks); });
+    if (rc != EXPV_MI_OK) return rc;
+  }
   if (m) *m = ks->m;
   if (maxiter) *maxiter = ks->maxiter;
   if (augmented) *augmented = ks->augmented;
@@ -1804,11 +1810,16 @@ int expv_mi_ks_get(expv_mi_ks_t ks, int *m, int *maxiter, int *augmented, double
 int expv_mi_ks_set_m(expv_mi_ks_t ks, int m) {
   return guarded(ks->ctx, [&] {
     if (m < 0 || m > ks->maxiter) fail(EXPV_MI_ARGUMENT_ERROR, "Ks.m out of range");
+    ks_finish_tail(*ks);
     ks->m = m;
   });
 }
 int expv_mi_ks_H(expv_mi_ks_t ks, void **H, int *ldh, int *nrows, int *ncols) {
   if (!ks) return EXPV_MI_ARGUMENT_ERROR;
+  if (ks->tail.pending) {
+    const int rc = guarded(ks->ctx, [&] { ks_finish_tail(*ks); });
+    if (rc != EXPV_MI_OK) return rc;
+  }
   if (H) *H = ks->H.data();
   if (ldh) *ldh = ks->ldh;
   if (nrows) *nrows = ks->maxiter + 1;
@@ -1819,6 +1830,7 @@ int expv_mi_ks_V_download(expv_mi_ks_t ks, int col0, int ncols, void *dst, int64
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_finish_tail(*ks);
     ks_set_row_order(*ks, nullptr);      // (a basis kept in a reordered operator's ordering: rows back to their natural places)
     ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
@@ -1830,6 +1842,7 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
   return guarded(ks->ctx, [&] {
     ks->ctx->use();
     if (col0 < 0 || ncols < 0 || col0 + ncols > ks->maxiter + 1) fail(EXPV_MI_BOUNDS, "V columns out of range");
+    ks_finish_tail(*ks);
     ks_set_row_order(*ks, nullptr);
     ks_materialize(*ks);
     const size_t esz = dtype_size(ks->dtypeT);
@@ -1842,7 +1855,7 @@ int expv_mi_ks_V_upload(expv_mi_ks_t ks, int col0, int ncols, const void *src, i
 }
 int expv_mi_ks_V_devptr(expv_mi_ks_t ks, void **V, int64_t *ldv) {
   if (!ks) return EXPV_MI_ARGUMENT_ERROR;
-  const int rc = guarded(ks->ctx, [&] { ks_set_row_order(*ks, nullptr); ks_materialize(*ks); });
+  const int rc = guarded(ks->ctx, [&] { ks_finish_tail(*ks); ks_set_row_order(*ks, nullptr); ks_materialize(*ks); });
   if (rc != EXPV_MI_OK) return rc;
   if (V) *V = ks->V.p;
   if (ldv) *ldv = ks->ldv;
@@ -1855,10 +1868,19 @@ void expv_mi_arnoldi_opts_default(expv_mi_arnoldi_opts *o) {
   o->init = 0;
   o->ishermitian = -1;
   o->ortho = EXPV_MI_ORTHO_AUTO;
-  o->reserved = 0;
+  o->flags = 0;
   o->tol = 1.0e-7;
 }
 
+// EXPV_MI_ARNOLDI_DEFER_TAIL: the factorisation returns at the early mailbox flag (engine_core.hip: Ks::defer_tail_req); whoever touches the
+// subspace next collects the closing pass (ks_finish_tail)
+namespace {
+struct DeferTail {
+  Ks &k;
+  DeferTail(Ks &ks, bool on) : k(ks) { k.defer_tail_req = on; }
+  ~DeferTail() { k.defer_tail_req = false; }
+};
+}
 int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, const expv_mi_arnoldi_opts *opts) {
   return guarded(ks->ctx, [&] {
     expv_mi_arnoldi_opts o;
@@ -1873,6 +1895,7 @@ int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
       bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
     }
     ks_bind_row_order(*ks, *op, o.init);
+    DeferTail defer(*ks, (o.flags & EXPV_MI_ARNOLDI_DEFER_TAIL) != 0);
     arnoldi_run(*ks, *op, bd, o, nullptr, false);
     scope.done = true;
   });
@@ -1885,6 +1908,7 @@ int expv_mi_lanczos(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc, 
     FactorisationScope scope(*ks, o.init);
     const void *bd = vector_in(ks->ctx, *op, b, b_loc, ks->n, dtype_size(ks->dtypeT), tmp);
     ks_bind_row_order(*ks, *op, o.init);
+    DeferTail defer(*ks, (o.flags & EXPV_MI_ARNOLDI_DEFER_TAIL) != 0);
     arnoldi_run(*ks, *op, bd, o, nullptr, true);
     scope.done = true;
   });
@@ -1933,6 +1957,7 @@ int expv_mi_phiv_ks(expv_mi_ks_t ks, double t_re, double t_im, int k, int correc
 int expv_mi_combine(expv_mi_ks_t ks, int mcols, int ncols, const void *coef_host, int ldc, int coef_dtype,
                     double beta_scale, void *W, int64_t ldw, int w_loc, int w_dtype) {
   return guarded(ks->ctx, [&] {
+    ks_finish_tail(*ks);
     combine_host_coef(*ks, mcols, ncols, coef_host, ldc, coef_dtype, beta_scale, W, ldw, w_loc, w_dtype);
   });
 }
@@ -2280,7 +2305,7 @@ const char *expv_mi_abi_layout(int kind) {
     };
     out[EXPV_MI_ABI_ARNOLDI_OPTS] = join({std::string(EXPV_MI_F(expv_mi_arnoldi_opts, m, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, iop, "i32")),
                                           std::string(EXPV_MI_F(expv_mi_arnoldi_opts, init, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, ishermitian, "i32")),
-                                          std::string(EXPV_MI_F(expv_mi_arnoldi_opts, ortho, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, reserved, "i32")),
+                                          std::string(EXPV_MI_F(expv_mi_arnoldi_opts, ortho, "i32")), std::string(EXPV_MI_F(expv_mi_arnoldi_opts, flags, "i32")),
                                           std::string(EXPV_MI_F(expv_mi_arnoldi_opts, tol, "f64"))});
     out[EXPV_MI_ABI_EXPV_STATS] = join({std::string(EXPV_MI_F(expv_mi_expv_stats, m_used, "i32")), std::string(EXPV_MI_F(expv_mi_expv_stats, wasbreakdown, "i32")),
                                         std::string(EXPV_MI_F(expv_mi_expv_stats, matvecs, "i32")), std::string(EXPV_MI_F(expv_mi_expv_stats, path_flags, "i32")),

@@ -1297,13 +1297,15 @@ void ks_finish_tail(Ks &ks) {
   std::atomic_thread_fence(std::memory_order_acquire);
   const size_t hwords = mailbox_hwords(ks), swords = (size_t)ks.maxiter + 2;
   const double *mh = mv.H;
-  const size_t e = (size_t)(m - 1) * ks.ldhd + m;     // H[m+1, m]
-  if (ks.dtypeT == EXPV_MI_C64) {
-    const cd v(mh[2 * e], mh[2 * e + 1]);
-    if (ks.tail.lanczos) setH_realpart(ks, m, m - 1, v.real()); else setH(ks, m, m - 1, v);
-  } else {
-    if (ks.tail.lanczos) setH_realpart(ks, m, m - 1, mh[e]); else setH(ks, m, m - 1, cd(mh[e], 0.0));
+  const size_t e = (size_t)(m - 1) * ks.ldhd + m;     // H[m+1, m], in elements of the basis type (the mailbox mirrors Hdev as it is)
+  cd v;
+  switch (ks.dtypeT) {
+    case EXPV_MI_C64: v = cd(mh[2 * e], mh[2 * e + 1]); break;
+    case EXPV_MI_F32: v = cd((double)reinterpret_cast<const float *>(mh)[e], 0.0); break;      // (round 6: the 32-bit types read the entry as doubles)
+    case EXPV_MI_C32: v = cd((double)reinterpret_cast<const float *>(mh)[2 * e], (double)reinterpret_cast<const float *>(mh)[2 * e + 1]); break;
+    default: v = cd(mh[e], 0.0); break;
   }
+  if (ks.tail.lanczos) setH_realpart(ks, m, m - 1, v.real()); else setH(ks, m, m - 1, v);
   if ((int)ks.colscale_host.size() > m) ks.colscale_host[m] = mv.scales[m];
   ks.scale_cols = m + 1;
   if ((int32_t)mh[hwords + swords + 1] == 1) ks.wasbreakdown = true;      // beta_m < tol: Ks.m stays m (arnoldi.jl:370-374)

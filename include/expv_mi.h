@@ -277,9 +277,16 @@ typedef struct {
   int32_t init;         /* continue at step `init` (0 = fresh first step)                          */
   int32_t ishermitian;  /* 1 Lanczos, 0 Arnoldi, -1 LinearAlgebra.ishermitian(A)                   */
   int32_t ortho;        /* expv_mi_ortho                                                           */
-  int32_t reserved;
+  int32_t flags;        /* EXPV_MI_ARNOLDI_* bits, 0 by default                                     */
   double tol;           /* happy-breakdown threshold (absolute), default 1e-7                      */
 } expv_mi_arnoldi_opts;
+/* flags bit 0 (expv_mi_arnoldi / expv_mi_lanczos): return as soon as H[1:m, 1:m], beta and the first m basis columns are final; the
+ * closing pass of the single-pass step (v_{m+1}, H[m+1, m], the breakdown test of step m) finishes on the device and is collected by
+ * the NEXT library call that touches the subspace (expv_mi_ks_get / _H / _V_* / _set_m / _resize, expv_mi_expv_ks, expv_mi_phiv_ks,
+ * expv_mi_combine, another factorisation, destroy).  expv!(w, t, Ks) then runs its host exponential -- which needs H[1:m, 1:m] only --
+ * UNDER that pass instead of behind it (krylov_phiv.jl:200-247; round 6).  A host that caches the pointer of expv_mi_ks_H across a
+ * factorisation must not set it; the Julia shim and the Python mirror fetch H through the call every time and do. */
+#define EXPV_MI_ARNOLDI_DEFER_TAIL 1
 void expv_mi_arnoldi_opts_default(expv_mi_arnoldi_opts *o);
 int expv_mi_arnoldi(expv_mi_ks_t ks, expv_mi_op_t op, const void *b, int b_loc,
                     const expv_mi_arnoldi_opts *opts);

@@ -49,7 +49,7 @@ struct ArnoldiOpts
     init::Cint
     ishermitian::Cint
     ortho::Cint
-    reserved::Cint
+    flags::Cint
     tol::Cdouble
 end
 struct ExpvStats
@@ -369,7 +369,9 @@ function getV(Ks::MIKs{T, U}) where {T, U}
     MIArray{T, 2}(vp[], (Int(ldv[]), Ks.m + 1), false)       # leading dimension ldv >= rows; rows beyond n + augmented are zero padding
 end
 
-opts(m, tol, iop, init, herm) = Ref(ArnoldiOpts(m, iop, init, herm, 0, 0, tol))
+opts(m, tol, iop, init, herm; flags = 0) = Ref(ArnoldiOpts(m, iop, init, herm, 0, flags, tol))
+const DEFER_TAIL = Cint(1)      # EXPV_MI_ARNOLDI_DEFER_TAIL: arnoldi! / lanczos! return before the closing pass has finished; every accessor below
+                                # (getH, getV, Ks.m, expv!, phiv!, ...) goes through a library call that collects it
 
 # arnoldi!(Ks, A, b; tol, m, ishermitian, opnorm, iop, init)                                  (src/arnoldi.jl:345-377)
 function arnoldi!(Ks::MIKs{T, U}, A::MIOperator{T}, b::MIVector{T};
@@ -377,7 +379,7 @@ function arnoldi!(Ks::MIKs{T, U}, A::MIOperator{T}, b::MIVector{T};
                   opnorm = nothing, iop::Int = 0, init::Int = 0, kw...) where {T, U}
     grow = m > Ks.maxiter
     check(ccall((:expv_mi_arnoldi, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{ArnoldiOpts}),
-                handle(Ks), A.h, b.ptr, DEVICE, opts(m, tol, iop, init, ishermitian)), ctx().h)
+                handle(Ks), A.h, b.ptr, DEVICE, opts(m, tol, iop, init, ishermitian; flags = DEFER_TAIL)), ctx().h)
     grow && ((Ks.V, Ks.H) = views_of(T, U, handle(Ks), size(Ks.V, 1)); Ks.maxiter = m)         # resize!(Ks, m) happened inside (:355-357)
     sync_fields!(Ks)
 end
@@ -385,7 +387,7 @@ end
 function lanczos!(Ks::MIKs{T, U}, A::MIOperator{T}, b::MIVector{T};
                   tol::Real = 1.0e-7, m::Int = min(Ks.maxiter, size(A, 1)), opnorm = nothing, init::Int = 0, kw...) where {T, U}
     check(ccall((:expv_mi_lanczos, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{ArnoldiOpts}),
-                handle(Ks), A.h, b.ptr, DEVICE, opts(m, tol, 0, init, 1)), ctx().h)
+                handle(Ks), A.h, b.ptr, DEVICE, opts(m, tol, 0, init, 1; flags = DEFER_TAIL)), ctx().h)
     sync_fields!(Ks)
 end
 # arnoldi(A, b; m, ishermitian, kwargs...)                                                     (src/arnoldi.jl:161-180)

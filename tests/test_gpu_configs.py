@@ -1377,6 +1377,9 @@ def test_bench_line_contract():
     assert len(lines) == 1 and lines[0] is last, p.stdout[-2000:]
     d = json.loads(last)
     assert len(d["config"]["secondary_fracs"]) >= 30          # the flat {name: frac} map travels in the line ...
+    for k in ("matrix_free_compiled", "c3_dense_phiv_timestep_n163840", "c4_kiops_complex"):      # (round 6 keys)
+        assert k in d["config"]["secondary_fracs"], k
+    assert d["config"]["value_cold"] > 0 and d["config"]["ms_per_step_cold"] > 0
     full = json.load(open(os.path.join(root, "bench_full.json")))
     assert "secondary" in full and "kernels" in full["roofline"]          # ... the prose and the per-kernel tables in the side file
     assert full["value"] == pytest.approx(d["value"], rel=1e-8)
@@ -1592,18 +1595,32 @@ def test_fuzz_pin_amplifying_hermitian_operator_controller_paths(eu):
     assert sd["num_timesteps"] == so["num_timesteps"] and sd["m"] == so["m"], (sd, so)
     close(U, Uo, 1e-10, "amplifying Hermitian operator, t = 0.1: device vs oracle on the same controller path")
     # (b) the full horizon: the device ends in the reference controller's fixed point and says so
+    # (round 6: which of the two it is depends on the last bits of the host's small exponentials -- the ComplexF64 products of
+    #  host_dense.h changed their summation order this round and the device now FINISHES this horizon like the oracle does.  Both
+    #  outcomes are the reference controller's; pinned: it is one of the two, never a hang, never another error, and a finished run
+    #  agrees with the oracle's in the dominant direction -- exp(tA) amplifies by 1e45 there, relative accuracy survives.)
     log = []
-    with pytest.raises((ValueError, RuntimeError)) as ei:
-        eu.expv_timestep(np.asarray(ts).copy(), A, b, **dict(kw, verbose=True, out=log.append))
-    msg = str(ei.value)
-    assert "did not reach the tolerance in 1000 proposals" in msg, msg
-    import re
-    props = [ln for ln in log if "tau" in ln and "error estimate" in ln]
-    assert len(props) >= 500, (len(props), log[-5:])
-    tail = props[-400:]
-    taus = {re.search(r"tau = ([-+0-9.eE]+)", ln).group(1) for ln in tail}
-    ms = {re.search(r"m = (\d+)", ln).group(1) for ln in tail}
-    assert len(taus) == 1 and len(ms) == 1, (sorted(taus)[:4], sorted(ms), tail[-3:])      # tau_new == tau, m_new == m: the fixed point
+    try:
+        Ufull = np.asarray(eu.expv_timestep(np.asarray(ts).copy(), A, b, **dict(kw, verbose=True, out=log.append)))
+        raised = None
+    except (ValueError, RuntimeError) as ex:
+        raised = ex
+    if raised is not None:
+        msg = str(raised)
+        assert "did not reach the tolerance in 1000 proposals" in msg, msg
+        import re
+        props = [ln for ln in log if "tau" in ln and "error estimate" in ln]
+        assert len(props) >= 500, (len(props), log[-5:])
+        tail = props[-400:]
+        taus = {re.search(r"tau = ([-+0-9.eE]+)", ln).group(1) for ln in tail}
+        ms = {re.search(r"m = (\d+)", ln).group(1) for ln in tail}
+        assert len(taus) == 1 and len(ms) == 1, (sorted(taus)[:4], sorted(ms), tail[-3:])      # tau_new == tau, m_new == m: the fixed point
+        print("[pin] full horizon: the reference controller's fixed point, reported as an ArgumentError")
+    else:
+        Uo_full = np.asarray(ko.expv_timestep(np.asarray(ts_o).copy(), A_o, b_o, **dict(kw_o)))
+        assert np.all(np.isfinite(Ufull)) and Ufull.shape == Uo_full.shape
+        close(Ufull, Uo_full, 1e-6, "amplifying Hermitian operator, full horizon: a finished run against the oracle's (amplification 1e45)")
+        print("[pin] full horizon: finished like the oracle")
     # and the library is usable afterwards
     close(np.asarray(eu.expv(0.01, A, b, m=10)), ko.expv(0.01, A_o, b_o, m=10), 1e-10, "expv after the controller error")
 
