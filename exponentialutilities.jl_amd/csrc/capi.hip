@@ -650,6 +650,8 @@ struct PatchPlan;
 struct OrderPlan {
   int64_t n = 0, nnz = 0;
   int value_bytes = 0, reorder_mode = 0, patch_mode = 0;
+  int dtype = -1;                                 // the element type the plan was made for: real and complex types of equal size (Float64 / ComplexF32)
+                                                  // choose between orderings differently (maybe_reorder, pattern_class_ex) -- ADVICE r5
   uint64_t hash = 0;
   std::vector<int32_t> rp0, ci0;                  // the pattern the plan was made for (compared on a hit: a hash is not an identity)
   bool reordered = false;
@@ -683,11 +685,11 @@ struct OrderPlanCache {
     const char *e = std::getenv("EXPV_MI_PLAN_CACHE");
     capacity = e ? (size_t)std::max(0, std::atoi(e)) : 2;
   }
-  std::shared_ptr<OrderPlan> find(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, int value_bytes, int rmode, int pmode, uint64_t h) {
+  std::shared_ptr<OrderPlan> find(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, int value_bytes, int dtype, int rmode, int pmode, uint64_t h) {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < entries.size(); ++i) {
       const auto &e = entries[i];
-      if (e->hash != h || e->n != n || e->nnz != (int64_t)ci.size() || e->value_bytes != value_bytes || e->reorder_mode != rmode || e->patch_mode != pmode) continue;
+      if (e->hash != h || e->n != n || e->nnz != (int64_t)ci.size() || e->value_bytes != value_bytes || e->dtype != dtype || e->reorder_mode != rmode || e->patch_mode != pmode) continue;
       if (std::memcmp(e->rp0.data(), rp.data(), sizeof(int32_t) * rp.size()) != 0 || std::memcmp(e->ci0.data(), ci.data(), sizeof(int32_t) * ci.size()) != 0) continue;
       auto hit = e;
       entries.erase(entries.begin() + (long)i);
@@ -1120,7 +1122,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
   const bool cacheable = cache.capacity > 0 && n >= 4096 && !ci.empty();
   if (cacheable) {
     ph = pattern_hash(rp.data(), (int64_t)rp.size(), ci.data(), (int64_t)ci.size());
-    plan = cache.find(n, rp, ci, (int)sizeof(V), op.ctx->opt.reorder, op.ctx->opt.patch, ph);
+    plan = cache.find(n, rp, ci, (int)sizeof(V), op.dtype, op.ctx->opt.reorder, op.ctx->opt.patch, ph);
     lap("pattern hash + plan lookup");
   }
   if (plan) {
@@ -1139,7 +1141,7 @@ void make_csr_op(Op &op, int64_t n, std::vector<int32_t> &rp, std::vector<int32_
     std::shared_ptr<OrderPlan> rec;
     if (cacheable) {
       rec = std::make_shared<OrderPlan>();
-      rec->n = n; rec->nnz = (int64_t)ci.size(); rec->value_bytes = (int)sizeof(V);
+      rec->n = n; rec->nnz = (int64_t)ci.size(); rec->value_bytes = (int)sizeof(V); rec->dtype = op.dtype;
       rec->reorder_mode = op.ctx->opt.reorder; rec->patch_mode = op.ctx->opt.patch; rec->hash = ph;
       rec->rp0 = rp; rec->ci0 = ci;
       g_plan_rec = rec.get();

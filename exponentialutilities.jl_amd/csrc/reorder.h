@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <exception>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -35,11 +36,20 @@ inline void parallel_chunks(int64_t n, F f, int64_t min_chunk = 1 << 15) {
   }();
   const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(hw, n / std::max<int64_t>(1, min_chunk)));
   if (nt <= 1) { f((int64_t)0, n); return; }
+  // an exception inside a chunk (std::bad_alloc of a per-row vector at n ~ 1e6+) must reach the caller -- guarded() turns it into
+  // EXPV_MI_OUT_OF_MEMORY -- instead of std::terminate: every worker catches into its own slot, ALL threads are joined (also when the
+  // calling thread's own chunk or a thread's creation throws), then the first exception is rethrown  
+  std::vector<std::exception_ptr> err((size_t)nt);
   std::vector<std::thread> th;
+  struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{th};
   th.reserve((size_t)nt - 1);
-  for (int64_t t = 1; t < nt; ++t) th.emplace_back([=, &f] { f(n * t / nt, n * (t + 1) / nt); });
-  f((int64_t)0, n / nt);
+  for (int64_t t = 1; t < nt; ++t)
+    th.emplace_back([=, &f, &err] {
+      try { f(n * t / nt, n * (t + 1) / nt); } catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
+  try { f((int64_t)0, n / nt); } catch (...) { err[0] = std::current_exception(); }
   for (auto &x : th) x.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
 // symmetric adjacency of the pattern of A + A' without self loops: node i's neighbours are adj[ap[i] .. ap[i] + deg[i]), ascending.

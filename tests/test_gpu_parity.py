@@ -1611,6 +1611,40 @@ def test_matrix_free_callback_sees_normalised_columns_by_default(eu):
 
 
 @pytest.mark.gpu
+def test_ordering_plan_cache_keeps_element_types_of_equal_size_apart(eu):
+    """the plan cache was keyed by sizeof(value), and Float64 / ComplexF32 are both 8 bytes -- but creation decides between
+    orderings differently for real and complex types, so a ComplexF32 operator created first made a later Float64 operator with the
+    same pattern inherit its plan: storage form and result bits depended on process history.  The key now holds the element type:
+    same pattern, other type = a miss, and the operator comes out bit for bit as with the cache switched off."""
+    rng = np.random.default_rng(72)
+    k = 200
+    n = k * 120
+    A0 = sp.diags([0.3, 1.2, -2.0, 0.8, -0.1], [-k, -1, 0, 1, k], shape=(n, n), format="csr")
+    q = rng.permutation(n)
+    A0 = A0[q][:, q].tocsr()
+    A0.sort_indices()
+    b = rng.standard_normal(n)
+    ctx = eu.Context()
+    eu.plan_cache(clear=True, capacity=0)
+    op_ref = eu.MIOperator(A0, ctx)
+    w_ref = np.asarray(eu.expv(0.5, op_ref, b, m=12, ishermitian=False)).copy()
+    info_ref = (op_ref.reorder_info, op_ref.patch_info)
+    eu.plan_cache(clear=True, capacity=2)
+    op_c = eu.MIOperator((A0 * (1 + 0.25j)).astype(np.complex64), ctx)          # 8-byte values, complex: its plan goes into the cache
+    st0 = eu.plan_cache()
+    op_r = eu.MIOperator(A0, ctx)                                              # 8-byte values, real, same pattern
+    st1 = eu.plan_cache()
+    assert st1["hits"] == st0["hits"], (st0, st1)                              # ... must NOT take the complex plan
+    assert (op_r.reorder_info, op_r.patch_info) == info_ref
+    assert np.array_equal(np.asarray(eu.expv(0.5, op_r, b, m=12, ishermitian=False)), w_ref)
+    op_r2 = eu.MIOperator(A0, ctx)                                             # the same type again: a hit, same bits
+    assert eu.plan_cache()["hits"] == st1["hits"] + 1
+    assert np.array_equal(np.asarray(eu.expv(0.5, op_r2, b, m=12, ishermitian=False)), w_ref)
+    eu.plan_cache(clear=True, capacity=2)
+    del op_c, op_r, op_r2, op_ref
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,m,iop,herm", [(1, 22, 0, False), (17, 2, 7, False), (129, 6, 7, True), (130, 30, 0, False), (257, 12, 2, False), (1001, 30, 0, True)])
 def test_matrix_free_operator_on_the_two_kernel_step_odd_sizes(eu, n, m, iop, herm):
     """Round 5: matrix-free operators (docs/src/interfaces.md:7-36, basictests.jl:786-816) run the two-kernel step, their mul! feeding its
