@@ -462,6 +462,8 @@ struct ArnoldiAug {  // augmented operator pieces (kiops)
   const void *w = nullptr;  // device n-vector, dtype T
   double *w_aug_host = nullptr;
   double t = 0, mu = 0;
+  bool B_zero = false;      // B is the all-zero column kiops appends to a single input vector (kiops.jl:65-69): the single-pass step skips the
+                            // product B u_j[n:] instead of streaming s n bytes of zeros per Krylov step (round 6)
 };
 // returns the number of operator applications performed
 int arnoldi_run(Ks &ks, Op &op, const void *b_dev, const expv_mi_arnoldi_opts &o, const ArnoldiAug *aug,

@@ -877,7 +877,7 @@ struct ArnoldiCall {
       pa.u0 = (j == 1 && fresh) ? (isaug ? reinterpret_cast<const T *>(aug->w) : b) : nullptr;
       pa.u0_map = (j == 1 && fresh && !isaug) ? b_map : nullptr;
       if (isaug) {
-        pa.aug_p = p; pa.n_op = ks.n; pa.B = reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;
+        pa.aug_p = p; pa.n_op = ks.n; pa.B = aug->B_zero ? nullptr : reinterpret_cast<const T *>(aug->B); pa.ldb = aug->ldb;      // (nullptr: B == 0, nothing to add)
         if (j == 1 && fresh)
           for (int k = 0; k < p; ++k) pa.u0_tail[k] = ST<T>::from_real(aug->w_aug_host[k]);
       }

@@ -528,6 +528,7 @@ static void kiops_T(Ctx *ctx, Op &op, const double *tau_out, int ntau, int tau_n
   aug.B = uf;
   aug.ldb = n;
   aug.p = p;
+  aug.B_zero = padded;
   aug.w = u;
   aug.w_aug_host = w_aug.data();
   aug.mu = mu;

@@ -1011,7 +1011,8 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int e = 0; e < N; ++e) {
         const int64_t r = i + e;
         if (r < n_op) {
-          for (int q = 0; q < p_aug; ++q) ST<T>::fma_(y.v[e], pa.B[r + (int64_t)q * pa.ldb], sh.ut[q]);
+          if (pa.B != nullptr)      // (nullptr: the zero column of a padded kiops input -- y~ + 0 * u_j[n:] is y~)
+            for (int q = 0; q < p_aug; ++q) ST<T>::fma_(y.v[e], pa.B[r + (int64_t)q * pa.ldb], sh.ut[q]);
         } else if (r < n_op + p_aug - 1) {
           y.v[e] = sh.ut[r - n_op + 1];
         } else {

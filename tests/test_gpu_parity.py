@@ -1628,14 +1628,15 @@ def test_ordering_plan_cache_keeps_element_types_of_equal_size_apart(eu):
     eu.plan_cache(clear=True, capacity=0)
     op_ref = eu.MIOperator(A0, ctx)
     w_ref = np.asarray(eu.expv(0.5, op_ref, b, m=12, ishermitian=False)).copy()
-    info_ref = (op_ref.reorder_info, op_ref.patch_info)
+    strip = lambda d: {k: v for k, v in dict(d).items() if not k.endswith("_s")}      # (without the timing fields)
+    info_ref = (strip(op_ref.reorder_info), strip(op_ref.patch_info))
     eu.plan_cache(clear=True, capacity=2)
     op_c = eu.MIOperator((A0 * (1 + 0.25j)).astype(np.complex64), ctx)          # 8-byte values, complex: its plan goes into the cache
     st0 = eu.plan_cache()
     op_r = eu.MIOperator(A0, ctx)                                              # 8-byte values, real, same pattern
     st1 = eu.plan_cache()
     assert st1["hits"] == st0["hits"], (st0, st1)                              # ... must NOT take the complex plan
-    assert (op_r.reorder_info, op_r.patch_info) == info_ref
+    assert (strip(op_r.reorder_info), strip(op_r.patch_info)) == info_ref
     assert np.array_equal(np.asarray(eu.expv(0.5, op_r, b, m=12, ishermitian=False)), w_ref)
     op_r2 = eu.MIOperator(A0, ctx)                                             # the same type again: a hit, same bits
     assert eu.plan_cache()["hits"] == st1["hits"] + 1
