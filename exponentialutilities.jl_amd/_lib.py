@@ -11,9 +11,9 @@ LIB_PATH = os.environ.get("EXPV_MI_LIB") or os.path.join(HERE, "libexpv_mi.so") 
 
 F64, C64, F32, C32 = 0, 1, 2, 3
 HOST, DEVICE = 0, 1
-ORTHO_AUTO, ORTHO_MGS, ORTHO_LOWSYNC = 0, 1, 2
+ORTHO_AUTO, ORTHO_MGS, ORTHO_LOWSYNC, ORTHO_PIPELINED = 0, 1, 2, 3
 PATH_FLAGS = {"modular": 1, "two_kernel": 2, "pipeline": 4, "wave": 8, "overlapped": 16, "redo_serial": 32,
-              "redo_wave_off": 64, "resident": 128, "patch": 256}
+              "redo_wave_off": 64, "resident": 128, "patch": 256, "pipelined_lanczos": 512}
 
 STATUS_NAMES = {
     0: "OK", 1: "DimensionMismatch", 2: "ArgumentError", 3: "AssertionError", 4: "SingularException",

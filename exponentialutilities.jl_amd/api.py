@@ -710,7 +710,7 @@ def _opts(m=None, tol=1e-7, iop=0, init=0, ishermitian=None, ortho="auto", flags
     o.iop = int(iop)
     o.init = int(init)
     o.ishermitian = -1 if ishermitian is None else int(bool(ishermitian))
-    o.ortho = {"auto": L.ORTHO_AUTO, "mgs": L.ORTHO_MGS, "lowsync": L.ORTHO_LOWSYNC}[ortho] \
+    o.ortho = {"auto": L.ORTHO_AUTO, "mgs": L.ORTHO_MGS, "lowsync": L.ORTHO_LOWSYNC, "pipelined": L.ORTHO_PIPELINED}[ortho] \
         if isinstance(ortho, str) else int(ortho)
     return o
 
@@ -732,13 +732,13 @@ def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0
     return Ks
 
 
-def lanczos_(Ks, A, b, *, tol=1e-7, m=None, opnorm=None, init=0):
-    """lanczos!(Ks, A, b; tol, m)  (arnoldi.jl:456-490)."""
+def lanczos_(Ks, A, b, *, tol=1e-7, m=None, opnorm=None, init=0, ortho="auto"):
+    """lanczos!(Ks, A, b; tol, m)  (arnoldi.jl:456-490).  ``ortho="pipelined"``: the opt-in pipelined recurrence (include/expv_mi.h)."""
     op = _as_operator(A, Ks.T, Ks.ctx)
     ba = _Arg(b, Ks.T)
     if int(np.prod(ba.shape)) != op.shape[0]:
         raise DimensionMismatch("length(b) == size(A,1) doesn't hold")
-    o = _opts(m, tol, 0, init, True, "auto", flags=1)
+    o = _opts(m, tol, 0, init, True, ortho, flags=1)
     _check(L.load().expv_mi_lanczos(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
     return Ks
 

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libexpv_mi.so")
-SOURCES = ["kernels.hip", "fused.hip", "pipe.hip", "engine_core.hip", "engine_drivers.hip", "engine_batch.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "fused.hip", "pipe.hip", "lanczos_pl.hip", "engine_core.hip", "engine_drivers.hip", "engine_batch.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma",
          "-Xarch_host", "-fcx-limited-range"]   # complex products of the host small-dense code: plain (ac-bd, ad+bc), no __muldc3 NaN recovery   # host small-dense exp: every MI355X host is x86-64-v3

@@ -355,6 +355,7 @@ struct Ks {
   int ldg = 0;
   int gram_rows = 0;   // leading basis vectors whose Gram rows are valid
   DevBuf hcoef, part, gpart, state;
+  DevBuf plbuf;            // pipelined Lanczos (lanczos_pl.hip): partial-sum ring, arrival counters, step flags, scalar output
   StepState state_host;   // staging of the step-state reset of a continuation (asynchronous copy source)
   void *pin = nullptr;   // pinned host staging for the Hessenberg / step-state read-back
   size_t pin_bytes = 0;

@@ -524,6 +524,12 @@ struct ArnoldiCall {
         }
       }
     }
+    if constexpr (std::is_same<T, double>::value) {
+      if (lanczos_pipelined_applies()) {
+        const int r = run_lanczos_pipelined();
+        if (r >= 0) return r;      // (-1: not launched or a bounded wait expired -- the default path below runs instead)
+      }
+    }
     if (fresh) first_step();
     if (ks.beta == 0.0) return 0;
     iop = o.iop;
@@ -544,6 +550,72 @@ struct ArnoldiCall {
     else steps_modular();
     ct_mark("  arnoldi!: all step launches enqueued");
     return read_back();
+  }
+
+  // ---- opt-in: lanczos! as a pipelined recurrence, the whole factorisation one resident kernel (lanczos_pl.hip) ----------------
+  bool lanczos_pipelined_applies() const {
+    return lanczos && o.ortho == EXPV_MI_ORTHO_PIPELINED && fresh && !isaug && op.kind == OP_CSR && op.ndiag > 0 && !no_dia_env &&
+           op.bandwidth >= 1 && op.bandwidth <= dev::PIPE_WMAX && ks.dtypeT == EXPV_MI_F64 && !b_nat && b_map == nullptr && m >= 1 && m <= dev::PL_MAX_M &&
+           ks.n >= 2 * dev::PIPE_WMAX * 3 && !c->prof_on;
+  }
+  int run_lanczos_pipelined() {
+    if constexpr (!std::is_same<T, double>::value) return -1;
+    else {
+    const int cap = dev::lanczos_pl_capacity();
+    if (cap <= 0) return -1;
+    const size_t part_b = sizeof(double) * 4 * 12 * (size_t)dev::MAX_GRID, cnt_b = sizeof(uint32_t) * (size_t)(dev::PL_MAX_M + 8),
+                 flag_b = sizeof(uint32_t) * 2 * (size_t)dev::MAX_GRID, out_n = 8 + 2 * (size_t)(dev::PL_MAX_M + 3) + 8, out_b = sizeof(double) * out_n;
+    if (ks.plbuf.bytes < part_b + cnt_b + flag_b + out_b) ks.plbuf.alloc(part_b + cnt_b + flag_b + out_b);
+    char *base = ks.plbuf.as<char>();
+    dev::LanczosPlArgs a{};
+    a.dia_val = op.dia_val.as<double>(); a.dia_ld = op.dia_ld; a.ndiag = op.ndiag;
+    for (int d = 0; d < op.ndiag; ++d) a.dia_off[d] = op.dia_off[d];
+    a.w = (int)op.bandwidth;
+    a.n_dia = op.dia_ld;
+    a.V = ks.V.as<double>(); a.ldv = ks.ldv; a.n = ks.n;
+    a.u0 = reinterpret_cast<const double *>(b);
+    a.part = reinterpret_cast<double *>(base);
+    a.count = reinterpret_cast<uint32_t *>(base + part_b);
+    a.flags = reinterpret_cast<uint32_t *>(base + part_b + cnt_b);
+    a.out = reinterpret_cast<double *>(base + part_b + cnt_b + flag_b);
+    a.m = m; a.want_tail = ks.skip_tail ? 0 : 1; a.tol = tol; a.spin_limit = c->opt.spin_limit * 8;
+    HIPCHECK(hipMemsetAsync(base + part_b, 0, cnt_b + flag_b + out_b, s));      // counters, flags, output
+    for (int j = 0; j < hview_cols; ++j)
+      std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));
+    if (!dev::lanczos_pl(s, a)) return -1;
+    const size_t need = out_b;
+    if (ks.pin_bytes < need) {
+      if (ks.pin) (void)hipHostFree(ks.pin);
+      ks.pin = nullptr;
+      ks.pin_bytes = std::max(need, sizeof(T) * (size_t)ks.ldhd * (ks.maxiter + 1) + sizeof(StepState));
+      HIPCHECK(hipHostMalloc(&ks.pin, ks.pin_bytes, hipHostMallocDefault));
+    }
+    double *out = reinterpret_cast<double *>(ks.pin);
+    HIPCHECK(hipMemcpyAsync(out, a.out, out_b, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    ks.scale_pending = false;
+    ks.scale_cols = 0;
+    ks.gram_rows = 0;
+    ks.tail.pending = false;
+    if (out[2] != 0.0) { ++c->cnt_serial_redo; return -1; }      // a bounded wait expired (device shared): the default path redoes the call
+    ks.beta = std::sqrt(out[0]);
+    if (ks.beta == 0.0) return 0;                                // iszero(Ks.beta) && return Ks  (arnoldi.jl:366)
+    const int md = (int)out[1];
+    const int jlast = md > 0 ? std::min(md, m) : m;
+    const double *al = out + 8, *be = out + 8 + dev::PL_MAX_M + 3;
+    for (int j = 1; j <= jlast; ++j) {
+      setH(ks, j - 1, j - 1, cd(al[j], 0.0));                    // u[j] = alpha_j
+      setH_realpart(ks, j, j - 1, be[j]);                        // v[j] = beta_j
+    }
+    const int nsub = std::min(hview_rows - 1, hview_cols);       // copyto!(@diagview(H, 1), v[1:end-1])  (arnoldi.jl:488)
+    for (int i = 1; i < nsub; ++i)
+      if (i < hview_cols) setH(ks, i - 1, i, cd(getH(ks, i, i - 1).real(), 0.0));
+    if (md > 0 && md <= m) { ks.m = md; ks.wasbreakdown = true; }
+    c->cnt_steps += jlast;
+    ++c->cnt_fact;
+    c->last_path = EXPV_MI_PATH_PIPELINED_LANCZOS;
+    return jlast;
+    }
   }
 
   // ---- which step form runs ------------------------------------------------------------------

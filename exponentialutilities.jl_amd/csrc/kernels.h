@@ -310,6 +310,21 @@ struct ResArgs {
   int m, closing; double tol; int real_coeff;
   double *Hhost; double *mb_scales, *mb_state; unsigned long long *mb_done;
 };
+// pipelined Lanczos (lanczos_pl.hip): the whole factorisation as one cooperative kernel, no pass waits for the previous pass' reduction
+constexpr int PL_MAX_M = 128;       // Krylov dimensions up to this (the scalars live in LDS)
+struct LanczosPlArgs {
+  const double *dia_val; int64_t dia_ld; int ndiag; int dia_off[PIPE_DIA_MAX]; int w;
+  int64_t n_dia;                    // rows the DIA arrays may be read on in 16-byte packs
+  double *V; int64_t ldv; int64_t n;
+  const double *u0;                 // b
+  double *part;                     // [4][12][MAX_GRID]: per-workgroup sums of the last four passes
+  uint32_t *count;                  // [m + 3] arrivals per pass, zeroed by the launcher's caller
+  uint32_t *flags;                  // [2][MAX_GRID], zeroed: per worker the last pass + 1 whose edge tiles are in memory / whose partial sums are published
+  double *out;                      // [8 + 2 (PL_MAX_M + 3)]: beta_0^2, breakdown step, error, passes reduced; alpha_j at 8 + j, beta_j at 8 + PL_MAX_M + 3 + j
+  int m, want_tail; double tol; int spin_limit;
+};
+bool lanczos_pl(hipStream_t s, const LanczosPlArgs &a);      // false: not launched
+int lanczos_pl_capacity();
 bool pipe_resident(hipStream_t s, const ResArgs &ra);   // false: not launched (shape outside the resident form's scope)
 int pipe_resident_capacity();
 void pipe_step(hipStream_t s, const PipeArgsT<double> &pa, int nbatch = 1, int batch_rounds = 2);

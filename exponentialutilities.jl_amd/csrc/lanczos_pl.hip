@@ -1,0 +1,525 @@
+// lanczos_pl.hip -- pipelined Lanczos factorisation for narrow-banded Hermitian operators (fp64, gfx950): the opt-in mode
+// `ortho = EXPV_MI_ORTHO_PIPELINED` of lanczos! (round 6; VERDICT r5 item 4, DESIGN.md section 8 "short windows").
+//
+// The reference recurrence (arnoldi.jl:388-403) is a chain: alpha_j = <v_j, A v_j> must be reduced over the whole grid before
+// u_{j+1} = A v_j - alpha_j v_j - beta_{j-1} v_{j-1} exists, and beta_j = |u_{j+1}| before v_{j+1} does.  On the single-pass step that
+// chain is ~7 us of a 17 us Lanczos step at n = 1e6 and ALL of a step at n <= 1e5.  Here no pass waits for the
+// reduction of the pass before it:
+//
+//   pass k  reads v_{k-1}, v_{k-2} and the operator (nothing else), RECOMPUTES z_{k-1} = A v_{k-1} on its tile + halo, forms
+//           v_k = (z_{k-1} - alpha_{k-1} v_{k-1} - beta_{k-2} v_{k-2}) / beta_{k-1}      with scalars reduced TWO passes ago,
+//           z_k = A v_k, q_k = A z_k (a three-deep halo: 3 w rows either side of a 512-row tile, w <= 8), writes v_k, and adds this
+//           tile's share of 12 inner products of {v_k, z_k, q_k, v_{k-1}, z_{k-1}} to the workgroup's running sums;
+//   scalars alpha_{k+1} beta_k^2 = <z_k - alpha_k v_k - beta_{k-1} v_{k-1}, q_k - alpha_k z_k - beta_{k-1} z_{k-1}>  ("inner products by
+//           expansion"), |A v_{k+1}|^2 likewise, beta_{k+1}^2 = |A v_{k+1}|^2 - alpha_{k+1}^2 - beta_k^2 -- from the 12 sums of pass k,
+//           computed by EVERY workgroup for itself from the published per-workgroup partials in a fixed order (bit-identical
+//           everywhere: no last-workgroup chain, no broadcast), one pass after they were published.
+//
+// The whole factorisation is ONE cooperative kernel: workgroups own fixed runs of tiles, a pass hands its tile edges to the two
+// neighbouring workgroups through per-workgroup step flags (write-through stores, acknowledged before the flag), and the only
+// grid-wide waits are on partial sums that are a full pass old.  HBM traffic per step: the operator + two columns read + one
+// written = 64 MB at n = 1e6 for 5 diagonals (the reference recurrence on the single-pass step: 80 MB).
+//
+// This is NOT the reference's arithmetic: alpha and beta come from expansions instead of direct inner products.  Measured against
+// the reference recurrence (oracle/pipelined_lanczos.py: lanczos_p3 is this scheme in numpy; profiles/r06_pipelined_lanczos_accuracy.txt):
+// exp(tA)b agrees to <= 1.2e-14, H to <= 7e-14 of its largest entry on well-conditioned bases; where the reference recurrence itself
+// loses orthogonality completely (rand(300,300), basictests.jl:756-784) H differs like any two Lanczos runs do and exp(tA)b still agrees
+// to 1e-14.  The happy-breakdown test sees beta_j only as a difference of O(|A|^2) quantities: reliable down to ~1e-7 |A|, and two
+// passes late (the columns beyond Ks.m are then garbage, as in the reference they are rounding noise).  Opt-in for that reason.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "kernel_common.h"
+
+namespace expv_mi {
+namespace dev {
+
+constexpr int PL_TR = 2 * BLOCK;               // rows of a tile: 256 lanes x 16 bytes
+constexpr int PL_NP = 12;                      // inner products of a pass
+#ifndef PL_WGS_DEFAULT
+#define PL_WGS_DEFAULT 2
+#endif
+
+// write-through 16-byte store (the tile edges are read by other workgroups without a kernel boundary in between)
+__device__ __forceinline__ void pl_store_wt(double *p, double a, double b) {
+  typedef double vec2d __attribute__((ext_vector_type(2)));
+  vec2d d;
+  d.x = a;
+  d.y = b;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+}
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence: the compiler drains every outstanding
+// GLOBAL access in front of it (s_waitcnt vmcnt(0)) -- the loads requested one tile ahead and the write-through stores of the tile
+// before, 2-3 us each, four times per tile (measured: 5-8 us per tile, profiles/r06_pipelined_lanczos.txt).  Inside the tile loop only the
+// LDS images are shared between the waves of a workgroup.
+__device__ __forceinline__ void pl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pl_store_wt1(double *p, double a) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(a) : "memory");
+}
+__device__ __forceinline__ uint32_t pl_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef PL_TRACE
+__device__ unsigned long long g_pl_trace[8][40][6];      // [workgroup sample][pass][stamp]
+#define PL_STAMP(k, slot) do { if (tid == 0 && (wg % 64) == 7 && (wg / 64) < 8 && (k) < 40) g_pl_trace[wg / 64][k][slot] = wall_clock64(); } while (0)
+#else
+#define PL_STAMP(k, slot) do { } while (0)
+#endif
+struct PlShared {
+  double x1[PL_TR + 6 * PIPE_WMAX];            // v_{k-1} on the tile and 3w rows either side
+  double vk[PL_TR + 4 * PIPE_WMAX];            // v_k, 2w rows either side
+  double zk[PL_TR + 2 * PIPE_WMAX];            // z_k = A v_k, w rows either side
+  double red[BLOCK / 64][PL_NP];
+  double sums[PL_NP];
+  double al[PL_MAX_M + 3], be[PL_MAX_M + 3];   // alpha_j, beta_j (1-based; be[0] = 0)
+  int doff[PIPE_DIA_MAX];
+  int state[4];                                // [0] m_done (0: none), [1] error
+};
+
+// the scalars of pass r from its 12 sums (every workgroup runs this, bit for bit the same)
+__device__ __forceinline__ void pl_scalars(PlShared &sh, int r, double tol) {
+  const double *S = sh.sums;
+  double a, bk, bkm1;
+  if (r == 1) {
+    sh.al[1] = S[4];                                            // <v_1, z_1>
+    const double b2 = S[1] - S[4] * S[4];                        // |z_1|^2 - alpha_1^2
+    sh.be[1] = b2 > 0.0 ? sqrt(b2) : 0.0;
+    if (sh.state[0] == 0 && sh.be[1] < tol) sh.state[0] = 1;
+    bkm1 = 0.0;
+  } else {
+    bkm1 = sh.be[r - 1];
+  }
+  a = sh.al[r];
+  bk = sh.be[r];
+  const double zq = S[0], zz = S[1], zz1 = S[2], vq = S[3], vz = S[4], vz1 = S[5], xq = S[6], xz = S[7], xz1 = S[8], qq = S[9], qz1 = S[10], z1z1 = S[11];
+  const double num_a = zq - a * zz - bkm1 * zz1 - a * vq + a * a * vz + a * bkm1 * vz1 - bkm1 * xq + a * bkm1 * xz + bkm1 * bkm1 * xz1;
+  const double num_z = qq - 2.0 * a * zq - 2.0 * bkm1 * qz1 + a * a * zz + 2.0 * a * bkm1 * zz1 + bkm1 * bkm1 * z1z1;
+  const double ib2 = 1.0 / (bk * bk);
+  const double an = num_a * ib2;
+  const double b2 = num_z * ib2 - an * an - bk * bk;
+  sh.al[r + 1] = an;
+  sh.be[r + 1] = b2 > 0.0 ? sqrt(b2) : 0.0;
+  if (sh.state[0] == 0 && !(sh.be[r + 1] >= tol)) sh.state[0] = r + 1;      // happy breakdown of step r+1 (arnoldi.jl:480-486; NaN counts)
+}
+
+// ND: most diagonals held in registers per lane (5: the usual stencils; 8: everything the banded DIA form stores)
+template <int ND, int WGS>
+__global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs pa) {
+  __shared__ PlShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the LAST workgroup owns no tiles: it reduces the partial sums of every pass (one pass behind the workers) and publishes the scalars
+  // -- 12 x G uncached 8-byte loads per pass are ~4 us for one workgroup and were 30 us of EVERY pass when each workgroup did them for itself
+  const int G = (int)gridDim.x - 1, wg = blockIdx.x;
+  const bool reducer = (wg == G);
+  const int w = pa.w, m = pa.m;
+  const int64_t n = pa.n;
+  const int64_t ntiles = (n + PL_TR - 1) / PL_TR;
+  const int64_t t0 = reducer ? 0 : ntiles * wg / G, t1 = reducer ? 0 : ntiles * (wg + 1) / G;      // this workgroup's tiles, every pass
+  if (tid < PIPE_DIA_MAX) {
+    int v = 0;
+#pragma unroll
+    for (int q = 0; q < PIPE_DIA_MAX; ++q)
+      if (tid == q) v = pa.dia_off[q];
+    sh.doff[tid] = v;
+  }
+  if (tid < 4) sh.state[tid] = 0;
+  if (tid == 0) sh.be[0] = 0.0;
+  __syncthreads();
+  const int nd = pa.ndiag;
+  int spins_left = pa.spin_limit;
+  uint32_t *eflags = pa.flags;                 // per worker: last pass whose EDGE tiles are in memory, + 1 (what the two neighbours wait for)
+  uint32_t *pflags = pa.flags + MAX_GRID;      // per worker: last pass whose partial sums are published, + 1 (what the reducer polls)
+  auto wait_ge = [&](const uint32_t *p, uint32_t want) {      // thread 0 polls; false: the bound expired
+    bool ok = true;
+    if (tid == 0) {
+      while (pl_load_u32(p) < want) {
+        if (--spins_left <= 0) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) sh.state[1] = 99;
+    }
+    return ok;
+  };
+  // partial sums of pass r -> sh.sums (fixed order: thread t adds workgroups t, t + 256, ...; then the wave / block tree)
+  auto gather = [&](int r, int nvals) {
+    // every load of the pass is requested before the first one is used: ONE memory round trip (a loop that adds each partial as it
+    // arrives is 12-24 dependent round trips of an uncached load -- 30 us per pass, and the passes cannot outrun the reducer)
+    const double *src = pa.part + (size_t)(r & 3) * PL_NP * MAX_GRID;
+    constexpr int GI = MAX_GRID / BLOCK;      // workgroups per thread at most (8)
+    double x[PL_NP];
+#pragma unroll
+    for (int v = 0; v < PL_NP; ++v) x[v] = 0.0;
+    for (int g0 = 0; g0 < G; g0 += 4 * BLOCK) {
+      double tmp[PL_NP][4];
+#pragma unroll
+      for (int v = 0; v < PL_NP; ++v)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int b = g0 + it * BLOCK + tid;
+          tmp[v][it] = (v < nvals && b < G) ? consume_f64(src + (size_t)v * MAX_GRID + b) : 0.0;
+        }
+#pragma unroll
+      for (int v = 0; v < PL_NP; ++v)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) x[v] += tmp[v][it];
+    }
+    (void)GI;
+#pragma unroll
+    for (int v = 0; v < PL_NP; ++v) {
+      const double y = wave_sum(x[v]);
+      if (lane == 0) sh.red[wave][v] = y;
+    }
+    __syncthreads();
+    if (tid < nvals) sh.sums[tid] = sh.red[0][tid] + sh.red[1][tid] + sh.red[2][tid] + sh.red[3][tid];
+    __syncthreads();
+  };
+  auto publish = [&](int r, const double (&p)[PL_NP], int nvals) {      // this workgroup's sums of pass r, then its arrival and its step flag
+#pragma unroll
+    for (int v = 0; v < PL_NP; ++v) {      // (static indices: a dynamically indexed private array lives in scratch)
+      if (v < nvals) {
+        const double x = wave_sum(p[v]);
+        if (lane == 0) sh.red[wave][v] = x;
+      }
+    }
+    __syncthreads();
+    if (tid < nvals) publish_f64(pa.part + (size_t)(r & 3) * PL_NP * MAX_GRID + (size_t)tid * MAX_GRID + wg, sh.red[0][tid] + sh.red[1][tid] + sh.red[2][tid] + sh.red[3][tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // partials and this pass' tile stores are acknowledged
+    __syncthreads();
+    // (one flag per workgroup, one writer each: a shared arrival counter costs a serialised atomic per workgroup and pass -- 512 of them
+    //  were 40 us of every pass; the reducing workgroup polls the flags instead)
+    if (tid == 0) __hip_atomic_store(pflags + wg, (uint32_t)(r + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto wait_all = [&](uint32_t want) -> bool {      // every worker's flag >= want (all threads of the reducing workgroup poll)
+    for (;;) {
+      int ok = 1;
+      for (int b = tid; b < G; b += BLOCK) ok &= (pl_load_u32(pflags + b) >= want) ? 1 : 0;
+      if (__syncthreads_and(ok)) return true;
+      if (tid == 0 && --spins_left <= 0) sh.state[1] = 99;
+      __syncthreads();
+      if (sh.state[1] != 0) return false;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  };
+
+  double *sc_al = pa.out + 8, *sc_be = pa.out + 8 + PL_MAX_M + 3;      // alpha_j, beta_j as the reducer publishes them
+  uint32_t *sflag = pa.count + PL_MAX_M + 4;                             // passes reduced so far + 1 (0: nothing yet)
+  const int need_end = m > 1 ? m - 1 : 1;                                // (pass r yields alpha_{r+1}, beta_{r+1}; pass 1 also alpha_1, beta_1)
+  if (reducer) {
+    // ---- the reducing workgroup -------------------------------------------------------------------------------------------
+    (void)wait_all(1u);
+    double beta0sq = 0.0;
+    if (sh.state[1] == 0) {
+      gather(0, 1);
+      beta0sq = sh.sums[0];
+    }
+    if (tid == 0) {
+      publish_f64(pa.out + 0, beta0sq);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(sflag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int r = 0;
+    if (beta0sq > 0.0) {
+      for (r = 1; r <= need_end; ++r) {
+        if (sh.state[1] != 0) break;
+        if (sh.state[0] != 0 && r > sh.state[0]) break;              // after a happy breakdown at step md the workers stop behind pass md + 1
+        if (!wait_all((uint32_t)(r + 1))) break;
+        gather(r, PL_NP);
+        if (tid == 0) {
+          pl_scalars(sh, r, pa.tol);
+          if (r == 1) { publish_f64(sc_al + 1, sh.al[1]); publish_f64(sc_be + 1, sh.be[1]); }
+          publish_f64(sc_al + r + 1, sh.al[r + 1]);
+          publish_f64(sc_be + r + 1, sh.be[r + 1]);
+          publish_f64(pa.out + 1, (double)sh.state[0]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(sflag, (uint32_t)(r + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      publish_f64(pa.out + 2, (double)sh.state[1]);                  // 99: a bounded wait expired
+      if (sh.state[1] != 0) __hip_atomic_store(sflag, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // release the workers
+    }
+    return;
+  }
+  // ---- the workers -------------------------------------------------------------------------------------------------------
+  // pass 0: beta_0 = |b|  (firststep!, arnoldi.jl:230-250)
+  {
+    double p0[PL_NP];
+#pragma unroll
+    for (int v = 0; v < PL_NP; ++v) p0[v] = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t i = t * PL_TR + 2 * (int64_t)tid;
+      if (i < n) { const double x = pa.u0[i]; p0[0] = fma(x, x, p0[0]); }
+      if (i + 1 < n) { const double x = pa.u0[i + 1]; p0[0] = fma(x, x, p0[0]); }
+    }
+    publish(0, p0, 1);
+  }
+  // scalars the reducer has published up to pass `upto` -> LDS (thread 0 reads, everybody uses)
+  int have = -1;                                                 // sh.al / sh.be hold the scalars of passes <= have
+  auto fetch_scalars = [&](int upto) {
+    if (upto <= have) return;
+    (void)wait_ge(sflag, (uint32_t)(upto + 1));
+    if (tid == 0) {
+      if (pl_load_u32(sflag) == 0xffffffffu) sh.state[1] = 99;
+      if (have < 0) sh.sums[0] = consume_f64(pa.out + 0);
+      for (int j = (have < 1 ? 1 : have + 1); j <= upto + 1; ++j) { sh.al[j] = consume_f64(sc_al + j); sh.be[j] = consume_f64(sc_be + j); }
+      if (upto >= 1) sh.state[0] = (int)consume_f64(pa.out + 1);
+    }
+    __syncthreads();
+    have = upto;
+  };
+  fetch_scalars(0);
+  const double beta0sq = sh.sums[0];
+  const double inv0 = beta0sq > 0.0 ? 1.0 / sqrt(beta0sq) : 0.0;
+  const int last_pass = pa.want_tail ? m + 1 : m;
+  if (beta0sq > 0.0 && sh.state[1] == 0) {
+#pragma unroll 1
+    for (int k = 1; k <= last_pass; ++k) {
+      // scalars for v_k: alpha_{k-1}, beta_{k-1}, beta_{k-2} -- from the reduction of pass k-2 (pass 2: of pass 1, the one start-up wait)
+      PL_STAMP(k, 0);
+      if (k >= 2) fetch_scalars((k == 2) ? 1 : k - 2);
+      PL_STAMP(k, 1);
+      if (sh.state[1] != 0) break;
+      const int md = sh.state[0];
+      if (md != 0 && k > md + 1) break;                          // happy breakdown at step md: v_1 .. v_{md+1} are all there is
+      const bool tail = (k == m + 1);                            // only v_{m+1} is wanted
+      const double a = k >= 2 ? sh.al[k - 1] : 0.0, b2 = k >= 3 ? sh.be[k - 2] : 0.0;
+      const double invb = k >= 2 ? 1.0 / sh.be[k - 1] : inv0;
+      const double *X1 = k >= 2 ? pa.V + (int64_t)(k - 2) * pa.ldv : nullptr;      // v_{k-1}
+      const double *X2 = k >= 3 ? pa.V + (int64_t)(k - 3) * pa.ldv : nullptr;      // v_{k-2}
+      double *VK = pa.V + (int64_t)(k - 1) * pa.ldv;
+      // the edges of v_{k-1} come from the neighbouring workgroups' pass k-1 (flagged as soon as THEIR edge tiles were in memory)
+      if (k >= 2) {
+        if (wg > 0) (void)wait_ge(eflags + wg - 1, (uint32_t)k);              // (a flag holds the last completed pass + 1)
+        if (wg + 1 < G) (void)wait_ge(eflags + wg + 1, (uint32_t)k);
+        __syncthreads();
+        if (sh.state[1] != 0) break;
+      }
+      PL_STAMP(k, 2);
+      double p[PL_NP];
+#pragma unroll
+      for (int v = 0; v < PL_NP; ++v) p[v] = 0.0;
+      // Tile order: the two EDGE tiles first -- they are stored through to memory, acknowledged, and this workgroup's edge flag goes up
+      // while the interior tiles (plain stores: only this workgroup reads them) are still being worked on.
+      const int nt = (int)(t1 - t0);
+      const int nedge = nt >= 2 ? 2 : nt;
+      auto tile_of = [&](int q) -> int64_t { return q == 0 ? t0 : (q == 1 ? t1 - 1 : t0 + (q - 1)); };
+      // everything a tile reads from memory, requested in ONE round trip and one tile AHEAD of its use (registers)
+      struct TL {
+        double x1a, x1b, x2a, x2b, xh, x2h, u0h, u0a, u0b;
+        double dva[ND], dvb[ND], dh[ND];
+        int64_t hrow;
+      };
+      auto load_tile = [&](int64_t t, TL &L) {
+        // (a lane's two rows are r0 + tid and r0 + 256 + tid: the lanes of a wave then read CONSECUTIVE 8-byte words of the LDS images --
+        //  with rows 2 tid, 2 tid + 1 every ds_read_b64 of the stencil phases was an 8-way bank conflict: 4 us of a 5.5 us tile)
+        const int64_t r0 = t * PL_TR, ia = r0 + tid, ib = ia + BLOCK;
+        L.x1a = L.x1b = L.x2a = L.x2b = L.xh = L.x2h = L.u0h = L.u0a = L.u0b = 0.0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          L.dva[d] = L.dvb[d] = L.dh[d] = 0.0;
+          if (d < nd) {
+            if (ia < pa.n_dia) L.dva[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ia];
+            if (ib < pa.n_dia) L.dvb[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ib];
+          }
+        }
+        L.hrow = -1;
+        if (tid < 4 * w) {
+          const int64_t hr = (tid < 2 * w) ? r0 - 2 * w + tid : r0 + PL_TR + (tid - 2 * w);
+          if (hr >= 0 && hr < n) {
+            L.hrow = hr;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+              if (d < nd) L.dh[d] = pa.dia_val[(int64_t)d * pa.dia_ld + hr];
+            if (k >= 3) L.x2h = X2[hr];
+            if (k == 1) L.u0h = pa.u0[hr];
+          }
+        }
+        if (k >= 2) {
+          if (ia < pa.ldv) L.x1a = X1[ia];      // (library vectors: zeros from n up to ldv, a multiple of 128 rows; a tile may reach beyond it)
+          if (ib < pa.ldv) L.x1b = X1[ib];
+          if (k >= 3) {
+            if (ia < pa.ldv) L.x2a = X2[ia];
+            if (ib < pa.ldv) L.x2b = X2[ib];
+          }
+          if (tid < 6 * w) {
+            const int64_t row = (tid < 3 * w) ? r0 - 3 * w + tid : r0 + PL_TR + (tid - 3 * w);
+            if (row >= 0 && row < n) L.xh = X1[row];
+          }
+        } else {
+          if (ia < n) L.u0a = pa.u0[ia];
+          if (ib < n) L.u0b = pa.u0[ib];
+        }
+      };
+      TL cur, nxt;
+      if (nt > 0) load_tile(tile_of(0), cur);
+#pragma unroll 1
+      for (int q = 0; q < nt; ++q) {
+        const int64_t t = tile_of(q);
+        const bool edge = q < nedge;
+        if (q + 1 < nt) load_tile(tile_of(q + 1), nxt);
+        const int64_t r0 = t * PL_TR, ia = r0 + tid, ib = ia + BLOCK;
+        const double x1a = cur.x1a, x1b = cur.x1b;
+        // ---- A: v_{k-1} on the tile + 3w rows either side -> LDS ----
+        if (k >= 2) {
+          sh.x1[3 * w + tid] = x1a;
+          sh.x1[3 * w + BLOCK + tid] = x1b;
+          if (tid < 6 * w) sh.x1[(tid < 3 * w) ? tid : PL_TR + tid] = cur.xh;
+          pl_barrier();
+        }
+        // ---- B: z_{k-1} = A v_{k-1} and v_k on the tile + 2w rows either side ----
+        double z1a = 0.0, z1b = 0.0, vka, vkb;
+        if (k >= 2) {
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (d < nd) {
+              const int o = 3 * w + tid + sh.doff[d];
+              z1a = fma(cur.dva[d], sh.x1[o], z1a);
+              z1b = fma(cur.dvb[d], sh.x1[o + BLOCK], z1b);
+            }
+          vka = (z1a - a * x1a - b2 * cur.x2a) * invb;
+          vkb = (z1b - a * x1b - b2 * cur.x2b) * invb;
+        } else {
+          vka = cur.u0a * inv0;
+          vkb = cur.u0b * inv0;
+        }
+        if (ia >= n) vka = 0.0;                                  // (the padding rows of the basis stay zero whatever 1/beta is)
+        if (ib >= n) vkb = 0.0;
+        sh.vk[2 * w + tid] = vka;
+        sh.vk[2 * w + BLOCK + tid] = vkb;
+        const int64_t hrow = cur.hrow;
+        if (tid < 4 * w) {
+          double vh = 0.0;
+          if (hrow >= 0) {
+            if (k >= 2) {
+              const int c = (int)(hrow - r0) + 3 * w;             // position of this row in sh.x1
+              double z1h = 0.0;
+#pragma unroll
+              for (int d = 0; d < ND; ++d)
+                if (d < nd) z1h = fma(cur.dh[d], sh.x1[c + sh.doff[d]], z1h);
+              vh = (z1h - a * sh.x1[c] - b2 * cur.x2h) * invb;
+            } else {
+              vh = cur.u0h * inv0;
+            }
+          }
+          sh.vk[(tid < 2 * w) ? tid : PL_TR + tid] = vh;
+        }
+        if (edge) {                                              // v_k, this lane's rows
+          if (ia < pa.ldv) pl_store_wt1(VK + ia, vka);
+          if (ib < pa.ldv) pl_store_wt1(VK + ib, vkb);
+        } else {
+          if (ia < pa.ldv) VK[ia] = vka;
+          if (ib < pa.ldv) VK[ib] = vkb;
+        }
+        if (!tail) {
+          pl_barrier();
+          // ---- C: z_k = A v_k on the tile + w rows either side ----
+          double zka = 0.0, zkb = 0.0;
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (d < nd) {
+              const int o = 2 * w + tid + sh.doff[d];
+              zka = fma(cur.dva[d], sh.vk[o], zka);
+              zkb = fma(cur.dvb[d], sh.vk[o + BLOCK], zkb);
+            }
+          sh.zk[w + tid] = zka;
+          sh.zk[w + BLOCK + tid] = zkb;
+          if (tid < 4 * w) {
+            const bool left = tid < 2 * w;
+            const int qq = left ? tid - w : tid - 2 * w;            // left strip: rows r0 - w + qq, qq in [0, w); right strip: r0 + TR + qq
+            if (qq >= 0 && qq < w) {
+              double zh = 0.0;
+              if (hrow >= 0) {
+                const int c = (int)(hrow - r0) + 2 * w;            // position in sh.vk
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                  if (d < nd) zh = fma(cur.dh[d], sh.vk[c + sh.doff[d]], zh);
+              }
+              sh.zk[left ? qq : PL_TR + w + qq] = zh;
+            }
+          }
+          pl_barrier();
+          // ---- D: q_k = A z_k on the tile; this tile's share of the 12 products ----
+          double qka = 0.0, qkb = 0.0;
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (d < nd) {
+              const int o = w + tid + sh.doff[d];
+              qka = fma(cur.dva[d], sh.zk[o], qka);
+              qkb = fma(cur.dvb[d], sh.zk[o + BLOCK], qkb);
+            }
+          p[0] = fma(zka, qka, fma(zkb, qkb, p[0]));
+          p[1] = fma(zka, zka, fma(zkb, zkb, p[1]));
+          p[2] = fma(zka, z1a, fma(zkb, z1b, p[2]));
+          p[3] = fma(vka, qka, fma(vkb, qkb, p[3]));
+          p[4] = fma(vka, zka, fma(vkb, zkb, p[4]));
+          p[5] = fma(vka, z1a, fma(vkb, z1b, p[5]));
+          p[6] = fma(x1a, qka, fma(x1b, qkb, p[6]));
+          p[7] = fma(x1a, zka, fma(x1b, zkb, p[7]));
+          p[8] = fma(x1a, z1a, fma(x1b, z1b, p[8]));
+          p[9] = fma(qka, qka, fma(qkb, qkb, p[9]));
+          p[10] = fma(qka, z1a, fma(qkb, z1b, p[10]));
+          p[11] = fma(z1a, z1a, fma(z1b, z1b, p[11]));
+          // (no barrier here: the next tile's phase A writes sh.x1 only, which nobody reads after phase B)
+        } else {
+          pl_barrier();                                       // (sh.x1 is rewritten by the next tile)
+        }
+        if (q == nedge - 1) {      // both edge tiles are on their way: once acknowledged the neighbours may start their next pass
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(eflags + wg, (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          PL_STAMP(k, 3);
+        }
+        cur = nxt;
+      }
+      if (nt == 0 && tid == 0) __hip_atomic_store(eflags + wg, (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      PL_STAMP(k, 4);
+      publish(k, p, tail ? 0 : PL_NP);
+      PL_STAMP(k, 5);
+    }
+  }
+}
+
+// workgroups per CU the kernel is built for: 2 (no spills, 252 VGPRs), 3, 4 (hoisted addresses spilled once per pass); EXPV_MI_PL_WGS picks
+// (developer A/B; default: what measured fastest, profiles/r06_pipelined_lanczos.txt)
+static int pl_wgs() {
+  static const int v = [] { const char *e = std::getenv("EXPV_MI_PL_WGS"); const int q = e ? std::atoi(e) : PL_WGS_DEFAULT; return q < 2 ? 2 : (q > 4 ? 4 : q); }();
+  return v;
+}
+template <int ND>
+static const void *pl_kernel(int wgs) {
+  return wgs == 2 ? (const void *)k_lanczos_pl<ND, 2> : wgs == 3 ? (const void *)k_lanczos_pl<ND, 3> : (const void *)k_lanczos_pl<ND, 4>;
+}
+template <int ND>
+static int lanczos_pl_capacity_t() {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl_kernel<ND>(pl_wgs()), BLOCK, 0) != hipSuccess || per_cu < 1) return 0;
+  int cap = std::min(per_cu, pl_wgs()) * device_cus();
+  return cap > MAX_GRID ? MAX_GRID : cap;
+}
+int lanczos_pl_capacity() {      // workgroups of a resident launch (0: not available)
+  static int cap = -1;
+  if (cap < 0) cap = std::min(lanczos_pl_capacity_t<5>(), lanczos_pl_capacity_t<8>());
+  return cap;
+}
+bool lanczos_pl(hipStream_t s, const LanczosPlArgs &a) {
+  if (a.ndiag < 1 || a.ndiag > PIPE_DIA_MAX || a.w < 1 || a.w > PIPE_WMAX || a.m < 1 || a.m > PL_MAX_M) return false;
+  static const int cap5 = lanczos_pl_capacity_t<5>(), cap8 = lanczos_pl_capacity_t<8>();
+  const int cap = a.ndiag <= 5 ? cap5 : cap8;
+  if (cap <= 1) return false;
+  const int64_t ntiles = (a.n + PL_TR - 1) / PL_TR;
+  const int grid = (int)std::min<int64_t>(cap - 1, std::max<int64_t>(1, ntiles)) + 1;      // workers + the reducing workgroup
+  LanczosPlArgs args = a;
+  void *kargs[] = {&args};
+  const void *k = a.ndiag <= 5 ? pl_kernel<5>(pl_wgs()) : pl_kernel<8>(pl_wgs());
+  static const bool plain = std::getenv("EXPV_MI_PL_PLAIN") != nullptr;      // developer A/B: an ordinary launch (residency then rests on the grid fitting the device)
+  if (plain) return hipLaunchKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
+  return hipLaunchCooperativeKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
+}
+
+#ifdef PL_TRACE
+extern "C" int expv_mi_pl_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pl_trace), sizeof(g_pl_trace)); }
+#endif
+}  // namespace dev
+}  // namespace expv_mi

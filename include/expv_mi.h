@@ -60,7 +60,14 @@ typedef enum { EXPV_MI_HOST = 0, EXPV_MI_DEVICE = 1 } expv_mi_loc;
  *            of V^H V), which is algebraically identical to MGS on the computed basis but needs
  *            one grid-wide reduction per Krylov step instead of one per column.
  *   AUTO   : LOWSYNC whenever the window holds at least 2 columns (a 1-column window is MGS). */
-typedef enum { EXPV_MI_ORTHO_AUTO = 0, EXPV_MI_ORTHO_MGS = 1, EXPV_MI_ORTHO_LOWSYNC = 2 } expv_mi_ortho;
+typedef enum { EXPV_MI_ORTHO_AUTO = 0, EXPV_MI_ORTHO_MGS = 1, EXPV_MI_ORTHO_LOWSYNC = 2,
+               /* OPT-IN, not the reference's arithmetic: lanczos! for a Hermitian banded Float64 operator as a PIPELINED recurrence (csrc/lanczos_pl.hip)
+                * -- alpha_j, beta_j from inner products "by expansion", reduced one pass behind the pass that needs nothing of them, the whole
+                * factorisation one resident kernel.  Stated bars (tests/test_gpu_parity.py::test_pipelined_lanczos_*): expv!(w, t, Ks) within 1e-11 of
+                * the reference recurrence's, H within 1e-11 of its largest entry while the reference's own basis keeps its orthogonality; happy
+                * breakdown detected down to ~1e-7 |A| only.  Where it does not apply (not Hermitian, not banded fp64, augmented, a continuation,
+                * m > 128) the call runs the default path; expv_mi_expv_stats.path_flags says which ran (EXPV_MI_PATH_PIPELINED_LANCZOS). */
+               EXPV_MI_ORTHO_PIPELINED = 3 } expv_mi_ortho;
 
 /* ------------------------------------------------------------------ context ---------- */
 /* One context = one GPU + one HIP stream.  `stream` may be NULL (library creates its own) or an
@@ -140,7 +147,8 @@ enum {
   EXPV_MI_PATH_MODULAR = 1, EXPV_MI_PATH_TWO_KERNEL = 2, EXPV_MI_PATH_PIPELINE = 4, EXPV_MI_PATH_WAVE = 8,
   EXPV_MI_PATH_OVERLAPPED = 16, EXPV_MI_PATH_REDO_SERIAL = 32, EXPV_MI_PATH_REDO_WAVE_OFF = 64,
   EXPV_MI_PATH_RESIDENT = 128,  /* the whole factorisation ran as one resident (cooperative) kernel */
-  EXPV_MI_PATH_PATCH = 256      /* single-pass step, patch form: operator stored in a grid-patch ordering, ring recomputed */
+  EXPV_MI_PATH_PATCH = 256,     /* single-pass step, patch form: operator stored in a grid-patch ordering, ring recomputed */
+  EXPV_MI_PATH_PIPELINED_LANCZOS = 512      /* the opt-in pipelined Lanczos recurrence ran (EXPV_MI_ORTHO_PIPELINED) */
 };
 const char *expv_mi_last_error(expv_mi_ctx_t ctx);
 const char *expv_mi_version(void);

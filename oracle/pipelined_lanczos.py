@@ -146,3 +146,57 @@ def expv_from_lanczos(t, beta0, alpha, beta, V, m):
         lam, Z = eigh_tridiagonal(alpha[:m], beta[:m - 1])
     e = Z @ (np.exp(t * lam) * Z[0, :])
     return beta0 * (V[:, :m] @ e)
+
+
+def lanczos_p3(A, b, m):
+    """The DEVICE scheme of the opt-in ``ortho = "pipelined"`` mode (csrc/lanczos_pl.hip), restated in numpy: pass k reads only v_{k-1} and
+    v_{k-2}, RECOMPUTES z_{k-1} = A v_{k-1} (and, for the products, z_k = A v_k, q_k = A z_k: a three-deep halo on a banded operator),
+    forms v_k with scalars that come from the reduction of pass k-2, and reduces 12 inner products from which the scalars of step k+1
+    follow by expansion.  No pass waits for the reduction of the pass before it.
+
+        v_k = (z_{k-1} - alpha_{k-1} v_{k-1} - beta_{k-2} v_{k-2}) / beta_{k-1}
+        alpha_{k+1} beta_k^2 = < z_k - alpha_k v_k - beta_{k-1} v_{k-1},  q_k - alpha_k z_k - beta_{k-1} z_{k-1} >
+        |A v_{k+1}|^2 beta_k^2 = | q_k - alpha_k z_k - beta_{k-1} z_{k-1} |^2,     beta_{k+1}^2 = |A v_{k+1}|^2 - alpha_{k+1}^2 - beta_k^2
+
+    (alpha_k, beta_k themselves were expanded the same way one pass earlier; pass 1 takes alpha_1, beta_1 directly.)"""
+    n = b.shape[0]
+    T = np.result_type(A.dtype, b.dtype, np.float64)
+    V = np.zeros((n, m + 1), dtype=T)
+    alpha = np.zeros(m + 2)
+    beta = np.zeros(m + 2)          # beta[k] = beta_k, beta[0] = 0
+    beta0 = float(np.linalg.norm(b))
+    V[:, 0] = b / beta0
+    rd = lambda x, y: np.vdot(x, y).real
+    zero = np.zeros(n, dtype=T)
+    for k in range(1, m + 1):       # pass k: v_k is column k-1
+        if k == 1:
+            vk = V[:, 0]
+            x1, z1, bkm1 = zero, zero, 0.0
+        else:
+            x1 = V[:, k - 2]
+            x2 = V[:, k - 3] if k >= 3 else zero
+            z1 = _mul(A, x1)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                vk = (z1 - alpha[k - 1] * x1 - beta[k - 2] * x2) / beta[k - 1]
+            V[:, k - 1] = vk
+            bkm1 = beta[k - 1]
+        zk = _mul(A, vk)
+        qk = _mul(A, zk)
+        if k == 1:                  # start-up: the first step's scalars directly
+            alpha[1] = rd(vk, zk)
+            b2 = rd(zk, zk) - alpha[1] ** 2
+            beta[1] = np.sqrt(b2) if b2 > 0 else 0.0
+        a, bk = alpha[k], beta[k]
+        # the 12 products of the pass (the device reduces exactly these)
+        zq, zz, zz1, vq, vz, vz1 = rd(zk, qk), rd(zk, zk), rd(zk, z1), rd(vk, qk), rd(vk, zk), rd(vk, z1)
+        xq, xz, xz1, qq, qz1, z1z1 = rd(x1, qk), rd(x1, zk), rd(x1, z1), rd(qk, qk), rd(qk, z1), rd(z1, z1)
+        num_a = zq - a * zz - bkm1 * zz1 - a * vq + a * a * vz + a * bkm1 * vz1 - bkm1 * xq + a * bkm1 * xz + bkm1 * bkm1 * xz1
+        num_z = qq - 2 * a * zq - 2 * bkm1 * qz1 + a * a * zz + 2 * a * bkm1 * zz1 + bkm1 * bkm1 * z1z1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha[k + 1] = num_a / (bk * bk)
+            b2 = num_z / (bk * bk) - alpha[k + 1] ** 2 - bk * bk
+        beta[k + 1] = np.sqrt(b2) if b2 > 0 else 0.0
+    # v_{m+1} (the reference's lanczos! leaves it in column m)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        V[:, m] = (_mul(A, V[:, m - 1]) - alpha[m] * V[:, m - 1] - (beta[m - 1] * V[:, m - 2] if m >= 2 else 0.0)) / beta[m]
+    return beta0, alpha[1:m + 1].copy(), beta[1:m + 1].copy(), V

@@ -1611,6 +1611,47 @@ def test_matrix_free_callback_sees_normalised_columns_by_default(eu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(513, 7), (2000, 30), (70_001, 30), (300_000, 40)])
+def test_pipelined_lanczos_opt_in_mode(eu, n, m):
+    """the opt-in `ortho = "pipelined"` mode of lanczos! (csrc/lanczos_pl.hip) -- NOT the reference's arithmetic: alpha_j,
+    beta_j come from inner products by expansion, one pass behind (oracle/pipelined_lanczos.py: lanczos_p3 is the scheme in numpy).
+    Its stated bars, against the REFERENCE recurrence (arnoldi.jl:388-403, 456-490) on the symmetric C2 operator: expv!(w, t, Ks) to 1e-11,
+    H to 1e-11 of its largest entry, the basis orthonormal to 1e-9, beta and Ks.m equal; against the numpy restatement of the same scheme
+    H to 1e-10 (same arithmetic, other summation order); the path flag says the mode ran; the default path is untouched (ortho = "auto"
+    on the same subspace afterwards equals the oracle at the usual 1e-12)."""
+    rng = np.random.default_rng(77)
+    from oracle import pipelined_lanczos as pl
+    A = c2_operator(n, sym=True)
+    b = rng.standard_normal(n)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+    Ks = eu.KrylovSubspace(np.float64, np.float64, n, m, 0, ctx)
+    eu.lanczos_(Ks, op, b, m=m, ortho="pipelined")
+    Ko = ko.KrylovSubspace(np.float64, np.float64, n, m)
+    ko.lanczos_(Ko, A, b, m=m)
+    assert Ks.m == Ko.m == m and not Ks.wasbreakdown
+    assert abs(Ks.beta - Ko.beta) <= 1e-13 * Ko.beta
+    H, Ho = np.asarray(Ks.getH()), Ko.getH()
+    close(H, Ho, 1e-11, "pipelined Lanczos n=%d m=%d: H vs the reference recurrence" % (n, m), mat=True)
+    w = np.asarray(eu.expv_(np.empty(n), 0.7, Ks))
+    close(w, ko.expv_(np.empty(n), 0.7, Ko), 1e-11, "pipelined Lanczos n=%d m=%d: expv! vs the reference recurrence" % (n, m))
+    V = np.asarray(Ks.getV())[:, :m]
+    assert float(np.abs(V.T @ V - np.eye(m)).max()) < 1e-9
+    b0, al, be, _ = pl.lanczos_p3(A, b, m)
+    assert np.abs(np.diag(H)[:m] - al).max() <= 1e-10 * np.abs(al).max() and np.abs(np.diag(H, -1)[:m] - be).max() <= 1e-10 * np.abs(be).max()
+    wc = np.asarray(eu.expv(0.7, op, b, m=m, ishermitian=True, ortho="pipelined"))      # the whole-call form
+    assert "pipelined_lanczos" in eu.expv.last_stats["path"], eu.expv.last_stats
+    close(wc, w, 1e-13, "pipelined Lanczos: whole call vs lanczos! + expv!")
+    eu.lanczos_(Ks, op, b, m=m)                                                          # the default path on the same storage
+    close(np.asarray(Ks.getH()), Ho, TOL, "default Lanczos after a pipelined one on the same subspace", mat=True)
+    # where the mode does not apply the call runs the default path and says so
+    An = c2_operator(n)                                                                  # not Hermitian
+    wn = np.asarray(eu.expv(0.7, eu.MIOperator(An, ctx), b, m=min(m, 30), ishermitian=False, ortho="pipelined"))
+    assert "pipelined_lanczos" not in eu.expv.last_stats["path"]
+    close(wn, ko.expv(0.7, An, b, m=min(m, 30), ishermitian=False), TOL, "ortho = pipelined on a non-Hermitian operator: the default path")
+
+
+@pytest.mark.gpu
 def test_ordering_plan_cache_keeps_element_types_of_equal_size_apart(eu):
     """the plan cache was keyed by sizeof(value), and Float64 / ComplexF32 are both 8 bytes -- but creation decides between
     orderings differently for real and complex types, so a ComplexF32 operator created first made a later Float64 operator with the

@@ -263,3 +263,32 @@ def test_controller_arithmetic_follows_julia_not_python():
     # tau driven to zero: Int(ceil(maxtau / tau)) -> InexactError
     with pytest.raises(ValueError, match="InexactError"):
         ko._estimate_flops(10, 0.0, 100, 1, 500, 0, 3.0, 1.0)
+
+
+def test_pipelined_lanczos_restatements_hold_the_reference_results():
+    """oracle/pipelined_lanczos.py (test infrastructure for the opt-in `ortho = "pipelined"` mode): the one-reduction form (p1), the form
+    whose scalars arrive a pass late (p2) and the numpy restatement of the device scheme (p3) reproduce exp(tA)b of the reference
+    recurrence (arnoldi.jl:388-403) to 1e-12 on the symmetric C2 operator, the complex Hermitian tridiagonal operator of
+    basictests.jl:731-754 and rand(300,300) Hermitian (basictests.jl:756-784, where every Lanczos basis loses its orthogonality), and
+    H to 1e-11 where the reference's own basis keeps its orthogonality.  profiles/r06_pipelined_lanczos_accuracy.txt is the table."""
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import pipelined_lanczos as pl
+    rng = np.random.default_rng(2026)
+    n = 2000
+    C2 = sp.diags([np.full(n - abs(o), v) for o, v in zip((-2, -1, 0, 1, 2), (0.3, 1.2, -2.0, 1.2, 0.3))], (-2, -1, 0, 1, 2), format="csr")
+    e = np.ones(99)
+    P = (-1j * sp.diags([-e, np.zeros(100), e], (-1, 0, 1))).tocsr()
+    M = rng.random((300, 300))
+    cases = [("c2", C2, rng.standard_normal(n), 1.0, 30, True), ("herm_tridiag", P, rng.random(100) + 1j * rng.random(100), -1.0j, 15, True),
+             ("rand300", (M + M.T) / 2, rng.random(300), 1.0, 30, False)]
+    for name, A, b, t, m, h_bar in cases:
+        ref = pl.lanczos_ref(A, b, m)
+        w_ref = pl.expv_from_lanczos(t, *ref, m)
+        hmax = max(np.abs(ref[1]).max(), np.abs(ref[2]).max())
+        for fn in (pl.lanczos_p1, pl.lanczos_p2, pl.lanczos_p3):
+            r = fn(A, b, m)
+            w = pl.expv_from_lanczos(t, *r, m)
+            assert np.linalg.norm(w - w_ref) <= 1e-12 * np.linalg.norm(w_ref), (name, fn.__name__)
+            if h_bar:
+                assert max(np.abs(r[1] - ref[1]).max(), np.abs(r[2] - ref[2]).max()) <= 1e-11 * hmax, (name, fn.__name__)

@@ -57,7 +57,8 @@ def report(name, A, b, t, m, dense_truth=True):
     print("%s   n=%d  m=%d  t=%s" % (name, A.shape[0], m, t))
     rows = [("reference recurrence (arnoldi.jl:388-403)", ref, w_ref)]
     for label, fn in (("p1: Ghysels-Vanroose, one reduction per step", pl.lanczos_p1),
-                      ("p2: scalars one pass late (Gram expansion)", pl.lanczos_p2)):
+                      ("p2: scalars one pass late (Gram expansion)", pl.lanczos_p2),
+                      ("p3: the device scheme (recomputed A v, A^2 v)", pl.lanczos_p3)):
         r = fn(A, b, m)
         rows.append((label, r, pl.expv_from_lanczos(t, *r, m)))
     for label, r, w in rows:
