@@ -405,14 +405,22 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
           }
           sh.vk[(tid < 2 * w) ? tid : PL_TR + tid] = vh;
         }
+#ifdef PL_EXP_PLAINSTORE
+        if (false) {
+#else
         if (edge) {                                              // v_k, this lane's rows
+#endif
           if (ia < pa.ldv) pl_store_wt1(VK + ia, vka);
           if (ib < pa.ldv) pl_store_wt1(VK + ib, vkb);
         } else {
           if (ia < pa.ldv) VK[ia] = vka;
           if (ib < pa.ldv) VK[ib] = vkb;
         }
+#ifdef PL_EXP_NOSTENCIL
+        if (false) {
+#else
         if (!tail) {
+#endif
           pl_barrier();
           // ---- C: z_k = A v_k on the tile + w rows either side ----
           double zka = 0.0, zkb = 0.0;
