@@ -578,7 +578,7 @@ struct ArnoldiCall {
     a.count = reinterpret_cast<uint32_t *>(base + part_b);
     a.flags = reinterpret_cast<uint32_t *>(base + part_b + cnt_b);
     a.out = reinterpret_cast<double *>(base + part_b + cnt_b + flag_b);
-    a.m = m; a.want_tail = ks.skip_tail ? 0 : 1; a.tol = tol; a.spin_limit = c->opt.spin_limit * 8;
+    a.m = m; a.want_tail = ks.skip_tail ? 0 : 1; a.tol = tol; a.spin_limit = c->opt.spin_limit;
     HIPCHECK(hipMemsetAsync(base + part_b, 0, cnt_b + flag_b + out_b, s));      // counters, flags, output
     for (int j = 0; j < hview_cols; ++j)
       std::memset(&ks.H[(size_t)j * ks.ldh * dtype_size(ks.dtypeU)], 0, (size_t)hview_rows * dtype_size(ks.dtypeU));

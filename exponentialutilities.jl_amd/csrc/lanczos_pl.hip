@@ -57,6 +57,9 @@ __device__ __forceinline__ void pl_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void pl_store_wt1(double *p, double a) {
   asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(a) : "memory");
 }
+// Flags are RELAXED agent-scope stores behind an explicit s_waitcnt vmcnt(0): what they announce was stored THROUGH (sc0 sc1 / agent-scope
+// atomics) and is acknowledged by then.  A RELEASE store at agent scope makes the compiler write the whole L2 back first (buffer_wbl2 sc1) --
+// with the interior tiles' plain stores sitting dirty in it that was most of a pass: 37 us per Lanczos step instead of 14 (round 6).
 __device__ __forceinline__ uint32_t pl_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #ifdef PL_TRACE
@@ -187,7 +190,10 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
     __syncthreads();
     // (one flag per workgroup, one writer each: a shared arrival counter costs a serialised atomic per workgroup and pass -- 512 of them
     //  were 40 us of every pass; the reducing workgroup polls the flags instead)
-    if (tid == 0) __hip_atomic_store(pflags + wg, (uint32_t)(r + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(pflags + wg, (uint32_t)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(eflags + wg, (uint32_t)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the edge tiles went first: long acknowledged)
+    }
   };
   auto wait_all = [&](uint32_t want) -> bool {      // every worker's flag >= want (all threads of the reducing workgroup poll)
     for (;;) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
     if (tid == 0) {
       publish_f64(pa.out + 0, beta0sq);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(sflag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     int r = 0;
     if (beta0sq > 0.0) {
@@ -231,14 +237,14 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
           publish_f64(sc_be + r + 1, sh.be[r + 1]);
           publish_f64(pa.out + 1, (double)sh.state[0]);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(sflag, (uint32_t)(r + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sflag, (uint32_t)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
       }
     }
     if (tid == 0) {
       publish_f64(pa.out + 2, (double)sh.state[1]);                  // 99: a bounded wait expired
-      if (sh.state[1] != 0) __hip_atomic_store(sflag, 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // release the workers
+      if (sh.state[1] != 0) __hip_atomic_store(sflag, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // release the workers
     }
     return;
   }
@@ -269,6 +275,63 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
     __syncthreads();
     have = upto;
   };
+  // everything a tile reads from memory, requested in ONE round trip and one tile AHEAD of its use (registers)
+  struct TL {
+    double x1a, x1b, x2a, x2b, xh, x2h;      // (pass 1: x1a / x1b / x2h hold b on this lane's rows / its halo row instead)
+    double dva[ND], dvb[ND], dh[ND];
+    int64_t hrow;
+  };
+  // the 3w rows of v_{kk-1} either side of the tile: the only loads of a pass' FIRST tile that depend on the neighbouring workgroups
+  auto load_xh = [&](int kk, int64_t t, TL &L) {
+    if (kk >= 2 && tid < 6 * w) {
+      const int64_t r0 = t * PL_TR;
+      const int64_t row = (tid < 3 * w) ? r0 - 3 * w + tid : r0 + PL_TR + (tid - 3 * w);
+      if (row >= 0 && row < n) L.xh = pa.V[(int64_t)(kk - 2) * pa.ldv + row];
+    }
+  };
+  auto load_tile = [&](int kk, int64_t t, TL &L, bool with_xh) {
+    // (a lane's two rows are r0 + tid and r0 + 256 + tid: the lanes of a wave then read CONSECUTIVE 8-byte words of the LDS images --
+    //  with rows 2 tid, 2 tid + 1 every ds_read_b64 of the stencil phases was an 8-way bank conflict)
+    const double *X1 = kk >= 2 ? pa.V + (int64_t)(kk - 2) * pa.ldv : nullptr;      // v_{kk-1}
+    const double *X2 = kk >= 3 ? pa.V + (int64_t)(kk - 3) * pa.ldv : nullptr;      // v_{kk-2}
+    const int64_t r0 = t * PL_TR, ia = r0 + tid, ib = ia + BLOCK;
+    L.x1a = L.x1b = L.x2a = L.x2b = L.xh = L.x2h = 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      L.dva[d] = L.dvb[d] = L.dh[d] = 0.0;
+      if (d < nd) {
+        if (ia < pa.n_dia) L.dva[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ia];
+        if (ib < pa.n_dia) L.dvb[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ib];
+      }
+    }
+    L.hrow = -1;
+    if (tid < 4 * w) {
+      const int64_t hr = (tid < 2 * w) ? r0 - 2 * w + tid : r0 + PL_TR + (tid - 2 * w);
+      if (hr >= 0 && hr < n) {
+        L.hrow = hr;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+          if (d < nd) L.dh[d] = pa.dia_val[(int64_t)d * pa.dia_ld + hr];
+        if (kk >= 3) L.x2h = X2[hr];
+        if (kk == 1) L.x2h = pa.u0[hr];
+      }
+    }
+    if (kk >= 2) {
+      if (ia < pa.ldv) L.x1a = X1[ia];      // (library vectors: zeros from n up to ldv, a multiple of 128 rows; a tile may reach beyond it)
+      if (ib < pa.ldv) L.x1b = X1[ib];
+      if (kk >= 3) {
+        if (ia < pa.ldv) L.x2a = X2[ia];
+        if (ib < pa.ldv) L.x2b = X2[ib];
+      }
+      if (with_xh) load_xh(kk, t, L);
+    } else {
+      if (ia < n) L.x1a = pa.u0[ia];
+      if (ib < n) L.x1b = pa.u0[ib];
+    }
+  };
+  TL cur, nx1;                                                  // the tile being worked on and the one behind it (its loads in flight; two behind
+                                                                // need 256 VGPRs + 452 B of scratch per lane: 39.9 instead of 19.2 us per pass)
+  bool have_first = false;                                       // `cur` already holds the first tile of the coming pass (all but its edge rows)
   fetch_scalars(0);
   const double beta0sq = sh.sums[0];
   const double inv0 = beta0sq > 0.0 ? 1.0 / sqrt(beta0sq) : 0.0;
@@ -305,62 +368,21 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
       const int nt = (int)(t1 - t0);
       const int nedge = nt >= 2 ? 2 : nt;
       auto tile_of = [&](int q) -> int64_t { return q == 0 ? t0 : (q == 1 ? t1 - 1 : t0 + (q - 1)); };
-      // everything a tile reads from memory, requested in ONE round trip and one tile AHEAD of its use (registers)
-      struct TL {
-        double x1a, x1b, x2a, x2b, xh, x2h, u0h, u0a, u0b;
-        double dva[ND], dvb[ND], dh[ND];
-        int64_t hrow;
-      };
-      auto load_tile = [&](int64_t t, TL &L) {
-        // (a lane's two rows are r0 + tid and r0 + 256 + tid: the lanes of a wave then read CONSECUTIVE 8-byte words of the LDS images --
-        //  with rows 2 tid, 2 tid + 1 every ds_read_b64 of the stencil phases was an 8-way bank conflict: 4 us of a 5.5 us tile)
-        const int64_t r0 = t * PL_TR, ia = r0 + tid, ib = ia + BLOCK;
-        L.x1a = L.x1b = L.x2a = L.x2b = L.xh = L.x2h = L.u0h = L.u0a = L.u0b = 0.0;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-          L.dva[d] = L.dvb[d] = L.dh[d] = 0.0;
-          if (d < nd) {
-            if (ia < pa.n_dia) L.dva[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ia];
-            if (ib < pa.n_dia) L.dvb[d] = pa.dia_val[(int64_t)d * pa.dia_ld + ib];
-          }
-        }
-        L.hrow = -1;
-        if (tid < 4 * w) {
-          const int64_t hr = (tid < 2 * w) ? r0 - 2 * w + tid : r0 + PL_TR + (tid - 2 * w);
-          if (hr >= 0 && hr < n) {
-            L.hrow = hr;
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-              if (d < nd) L.dh[d] = pa.dia_val[(int64_t)d * pa.dia_ld + hr];
-            if (k >= 3) L.x2h = X2[hr];
-            if (k == 1) L.u0h = pa.u0[hr];
-          }
-        }
-        if (k >= 2) {
-          if (ia < pa.ldv) L.x1a = X1[ia];      // (library vectors: zeros from n up to ldv, a multiple of 128 rows; a tile may reach beyond it)
-          if (ib < pa.ldv) L.x1b = X1[ib];
-          if (k >= 3) {
-            if (ia < pa.ldv) L.x2a = X2[ia];
-            if (ib < pa.ldv) L.x2b = X2[ib];
-          }
-          if (tid < 6 * w) {
-            const int64_t row = (tid < 3 * w) ? r0 - 3 * w + tid : r0 + PL_TR + (tid - 3 * w);
-            if (row >= 0 && row < n) L.xh = X1[row];
-          }
+      if (nt > 0) {
+        if (have_first) {      // (requested at the end of the pass before; the edge rows now that the neighbours are done)
+          load_xh(k, tile_of(0), cur);
         } else {
-          if (ia < n) L.u0a = pa.u0[ia];
-          if (ib < n) L.u0b = pa.u0[ib];
+          load_tile(k, tile_of(0), cur, true);
         }
-      };
-      TL cur, nxt;
-      if (nt > 0) load_tile(tile_of(0), cur);
+      }
+      have_first = false;
 #pragma unroll 1
       for (int q = 0; q < nt; ++q) {
         const int64_t t = tile_of(q);
         const bool edge = q < nedge;
-        if (q + 1 < nt) load_tile(tile_of(q + 1), nxt);
+        if (q + 1 < nt) load_tile(k, tile_of(q + 1), nx1, true);
         const int64_t r0 = t * PL_TR, ia = r0 + tid, ib = ia + BLOCK;
-        const double x1a = cur.x1a, x1b = cur.x1b;
+        const double x1a = k >= 2 ? cur.x1a : 0.0, x1b = k >= 2 ? cur.x1b : 0.0;      // (pass 1: there is no v_0)
         // ---- A: v_{k-1} on the tile + 3w rows either side -> LDS ----
         if (k >= 2) {
           sh.x1[3 * w + tid] = x1a;
@@ -381,8 +403,8 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
           vka = (z1a - a * x1a - b2 * cur.x2a) * invb;
           vkb = (z1b - a * x1b - b2 * cur.x2b) * invb;
         } else {
-          vka = cur.u0a * inv0;
-          vkb = cur.u0b * inv0;
+          vka = cur.x1a * inv0;
+          vkb = cur.x1b * inv0;
         }
         if (ia >= n) vka = 0.0;                                  // (the padding rows of the basis stay zero whatever 1/beta is)
         if (ib >= n) vkb = 0.0;
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
                 if (d < nd) z1h = fma(cur.dh[d], sh.x1[c + sh.doff[d]], z1h);
               vh = (z1h - a * sh.x1[c] - b2 * cur.x2h) * invb;
             } else {
-              vh = cur.u0h * inv0;
+              vh = cur.x2h * inv0;
             }
           }
           sh.vk[(tid < 2 * w) ? tid : PL_TR + tid] = vh;
@@ -473,16 +495,15 @@ __global__ __launch_bounds__(BLOCK, WGS) void k_lanczos_pl(const LanczosPlArgs p
         } else {
           pl_barrier();                                       // (sh.x1 is rewritten by the next tile)
         }
-        if (q == nedge - 1) {      // both edge tiles are on their way: once acknowledged the neighbours may start their next pass
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) __hip_atomic_store(eflags + wg, (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          PL_STAMP(k, 3);
-        }
-        cur = nxt;
+        cur = nx1;
       }
-      if (nt == 0 && tid == 0) __hip_atomic_store(eflags + wg, (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       PL_STAMP(k, 4);
+      // the first tile of the NEXT pass, all but its edge rows: this lane's rows of v_k (stored by this very lane), v_{k-1}, the operator -- in flight
+      // under the publication of this pass' sums, the scalars' arrival and the neighbours' flags
+      if (k < last_pass && nt > 0 && (sh.state[0] == 0 || k + 1 <= sh.state[0] + 1)) {
+        load_tile(k + 1, tile_of(0), cur, false);
+        have_first = true;
+      }
       publish(k, p, tail ? 0 : PL_NP);
       PL_STAMP(k, 5);
     }
@@ -521,9 +542,14 @@ bool lanczos_pl(hipStream_t s, const LanczosPlArgs &a) {
   LanczosPlArgs args = a;
   void *kargs[] = {&args};
   const void *k = a.ndiag <= 5 ? pl_kernel<5>(pl_wgs()) : pl_kernel<8>(pl_wgs());
-  static const bool plain = std::getenv("EXPV_MI_PL_PLAIN") != nullptr;      // developer A/B: an ordinary launch (residency then rests on the grid fitting the device)
-  if (plain) return hipLaunchKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
-  return hipLaunchCooperativeKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
+  // An ORDINARY launch of a grid that fits the device (occupancy x CUs): every workgroup is resident when nothing else occupies the device, and when
+  // something does the bounded waits expire and the caller runs the default path instead (engine_core.hip: run_lanczos_pipelined returns -1).
+  // hipLaunchCooperativeKernel would guarantee residency, but cooperative launches disturb the rest of the library: after one, the two-stream
+  // overlapped step of a context created LATER in the process ran 3 x slower (1.09 instead of 0.33 ms per Lanczos expv at n = 1e5, no redo
+  // counted: profiles/r06_pipelined_lanczos.txt), and they cost ~20 us more per launch.  EXPV_MI_PL_COOP=1: the cooperative launch (A/B).
+  static const bool coop = std::getenv("EXPV_MI_PL_COOP") != nullptr;
+  if (coop) return hipLaunchCooperativeKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
+  return hipLaunchKernel(k, dim3(grid), dim3(BLOCK), kargs, 0, s) == hipSuccess;
 }
 
 #ifdef PL_TRACE
