@@ -1281,8 +1281,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> p
       if (tid == 0) {
         // early flag: everything but H[m+1, m], the scale of column m and the breakdown test of step m is final (a stop
         // ends the factorisation: both flags)
-        if (pa.early_step > 0) __hip_atomic_store(pa.mb_done + 1, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (mb_final) __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (relaxed: everything the flag announces was stored with system-scope atomics and is acknowledged -- the s_waitcnt + barrier above.  A
+        //  RELEASE store makes the compiler write the L2 back first (buffer_wbl2 sc1, >= 1.7 us) on the path the host is waiting on: round 6,
+        //  found in lanczos_pl.hip where the same construct was 18 us of every pass)
+        if (pa.early_step > 0) __hip_atomic_store(pa.mb_done + 1, (unsigned long long)pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mb_final) __hip_atomic_store(pa.mb_done, (unsigned long long)pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
