@@ -21,7 +21,7 @@
 // written = 64 MB at n = 1e6 for 5 diagonals (the reference recurrence on the single-pass step: 80 MB).
 //
 // This is NOT the reference's arithmetic: alpha and beta come from expansions instead of direct inner products.  Measured against
-// the reference recurrence (oracle/pipelined_lanczos.py: lanczos_p3 is this scheme in numpy; profiles/r06_pipelined_lanczos_accuracy.txt):
+// the reference recurrence (the test infrastructure holds this scheme in numpy -- pipelined_lanczos.py: lanczos_p3; profiles/r06_pipelined_lanczos_accuracy.txt):
 // exp(tA)b agrees to <= 1.2e-14, H to <= 7e-14 of its largest entry on well-conditioned bases; where the reference recurrence itself
 // loses orthogonality completely (rand(300,300), basictests.jl:756-784) H differs like any two Lanczos runs do and exp(tA)b still agrees
 // to 1e-14.  The happy-breakdown test sees beta_j only as a difference of O(|A|^2) quantities: reliable down to ~1e-7 |A|, and two
