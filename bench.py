@@ -568,6 +568,21 @@ def secondary_block(args, eu, env, op, b, w, n, nnz, m):
     lan = lambda: eu.expv(T_FINAL, ops, b, m=m, ishermitian=True, out=w)
     sec["lanczos"] = entry("expv, symmetric 5-diagonal operator (Lanczos, window 2), n=%d m=%d" % (n, m),
                            timed(lan, args.steps, 2, env.sync), m, alg_bytes_expv_window(n, As.nnz, m, 2))
+    # (3a) the same call in the OPT-IN pipelined Lanczos mode (ortho = "pipelined": not the reference's arithmetic, include/expv_mi.h) -- same contract
+    lanp = lambda: eu.expv(T_FINAL, ops, b, m=m, ishermitian=True, ortho="pipelined", out=w)
+    lan()
+    env.sync()
+    w_lan = w.clone()
+    lanp()
+    env.sync()
+    e = entry("expv, symmetric 5-diagonal operator, OPT-IN pipelined Lanczos recurrence (csrc/lanczos_pl.hip), n=%d m=%d" % (n, m),
+              timed(lanp, args.steps, 2, env.sync), m, alg_bytes_expv_window(n, As.nnz, m, 2))
+    e["path"] = list(eu.expv.last_stats["path"])
+    e["rel_diff_to_default_path_result"] = float(torch.linalg.norm(w - w_lan) / torch.linalg.norm(w_lan))
+    if "pipelined_lanczos" not in e["path"] or e["rel_diff_to_default_path_result"] > 1e-10:
+        raise SystemExit("lanczos_pipelined: the mode did not run or disagrees with the default path: %r" % (e,))
+    sec["lanczos_pipelined"] = e
+    del w_lan
     # (3') the same symmetric operator through expv(...; mode = :error_estimate) (krylov_phiv_error_estimate.jl): Lanczos with the
     # a-posteriori stopping test after every step; unit = the Lanczos steps it took
     est = {}
