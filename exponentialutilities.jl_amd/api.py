@@ -715,7 +715,7 @@ def _opts(m=None, tol=1e-7, iop=0, init=0, ishermitian=None, ortho="auto", flags
     return o
 
 
-def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0, init=0, ortho="auto"):
+def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0, init=0, ortho="auto", defer_tail=True):
     """arnoldi!(Ks, A, b; tol, m, ishermitian, opnorm, iop, init)  (arnoldi.jl:345-377).
     ``opnorm`` is accepted and ignored, like the reference."""
     op = _as_operator(A, Ks.T, Ks.ctx)
@@ -727,7 +727,7 @@ def arnoldi_(Ks, A, b, *, tol=1e-7, m=None, ishermitian=None, opnorm=None, iop=0
     if ishermitian is None:
         ishermitian = op.ishermitian
     # (EXPV_MI_ARNOLDI_DEFER_TAIL: the closing pass is collected by whatever touches Ks next -- every accessor here is a library call)
-    o = _opts(m, tol, iop, init, ishermitian, ortho, flags=1)
+    o = _opts(m, tol, iop, init, ishermitian, ortho, flags=1 if defer_tail else 0)
     _check(L.load().expv_mi_arnoldi(Ks._h, op._h, ba.ptr, ba.loc, C.byref(o)), Ks.ctx._h)
     return Ks
 

@@ -1611,6 +1611,71 @@ def test_matrix_free_callback_sees_normalised_columns_by_default(eu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T", [np.float64, np.complex128, np.float32])
+def test_deferred_closing_pass_is_collected_by_every_accessor(eu, T):
+    """Round 6: arnoldi! / lanczos! with EXPV_MI_ARNOLDI_DEFER_TAIL (what the Python mirror and the Julia shim set) return when H[1:m, 1:m] is
+    final; v_{m+1}, H[m+1, m] and the breakdown test of step m belong to the closing pass, which whoever touches the subspace next collects.
+    Every accessor must give what the undeferred call gives, bit for bit: getH (incl. H[m+1, m]) first, Ks.m / wasbreakdown first, getV first,
+    expv! first, resize! first, another factorisation first, destroy with the pass still pending; and a happy breakdown AT step m -- which only
+    the closing pass can see -- is reported (Ks.m = m, wasbreakdown) like the oracle reports it (arnoldi.jl:370-374)."""
+    rng = np.random.default_rng(83)
+    n, m = 70_001, 12
+    cplx = np.dtype(T).kind == "c"
+    A = (c2_operator(n) * ((1 + 0.25j) if cplx else 1.0)).astype(T).tocsr()
+    b = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)).astype(T)
+    ctx = eu.Context()
+    op = eu.MIOperator(A, ctx)
+
+    def fresh(defer):
+        Ks = eu.KrylovSubspace(T, T, n, m + 4, 0, ctx)
+        eu.arnoldi_(Ks, op, b, m=m, ishermitian=False, defer_tail=defer)
+        return Ks
+    K0 = fresh(False)
+    # (expv! before getV combines the raw columns with scaled coefficients, after it the normalised columns: equal to rounding, not bit for bit)
+    H0 = np.asarray(K0.getH()).copy()
+    w0 = np.asarray(eu.expv_(np.empty(n, dtype=T), 0.4, K0)).copy()
+    V0 = np.asarray(K0.getV()).copy()
+    w0v = np.asarray(eu.expv_(np.empty(n, dtype=T), 0.4, K0)).copy()
+    for first in ("getH", "m", "getV", "expv", "resize", "refactor", "set_m"):
+        Ks = fresh(True)
+        if first == "getH":
+            assert np.array_equal(np.asarray(Ks.getH()), H0)
+        elif first == "m":
+            assert Ks.m == m and not Ks.wasbreakdown
+        elif first == "getV":
+            assert np.array_equal(np.asarray(Ks.getV()), V0)
+        elif first == "expv":
+            assert np.array_equal(np.asarray(eu.expv_(np.empty(n, dtype=T), 0.4, Ks)), w0)      # (its host exponential ran UNDER the closing pass)
+        elif first == "resize":      # (resize! of a plain subspace starts it afresh, arnoldi.jl:80-93: the pending pass must be drained first, then a new factorisation)
+            Ks.resize(m + 9)
+            eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+        elif first == "refactor":
+            eu.arnoldi_(Ks, op, b, m=m, ishermitian=False)
+        elif first == "set_m":
+            Ks.m = m
+        assert np.array_equal(np.asarray(Ks.getH())[: m + 1, :m], H0[: m + 1, :m]), first
+        assert np.array_equal(np.asarray(eu.expv_(np.empty(n, dtype=T), 0.4, Ks)), w0v if first == "getV" else w0), first
+        assert np.array_equal(np.asarray(Ks.getV())[:, : m + 1], V0[:, : m + 1]), first
+    Ks = fresh(True)
+    del Ks                                                   # destroyed with the closing pass possibly still in flight
+    ctx.sync()
+    # a happy breakdown exactly at step m: b lives in an invariant subspace of dimension m of a block-diagonal operator
+    if T != np.float32:
+        k = 6
+        blk = (rng.standard_normal((k, k)) + (1j * rng.standard_normal((k, k)) if cplx else 0)).astype(T)
+        nn = 4096
+        Ab = sp.block_diag([sp.csr_matrix(blk)] + [sp.identity(nn - k, dtype=T, format="csr") * T(-1.0)], format="csr").astype(T)
+        bb = np.zeros(nn, dtype=T)
+        bb[:k] = (rng.standard_normal(k) + (1j * rng.standard_normal(k) if cplx else 0)).astype(T)
+        Ko = ko.arnoldi(Ab, bb, m=k, ishermitian=False)
+        for defer in (False, True):
+            Kd = eu.KrylovSubspace(T, T, nn, k, 0, ctx)
+            eu.arnoldi_(Kd, Ab, bb, m=k, ishermitian=False, defer_tail=defer)
+            assert (Kd.m, bool(Kd.wasbreakdown)) == (Ko.m, bool(Ko.wasbreakdown)), (defer, Kd.m, Kd.wasbreakdown, Ko.m, Ko.wasbreakdown)
+            close(np.asarray(Kd.getH())[:k, :k], Ko.getH()[:k, :k], 1e-11, "breakdown at step m, defer=%s: H vs oracle" % defer, mat=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,m", [(513, 7), (2000, 30), (70_001, 30), (300_000, 40)])
 def test_pipelined_lanczos_opt_in_mode(eu, n, m):
     """the opt-in `ortho = "pipelined"` mode of lanczos! (csrc/lanczos_pl.hip) -- NOT the reference's arithmetic: alpha_j,
