@@ -390,7 +390,11 @@ int expv_mi_phiv_timestep(expv_mi_ctx_t ctx, expv_mi_op_t op, int nts, double *t
 /* kiops(tau_out, A, u; mmin, mmax, m, tol, iop, ishermitian, task1)  (kiops.jl:57-281).
  * u is n x ncols_u; w is n x 1 (numSteps = size(tau_out,2) = 1 is the only reachable case, see
  * DESIGN.md); stats = (step, reject, krystep, exps, m_ret).  For dtype C64 (no reference method)
- * the mathematical extension is computed and w is complex. */
+ * the mathematical extension is computed and w is complex.
+ * Round 6: a device-resident w is complete on return unless the context's outputs are stream-ordered (expv_mi_ctx_set_async_outputs): then it is
+ * valid for later work on the context's stream / after expv_mi_ctx_sync, like every other result, and back-to-back calls overlap one call's solution
+ * update with the next call's first launches.  After a rejected sub-step the basis is continued behind the closing pass of the rejected factorisation
+ * instead of recomputing its last step (context option "kiops_skip_redo"); the statistics tuple is the reference's either way. */
 typedef struct {
   int32_t mmin, mmax, m, iop, ishermitian, task1, ortho, reserved;
   double tol;
