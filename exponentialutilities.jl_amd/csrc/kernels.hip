@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void k_mailbox_fill(const double *Hdev, int6
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(mb_done, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(mb_done, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (relaxed behind the drain + barrier: a RELEASE store costs a whole-L2 write-back, pipe.hip k_pipe)
 }
 void mailbox_fill(hipStream_t s, const double *Hdev, int64_t nwords, const StepState *st, double *mb_H, double *mb_state,
                   unsigned long long *mb_done, uint32_t seq, const double *scales, int nscales, double *mb_scales) {

@@ -227,6 +227,18 @@ template <> struct ColPack<4> {
 template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(const int32_t *p) { c[0] = *p; } };
 // one Krylov step; returns 0 in every workgroup but the last, 1 in the last one (results written), 2 when the
 // last one found the breakdown / zero-vector condition, 4 when a LIVE kernel was released by an earlier stop
+#ifndef PIPE_LEAN
+#define PIPE_LEAN 1             // lean tile loop (round 6): no per-value selects on the uniform `slot_dots`, window-column conditions as scalar compares on a
+#endif                          // per-tile copy of `und` (hoisted lane masks were spilled to VGPR lanes: 2 v_readlane per column and use), complex h_k read in batches
+#ifndef PIPE_LEAN_LD
+#define PIPE_LEAN_LD PIPE_LEAN
+#endif
+#ifndef PIPE_LEAN_H
+#define PIPE_LEAN_H PIPE_LEAN
+#endif
+#ifndef PIPE_LEAN_SET
+#define PIPE_LEAN_SET PIPE_LEAN
+#endif
 #ifndef PIPE_XPF_MIN_CH
 #define PIPE_XPF_MIN_CH 99      // window capacity from which the in-place cross-tile prefetch of the window is compiled in (99: off = the product; measured neutral, profiles/r05_ab_variants.txt item 3)
 #endif
@@ -508,13 +520,24 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
     }
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
-    if (!(XPF && xp_have)) {
+    const bool wload = !first && act;
+    constexpr bool LEAN_LD = PIPE_LEAN_LD && !PF && !XPF;      // zeros only where no load follows
+#ifndef PIPE_LEAN_ZERO      // 1: skip the zeros of the registers a load follows.  NOT the product: with it the overlapped Float32 SELL wave form returned wrong
+#define PIPE_LEAN_ZERO 0    // results from step 2 on, different from run to run (tools/f32_wave_dbg.py; the same source with the zeros kept is bit-exact) --
+#endif                      // the two forms are the same program text-wise, so until that is understood the 2 v_mov per column stay
+    if (!(XPF && xp_have) && !(LEAN_LD && PIPE_LEAN_ZERO && wload)) {
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
 #pragma unroll
         for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
     }
-    const bool wload = !first && act;
+    // und as the tile loop sees it: a scalar the compiler cannot hoist tests of (it would keep one lane mask per window column alive across
+    // the loop -- up to 31 SGPR pairs, spilled into VGPR lanes and read back with two v_readlane per column wherever a column is tested)
+    int und_t = und;
+    if constexpr (PIPE_LEAN_LD || PIPE_LEAN_H) {      // (through a vector register and back: one v_mov + one v_readfirstlane per tile)
+      asm volatile("" : "+v"(und_t));
+      und_t = __builtin_amdgcn_readfirstlane(und_t);
+    }
     const T *vp0 = a.V + (int64_t)pa.uc0 * a.ldv + i;    // window column k at vp0 + k * cstep
     if (XPF && xp_have) {
       // (requested during the previous tile's reductions)
@@ -529,10 +552,23 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       }
     } else if (wload) {
       const T *vp = vp0;                                  // one running pointer, stepped per column
+      if constexpr (LEAN_LD) {
+        const int skip = ready ? -1 : knew;               // (the column the previous step is still writing: fetched behind its flag)
+#pragma unroll
+        for (int k = 0; k < CH - 1; ++k) {
+          if (k < und_t && k != skip) vreg[k] = ld_stream<NT, T>(vp);
+          else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
+          }
+          vp += cstep;
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k) {
         if (k < und && (ready || k != knew)) vreg[k] = ld_stream<NT, T>(vp);
         vp += cstep;
+      }
       }
     }
     Pack<T> u;                 // u_j on this lane's rows (overlapped form, first tile: y~ of the previous step is loaded into it right behind the flag)
@@ -767,6 +803,26 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
       // MGS axpy order.  fp64: slots k >= und hold h = +0 and v = +0, and fma(-0, 0, u) is u bit for bit (either zero sign
       // included), so the chain runs unconditionally -- per column 2 FMAs instead of 2 FMAs + 4 selects on a spilled mask
+      if constexpr (PIPE_LEAN_H && ST<T>::is_complex && CH > 8) {
+        // complex, long windows: the coefficients of four columns are read from LDS together (one wait per four columns instead of a
+        // read + full LDS latency per column); a column beyond und is skipped by a scalar test -- the same operations on the same
+        // operands in the same order as the per-column form
+        constexpr int UB = (CH == 24) ? 2 : 4;      // (the 24-column variant runs at 3 workgroups per CU: 168 registers, no room for four coefficients)
+#pragma unroll
+        for (int k0 = 0; k0 < CH - 1; k0 += UB) {
+          if (k0 < und_t) {
+            T h[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) h[q] = hs[(k0 + q) & 31];
+#pragma unroll
+            for (int q = 0; q < UB; ++q)
+              if (k0 + q < CH - 1 && k0 + q < und_t) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) ST<T>::nfma(u.v[e], h[q], vreg[k0 + q].v[e]);
+              }
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)
         if (!ST<T>::is_complex || k < und) {
@@ -774,11 +830,26 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
 #pragma unroll
           for (int e = 0; e < N; ++e) ST<T>::nfma(u.v[e], h, vreg[k].v[e]);
         }
+      }
     }
     // products of one set (t = 0: against y~, t = 1: against u_j) of this tile, summed across the wave at once
     auto tile_set = [&](int sidx, const Pack<T> &o) {
       const int part = sidx % P;
       double arr[K];
+      if constexpr (PIPE_LEAN_SET && CH >= 16) {
+        // long windows: the uniform flag slot_dots is applied ONCE per accumulated sum (put_sum, below) instead of to every product -- a
+        // select per product is 2 v_cndmask per value: 128 of the ~1000 vector instructions of a 32-column fp64 tile, 192 of the ~1240 of
+        // a 24-column complex one.  Same stored sums: where the flag is off they are +0 either way.  (A scalar branch around the products
+        // instead costs 12 VGPRs on the complex variants -- all 16 values of a part live at the join -- and spills the 24-column one.)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int qq = part * K + k;
+          const int q = qq / NR, r = qq % NR;
+          if (q < CH - 1) arr[k] = pack_prod(vreg[q < CH - 1 ? q : 0], o, r);
+          else if (q == CH - 1) arr[k] = pack_prod(u, o, r);
+          else arr[k] = 0.0;
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int qq = part * K + k;                // position in the LSET-long vector of the set
@@ -786,6 +857,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         if (q < CH - 1) arr[k] = slot_dots ? pack_prod(vreg[q < CH - 1 ? q : 0], o, r) : 0.0;   // (slots >= und hold zeros, and their sums are never stored)
         else if (q == CH - 1) arr[k] = pack_prod(u, o, r);
         else arr[k] = 0.0;
+      }
       }
       wave_reduce_multi<K>(arr);
       if constexpr (TWO_ACC) {
@@ -1076,7 +1148,10 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       if (q == CH - 1) {
         if (t == 0) red_s[wave][o_self + r] = v;
         else if (r == 0) red_s[wave][o_nrm] = v;
-      } else if (q < und) red_s[wave][t * NR * und + NR * q + r] = v;
+      } else if (q < und) {
+        if constexpr (PIPE_LEAN_SET && CH >= 16) red_s[wave][t * NR * und + NR * q + r] = slot_dots ? v : 0.0;      // (see tile_set: the flag applied once per sum)
+        else red_s[wave][t * NR * und + NR * q + r] = v;
+      }
     };
     if constexpr (TWO_ACC) {
       const int part = lane & (COPIES - 1);
@@ -1583,7 +1658,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_pipe_resident(const ResArgs ra) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(ra.mb_done, (unsigned long long)ra.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid == 0) __hip_atomic_store(ra.mb_done, (unsigned long long)ra.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (relaxed behind the drain + barrier: a RELEASE store costs a whole-L2 write-back, pipe.hip k_pipe)
     }
     if (stop) return;
   }

@@ -1,6 +1,6 @@
 """Cost of a Krylov step as a function of the window length: expv at m = 4, 8, 12, ... on the C2 pattern (fp64 and x (1 + 0.25i)
 ComplexF64); the difference between two runs / the steps between them = us per step of that window range, beside the contract's
-bytes for those steps.  usage: python tools/window_cost.py [n]"""
+bytes for those steps.  usage: python tools/window_cost.py [n] [serial]      (serial: launches one after the other, option pipeline_serial)"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -9,6 +9,9 @@ from bench import c2_operator, timed, a_bytes
 eu = expv_mi_loader.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ctx = eu.Context(async_outputs=True)
+if len(sys.argv) > 2 and sys.argv[2] == "serial":
+    ctx.set_option("pipeline_serial", 1)
+    print("(serial mode)")
 for name, A, s in (("fp64", c2_operator(n), 8), ("complex", (c2_operator(n) * (1 + 0.25j)).tocsr(), 16)):
     op = eu.MIOperator(A, ctx)
     rng = np.random.default_rng(3)
