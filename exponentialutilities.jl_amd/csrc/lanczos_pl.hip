@@ -47,7 +47,7 @@ __device__ __forceinline__ void pl_store_wt(double *p, double a, double b) {
   vec2d d;
   d.x = a;
   d.y = b;
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");      // (s_nop: store-data hazard, see pipe.hip st_pack_wt)
 }
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence: the compiler drains every outstanding
 // GLOBAL access in front of it (s_waitcnt vmcnt(0)) -- the loads requested one tile ahead and the write-through stores of the tile

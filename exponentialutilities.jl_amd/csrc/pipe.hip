@@ -57,7 +57,12 @@ __device__ __forceinline__ void st_pack_wt(T *p, const Pack<T> &v) {
   const double *src = reinterpret_cast<const double *>(&v);
   d.x = src[0];
   d.y = src[1];
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+  // s_nop 1: a store of more than 8 bytes reads its data registers late -- a VALU write to one of them within 2 wait states of the store
+  // lands in memory instead of the value stored (gfx940+ "VMEM store data" hazard).  The compiler pads its OWN stores
+  // (GCNHazardRecognizer::checkVALUHazardsHelper) but cannot see into inline assembly: round 6 found
+  //   global_store_dwordx4 v[104:105], v[80:83], off sc0 sc1 ; s_or_b64 exec, ... ; v_mul_f32 v80, v38, v91
+  // in the overlapped Float32 SELL wave form (u_j[0] of every lane stored wrong, differently from run to run; tools/f32_wave_dbg.py).
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
 }
 template <bool WT, class T>
 __device__ __forceinline__ void st_tile(T *p, const Pack<T> &v) {
@@ -522,9 +527,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     // ---- phase 1: u_j on the tile rows; the window values of these rows stay in registers ----------
     const bool wload = !first && act;
     constexpr bool LEAN_LD = PIPE_LEAN_LD && !PF && !XPF;      // zeros only where no load follows
-#ifndef PIPE_LEAN_ZERO      // 1: skip the zeros of the registers a load follows.  NOT the product: with it the overlapped Float32 SELL wave form returned wrong
-#define PIPE_LEAN_ZERO 0    // results from step 2 on, different from run to run (tools/f32_wave_dbg.py; the same source with the zeros kept is bit-exact) --
-#endif                      // the two forms are the same program text-wise, so until that is understood the 2 v_mov per column stay
+#ifndef PIPE_LEAN_ZERO      // 1: no zeros for the registers a load follows (2 v_mov per column).  (This is the change that moved a VALU write right behind the
+#define PIPE_LEAN_ZERO 1    //  inline-assembly store of u_j and so exposed the store-data hazard st_pack_wt now pads against.)
+#endif
     if (!(XPF && xp_have) && !(LEAN_LD && PIPE_LEAN_ZERO && wload)) {
 #pragma unroll
       for (int k = 0; k < CH - 1; ++k)

@@ -56,6 +56,24 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
 
 
+def test_inline_assembly_wide_stores_are_padded_against_the_store_data_hazard():
+    """gfx940+: a VMEM store of more than 8 bytes reads its data registers late; a VALU write to one of them within 2 wait states of the
+    store reaches memory instead of the stored value.  The compiler pads its own stores (GCNHazardRecognizer) but not inline assembly --
+    round 6 found `global_store_dwordx4 v[104:105], v[80:83] ... ; v_mul_f32 v80, ...` in the overlapped Float32 SELL wave form.  Every
+    hand-written store wider than 8 bytes must carry its own `s_nop 1`."""
+    import re
+    pkg = os.path.join(ROOT, "exponentialutilities.jl_amd", "csrc")
+    seen = 0
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for ln, line in enumerate(open(os.path.join(pkg, f), errors="ignore").read().split("\n"), 1):
+            if "asm" in line and re.search(r"(global|flat|buffer|scratch)_store_(dwordx[34]|b96|b128)", line):
+                seen += 1
+                assert re.search(r"store_\w+[^\"]*\\n\\ts_nop [1-9]", line), "%s:%d: wide inline-assembly store without s_nop behind it" % (f, ln)
+    assert seen >= 2      # st_pack_wt (pipe.hip), pl_store_wt (lanczos_pl.hip)
+
+
 @pytest.mark.parametrize("T", [float, complex])
 @pytest.mark.parametrize("scale", [30.0, 3.0, 1.5, 0.5, 0.1, 0.005])
 def test_host_expm_every_pade_branch(eu, T, scale):
