@@ -241,6 +241,9 @@ template <> struct ColPack<1> { int c[1]; __device__ __forceinline__ void load(c
 #ifndef PIPE_LEAN_H
 #define PIPE_LEAN_H PIPE_LEAN
 #endif
+#ifndef PIPE_LEAN_H_MIN_CH
+#define PIPE_LEAN_H_MIN_CH 9    // window capacity from which the complex coefficients are read in batches (short windows: measured, see profiles/r06_lean_tile_loop_ab.txt)
+#endif
 #ifndef PIPE_LEAN_SET
 #define PIPE_LEAN_SET PIPE_LEAN
 #endif
@@ -808,7 +811,7 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       for (int e = 0; e < N; ++e) u.v[e] = ST<T>::mul_real(u.v[e], inv);
       // MGS axpy order.  fp64: slots k >= und hold h = +0 and v = +0, and fma(-0, 0, u) is u bit for bit (either zero sign
       // included), so the chain runs unconditionally -- per column 2 FMAs instead of 2 FMAs + 4 selects on a spilled mask
-      if constexpr (PIPE_LEAN_H && ST<T>::is_complex && CH > 8) {
+      if constexpr (PIPE_LEAN_H && ST<T>::is_complex && CH >= PIPE_LEAN_H_MIN_CH) {
         // complex, long windows: the coefficients of four columns are read from LDS together (one wait per four columns instead of a
         // read + full LDS latency per column); a column beyond und is skipped by a scalar test -- the same operations on the same
         // operands in the same order as the per-column form
