@@ -463,6 +463,9 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
     }
   };
   [[maybe_unused]] bool park_pending = false;      // LDS transfers of the next tile in flight: drained where this tile waits for its own loads anyway
+  // PARK: column pieces of the workgroup's second tile behind us[] (k_pipe_live sizes the area); parked_n of them are there (uniform)
+  constexpr int PKC = (LIVE && DIA && !WAVE && !RING && !AUG && !PF) ? (int)((sizeof(sh.us) / sizeof(T) - (Pack<T>::N * BLOCK + 2 * PIPE_WMAX)) / (Pack<T>::N * BLOCK)) : 0;
+  [[maybe_unused]] int parked_n = 0;
   // window columns of the current tile (XPF: hoisted out of the tile loop -- they carry the next tile's values across the back edge)
   Pack<T> vreg[CH - 1];
   [[maybe_unused]] bool xp_have = false;           // vreg already holds (or is receiving) this tile's window values
@@ -562,9 +565,16 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
       const T *vp = vp0;                                  // one running pointer, stepped per column
       if constexpr (LEAN_LD) {
         const int skip = ready ? -1 : knew;               // (the column the previous step is still writing: fetched behind its flag)
+        [[maybe_unused]] const int from_park = (PKC > 0 && tl == 1) ? parked_n : 0;      // (parked_n > 0 only behind a first tile that parked)
+        if constexpr (PKC > 0) {
+          // the LDS transfers were requested before everything the first tile has waited for since: they have landed (loads return in
+          // order); the drain is for the compiler, which does not order LDS-DMA against ds_reads
+          if (from_park > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int k = 0; k < CH - 1; ++k) {
-          if (k < und_t && k != skip) vreg[k] = ld_stream<NT, T>(vp);
+          if (PKC > 0 && k < PKC && k < from_park && k != knew) vreg[k] = *reinterpret_cast<const Pack<T> *>(&us[PARK0 + (k * BLOCK + tid) * N]);
+          else if (k < und_t && k != skip) vreg[k] = ld_stream<NT, T>(vp);
           else {
 #pragma unroll
             for (int e = 0; e < N; ++e) vreg[k].v[e] = ST<T>::zero();
@@ -602,6 +612,22 @@ __device__ __forceinline__ int pipe_pass(const PipeArgsT<T> &pa, int tiles_per_b
         int64_t hr;
         if (tid < 2 * w * 32 && halo_elem(tid, k, hr) && k < und && k != knew && k != 31)
           hpre = a.V[hr + (int64_t)(pa.uc0 + pa.udir * k) * a.ldv];
+      }
+    }
+    if constexpr (PKC > 0) {
+      // first tile of an overlapped step, before the wait: the older window columns of the SECOND tile -> LDS (see k_pipe_live)
+      if (!ready && tl == 0 && !pa.final && !deal_rr && tile + 1 < t1) {
+        parked_n = und_t < PKC ? und_t : PKC;
+        const int64_t i2 = i + TR;
+        if (i2 < nb) {      // (whole waves)
+          const T *vp2 = vp0 + TR;
+          const int wbase = (tid >> 6) * 64 * N;      // LDS destination of a wave: base + lane * 16 bytes
+#pragma unroll
+          for (int k = 0; k < PKC; ++k)
+            if (k < parked_n && k != knew)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vp2 + (int64_t)k * cstep),
+                                               (__attribute__((address_space(3))) void *)&us[PARK0 + k * BLOCK * N + wbase], 16, 0, 0);
+        }
       }
     }
     [[maybe_unused]] bool nx_post_due = false;
@@ -1318,12 +1344,26 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_ring(const PipeArgsT<T> p
   (void)pipe_pass<T, CH, PS, false, false, false, AUG, false, true, PipeSharedRing<T>>(pa, tiles_per_block, sh);
 }
 
+// PARK (overlapped banded DIA form; an experiment of round 6, compiled out: PIPE_PARK_COLS = 0).  While a step's workgroups wait for the previous step's
+// flag the previous step is in its reduction and epilogue (6-9 us of a 30-50 us step, tools/pipe_trace.py) and streams nothing, and a workgroup can hold
+// only ONE tile's window in registers.  With PIPE_PARK_COLS = K the older window columns of the workgroup's SECOND tile (K pieces of 4 KB) travel into LDS
+// during that wait (global_load_lds: no register destination) and are read from there when the tile's turn comes.  Measured with K = 6 (23 / 15.6 / 11.7 MB
+// per step moved out of the post-flag phase): results bit-identical, the streaming phase of a step 1.0-1.2 us shorter -- and the previous step's reduction
+// 1.3-1.4 us LONGER: its six dependent memory round trips queue behind the extra transfers.  Whole call unchanged (profiles/r06_park_ab.txt).
+#ifndef PIPE_PARK_COLS
+#define PIPE_PARK_COLS 0
+#endif
+template <class T, bool DIA, bool WAVE, bool AUG, bool RING, bool PF> constexpr int pipe_park_cols() {
+  return (std::is_same<T, double>::value && DIA && !WAVE && !AUG && !RING && !PF) ? PIPE_PARK_COLS : 0;
+}
 template <class T, int CH, int WAVES, int PS, bool DIA, bool WAVE = false, bool AUG = false, bool NT = false, bool RING = false, bool PF = false>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_pipe_live(const PipeArgsT<T> pa, int tiles_per_block) {
   // (the 16- and the 24-column variant run at the same 3 workgroups per CU and follow each other in a factorisation: the same LDS
   //  size for both, so that a workgroup of step 17 fits the hole a workgroup of step 16 leaves -- with different sizes the first
   //  24-column step waited ~25 us for two adjacent holes: profiles/r04_ab_variants.txt)
-  using SH = typename std::conditional<RING, PipeSharedRing<T, pipe_ring_stage_elems<T, CH>()>, PipeSharedT<T, PF ? (PS + 1) * Pack<T>::N * BLOCK : 0, PF>>::type;
+  constexpr int PKC = pipe_park_cols<T, DIA, WAVE, AUG, RING, PF>();
+  using SH = typename std::conditional<RING, PipeSharedRing<T, pipe_ring_stage_elems<T, CH>()>,
+                                       PipeSharedT<T, PF ? (PS + 1) * Pack<T>::N * BLOCK : PKC * Pack<T>::N * BLOCK, PF>>::type;
   __shared__ SH sh;
   if (threadIdx.x == 0)   // this workgroup is resident (see k_pipe_gate)
     (void)__hip_atomic_fetch_add(pa.arrive + (blockIdx.x % PIPE_FLAG_COPIES) * PIPE_ARRIVE_STRIDE, 1u, __ATOMIC_RELAXED,
